@@ -1,0 +1,163 @@
+/*
+ * shotfpfh.h -- C ABI of libshotfpfh.so, the MI355X (gfx950) SHOT / FPFH descriptor engine.
+ *
+ * This is the drop-in boundary for the hot path of aubin-tchoi/shot-fpfh.  The reference is pure
+ * Python with no FFI of its own; each entry point below replaces the NumPy / scikit-learn /
+ * SciPy call named next to it (file:line into the reference checkout) and is what a ctypes stub
+ * in the reference would bind.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  No torch / numpy types.
+ *   - Every int-returning call returns SF_OK (0) or a negative SF_ERR_* code; the message is
+ *     available from sf_last_error() (thread-local).  Handle-returning calls return NULL on error.
+ *   - All floating-point data is float64, row-major.  Indices into the cloud are int32/int64 in
+ *     the caller's ORIGINAL point numbering unless a parameter says otherwise.
+ *   - `flags` tells where the data pointers of a call live:
+ *       SF_HOST (0)      every data pointer is host memory (the library copies in/out)
+ *       SF_OUT_DEVICE    output pointers are device memory of ctx's GPU (no D2H copy)
+ *       SF_IN_DEVICE     input data pointers are device memory (no H2D copy)
+ *     Handles (sf_cloud, sf_nbrs, sf_spfh) always live on the device.
+ *   - The library never keeps a caller pointer after a call returns.
+ *   - One sf_ctx per GPU and per host thread; calls on one ctx are stream-ordered on the ctx's
+ *     own HIP stream (sf_stream).  Do not fork() after sf_create().
+ *   - There is NO CPU fallback: without a GPU sf_create() fails.
+ */
+#ifndef SHOTFPFH_H
+#define SHOTFPFH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_ERR_ARG (-1)
+#define SF_ERR_HIP (-2)
+#define SF_ERR_NOMEM (-3)
+#define SF_ERR_COMM (-4)
+#define SF_ERR_STATE (-5)
+#define SF_ERR_UNSUPPORTED (-6)
+
+#define SF_HOST 0
+#define SF_OUT_DEVICE 1
+#define SF_IN_DEVICE 2
+
+#define SF_SHOT_LEN 352 /* 11 cosine x 8 azimuth x 2 elevation x 2 radial bins (shot.py:195) */
+#define SF_MAX_FPFH_BINS 8 /* n_bins^3 <= 512 histogram cells per point */
+
+typedef struct sf_ctx sf_ctx;     /* one GPU: device id, stream, scratch, optional RCCL comm  */
+typedef struct sf_cloud sf_cloud; /* resident point cloud + uniform grid (replaces KDTree(X))  */
+typedef struct sf_nbrs sf_nbrs;   /* resident CSR radius-neighbour lists of a query set        */
+typedef struct sf_spfh sf_spfh;   /* resident SPFH table (integer bin counts + list lengths)   */
+
+/* ---- library / context ---------------------------------------------------------------- */
+const char *sf_last_error(void);
+const char *sf_version(void);
+int sf_device_count(void);
+sf_ctx *sf_create(int device);
+void sf_destroy(sf_ctx *ctx);
+int sf_sync(sf_ctx *ctx);
+void *sf_stream(sf_ctx *ctx); /* hipStream_t the kernels are launched on */
+
+/* ---- raw device memory (for callers that keep results resident) ------------------------- */
+void *sf_dev_alloc(sf_ctx *ctx, size_t bytes);
+int sf_dev_free(sf_ctx *ctx, void *dev_ptr);
+int sf_h2d(sf_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int sf_d2h(sf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- cloud + grid: replaces sklearn KDTree(X) -------------------------------------------
+ * call sites: fpfh.py:26, shot_parallelization.py:167,220,229,283, pca_based_descriptors.py:45-49
+ * sf_cloud_upload copies xyz (n x 3) and normals (n x 3, nullable) to the GPU.
+ * sf_cloud_build_grid (kernel K1) bins the points into cells of edge >= `cell`, sorts them by cell
+ * and keeps cell-sorted SoA copies of xyz / normals; it must be called with cell >= the largest
+ * radius later searched (re-callable; a search with a larger radius rebuilds automatically). */
+sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const double *normals, int64_t n, int flags);
+int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *cloud, const double *normals, int flags);
+int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *cloud, double cell);
+int64_t sf_cloud_size(const sf_cloud *cloud);
+void sf_cloud_free(sf_ctx *ctx, sf_cloud *cloud);
+
+/* ---- radius search: replaces KDTree.query_radius (kernels K2 count / fill) --------------
+ * Inclusion rule of sklearn's euclidean KDTree: ((dx*dx + dy*dy) + dz*dz) <= r*r in float64,
+ * evaluated without FMA, self-match included.
+ * sf_radius_search:        m arbitrary query points (shot_parallelization.py:167-169,
+ *                          pca_based_descriptors.py:48).
+ * sf_radius_search_self:   the cloud's own points as queries (fpfh.py:28-30); [begin, end) is a
+ *                          range of CELL-SORTED positions (0, n = everything), which is how a
+ *                          multi-GPU shard selects its block of queries.
+ * sf_nbrs_export returns the lists in the caller's numbering, ascending inside each list, with
+ * distances sqrt(d2) when `dist` is non-NULL (KDTree return_distance=True). Host pointers only. */
+sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, double radius,
+                          int flags);
+sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *cloud, double radius, int64_t begin, int64_t end);
+int64_t sf_nbrs_num_queries(const sf_nbrs *nbrs);
+int64_t sf_nbrs_total(const sf_nbrs *nbrs);
+int64_t sf_nbrs_max_count(const sf_nbrs *nbrs);
+int sf_nbrs_export(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int64_t *offsets /* m+1 */,
+                   int32_t *idx /* total */, double *dist /* nullable, total */);
+void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nbrs);
+
+/* ---- PCA normals: compute_normals radius branch (pca_based_descriptors.py:15-59), K3 ----
+ * `nbrs` = lists of the query points. pre (m x 3, nullable) = pre_computed_normals. Without it the
+ * sign is the one LAPACK dsyevd returns for the lower-triangle covariance (emulated on device). */
+int sf_normals(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *pre, double *out /* m x 3 */,
+               int flags);
+
+/* ---- SHOT --------------------------------------------------------------------------------
+ * sf_shot_lrf (K4): get_local_rf (shot.py:16-48) for every query of `nbrs`; radius = the search
+ *   radius of `nbrs`.  lrf is m x 9, row-major 3x3 with COLUMNS x, y, z (shot.py:48).
+ * sf_shot (K5): compute_single_shot_descriptor (shot.py:175-306) incl. the last-writer-wins
+ *   semantics of the ten fancy-index "+=" statements (shot.py:244-298).  out is m x 352. */
+int sf_shot_lrf(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, double *lrf /* m x 9 */, int flags);
+int sf_shot(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *lrf /* m x 9 */, int normalize,
+            int64_t min_neighborhood_size, double *out /* m x 352 */, int flags);
+
+/* ---- FPFH: compute_fpfh_descriptor (fpfh.py:16-117, decorrelated=False) -------------------
+ * sf_spfh_create allocates the table for all n cloud points; sf_spfh_compute (K6) fills the rows of
+ * the queries of `self_nbrs` (a sf_radius_search_self result); edges = 3 x (n_bins+1) histogram
+ * edges exactly as np.histogramdd builds them (np.linspace; fpfh.py:82-87).
+ * sf_fpfh (K7) reduces  spfh[kp] + sum_{j, d_j>0} spfh[j]/d_j / k  (fpfh.py:101-116) for keypoints
+ * given either as original indices kp_idx (m) or, when kp_idx == NULL, for every query of
+ * `self_nbrs` in cell-sorted order (m must equal its query count).
+ * sf_spfh_export writes the float64 SPFH table (n x n_bins^3, original numbering). */
+sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_count);
+int sf_spfh_compute(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const double *edges);
+int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *spfh, int64_t rows_per_rank); /* RCCL, in place */
+int sf_spfh_export(sf_ctx *ctx, sf_cloud *cloud, sf_spfh *spfh, double *out /* n x nb^3 */, int flags);
+void sf_spfh_free(sf_ctx *ctx, sf_spfh *spfh);
+int sf_fpfh(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const int64_t *kp_idx, int64_t m,
+            double *out /* m x nb^3 */, int flags);
+
+/* ---- matching: cdist + argmin (matching.py:47-52, 63-65, 164-168), K8 ---------------------
+ * a: m1 x d, b: m2 x d.  idx[i] = first j minimising sqrt(sum_t (a[i,t]-b[j,t])^2), summed left to
+ * right in float64 without FMA (scipy's cdist loop); dist (nullable) = that distance; col_idx
+ * (nullable, m2) = argmin over axis 0 (for the reciprocity test). */
+int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, int64_t m2, int64_t d,
+                    int64_t *idx, double *dist, int64_t *col_idx, int flags);
+
+/* ---- RANSAC scoring: inlier count of ransac.py:60-67, K9 ----------------------------------
+ * a, b: m x 3 matched points; Rt: n_draws x 12 (row-major R, then t); counts ||a R^T + t - b|| <= thr. */
+int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, int64_t m, const double *Rt, int64_t n_draws,
+                    double thr, int64_t *inliers, int flags);
+
+/* ---- multi-GPU: RCCL over xGMI (no counterpart in the reference) --------------------------
+ * One process per GPU.  Rank 0 calls sf_comm_unique_id, ships the 128 bytes to the other ranks by
+ * any host channel, then every rank calls sf_comm_init.  sf_comm_allgather gathers
+ * bytes_per_rank from each rank into recv (rank-major); send may alias recv + rank*bytes_per_rank. */
+int sf_comm_unique_id(char id[128]);
+int sf_comm_init(sf_ctx *ctx, const char id[128], int nranks, int rank);
+int sf_comm_allgather(sf_ctx *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+int sf_comm_destroy(sf_ctx *ctx);
+
+/* ---- per-kernel timing with HIP events on the ctx stream -------------------------------- */
+int sf_profile_enable(sf_ctx *ctx, int on);
+int sf_profile_reset(sf_ctx *ctx);
+/* writes "name launches total_ms\n" lines; returns bytes needed (call with buf == NULL to size) */
+int64_t sf_profile_report(sf_ctx *ctx, char *buf, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHOTFPFH_H */

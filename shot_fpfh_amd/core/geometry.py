@@ -1,0 +1,93 @@
+"""Host-side geometry that rides with the hot path: rigid transforms, the Kabsch solver RANSAC uses
+per draw, and voxel-grid support subsampling.
+
+These stay on the host on purpose: a RANSAC run needs 10^4 3x3 SVDs whose results must
+equal NumPy/LAPACK's bit for bit for the draw-by-draw inlier counts to match, and they cost
+microseconds each; only the O(draws x matches) scoring is a kernel (K9).
+"""
+from __future__ import annotations
+
+import numpy as np
+import numpy.typing as npt
+from scipy.spatial.transform import Rotation
+
+__all__ = ["RigidTransform", "solver_point_to_point", "grid_subsampling"]
+
+
+class RigidTransform:
+    """Rotation + translation acting on row-vector points: p -> p @ R.T + t
+    (mirrors shot_fpfh/core/rigid_transform.py:10-106; `transform[points]` applies it)."""
+
+    def __init__(self, rotation: npt.NDArray[np.float64] | None = None, translation: npt.NDArray[np.float64] | None = None):
+        self.rotation = np.eye(3) if rotation is None else rotation
+        self.translation = np.zeros(3) if translation is None else translation
+
+    def __getitem__(self, points: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:
+        return points.dot(self.rotation.T) + self.translation  # rigid_transform.py:81-88
+
+    def transform(self, points: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:
+        return self[points]
+
+    def normalize_rotation(self) -> None:
+        """Re-orthonormalise through a unit quaternion (rigid_transform.py:45-52)."""
+        quat = Rotation.from_matrix(self.rotation).as_quat()
+        self.rotation = Rotation.from_quat(quat / np.linalg.norm(quat)).as_matrix()
+
+    def __matmul__(self, other: "RigidTransform") -> "RigidTransform":
+        composed = RigidTransform(self.rotation @ other.rotation, self.rotation @ other.translation + self.translation)
+        composed.normalize_rotation()
+        return composed
+
+    def __invert__(self) -> "RigidTransform":
+        # the reference returns (R^T, -t) here (rigid_transform.py:72-79), not the true inverse; kept as is
+        return RigidTransform(self.rotation.T, -self.translation)
+
+    def inv(self) -> "RigidTransform":
+        return ~self
+
+    def as_row12(self) -> npt.NDArray[np.float64]:
+        """[R row-major (9), t (3)] -- the per-draw record sf_ransac_score consumes."""
+        return np.concatenate([np.asarray(self.rotation, dtype=np.float64).reshape(9), np.asarray(self.translation, dtype=np.float64)])
+
+    def __repr__(self) -> str:
+        m = np.vstack((np.hstack((self.rotation, self.translation[:, None])), [0, 0, 0, 1]))
+        with np.printoptions(suppress=True):
+            return str(m).replace("[", "").replace("]", "")
+
+
+def solver_point_to_point(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.float64]) -> RigidTransform:
+    """Least-squares rigid fit scan -> ref (Kabsch), following shot_fpfh/core/solvers.py:9-30 call for
+    call so the SVD sign conventions -- hence the transforms -- are identical."""
+    scan_center, ref_center = scan.mean(axis=0), ref.mean(axis=0)
+    cross_cov = (scan - scan_center).T.dot(ref - ref_center)
+    u, _, vt = np.linalg.svd(cross_cov)
+    rot = vt.T @ u.T
+    if np.linalg.det(rot) < 0:  # reflection: flip the last singular direction (solvers.py:23-26)
+        ut = u.T
+        ut[-1] *= -1
+        rot = vt.T @ ut
+    return RigidTransform(rot, ref_center - rot.dot(scan_center))
+
+
+def grid_subsampling(points: npt.NDArray[np.float64], voxel_size: float) -> npt.NDArray[np.int64]:
+    """Voxel subsampling: per occupied voxel keep the point closest to the voxel's barycentre; voxels
+    come out in np.unique's lexicographic key order (shot_fpfh/core/subsampling.py:5-39).
+
+    Segment-vectorised (no per-voxel Python loop).  The within-voxel visiting order is the one
+    np.argsort(inverse) yields, as in the reference, because the first minimum wins on distance ties
+    (two-point voxels tie by construction).
+    """
+    points = np.asarray(points)
+    keys = ((points - np.min(points, axis=0)) // voxel_size).astype(int)
+    _, inverse, counts = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
+    inverse = np.asarray(inverse).reshape(-1)
+    order = np.argsort(inverse)
+    starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    grouped = points[order]
+    bary = np.add.reduceat(grouped, starts, axis=0) / counts[:, None]
+    seg = np.repeat(np.arange(counts.shape[0]), counts)
+    dist = np.linalg.norm(grouped - bary[seg], axis=1)
+    seg_min = np.minimum.reduceat(dist, starts)
+    hit = np.flatnonzero(dist == seg_min[seg])
+    first = hit[np.unique(seg[hit], return_index=True)[1]]
+    return order[first]

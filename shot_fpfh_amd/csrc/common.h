@@ -1,0 +1,144 @@
+// common.h -- shared host-side plumbing of libshotfpfh.so (context, errors, launch + timing).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/shotfpfh.h"
+
+#define SF_WAVE 64
+
+void sf_set_error(const char *fmt, ...);
+
+#define SF_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            sf_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SF_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+
+#define SF_HIP_NULL(call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            sf_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return nullptr;                                                                           \
+        }                                                                                             \
+    } while (0)
+
+#define SF_CHECK(expr)      \
+    do {                    \
+        int rc_ = (expr);   \
+        if (rc_ != SF_OK) return rc_; \
+    } while (0)
+
+struct sf_prof_entry {
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+};
+
+struct sf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    std::map<std::string, sf_prof_entry> prof;
+    std::vector<hipEvent_t> event_pool;
+    void *comm = nullptr; // ncclComm_t
+    int nranks = 1, rank = 0;
+    // small reusable device scratch (bbox partials etc.)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out);
+hipEvent_t sf_ctx_event(sf_ctx *ctx);
+
+// RAII-ish timing scope around one kernel launch (active only when profiling is on).
+struct sf_launch_timer {
+    sf_ctx *ctx;
+    const char *name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    sf_launch_timer(sf_ctx *c, const char *n) : ctx(c), name(n)
+    {
+        if (ctx->profiling) {
+            e0 = sf_ctx_event(ctx);
+            e1 = sf_ctx_event(ctx);
+            (void)hipEventRecord(e0, ctx->stream);
+        }
+    }
+    ~sf_launch_timer()
+    {
+        if (ctx->profiling) {
+            (void)hipEventRecord(e1, ctx->stream);
+            sf_prof_entry &p = ctx->prof[name];
+            p.launches++;
+            p.pending.emplace_back(e0, e1);
+        } else {
+            ctx->prof[name].launches++;
+        }
+    }
+};
+
+// Launch `kernel<<<grid, block, 0, ctx->stream>>>(args...)` under a named timer.
+#define SF_LAUNCH(ctx, name, kernel, grid, block, ...)                                   \
+    do {                                                                                 \
+        sf_launch_timer t_((ctx), (name));                                               \
+        hipLaunchKernelGGL(kernel, (grid), (block), 0, (ctx)->stream, __VA_ARGS__);      \
+    } while (0);                                                                         \
+    SF_HIP(hipGetLastError())
+
+struct sf_cloud {
+    int64_t n = 0;
+    // original order (as uploaded)
+    double *xyz_orig = nullptr;     // n x 3 AoS
+    double *nrm_orig = nullptr;     // n x 3 AoS or null
+    // grid
+    double cell = 0.0;              // actual cell edge used
+    double inv_cell = 0.0;
+    double lo[3] = {0, 0, 0};
+    int dim[3] = {1, 1, 1};
+    int64_t ncell = 0;
+    int32_t *cell_start = nullptr;  // ncell + 1
+    int32_t *perm = nullptr;        // sorted position -> original index
+    int32_t *inv_perm = nullptr;    // original index -> sorted position
+    // cell-sorted SoA
+    double *xs = nullptr, *ys = nullptr, *zs = nullptr;
+    double *nxs = nullptr, *nys = nullptr, *nzs = nullptr;
+    bool normals_sorted = false;
+};
+
+struct sf_nbrs {
+    int64_t m = 0;
+    double radius = 0.0;
+    int64_t total = 0;
+    int64_t max_count = 0;
+    bool self = false;       // queries are cloud points
+    int64_t self_begin = 0;  // first sorted position when self
+    double *qx = nullptr, *qy = nullptr, *qz = nullptr; // query coords in PROCESSING order (owned unless self)
+    int32_t *qrow = nullptr; // processing slot -> caller's query row (null = identity)
+    int32_t *count = nullptr; // per processing slot
+    int64_t *offset = nullptr; // m + 1, per processing slot
+    int32_t *idx = nullptr;    // total, sorted positions
+};
+
+struct sf_spfh {
+    int64_t n = 0;
+    int64_t rows_alloc = 0; // >= n, padded so that an all-gather of equal blocks fits
+    int n_bins = 0;
+    int nb3 = 0;
+    int stride = 0;      // elements per row (padded)
+    int elem_bytes = 2;  // 2 = uint16 counts, 4 = uint32 counts
+    void *counts = nullptr; // n x stride, by sorted position
+    int32_t *k = nullptr;   // n, neighbourhood size (self included), by sorted position
+};
+
+static inline int64_t sf_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }

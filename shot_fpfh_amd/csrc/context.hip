@@ -1,0 +1,187 @@
+// context.hip -- library context, error reporting, device memory helpers, HIP-event profiling.
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void sf_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *sf_last_error(void) { return g_err; }
+extern "C" const char *sf_version(void) { return "shotfpfh-gfx950 0.1"; }
+
+extern "C" int sf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" sf_ctx *sf_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        sf_set_error("no HIP device available (%s); libshotfpfh has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        sf_set_error("device %d out of range (0..%d)", device, n - 1);
+        return nullptr;
+    }
+    SF_HIP_NULL(hipSetDevice(device));
+    sf_ctx *ctx = new sf_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        sf_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void sf_destroy(sf_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    sf_comm_destroy(ctx);
+    for (auto &kv : ctx->prof)
+        for (auto &p : kv.second.pending) {
+            ctx->event_pool.push_back(p.first);
+            ctx->event_pool.push_back(p.second);
+        }
+    for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int sf_sync(sf_ctx *ctx)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+extern "C" void *sf_stream(sf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" void *sf_dev_alloc(sf_ctx *ctx, size_t bytes)
+{
+    if (!ctx) { sf_set_error("null ctx"); return nullptr; }
+    void *p = nullptr;
+    SF_HIP_NULL(hipSetDevice(ctx->device));
+    SF_HIP_NULL(hipMalloc(&p, bytes ? bytes : 8));
+    return p;
+}
+
+extern "C" int sf_dev_free(sf_ctx *ctx, void *p)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    if (!p) return SF_OK;
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    SF_HIP(hipFree(p));
+    return SF_OK;
+}
+
+extern "C" int sf_h2d(sf_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    if (!bytes) return SF_OK;
+    SF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_d2h(sf_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    if (!bytes) return SF_OK;
+    SF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) {
+            SF_HIP(hipStreamSynchronize(ctx->stream));
+            SF_HIP(hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        SF_HIP(hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return SF_OK;
+}
+
+hipEvent_t sf_ctx_event(sf_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t ev = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+static void prof_collect(sf_ctx *ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->prof) {
+        for (auto &p : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) kv.second.total_ms += ms;
+            ctx->event_pool.push_back(p.first);
+            ctx->event_pool.push_back(p.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+extern "C" int sf_profile_enable(sf_ctx *ctx, int on)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    if (!on) prof_collect(ctx);
+    ctx->profiling = on != 0;
+    return SF_OK;
+}
+
+extern "C" int sf_profile_reset(sf_ctx *ctx)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    prof_collect(ctx);
+    ctx->prof.clear();
+    return SF_OK;
+}
+
+extern "C" int64_t sf_profile_report(sf_ctx *ctx, char *buf, int64_t cap)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    prof_collect(ctx);
+    std::string s;
+    char line[256];
+    for (auto &kv : ctx->prof) {
+        snprintf(line, sizeof(line), "%s %lld %.6f\n", kv.first.c_str(), (long long)kv.second.launches,
+                 kv.second.total_ms);
+        s += line;
+    }
+    if (buf && cap > 0) {
+        size_t ncopy = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1;
+        memcpy(buf, s.data(), ncopy);
+        buf[ncopy] = 0;
+    }
+    return (int64_t)s.size() + 1;
+}

@@ -1,0 +1,446 @@
+// descriptors.hip -- K3 (PCA normals), K4 (SHOT local reference frames), K5 (SHOT descriptor).
+//
+// Replaces: compute_normals / pca        pca_based_descriptors.py:15-59   (K3)
+//           get_local_rf                 shot.py:16-48                     (K4)
+//           compute_single_shot_descriptor  shot.py:175-306                (K5)
+// Mapping: one wave per query point; the wave walks the query's CSR neighbour list (search.hip) 64
+// neighbours at a time, gathering cell-sorted SoA xyz / normals (L2-resident: consecutive queries
+// share cells).  All bin-deciding arithmetic is float64 with FMA contraction off.
+// HBM roofline, algorithmic bytes: K3 24 B in + 24 B out per query; K4 24 + 72; K5 writes the
+// 352 x 8 = 2816 B descriptor row + 24 B keypoint + 72 B frame per keypoint.
+#include "common.h"
+#include "device_util.h"
+#include "eigh3.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------------
+// K3: normals.  cov = centered^T centered / k about the barycentre (pca_based_descriptors.py:21-23),
+// eigh, eigenvector of the smallest eigenvalue (:51), optional re-orientation (:53-57).
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                 const double *__restrict__ zs, const double *__restrict__ qx,
+                                                 const double *__restrict__ qy, const double *__restrict__ qz,
+                                                 const int64_t *__restrict__ offset, const int32_t *__restrict__ idx,
+                                                 const int32_t *__restrict__ qrow, int64_t m,
+                                                 const double *__restrict__ pre, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (q >= m) return;
+    const int64_t s = offset[q];
+    const int k = (int)(offset[q + 1] - s);
+    const int64_t row = qrow ? qrow[q] : q;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    // pass 1: barycentre, accumulated relative to the query to keep the sums small
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int t = lane; t < k; t += 64) {
+        const int j = idx[s + t];
+        sx += xs[j] - px;
+        sy += ys[j] - py;
+        sz += zs[j] - pz;
+    }
+    const double kk = (double)k;
+    const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
+    // pass 2: lower triangle of the centred second moments
+    double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
+    for (int t = lane; t < k; t += 64) {
+        const int j = idx[s + t];
+        const double ax = (xs[j] - px) - mx, ay = (ys[j] - py) - my, az = (zs[j] - pz) - mz;
+        c11 += ax * ax;
+        c21 += ay * ax;
+        c31 += az * ax;
+        c22 += ay * ay;
+        c32 += az * ay;
+        c33 += az * az;
+    }
+    c11 = sf_wave_sum(c11) / kk;
+    c21 = sf_wave_sum(c21) / kk;
+    c31 = sf_wave_sum(c31) / kk;
+    c22 = sf_wave_sum(c22) / kk;
+    c32 = sf_wave_sum(c32) / kk;
+    c33 = sf_wave_sum(c33) / kk;
+    const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33);
+    double nx = e.v11, ny = e.v21, nz = e.v31;
+    if (pre) {
+        const double dot = (nx * pre[3 * row] + ny * pre[3 * row + 1]) + nz * pre[3 * row + 2];
+        if (dot < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+    }
+    if (lane == 0) {
+        out[3 * row + 0] = nx;
+        out[3 * row + 1] = ny;
+        out[3 * row + 2] = nz;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K4: SHOT local reference frame (shot.py:16-48), query included in its own support.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                  const double *__restrict__ zs, const double *__restrict__ qx,
+                                                  const double *__restrict__ qy, const double *__restrict__ qz,
+                                                  const int64_t *__restrict__ offset, const int32_t *__restrict__ idx,
+                                                  const int32_t *__restrict__ qrow, int64_t m, double radius,
+                                                  double *__restrict__ lrf)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (q >= m) return;
+    const int64_t s = offset[q];
+    const int k = (int)(offset[q + 1] - s);
+    const int64_t row = qrow ? qrow[q] : q;
+    double *o = lrf + 9 * row;
+    if (k == 0) { // shot.py:24-25
+        if (lane < 9) o[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    // weighted covariance, w = r - ||c|| (shot.py:27-35)
+    double ws = 0, c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
+    for (int t = lane; t < k; t += 64) {
+        const int j = idx[s + t];
+        const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+        const double w = radius - sqrt((cx * cx + cy * cy) + cz * cz);
+        ws += w;
+        const double wx = cx * w, wy = cy * w, wz = cz * w;
+        c11 += cx * wx;
+        c21 += cy * wx;
+        c31 += cz * wx;
+        c22 += cy * wy;
+        c32 += cz * wy;
+        c33 += cz * wz;
+    }
+    ws = sf_wave_sum(ws);
+    c11 = sf_wave_sum(c11) / ws;
+    c21 = sf_wave_sum(c21) / ws;
+    c31 = sf_wave_sum(c31) / ws;
+    c22 = sf_wave_sum(c22) / ws;
+    c32 = sf_wave_sum(c32) / ws;
+    c33 = sf_wave_sum(c33) / ws;
+    const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33); // shot.py:36
+    double x0 = e.v13, x1 = e.v23, x2 = e.v33; // eigenvectors[:, 2]
+    double z0 = e.v11, z1 = e.v21, z2 = e.v31; // eigenvectors[:, 0]
+    // sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
+    int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
+    for (int t0 = 0; t0 < k; t0 += 64) {
+        const int t = t0 + lane;
+        bool xn = false, xp = false, zn = false, zp = false;
+        if (t < k) {
+            const int j = idx[s + t];
+            const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+            const double xo = (cx * x0 + cy * x1) + cz * x2;
+            const double zo = (cx * z0 + cy * z1) + cz * z2;
+            xn = xo < 0.0; xp = xo >= 0.0;
+            zn = zo < 0.0; zp = zo >= 0.0;
+        }
+        xneg += __popcll(__ballot(xn)); xpos += __popcll(__ballot(xp));
+        zneg += __popcll(__ballot(zn)); zpos += __popcll(__ballot(zp));
+    }
+    if (xneg > xpos) { x0 = -x0; x1 = -x1; x2 = -x2; }
+    if (zneg > zpos) { z0 = -z0; z1 = -z1; z2 = -z2; }
+    const double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0; // cross(z, x) :46
+    if (lane == 0) { // columns [x y z] (:48)
+        o[0] = x0; o[1] = y0; o[2] = z0;
+        o[3] = x1; o[4] = y1; o[5] = z1;
+        o[6] = x2; o[7] = y2; o[8] = z2;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K5: SHOT descriptor.
+//
+// The reference accumulates with ten NumPy fancy-index statements "D[idx] += val" (shot.py:244-298).
+// With duplicate indices NumPy keeps only the LAST write of each statement, and neighbours are
+// ordered by ascending rho (shot.py:218), so per statement and bin the neighbour with the LARGEST rho
+// wins and the ten per-statement winners are summed.  The ten statements use five distinct writer
+// keys: A = (ci,ti,pi,ri) [S2,S5,S8,S10], B = (ci+-1,ti,pi,ri) [S1], G = (ci,ti+-1,pi,ri) [S9],
+// CD = (ci,ti,pi) [S3 -> radial bin 1, S4 -> radial bin 0], EF = (ci,ti,ri) [S6 -> elevation bin 1,
+// S7 -> elevation bin 0].  Sweep 1 elects winners with 64-bit LDS atomicMax on the bit pattern of rho
+// (positive doubles order like unsigned integers); sweep 2 lets each winner overwrite its slot with its
+// value, tagged by the sign bit (all values are >= 0) so that later lanes cannot mistake it for a key.
+// One wave per keypoint, 14 KB of LDS per wave.
+// --------------------------------------------------------------------------------------------------
+#define SHOT_PI 3.141592653589793
+
+struct shot_sample {
+    double rho;
+    int base, bcos, bth, cd, ef;
+    double vA, vB, vG, vC, vD, vE, vF;
+};
+
+__device__ inline int azimuth_octant(double x, double y) // get_azimuth_idx, shot.py:51-70
+{
+    const bool a = (y > 0.0) || ((y == 0.0) && (x < 0.0));
+    const bool b = ((x > 0.0) || ((x == 0.0) && (y > 0.0))) != a;
+    const bool c = ((x * y > 0.0) || (x == 0.0)) ? (fabs(x) < fabs(y)) : (fabs(x) > fabs(y));
+    return 4 * (int)a + 2 * (int)b + (int)c;
+}
+
+template <bool VALUES>
+__device__ inline void shot_eval(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
+                                 const double *E /* row-major, columns x y z */, double radius, shot_sample &o)
+{
+    const double rho = sqrt(d2);
+    o.rho = rho;
+    const double lx = (cx * E[0] + cy * E[3]) + cz * E[6]; // (neighbors - point) @ eigenvectors  :214
+    const double ly = (cx * E[1] + cy * E[4]) + cz * E[7];
+    const double lz = (cx * E[2] + cy * E[5]) + cz * E[8];
+    double cosine = (nx * E[2] + ny * E[5]) + nz * E[8]; // normals @ eigenvectors[:, 2]  :215
+    cosine = fmin(fmax(cosine, -1.0), 1.0);
+    const double cpos = (cosine + 1.0) * 11.0 / 2.0 - 0.5; // :228
+    const double cf = rint(cpos);                          // np.rint, half to even  :229
+    const int ci = (int)cf;
+    const int ti = azimuth_octant(lx, ly);                 // :230-232
+    const int pi_ = lz > 0.0 ? 1 : 0;                      // :234
+    const int ri = rho > radius / 2 ? 1 : 0;               // :235
+    const double dc = cpos - cf;
+    const double sc = (double)((dc > 0.0) - (dc < 0.0));
+    int cin = (int)(cf + sc) % 11;
+    if (cin < 0) cin += 11;
+    const double theta = atan2(ly, lx); // :224
+    const double tsz = 2 * SHOT_PI / 8;
+    double dth = (theta - (-SHOT_PI + ti * tsz)) / tsz - 0.5; // :283-287
+    dth = fmin(fmax(dth, -0.5), 0.5);
+    const double sth = (double)((dth > 0.0) - (dth < 0.0));
+    int tin = (int)((double)ti + sth) % 8;
+    if (tin < 0) tin += 8;
+    o.cd = (ci * 8 + ti) * 2 + pi_;
+    o.ef = (ci * 8 + ti) * 2 + ri;
+    o.base = o.cd * 2 + ri;
+    o.bcos = ((cin * 8 + ti) * 2 + pi_) * 2 + ri;
+    o.bth = ((ci * 8 + tin) * 2 + pi_) * 2 + ri;
+    if (VALUES) {
+        const double adc = sc * dc, adth = sth * dth;
+        const double half_r = radius / 2, q1 = radius / 4, q3 = radius * 3 / 4;
+        // interpolate_on_adjacent_husks, shot.py:73-118
+        const double inner = (double)((rho > half_r) && (rho < q3)) * (q3 - rho) / half_r;
+        const double outer = (double)((rho < half_r) && (rho > q1)) * (rho - q1) / half_r;
+        const double cur = (double)(rho < half_r) * (1 - fabs(rho - q1) / half_r) +
+                           (double)(rho > half_r) * (1 - fabs(rho - q3) / half_r);
+        // interpolate_vertical_volumes, shot.py:121-171
+        double lzr = lz / rho;
+        lzr = fmin(fmax(lzr, -1.0), 1.0);
+        const double phi = acos(lzr); // :225
+        const double hpi = SHOT_PI / 2, pi34 = SHOT_PI * 3 / 4, pi4 = SHOT_PI / 4;
+        const double upper =
+            (double)(((phi > hpi) || ((fabs(phi - hpi) < 1e-10) && (lz <= 0.0))) && (phi <= pi34)) * (pi34 - phi) / hpi;
+        const double lower =
+            (double)(((phi < hpi) && ((fabs(phi - hpi) >= 1e-10) || (lz > 0.0))) && (phi >= pi4)) * (phi - pi4) / hpi;
+        const double curv = (double)(phi < hpi) * (1 - fabs(phi - pi4) / hpi) +
+                            (double)(phi >= hpi) * (1 - fabs(phi - pi34) / hpi);
+        o.vB = adc * (double)((cf > -0.5) && (cf < 11 - 0.5)); // S1  :249-251
+        o.vA = (((1 - adc) + cur) + curv) + (1 - adth);         // S2 + S5 + S8 + S10
+        o.vC = outer * (double)(ri == 0);                       // S3  :258-260
+        o.vD = inner * (double)(ri == 1);                       // S4  :261-263
+        o.vE = upper * (double)(pi_ == 0);                      // S6  :270-272
+        o.vF = lower * (double)(pi_ == 1);                      // S7  :273-275
+        o.vG = adth;                                            // S9  :289-295
+    }
+}
+
+__device__ inline unsigned long long tag_value(double v)
+{
+    return (unsigned long long)__double_as_longlong(v) | 0x8000000000000000ull;
+}
+__device__ inline double untag_value(unsigned long long s)
+{
+    return (s >> 63) ? __longlong_as_double((long long)(s & 0x7fffffffffffffffull)) : 0.0;
+}
+
+__global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, const double *__restrict__ ys,
+                                             const double *__restrict__ zs, const double *__restrict__ nxs,
+                                             const double *__restrict__ nys, const double *__restrict__ nzs,
+                                             const double *__restrict__ qx, const double *__restrict__ qy,
+                                             const double *__restrict__ qz, const int64_t *__restrict__ offset,
+                                             const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
+                                             int64_t m, double radius, const double *__restrict__ lrf, int normalize,
+                                             int64_t min_nb, double *__restrict__ out)
+{
+    __shared__ unsigned long long sA[352], sB[352], sG[352], sCD[176], sEF[176];
+    __shared__ double sD[176], sF[176];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    if (q >= m) return;
+    const int64_t s = offset[q];
+    const int k = (int)(offset[q + 1] - s);
+    const int64_t row = qrow ? qrow[q] : q;
+    double *o = out + (int64_t)SF_SHOT_LEN * row;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+
+    // gate: strictly more than min_nb neighbours at non-zero distance (shot.py:212, 306)
+    int npos = 0;
+    for (int t0 = 0; t0 < k; t0 += 64) {
+        const int t = t0 + lane;
+        bool pos = false;
+        if (t < k) {
+            const int j = idx[s + t];
+            const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+            pos = ((cx * cx + cy * cy) + cz * cz) > 0.0;
+        }
+        npos += __popcll(__ballot(pos));
+    }
+    if (!((int64_t)npos > min_nb)) {
+        for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
+        return;
+    }
+    double E[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+
+    for (int b = lane; b < 352; b += 64) { sA[b] = 0; sB[b] = 0; sG[b] = 0; }
+    for (int b = lane; b < 176; b += 64) { sCD[b] = 0; sEF[b] = 0; sD[b] = 0.0; sF[b] = 0.0; }
+    __syncthreads();
+
+    // sweep 1: elect the max-rho writer of every (key, bin)
+    for (int t = lane; t < k; t += 64) {
+        const int j = idx[s + t];
+        const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+        const double d2 = (cx * cx + cy * cy) + cz * cz;
+        if (d2 > 0.0) {
+            shot_sample sm;
+            shot_eval<false>(cx, cy, cz, d2, nxs[j], nys[j], nzs[j], E, radius, sm);
+            const unsigned long long key = (unsigned long long)__double_as_longlong(sm.rho);
+            atomicMax(&sA[sm.base], key);
+            atomicMax(&sB[sm.bcos], key);
+            atomicMax(&sG[sm.bth], key);
+            atomicMax(&sCD[sm.cd], key);
+            atomicMax(&sEF[sm.ef], key);
+        }
+    }
+    __syncthreads();
+    // sweep 2: winners replace their key by their (tagged) value
+    for (int t = lane; t < k; t += 64) {
+        const int j = idx[s + t];
+        const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+        const double d2 = (cx * cx + cy * cy) + cz * cz;
+        if (d2 > 0.0) {
+            shot_sample sm;
+            shot_eval<true>(cx, cy, cz, d2, nxs[j], nys[j], nzs[j], E, radius, sm);
+            const unsigned long long key = (unsigned long long)__double_as_longlong(sm.rho);
+            if (sA[sm.base] == key) sA[sm.base] = tag_value(sm.vA);
+            if (sB[sm.bcos] == key) sB[sm.bcos] = tag_value(sm.vB);
+            if (sG[sm.bth] == key) sG[sm.bth] = tag_value(sm.vG);
+            if (sCD[sm.cd] == key) { sCD[sm.cd] = tag_value(sm.vC); sD[sm.cd] = sm.vD; }
+            if (sEF[sm.ef] == key) { sEF[sm.ef] = tag_value(sm.vE); sF[sm.ef] = sm.vF; }
+        }
+    }
+    __syncthreads();
+    // assemble the 352 bins (C order: cosine slowest, radial fastest) and normalise (shot.py:301-305)
+    double vals[6];
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int b = lane + 64 * u;
+        double v = 0.0;
+        if (b < 352) {
+            const int cdi = b >> 1, efi = ((b >> 2) << 1) | (b & 1);
+            const int rb = b & 1, pb = (b >> 1) & 1;
+            v = untag_value(sB[b]);
+            v += untag_value(sA[b]);
+            v += rb ? untag_value(sCD[cdi]) : sD[cdi];
+            v += pb ? untag_value(sEF[efi]) : sF[efi];
+            v += untag_value(sG[b]);
+        }
+        vals[u] = v;
+        ss += v * v;
+    }
+    const double nrm = sqrt(sf_wave_sum(ss));
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int b = lane + 64 * u;
+        if (b < 352) o[b] = nrm > 0.0 ? (normalize ? vals[u] / nrm : vals[u]) : 0.0;
+    }
+}
+
+} // namespace
+
+static int check_nbrs(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const char *who)
+{
+    if (!ctx || !c || !nb) { sf_set_error("%s: null argument", who); return SF_ERR_ARG; }
+    if (!c->xs) { sf_set_error("%s: grid not built", who); return SF_ERR_STATE; }
+    SF_HIP(hipSetDevice(ctx->device));
+    return SF_OK;
+}
+
+// stage an optional host input (rows x cols doubles) on the device
+static int stage_in(sf_ctx *ctx, const double *src, size_t count, int flags, const double **dev, double **owned)
+{
+    *owned = nullptr;
+    if (!src) { *dev = nullptr; return SF_OK; }
+    if (flags & SF_IN_DEVICE) { *dev = src; return SF_OK; }
+    SF_HIP(hipMalloc(owned, (count ? count : 1) * sizeof(double)));
+    if (count) SF_HIP(hipMemcpyAsync(*owned, src, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    *dev = *owned;
+    return SF_OK;
+}
+
+static int stage_out(sf_ctx *ctx, double *dst, size_t count, int flags, double **dev, double **owned)
+{
+    *owned = nullptr;
+    if (flags & SF_OUT_DEVICE) { *dev = dst; return SF_OK; }
+    SF_HIP(hipMalloc(owned, (count ? count : 1) * sizeof(double)));
+    *dev = *owned;
+    return SF_OK;
+}
+
+static int finish_out(sf_ctx *ctx, double *dst, size_t count, double *dev, double *owned)
+{
+    if (owned) {
+        if (count) SF_HIP(hipMemcpyAsync(dst, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_HIP(hipFree(owned));
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *pre, double *out, int flags)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_normals"));
+    if (!out) { sf_set_error("sf_normals: null output"); return SF_ERR_ARG; }
+    const int64_t m = nb->m;
+    const double *dpre;
+    double *opre, *dout, *oout;
+    SF_CHECK(stage_in(ctx, pre, (size_t)m * 3, flags, &dpre, &opre));
+    SF_CHECK(stage_out(ctx, out, (size_t)m * 3, flags, &dout, &oout));
+    if (m) {
+        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs, nb->qx,
+                  nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, dpre, dout);
+    }
+    SF_CHECK(finish_out(ctx, out, (size_t)m * 3, dout, oout));
+    if (opre) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(opre)); }
+    return SF_OK;
+}
+
+extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, int flags)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_lrf"));
+    if (!lrf) { sf_set_error("sf_shot_lrf: null output"); return SF_ERR_ARG; }
+    const int64_t m = nb->m;
+    double *dout, *oout;
+    SF_CHECK(stage_out(ctx, lrf, (size_t)m * 9, flags, &dout, &oout));
+    if (m) {
+        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs,
+                  nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, nb->radius, dout);
+    }
+    return finish_out(ctx, lrf, (size_t)m * 9, dout, oout);
+}
+
+extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf, int normalize, int64_t min_nb,
+                       double *out, int flags)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot"));
+    if (!lrf || !out) { sf_set_error("sf_shot: null lrf/out"); return SF_ERR_ARG; }
+    SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
+    const int64_t m = nb->m;
+    const double *dlrf;
+    double *olrf, *dout, *oout;
+    SF_CHECK(stage_in(ctx, lrf, (size_t)m * 9, flags, &dlrf, &olrf));
+    SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
+    if (m) {
+        SF_LAUNCH(ctx, "k5_shot", k_shot, dim3((unsigned)m), dim3(64), c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs,
+                  nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, nb->radius, dlrf, normalize, min_nb, dout);
+    }
+    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
+    if (olrf) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(olrf)); }
+    return SF_OK;
+}

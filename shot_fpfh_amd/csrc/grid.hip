@@ -1,0 +1,277 @@
+// grid.hip -- K1: resident cloud + uniform grid (the MI355X stand-in for sklearn's KDTree(X)).
+//
+// Replaces: KDTree(cloud_points) at fpfh.py:26, shot_parallelization.py:167/220/229/283,
+//           pca_based_descriptors.py:45-49.
+// Layout in HBM: the caller's AoS xyz / normals are kept as uploaded; the grid build writes
+// cell-sorted SoA copies (xs, ys, zs, nxs, nys, nzs) so that a wave scanning a run of cells reads
+// 64 consecutive doubles per load, plus perm / inv_perm (sorted position <-> original index) and
+// cell_start (first sorted position of every cell, x fastest).
+// Roofline: HBM; ~ n * (24 read + 4+4 id/idx + sort passes + 48 gather + 48 write) bytes, one-off.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+#include "device_util.h"
+
+namespace {
+
+__global__ void k_bbox_partial(const double *__restrict__ xyz, int64_t n, double *__restrict__ partial)
+{
+    // partial[block][6] = min xyz, max xyz
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) {
+            double v = xyz[3 * i + a];
+            mn[a] = fmin(mn[a], v);
+            mx[a] = fmax(mx[a], v);
+        }
+    __shared__ double s[6][4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = 0; a < 3; ++a) {
+        double v0 = mn[a], v1 = mx[a];
+        for (int off = 32; off > 0; off >>= 1) {
+            v0 = fmin(v0, __shfl_xor(v0, off));
+            v1 = fmax(v1, __shfl_xor(v1, off));
+        }
+        if (lane == 0) {
+            s[a][wave] = v0;
+            s[3 + a][wave] = v1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int a = threadIdx.x;
+        double v = s[a][0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = a < 3 ? fmin(v, s[a][w]) : fmax(v, s[a][w]);
+        partial[blockIdx.x * 6 + a] = v;
+    }
+}
+
+__global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_desc g, int32_t *__restrict__ cid,
+                           int32_t *__restrict__ val)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cx = sf_cell_coord(xyz[3 * i + 0], g.lo[0], g.inv_cell, g.dim[0]);
+    int cy = sf_cell_coord(xyz[3 * i + 1], g.lo[1], g.inv_cell, g.dim[1]);
+    int cz = sf_cell_coord(xyz[3 * i + 2], g.lo[2], g.inv_cell, g.dim[2]);
+    cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    val[i] = (int32_t)i;
+}
+
+__global__ void k_gather_sorted(const double *__restrict__ xyz, const int32_t *__restrict__ perm, int64_t n,
+                                double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ zs,
+                                int32_t *__restrict__ inv_perm)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t o = perm[i];
+    xs[i] = xyz[3 * o + 0];
+    ys[i] = xyz[3 * o + 1];
+    zs[i] = xyz[3 * o + 2];
+    if (inv_perm) inv_perm[o] = (int32_t)i;
+}
+
+__global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t n, int64_t ncell,
+                             int32_t *__restrict__ cell_start)
+{
+    // cell_start[c] = first sorted position whose cell id >= c (lower bound); cell_start[ncell] = n
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncell) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)sorted_cid[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    cell_start[c] = (int32_t)lo;
+}
+
+} // namespace
+
+static void cloud_release_grid(sf_cloud *c)
+{
+    void *ptrs[] = {c->cell_start, c->perm, c->inv_perm, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    c->cell_start = c->perm = c->inv_perm = nullptr;
+    c->xs = c->ys = c->zs = c->nxs = c->nys = c->nzs = nullptr;
+    c->normals_sorted = false;
+    c->cell = 0.0;
+}
+
+extern "C" sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const double *normals, int64_t n, int flags)
+{
+    if (!ctx || (!xyz && n > 0) || n < 0 || n > 2147483000LL) {
+        sf_set_error("sf_cloud_upload: bad arguments (n=%lld)", (long long)n);
+        return nullptr;
+    }
+    SF_HIP_NULL(hipSetDevice(ctx->device));
+    sf_cloud *c = new sf_cloud();
+    c->n = n;
+    size_t bytes = (size_t)(n ? n : 1) * 3 * sizeof(double);
+    hipMemcpyKind kind = (flags & SF_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (hipMalloc(&c->xyz_orig, bytes) != hipSuccess) {
+        sf_set_error("sf_cloud_upload: out of device memory");
+        delete c;
+        return nullptr;
+    }
+    if (n) {
+        hipError_t e = hipMemcpyAsync(c->xyz_orig, xyz, (size_t)n * 24, kind, ctx->stream);
+        if (e == hipSuccess && normals) {
+            e = hipMalloc(&c->nrm_orig, bytes);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->nrm_orig, normals, (size_t)n * 24, kind, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            sf_set_error("sf_cloud_upload: %s", hipGetErrorString(e));
+            sf_cloud_free(ctx, c);
+            return nullptr;
+        }
+    }
+    return c;
+}
+
+extern "C" int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *c, const double *normals, int flags)
+{
+    if (!ctx || !c || !normals) { sf_set_error("sf_cloud_set_normals: null argument"); return SF_ERR_ARG; }
+    size_t bytes = (size_t)(c->n ? c->n : 1) * 24;
+    if (!c->nrm_orig) SF_HIP(hipMalloc(&c->nrm_orig, bytes));
+    hipMemcpyKind kind = (flags & SF_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (c->n) SF_HIP(hipMemcpyAsync(c->nrm_orig, normals, (size_t)c->n * 24, kind, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    c->normals_sorted = false;
+    return SF_OK;
+}
+
+// Sort the normals into cell order on first use (lazy: a normals-less cloud never pays for it).
+int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
+{
+    if (c->normals_sorted) return SF_OK;
+    if (!c->nrm_orig) { sf_set_error("this operation needs normals, but the cloud has none"); return SF_ERR_STATE; }
+    if (!c->perm) { sf_set_error("grid not built"); return SF_ERR_STATE; }
+    size_t bytes = (size_t)(c->n ? c->n : 1) * sizeof(double);
+    if (!c->nxs) {
+        SF_HIP(hipMalloc(&c->nxs, bytes));
+        SF_HIP(hipMalloc(&c->nys, bytes));
+        SF_HIP(hipMalloc(&c->nzs, bytes));
+    }
+    if (c->n) {
+        SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(c->n, 256)), dim3(256),
+                  c->nrm_orig, c->perm, c->n, c->nxs, c->nys, c->nzs, (int32_t *)nullptr);
+    }
+    c->normals_sorted = true;
+    return SF_OK;
+}
+
+extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
+{
+    if (!ctx || !c || !(cell > 0.0) || !std::isfinite(cell)) {
+        sf_set_error("sf_cloud_build_grid: bad arguments (cell=%g)", cell);
+        return SF_ERR_ARG;
+    }
+    SF_HIP(hipSetDevice(ctx->device));
+    cloud_release_grid(c);
+    const int64_t n = c->n;
+    // ---- bounding box -------------------------------------------------------------------------
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (n) {
+        const int nb = 1024;
+        void *scr = nullptr;
+        SF_CHECK(sf_ctx_scratch(ctx, (size_t)nb * 6 * sizeof(double), &scr));
+        SF_LAUNCH(ctx, "k1_bbox", k_bbox_partial, dim3(nb), dim3(256), c->xyz_orig, n, (double *)scr);
+        std::vector<double> part((size_t)nb * 6);
+        SF_HIP(hipMemcpyAsync(part.data(), scr, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (int b = 0; b < nb; ++b)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
+                hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
+            }
+        for (int a = 0; a < 3; ++a)
+            if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) {
+                sf_set_error("sf_cloud_build_grid: cloud has non-finite coordinates");
+                return SF_ERR_ARG;
+            }
+    }
+    // ---- grid geometry: edge slightly above `cell` so that |a-b| <= cell never spans 2 cells ----
+    double edge = cell * (1.0 + 9.5367431640625e-07); // 1 + 2^-20
+    int64_t ncell;
+    for (;;) {
+        double tot = 1.0;
+        bool too_long = false;
+        for (int a = 0; a < 3; ++a) {
+            double d = std::floor((hi[a] - lo[a]) / edge) + 1.0;
+            if (!(d >= 1.0)) d = 1.0;
+            if (d > 2097152.0) too_long = true;
+            c->dim[a] = (int)std::min(d, 2097152.0);
+            tot *= d;
+        }
+        if (!too_long && tot <= 67108864.0) { ncell = (int64_t)tot; break; }
+        edge *= 2.0; // coarser cells stay correct (edge >= radius), only slower
+    }
+    c->cell = edge;
+    c->inv_cell = 1.0 / edge;
+    c->ncell = ncell;
+    for (int a = 0; a < 3; ++a) c->lo[a] = lo[a];
+
+    size_t nn = (size_t)(n ? n : 1);
+    SF_HIP(hipMalloc(&c->cell_start, (size_t)(ncell + 1) * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&c->perm, nn * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&c->inv_perm, nn * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&c->xs, nn * sizeof(double)));
+    SF_HIP(hipMalloc(&c->ys, nn * sizeof(double)));
+    SF_HIP(hipMalloc(&c->zs, nn * sizeof(double)));
+    if (!n) {
+        SF_HIP(hipMemsetAsync(c->cell_start, 0, (size_t)(ncell + 1) * sizeof(int32_t), ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        return SF_OK;
+    }
+    // ---- cell ids, stable radix sort (ties keep ascending original index), SoA gather ---------
+    int32_t *cid = nullptr, *cid_sorted = nullptr, *val = nullptr;
+    SF_HIP(hipMalloc(&cid, nn * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&cid_sorted, nn * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&val, nn * sizeof(int32_t)));
+    sf_grid_desc g = sf_make_grid_desc(c);
+    SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, g, cid,
+              val);
+    int bits = 1;
+    while (((int64_t)1 << bits) < ncell) ++bits;
+    size_t tmp_bytes = 0;
+    SF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, cid, cid_sorted, val, c->perm, (size_t)n, 0, bits,
+                                     ctx->stream));
+    void *tmp = nullptr;
+    SF_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    {
+        sf_launch_timer t_(ctx, "k1_radix_sort");
+        SF_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cid, cid_sorted, val, c->perm, (size_t)n, 0, bits,
+                                         ctx->stream));
+    }
+    SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig,
+              c->perm, n, c->xs, c->ys, c->zs, c->inv_perm);
+    SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, n,
+              ncell, c->cell_start);
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    SF_HIP(hipFree(tmp));
+    SF_HIP(hipFree(cid));
+    SF_HIP(hipFree(cid_sorted));
+    SF_HIP(hipFree(val));
+    return SF_OK;
+}
+
+extern "C" int64_t sf_cloud_size(const sf_cloud *c) { return c ? c->n : -1; }
+
+extern "C" void sf_cloud_free(sf_ctx *ctx, sf_cloud *c)
+{
+    if (!c) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    cloud_release_grid(c);
+    if (c->xyz_orig) (void)hipFree(c->xyz_orig);
+    if (c->nrm_orig) (void)hipFree(c->nrm_orig);
+    delete c;
+}

@@ -1,0 +1,238 @@
+// match.hip -- K8 (brute-force L2 arg-min matching) and K9 (RANSAC inlier scoring).
+//
+// K8 replaces scipy.spatial.distance.cdist + argmin at matching.py:47-52, 63-65, 164-168.
+//   dist(i, j) = sqrt(sum_t (a[i,t] - b[j,t])^2), the sum taken left to right in float64 without FMA
+//   (scipy's euclidean loop), argmin = FIRST minimum.  The M1 x M2 matrix is never materialised: a
+//   256-thread workgroup owns a 64 x 64 tile of it (4 x 4 per thread), streams the descriptor
+//   dimension through LDS in slices of 16, reduces the tile to per-row minima with wave shuffles and
+//   walks the reference rows in ascending order so "first minimum" is preserved.  Small M1 is split
+//   over several workgroups along M2 and merged by k_match_merge.
+//   Roofline: FP64 vector ALU (3 flop per pair-dimension), bytes are negligible.
+// K9 replaces the inlier count of ransac.py:60-67 (RigidTransform.__getitem__, rigid_transform.py:81-88).
+#include "common.h"
+#include "device_util.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+
+__global__ __launch_bounds__(256) void k_match_tile(const double *__restrict__ a, int64_t m1,
+                                                    const double *__restrict__ b, int64_t m2, int64_t d,
+                                                    int64_t tiles_per_split, double *__restrict__ pdist,
+                                                    int64_t *__restrict__ pidx)
+{
+    __shared__ double As[TK][TM + 1];
+    __shared__ double Bs[TK][TN + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * TM;
+    const int split = blockIdx.y;
+    const int64_t ntiles = (m2 + TN - 1) / TN;
+    const int64_t jt0 = (int64_t)split * tiles_per_split;
+    const int64_t jt1 = jt0 + tiles_per_split < ntiles ? jt0 + tiles_per_split : ntiles;
+    double best[4];
+    int64_t bidx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { best[u] = INFINITY; bidx[u] = 0; }
+
+    for (int64_t jt = jt0; jt < jt1; ++jt) {
+        const int64_t j0 = jt * TN;
+        double acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+        for (int64_t t0 = 0; t0 < d; t0 += TK) {
+            // stage TM x TK of a and TN x TK of b (zero padded); 1024 elements each, 4 per thread
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int lin = tid + 256 * e; // 0..1023
+                const int r = lin >> 4, cc = lin & 15;
+                const int64_t t = t0 + cc;
+                As[cc][r] = (i0 + r < m1 && t < d) ? a[(i0 + r) * d + t] : 0.0;
+                Bs[cc][r] = (j0 + r < m2 && t < d) ? b[(j0 + r) * d + t] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < TK; ++t) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = As[t][ty * 4 + u]; bv[u] = Bs[t][tx * 4 + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double df = av[u] - bv[v];
+                        acc[u][v] += df * df;
+                    }
+            }
+            __syncthreads();
+        }
+        // per-row minimum over this tile's 64 columns: 4 local columns, then the 16 tx lanes of the row group
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double bd = INFINITY;
+            int64_t bj = 0x7fffffffffffffffLL;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t j = j0 + tx * 4 + v;
+                const double dist = j < m2 ? sqrt(acc[u][v]) : INFINITY;
+                if (dist < bd) { bd = dist; bj = j; } // ascending j: first minimum kept
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const double od = __shfl_xor(bd, off, 16);
+                const int64_t oj = __shfl_xor(bj, off, 16);
+                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+            }
+            if (bd < best[u]) { best[u] = bd; bidx[u] = bj; }
+        }
+    }
+    if (tx == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + ty * 4 + u;
+            if (i < m1) {
+                pdist[(int64_t)split * m1 + i] = best[u];
+                pidx[(int64_t)split * m1 + i] = bidx[u];
+            }
+        }
+    }
+}
+
+__global__ void k_match_merge(const double *__restrict__ pdist, const int64_t *__restrict__ pidx, int64_t m1, int nsplit,
+                              int64_t *__restrict__ idx, double *__restrict__ dist)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m1) return;
+    double bd = pdist[i];
+    int64_t bj = pidx[i];
+    for (int s = 1; s < nsplit; ++s) {
+        const double od = pdist[(int64_t)s * m1 + i];
+        if (od < bd) { bd = od; bj = pidx[(int64_t)s * m1 + i]; }
+    }
+    idx[i] = bj;
+    if (dist) dist[i] = bd;
+}
+
+__global__ __launch_bounds__(256) void k_ransac_score(const double *__restrict__ a, const double *__restrict__ b,
+                                                      int64_t m, const double *__restrict__ Rt, double thr,
+                                                      int64_t *__restrict__ inliers)
+{
+    __shared__ int wsum[4];
+    const double *R = Rt + 12 * (int64_t)blockIdx.x;
+    const double r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4], r5 = R[5], r6 = R[6], r7 = R[7], r8 = R[8];
+    const double t0 = R[9], t1 = R[10], t2 = R[11];
+    int cnt = 0;
+    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const double p0 = a[3 * i], p1 = a[3 * i + 1], p2 = a[3 * i + 2];
+        const double e0 = ((p0 * r0 + p1 * r1) + p2 * r2) + t0 - b[3 * i];
+        const double e1 = ((p0 * r3 + p1 * r4) + p2 * r5) + t1 - b[3 * i + 1];
+        const double e2 = ((p0 * r6 + p1 * r7) + p2 * r8) + t2 - b[3 * i + 2];
+        cnt += sqrt((e0 * e0 + e1 * e1) + e2 * e2) <= thr ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) inliers[blockIdx.x] = (int64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+} // namespace
+
+static int match_one_way(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d,
+                         int64_t *didx, double *ddist, const char *name)
+{
+    const int64_t row_tiles = sf_div_up(m1, TM), col_tiles = sf_div_up(m2, TN);
+    int64_t nsplit = 1;
+    if (row_tiles < 2048) nsplit = std::min<int64_t>(col_tiles, sf_div_up(2048, row_tiles));
+    if (nsplit > 65535) nsplit = 65535;
+    const int64_t tiles_per_split = sf_div_up(col_tiles, nsplit);
+    nsplit = sf_div_up(col_tiles, tiles_per_split);
+    double *pdist = nullptr;
+    int64_t *pidx = nullptr;
+    SF_HIP(hipMalloc(&pdist, (size_t)(nsplit * m1) * sizeof(double)));
+    SF_HIP(hipMalloc(&pidx, (size_t)(nsplit * m1) * sizeof(int64_t)));
+    SF_LAUNCH(ctx, name, k_match_tile, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(256), da, m1, db, m2, d,
+              tiles_per_split, pdist, pidx);
+    SF_LAUNCH(ctx, "k8_match_merge", k_match_merge, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), pdist, pidx, m1,
+              (int)nsplit, didx, ddist);
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    SF_HIP(hipFree(pdist));
+    SF_HIP(hipFree(pidx));
+    return SF_OK;
+}
+
+extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, int64_t m2, int64_t d,
+                               int64_t *idx, double *dist, int64_t *col_idx, int flags)
+{
+    if (!ctx || !a || !b || !idx || m1 < 0 || m2 < 0 || d <= 0) { sf_set_error("sf_match_argmin: bad argument"); return SF_ERR_ARG; }
+    if (m2 == 0 && m1 > 0) { sf_set_error("sf_match_argmin: empty reference set (argmin of an empty sequence)"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    const bool in_dev = flags & SF_IN_DEVICE, out_dev = flags & SF_OUT_DEVICE;
+    double *da = const_cast<double *>(a), *db = const_cast<double *>(b);
+    if (!in_dev) {
+        SF_HIP(hipMalloc(&da, (size_t)std::max<int64_t>(m1 * d, 1) * sizeof(double)));
+        SF_HIP(hipMalloc(&db, (size_t)std::max<int64_t>(m2 * d, 1) * sizeof(double)));
+        if (m1) SF_HIP(hipMemcpyAsync(da, a, (size_t)(m1 * d) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (m2) SF_HIP(hipMemcpyAsync(db, b, (size_t)(m2 * d) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    int64_t *didx = idx, *dcol = col_idx;
+    double *ddist = dist;
+    if (!out_dev) {
+        SF_HIP(hipMalloc(&didx, (size_t)std::max<int64_t>(m1, 1) * sizeof(int64_t)));
+        if (dist) SF_HIP(hipMalloc(&ddist, (size_t)std::max<int64_t>(m1, 1) * sizeof(double)));
+        if (col_idx) SF_HIP(hipMalloc(&dcol, (size_t)std::max<int64_t>(m2, 1) * sizeof(int64_t)));
+    }
+    if (m1) SF_CHECK(match_one_way(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_tile"));
+    if (col_idx && m2 && m1) SF_CHECK(match_one_way(ctx, db, m2, da, m1, d, dcol, nullptr, "k8_match_tile_cols"));
+    if (!out_dev) {
+        if (m1) SF_HIP(hipMemcpyAsync(idx, didx, (size_t)m1 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (dist && m1) SF_HIP(hipMemcpyAsync(dist, ddist, (size_t)m1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (col_idx && m2) SF_HIP(hipMemcpyAsync(col_idx, dcol, (size_t)m2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_HIP(hipFree(didx));
+        if (dist) SF_HIP(hipFree(ddist));
+        if (col_idx) SF_HIP(hipFree(dcol));
+    }
+    if (!in_dev) {
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_HIP(hipFree(da));
+        SF_HIP(hipFree(db));
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, int64_t m, const double *Rt,
+                               int64_t n_draws, double thr, int64_t *inliers, int flags)
+{
+    if (!ctx || !a || !b || !Rt || !inliers || m < 0 || n_draws < 0) { sf_set_error("sf_ransac_score: bad argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    const bool in_dev = flags & SF_IN_DEVICE, out_dev = flags & SF_OUT_DEVICE;
+    double *da = const_cast<double *>(a), *db = const_cast<double *>(b), *dR = const_cast<double *>(Rt);
+    if (!in_dev) {
+        SF_HIP(hipMalloc(&da, (size_t)std::max<int64_t>(m * 3, 1) * sizeof(double)));
+        SF_HIP(hipMalloc(&db, (size_t)std::max<int64_t>(m * 3, 1) * sizeof(double)));
+        SF_HIP(hipMalloc(&dR, (size_t)std::max<int64_t>(n_draws * 12, 1) * sizeof(double)));
+        if (m) {
+            SF_HIP(hipMemcpyAsync(da, a, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+            SF_HIP(hipMemcpyAsync(db, b, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (n_draws) SF_HIP(hipMemcpyAsync(dR, Rt, (size_t)n_draws * 96, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int64_t *dinl = inliers;
+    if (!out_dev) SF_HIP(hipMalloc(&dinl, (size_t)std::max<int64_t>(n_draws, 1) * sizeof(int64_t)));
+    if (n_draws) {
+        SF_LAUNCH(ctx, "k9_ransac_score", k_ransac_score, dim3((unsigned)n_draws), dim3(256), da, db, m, dR, thr, dinl);
+    }
+    if (!out_dev) {
+        if (n_draws) SF_HIP(hipMemcpyAsync(inliers, dinl, (size_t)n_draws * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_HIP(hipFree(dinl));
+    }
+    if (!in_dev) {
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_HIP(hipFree(da));
+        SF_HIP(hipFree(db));
+        SF_HIP(hipFree(dR));
+    }
+    return SF_OK;
+}

@@ -1,0 +1,369 @@
+// search.hip -- K2: fixed-radius neighbour search on the uniform grid (count pass, scan, fill pass).
+//
+// Replaces: KDTree.query_radius at fpfh.py:28-30, shot_parallelization.py:167-169/220-231/283-285,
+//           pca_based_descriptors.py:48 (sklearn, un-vendored; rule restated in SURVEY 8a-1):
+//           j is a neighbour of q  <=>  ((dx*dx + dy*dy) + dz*dz) <= r*r   in float64, no FMA
+//           (this TU is compiled with -ffp-contract=off), self-match included.
+// Mapping: one 64-lane wave per query.  The 27-cell stencil is 9 contiguous runs of cell-sorted
+// points (x is the fastest grid axis); a wave sweeps each run 64 candidates at a time with
+// coalesced SoA loads, ballots the hits and compacts them with mbcnt prefix counts.
+// Output: CSR in HBM -- int32 sorted positions, int64 offsets -- consumed by K3..K7.
+// Roofline: HBM/L2 bound integer+compare work; algorithmic bytes = 24 B per query in + 4 B per pair out.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+#include "device_util.h"
+
+sf_grid_desc sf_make_grid_desc(const sf_cloud *c)
+{
+    sf_grid_desc g;
+    for (int a = 0; a < 3; ++a) {
+        g.lo[a] = c->lo[a];
+        g.dim[a] = c->dim[a];
+    }
+    g.inv_cell = c->inv_cell;
+    return g;
+}
+
+namespace {
+
+struct to_i64 {
+    __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
+};
+
+__device__ inline void stencil_bounds(double v, double lo, double inv_cell, int dim, int &c0, int &c1)
+{
+    double t = floor((v - lo) * inv_cell);
+    double top = (double)(dim - 1);
+    double a = t - 1.0, b = t + 1.0;
+    if (!(a >= 0.0)) a = 0.0;
+    if (a > top) a = top;
+    if (!(b >= 0.0)) b = 0.0;
+    if (b > top) b = top;
+    c0 = (int)a;
+    c1 = (int)b;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *__restrict__ cell_start,
+                                                const double *__restrict__ xs, const double *__restrict__ ys,
+                                                const double *__restrict__ zs, const double *__restrict__ qx,
+                                                const double *__restrict__ qy, const double *__restrict__ qz,
+                                                int64_t m, double r2, int32_t *__restrict__ count,
+                                                const int64_t *__restrict__ offset, int32_t *__restrict__ idx)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (q >= m) return;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    int x0, x1, y0, y1, z0, z1;
+    stencil_bounds(px, g.lo[0], g.inv_cell, g.dim[0], x0, x1);
+    stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
+    stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
+    int total = 0;
+    int64_t out = FILL ? offset[q] : 0;
+    for (int cz = z0; cz <= z1; ++cz)
+        for (int cy = y0; cy <= y1; ++cy) {
+            const int64_t row = ((int64_t)cz * g.dim[1] + cy) * g.dim[0];
+            const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+            for (int j0 = s; j0 < e; j0 += 64) {
+                const int j = j0 + lane;
+                bool hit = false;
+                if (j < e) {
+                    const double dx = xs[j] - px, dy = ys[j] - py, dz = zs[j] - pz;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    hit = d2 <= r2;
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (FILL && hit) idx[out + total + sf_prefix_count(mask)] = j;
+                total += __popcll(mask);
+            }
+        }
+    if (!FILL && lane == 0) count[q] = total;
+}
+
+__global__ void k_query_cells(const double *__restrict__ q, int64_t m, sf_grid_desc g, int32_t *__restrict__ cid,
+                              int32_t *__restrict__ val)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int cx = sf_cell_coord(q[3 * i + 0], g.lo[0], g.inv_cell, g.dim[0]);
+    int cy = sf_cell_coord(q[3 * i + 1], g.lo[1], g.inv_cell, g.dim[1]);
+    int cz = sf_cell_coord(q[3 * i + 2], g.lo[2], g.inv_cell, g.dim[2]);
+    cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    val[i] = (int32_t)i;
+}
+
+__global__ void k_gather_queries(const double *__restrict__ q, const int32_t *__restrict__ qrow, int64_t m,
+                                 double *__restrict__ qx, double *__restrict__ qy, double *__restrict__ qz)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int64_t o = qrow[i];
+    qx[i] = q[3 * o + 0];
+    qy[i] = q[3 * o + 1];
+    qz[i] = q[3 * o + 2];
+}
+
+// sqrt(d2) of every stored pair, in list order (KDTree.query_radius(..., return_distance=True))
+__global__ __launch_bounds__(256) void k_pair_dist(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                   const double *__restrict__ zs, const double *__restrict__ qx,
+                                                   const double *__restrict__ qy, const double *__restrict__ qz,
+                                                   const int64_t *__restrict__ offset, const int32_t *__restrict__ idx,
+                                                   int64_t m, double *__restrict__ dist)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (q >= m) return;
+    const int64_t s = offset[q], e = offset[q + 1];
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    for (int64_t t = s + lane; t < e; t += 64) {
+        const int j = idx[t];
+        const double dx = xs[j] - px, dy = ys[j] - py, dz = zs[j] - pz;
+        dist[t] = sqrt((dx * dx + dy * dy) + dz * dz);
+    }
+}
+
+} // namespace
+
+static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
+{
+    const int64_t m = nb->m;
+    const double r2 = nb->radius * nb->radius;
+    SF_HIP(hipMalloc(&nb->count, (size_t)(m + 1) * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&nb->offset, (size_t)(m + 1) * sizeof(int64_t)));
+    SF_HIP(hipMemsetAsync(nb->count, 0, (size_t)(m + 1) * sizeof(int32_t), ctx->stream));
+    sf_grid_desc g = sf_make_grid_desc(c);
+    const dim3 grid((unsigned)sf_div_up(m ? m : 1, 4)), block(256);
+    if (m) {
+        SF_LAUNCH(ctx, "k2_radius_count", k_radius<false>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
+                  nb->qy, nb->qz, m, r2, nb->count, (const int64_t *)nullptr, (int32_t *)nullptr);
+    }
+    // exclusive scan of m+1 counts (last is 0) -> offset[m] = total; max over counts
+    auto in = rocprim::make_transform_iterator(nb->count, to_i64());
+    size_t tb1 = 0, tb2 = 0;
+    int32_t *d_max = nullptr;
+    SF_HIP(rocprim::exclusive_scan(nullptr, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
+                                   ctx->stream));
+    SF_HIP(rocprim::reduce(nullptr, tb2, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
+                           ctx->stream));
+    void *tmp = nullptr;
+    size_t tb = std::max(tb1, tb2);
+    SF_HIP(hipMalloc(&tmp, (tb ? tb : 8) + 16));
+    d_max = (int32_t *)((char *)tmp + ((tb + 7) / 8) * 8);
+    {
+        sf_launch_timer t_(ctx, "k2_scan");
+        SF_HIP(rocprim::exclusive_scan(tmp, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
+                                       ctx->stream));
+        SF_HIP(rocprim::reduce(tmp, tb2, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
+                               ctx->stream));
+    }
+    int64_t total = 0;
+    int32_t mx = 0;
+    SF_HIP(hipMemcpyAsync(&total, nb->offset + m, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipMemcpyAsync(&mx, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    SF_HIP(hipFree(tmp));
+    nb->total = total;
+    nb->max_count = mx;
+    SF_HIP(hipMalloc(&nb->idx, (size_t)(total ? total : 1) * sizeof(int32_t)));
+    if (m && total) {
+        SF_LAUNCH(ctx, "k2_radius_fill", k_radius<true>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
+                  nb->qy, nb->qz, m, r2, (int32_t *)nullptr, (const int64_t *)nb->offset, nb->idx);
+    }
+    return SF_OK;
+}
+
+static int ensure_grid(sf_ctx *ctx, sf_cloud *c, double radius)
+{
+    if (!(radius > 0.0) || !std::isfinite(radius)) {
+        sf_set_error("radius must be positive and finite (got %g)", radius);
+        return SF_ERR_ARG;
+    }
+    // a grid built for a larger radius stays valid; a far too coarse one is rebuilt for speed
+    if (c->cell_start && c->cell >= radius && c->cell <= 2.0 * radius * (1.0 + 1e-6)) return SF_OK;
+    return sf_cloud_build_grid(ctx, c, radius);
+}
+
+extern "C" sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *c, double radius, int64_t begin, int64_t end)
+{
+    if (!ctx || !c) { sf_set_error("sf_radius_search_self: null argument"); return nullptr; }
+    if (begin < 0 || end > c->n || begin > end) {
+        sf_set_error("sf_radius_search_self: bad range [%lld, %lld) for n=%lld", (long long)begin, (long long)end,
+                     (long long)c->n);
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
+    if (ensure_grid(ctx, c, radius) != SF_OK) return nullptr;
+    sf_nbrs *nb = new sf_nbrs();
+    nb->m = end - begin;
+    nb->radius = radius;
+    nb->self = true;
+    nb->self_begin = begin;
+    nb->qx = c->xs + begin;
+    nb->qy = c->ys + begin;
+    nb->qz = c->zs + begin;
+    if (run_search(ctx, c, nb) != SF_OK) {
+        sf_nbrs_free(ctx, nb);
+        return nullptr;
+    }
+    return nb;
+}
+
+static int prepare_queries(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *queries, int flags)
+{
+    const int64_t m = nb->m;
+    size_t mm = (size_t)(m ? m : 1);
+    double *dq = nullptr;
+    bool own_dq = false;
+    if (flags & SF_IN_DEVICE) {
+        dq = const_cast<double *>(queries);
+    } else {
+        SF_HIP(hipMalloc(&dq, mm * 24));
+        own_dq = true;
+        if (m) SF_HIP(hipMemcpyAsync(dq, queries, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SF_HIP(hipMalloc(&nb->qx, mm * sizeof(double)));
+    SF_HIP(hipMalloc(&nb->qy, mm * sizeof(double)));
+    SF_HIP(hipMalloc(&nb->qz, mm * sizeof(double)));
+    SF_HIP(hipMalloc(&nb->qrow, mm * sizeof(int32_t)));
+    if (m) {
+        int32_t *cid = nullptr, *cid_s = nullptr, *val = nullptr;
+        SF_HIP(hipMalloc(&cid, mm * sizeof(int32_t)));
+        SF_HIP(hipMalloc(&cid_s, mm * sizeof(int32_t)));
+        SF_HIP(hipMalloc(&val, mm * sizeof(int32_t)));
+        sf_grid_desc g = sf_make_grid_desc(c);
+        SF_LAUNCH(ctx, "k2_query_cells", k_query_cells, dim3((unsigned)sf_div_up(m, 256)), dim3(256), dq, m, g, cid,
+                  val);
+        int bits = 1;
+        while (((int64_t)1 << bits) < c->ncell) ++bits;
+        size_t tb = 0;
+        SF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
+        void *tmp = nullptr;
+        SF_HIP(hipMalloc(&tmp, tb ? tb : 8));
+        {
+            sf_launch_timer t_(ctx, "k2_query_sort");
+            SF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
+        }
+        SF_LAUNCH(ctx, "k2_gather_queries", k_gather_queries, dim3((unsigned)sf_div_up(m, 256)), dim3(256), dq,
+                  nb->qrow, m, nb->qx, nb->qy, nb->qz);
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_HIP(hipFree(tmp));
+        SF_HIP(hipFree(cid));
+        SF_HIP(hipFree(cid_s));
+        SF_HIP(hipFree(val));
+    }
+    if (own_dq) SF_HIP(hipFree(dq));
+    return SF_OK;
+}
+
+extern "C" sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *c, const double *queries, int64_t m, double radius,
+                                     int flags)
+{
+    if (!ctx || !c || (!queries && m > 0) || m < 0 || m > 2147483000LL) {
+        sf_set_error("sf_radius_search: bad arguments (m=%lld)", (long long)m);
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
+    if (ensure_grid(ctx, c, radius) != SF_OK) return nullptr;
+    sf_nbrs *nb = new sf_nbrs();
+    nb->m = m;
+    nb->radius = radius;
+    nb->self = false;
+    if (prepare_queries(ctx, c, nb, queries, flags) != SF_OK || run_search(ctx, c, nb) != SF_OK) {
+        sf_nbrs_free(ctx, nb);
+        return nullptr;
+    }
+    return nb;
+}
+
+extern "C" int64_t sf_nbrs_num_queries(const sf_nbrs *nb) { return nb ? nb->m : -1; }
+extern "C" int64_t sf_nbrs_total(const sf_nbrs *nb) { return nb ? nb->total : -1; }
+extern "C" int64_t sf_nbrs_max_count(const sf_nbrs *nb) { return nb ? nb->max_count : -1; }
+
+extern "C" int sf_nbrs_export(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t *offsets, int32_t *idx, double *dist)
+{
+    // Host-side plumbing only: copy the device CSR back, map cell-sorted positions to the caller's point
+    // numbering, order each list by ascending index and rows by the caller's query order.  For a self
+    // search row i is the point at cell-sorted position self_begin + i.
+    if (!ctx || !c || !nb || !offsets) { sf_set_error("sf_nbrs_export: null argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    const int64_t m = nb->m, total = nb->total;
+    std::vector<int64_t> off((size_t)m + 1);
+    std::vector<int32_t> qrow;
+    SF_HIP(hipMemcpyAsync(off.data(), nb->offset, (size_t)(m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    if (nb->qrow && m) {
+        qrow.resize((size_t)m);
+        SF_HIP(hipMemcpyAsync(qrow.data(), nb->qrow, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> cnt_by_row((size_t)m), slot_of_row((size_t)m);
+    for (int64_t s = 0; s < m; ++s) {
+        int64_t row = nb->qrow ? qrow[(size_t)s] : s;
+        cnt_by_row[(size_t)row] = off[(size_t)s + 1] - off[(size_t)s];
+        slot_of_row[(size_t)row] = s;
+    }
+    offsets[0] = 0;
+    for (int64_t r = 0; r < m; ++r) offsets[r + 1] = offsets[r] + cnt_by_row[(size_t)r];
+    if (!idx) return SF_OK;
+    std::vector<int32_t> raw((size_t)(total ? total : 1)), perm((size_t)(c->n ? c->n : 1));
+    std::vector<double> rawd;
+    if (total) SF_HIP(hipMemcpyAsync(raw.data(), nb->idx, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                     ctx->stream));
+    if (c->n) SF_HIP(hipMemcpyAsync(perm.data(), c->perm, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    if (dist && total) {
+        double *dd = nullptr;
+        SF_HIP(hipMalloc(&dd, (size_t)total * sizeof(double)));
+        SF_LAUNCH(ctx, "k2_pair_dist", k_pair_dist, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs,
+                  nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, m, dd);
+        rawd.resize((size_t)total);
+        SF_HIP(hipMemcpyAsync(rawd.data(), dd, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_HIP(hipFree(dd));
+    }
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<std::pair<int32_t, double>> tmp;
+    for (int64_t r = 0; r < m; ++r) {
+        const int64_t s = slot_of_row[(size_t)r], k = cnt_by_row[(size_t)r], base = off[(size_t)s];
+        int32_t *dst = idx + offsets[r];
+        if (!dist) {
+            for (int64_t t = 0; t < k; ++t) dst[t] = perm[(size_t)raw[(size_t)(base + t)]];
+            std::sort(dst, dst + k);
+        } else {
+            tmp.resize((size_t)k);
+            for (int64_t t = 0; t < k; ++t)
+                tmp[(size_t)t] = {perm[(size_t)raw[(size_t)(base + t)]], rawd[(size_t)(base + t)]};
+            std::sort(tmp.begin(), tmp.end());
+            for (int64_t t = 0; t < k; ++t) {
+                dst[t] = tmp[(size_t)t].first;
+                dist[offsets[r] + t] = tmp[(size_t)t].second;
+            }
+        }
+    }
+    return SF_OK;
+}
+
+extern "C" void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nb)
+{
+    if (!nb) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (!nb->self) {
+        if (nb->qx) (void)hipFree(nb->qx);
+        if (nb->qy) (void)hipFree(nb->qy);
+        if (nb->qz) (void)hipFree(nb->qz);
+    }
+    if (nb->qrow) (void)hipFree(nb->qrow);
+    if (nb->count) (void)hipFree(nb->count);
+    if (nb->offset) (void)hipFree(nb->offset);
+    if (nb->idx) (void)hipFree(nb->idx);
+    delete nb;
+}

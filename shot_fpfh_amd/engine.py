@@ -1,0 +1,394 @@
+"""Object layer over the C ABI: Engine (one GPU), Cloud (resident points + grid), Neighbors (CSR lists).
+
+Everything that computes runs in HIP kernels inside libshotfpfh.so; this module only moves NumPy
+arrays across the boundary and keeps device handles alive.  NumPy inputs are cast to C-contiguous
+float64 at the boundary (the reference computes in float64 throughout).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import SF_HOST, SF_IN_DEVICE, SF_OUT_DEVICE, ShotFpfhError
+
+__all__ = ["Engine", "Cloud", "Neighbors", "Spfh", "DeviceArray", "default_engine", "ShotFpfhError", "fpfh_edges"]
+
+
+def _f64(a, cols: Optional[int] = None) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.float64)
+    if cols is not None and (arr.ndim != 2 or arr.shape[1] != cols):
+        raise ValueError(f"expected an (N, {cols}) array, got shape {arr.shape}")
+    return arr
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def fpfh_edges(n_bins: int) -> np.ndarray:
+    """The 3 x (n_bins+1) bin edges np.histogramdd derives from `bins=n_bins` and the ranges of
+    fpfh.py:82-87.  Computed with np.linspace on the host so the device compares against the very
+    same float64 edge values (they are not ideal fractions)."""
+    return np.ascontiguousarray(
+        np.stack(
+            [
+                np.linspace(-1, 1, n_bins + 1),
+                np.linspace(-1, 1, n_bins + 1),
+                np.linspace(-np.pi / 2, np.pi / 2, n_bins + 1),
+            ]
+        ),
+        dtype=np.float64,
+    )
+
+
+class DeviceArray:
+    """A typed, shaped view of device memory owned by an Engine (results kept resident in HBM)."""
+
+    def __init__(self, engine: "Engine", shape, dtype):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = _ffi.check_handle(engine.lib.sf_dev_alloc(engine.h, max(self.nbytes, 8)), "sf_dev_alloc")
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        _ffi.check(self.engine.lib.sf_d2h(self.engine.h, _ptr(out), self.ptr, self.nbytes), "sf_d2h")
+        return out
+
+    def from_host(self, a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        _ffi.check(self.engine.lib.sf_h2d(self.engine.h, self.ptr, _ptr(a), self.nbytes), "sf_h2d")
+        return self
+
+    def offset_ptr(self, byte_offset: int):
+        return C.c_void_p(self.ptr + byte_offset)
+
+    def free(self) -> None:
+        if self.ptr:
+            self.engine.lib.sf_dev_free(self.engine.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One GPU: a libshotfpfh context with its own HIP stream.  Fails loudly when the native library
+    or the GPU is missing -- there is no CPU path."""
+
+    def __init__(self, device: Optional[int] = None):
+        self.lib = _ffi.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+            n = self.lib.sf_device_count()
+            if n > 0:
+                device %= n
+        self.device = device
+        self.h = _ffi.check_handle(self.lib.sf_create(device), f"sf_create({device})")
+        self.pid = os.getpid()
+        self.nranks, self.rank = 1, 0
+
+    # ---- lifetime -----------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "h", None) and os.getpid() == self.pid:
+            self.lib.sf_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self) -> None:
+        _ffi.check(self.lib.sf_sync(self.h), "sf_sync")
+
+    def empty(self, shape, dtype=np.float64) -> DeviceArray:
+        return DeviceArray(self, shape, dtype)
+
+    # ---- cloud / search ---------------------------------------------------------------------------
+    def cloud(self, points, normals=None) -> "Cloud":
+        return Cloud(self, points, normals)
+
+    # ---- matching (K8) / RANSAC scoring (K9) ------------------------------------------------------
+    def match_argmin(self, a, b, want_dist=True, want_col=False):
+        """Row arg-min of cdist(a, b) (first minimum), winners' distances, optional column arg-min."""
+        a, b = _f64(a), _f64(b)
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+            raise ValueError("descriptor matrices must be 2-D with equal width")
+        m1, m2 = a.shape[0], b.shape[0]
+        idx = np.zeros(m1, dtype=np.int64)
+        dist = np.zeros(m1, dtype=np.float64) if want_dist else None
+        col = np.zeros(m2, dtype=np.int64) if want_col else None
+        if m1 and not m2:
+            raise ValueError("attempt to get argmin of an empty sequence")
+        if m1:
+            _ffi.check(
+                self.lib.sf_match_argmin(self.h, _ptr(a), m1, _ptr(b), m2, a.shape[1], _ptr(idx), _ptr(dist), _ptr(col), SF_HOST),
+                "sf_match_argmin",
+            )
+        return idx, dist, col
+
+    def match_argmin_device(self, a: DeviceArray, b: DeviceArray, idx: DeviceArray, dist: Optional[DeviceArray] = None,
+                            col: Optional[DeviceArray] = None, rows: Optional[int] = None, row_offset: int = 0) -> None:
+        """Resident variant: a (rows starting at row_offset) vs all of b, outputs stay on the device."""
+        d = a.shape[1]
+        m1 = a.shape[0] - row_offset if rows is None else rows
+        _ffi.check(
+            self.lib.sf_match_argmin(self.h, a.offset_ptr(row_offset * d * 8), m1, b.ptr, b.shape[0], d, idx.ptr,
+                                     None if dist is None else dist.ptr, None if col is None else col.ptr,
+                                     SF_IN_DEVICE | SF_OUT_DEVICE),
+            "sf_match_argmin",
+        )
+
+    def ransac_score(self, a, b, rt, thr: float) -> np.ndarray:
+        a, b = _f64(a, 3), _f64(b, 3)
+        rt = _f64(rt).reshape(-1, 12)
+        out = np.zeros(rt.shape[0], dtype=np.int64)
+        _ffi.check(
+            self.lib.sf_ransac_score(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(rt), rt.shape[0], float(thr), _ptr(out), SF_HOST),
+            "sf_ransac_score",
+        )
+        return out
+
+    # ---- multi-GPU (RCCL) -------------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _ffi.check(self.lib.sf_comm_unique_id(buf), "sf_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int) -> None:
+        buf = C.create_string_buffer(unique_id, 128)
+        _ffi.check(self.lib.sf_comm_init(self.h, buf, nranks, rank), "sf_comm_init")
+        self.nranks, self.rank = nranks, rank
+
+    def allgather(self, buf: DeviceArray, bytes_per_rank: int) -> None:
+        """In-place all-gather: rank r's block lives at byte offset r * bytes_per_rank of `buf`."""
+        if bytes_per_rank * self.nranks > buf.nbytes:
+            raise ValueError("buffer too small for the all-gather")
+        _ffi.check(
+            self.lib.sf_comm_allgather(self.h, buf.offset_ptr(self.rank * bytes_per_rank), buf.ptr, bytes_per_rank),
+            "sf_comm_allgather",
+        )
+
+    # ---- profiling ----------------------------------------------------------------------------------
+    def profile(self, on: bool) -> None:
+        _ffi.check(self.lib.sf_profile_enable(self.h, int(on)), "sf_profile_enable")
+
+    def profile_reset(self) -> None:
+        _ffi.check(self.lib.sf_profile_reset(self.h), "sf_profile_reset")
+
+    def profile_report(self) -> dict:
+        """{kernel name: (launches, total milliseconds measured with HIP events on the engine's stream)}"""
+        need = self.lib.sf_profile_report(self.h, None, 0)
+        buf = C.create_string_buffer(int(need) + 16)
+        self.lib.sf_profile_report(self.h, buf, len(buf))
+        rep = {}
+        for line in buf.value.decode().splitlines():
+            name, launches, ms = line.split()
+            rep[name] = (int(launches), float(ms))
+        return rep
+
+
+class Cloud:
+    """Point cloud resident in HBM with its uniform grid -- the stand-in for sklearn's KDTree(X)."""
+
+    def __init__(self, engine: Engine, points, normals=None):
+        self.engine = engine
+        pts = _f64(points, 3)
+        nrm = None if normals is None else _f64(normals, 3)
+        if nrm is not None and nrm.shape != pts.shape:
+            raise ValueError("normals must have the same shape as points")
+        self.n = pts.shape[0]
+        self.h = _ffi.check_handle(
+            engine.lib.sf_cloud_upload(engine.h, _ptr(pts), _ptr(nrm), self.n, SF_HOST), "sf_cloud_upload"
+        )
+
+    def set_normals(self, normals) -> None:
+        nrm = _f64(normals, 3)
+        if nrm.shape[0] != self.n:
+            raise ValueError("normals must have one row per point")
+        _ffi.check(self.engine.lib.sf_cloud_set_normals(self.engine.h, self.h, _ptr(nrm), SF_HOST), "sf_cloud_set_normals")
+
+    def build_grid(self, cell: float) -> None:
+        _ffi.check(self.engine.lib.sf_cloud_build_grid(self.engine.h, self.h, float(cell)), "sf_cloud_build_grid")
+
+    def radius_search(self, queries, radius: float) -> "Neighbors":
+        q = _f64(queries, 3)
+        h = _ffi.check_handle(
+            self.engine.lib.sf_radius_search(self.engine.h, self.h, _ptr(q), q.shape[0], float(radius), SF_HOST),
+            "sf_radius_search",
+        )
+        return Neighbors(self, h)
+
+    def radius_search_self(self, radius: float, begin: int = 0, end: Optional[int] = None) -> "Neighbors":
+        end = self.n if end is None else end
+        h = _ffi.check_handle(
+            self.engine.lib.sf_radius_search_self(self.engine.h, self.h, float(radius), begin, end), "sf_radius_search_self"
+        )
+        return Neighbors(self, h)
+
+    def free(self) -> None:
+        if getattr(self, "h", None) and self.engine.h:
+            self.engine.lib.sf_cloud_free(self.engine.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Neighbors:
+    """Device-resident CSR radius-neighbour lists of one query set (result of kernels K2)."""
+
+    def __init__(self, cloud: Cloud, handle):
+        self.cloud, self.engine, self.h = cloud, cloud.engine, handle
+        lib = self.engine.lib
+        self.m = lib.sf_nbrs_num_queries(handle)
+        self.total = lib.sf_nbrs_total(handle)
+        self.max_count = lib.sf_nbrs_max_count(handle)
+
+    def export(self, return_distance: bool = False):
+        """(offsets[m+1], idx[total]) with ascending original indices inside each list
+        [+ dist[total] = sqrt(d2)], the canonical form of KDTree.query_radius's output."""
+        off = np.zeros(self.m + 1, dtype=np.int64)
+        idx = np.zeros(max(self.total, 1), dtype=np.int32)
+        dist = np.zeros(max(self.total, 1), dtype=np.float64) if return_distance else None
+        _ffi.check(
+            self.engine.lib.sf_nbrs_export(self.engine.h, self.cloud.h, self.h, _ptr(off), _ptr(idx), _ptr(dist)),
+            "sf_nbrs_export",
+        )
+        if return_distance:
+            return off, idx[: self.total], dist[: self.total]
+        return off, idx[: self.total]
+
+    # ---- descriptors on these lists ---------------------------------------------------------------
+    def normals(self, pre_computed_normals=None) -> np.ndarray:
+        pre = None if pre_computed_normals is None else _f64(pre_computed_normals, 3)
+        if pre is not None and pre.shape[0] != self.m:
+            raise ValueError("pre_computed_normals must have one row per query point")
+        out = np.zeros((self.m, 3))
+        _ffi.check(self.engine.lib.sf_normals(self.engine.h, self.cloud.h, self.h, _ptr(pre), _ptr(out), SF_HOST), "sf_normals")
+        return out
+
+    def shot_lrf(self, out: Optional[DeviceArray] = None):
+        if out is not None:
+            _ffi.check(self.engine.lib.sf_shot_lrf(self.engine.h, self.cloud.h, self.h, out.ptr, SF_OUT_DEVICE), "sf_shot_lrf")
+            return out
+        lrf = np.zeros((self.m, 3, 3))
+        _ffi.check(self.engine.lib.sf_shot_lrf(self.engine.h, self.cloud.h, self.h, _ptr(lrf), SF_HOST), "sf_shot_lrf")
+        return lrf
+
+    def shot(self, lrf, normalize: bool = True, min_neighborhood_size: int = 100, out: Optional[DeviceArray] = None):
+        if isinstance(lrf, DeviceArray):
+            if out is None:
+                raise ValueError("device-resident LRFs need a device output")
+            _ffi.check(
+                self.engine.lib.sf_shot(self.engine.h, self.cloud.h, self.h, lrf.ptr, int(bool(normalize)),
+                                        int(min_neighborhood_size), out.ptr, SF_IN_DEVICE | SF_OUT_DEVICE),
+                "sf_shot",
+            )
+            return out
+        lrf = _f64(lrf).reshape(-1, 9)
+        if lrf.shape[0] != self.m:
+            raise ValueError("one local reference frame per keypoint expected")
+        res = np.zeros((self.m, _ffi.SHOT_LEN))
+        _ffi.check(
+            self.engine.lib.sf_shot(self.engine.h, self.cloud.h, self.h, _ptr(lrf), int(bool(normalize)),
+                                    int(min_neighborhood_size), _ptr(res), SF_HOST),
+            "sf_shot",
+        )
+        return res
+
+    def free(self) -> None:
+        if getattr(self, "h", None) and self.engine.h:
+            self.engine.lib.sf_nbrs_free(self.engine.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Spfh:
+    """Device-resident SPFH table (integer bin counts + neighbourhood sizes) of a whole cloud."""
+
+    def __init__(self, cloud: Cloud, n_bins: int, max_count: int):
+        self.cloud, self.engine, self.n_bins = cloud, cloud.engine, int(n_bins)
+        self.edges = fpfh_edges(self.n_bins)
+        self.h = _ffi.check_handle(
+            self.engine.lib.sf_spfh_create(self.engine.h, cloud.h, self.n_bins, int(max_count)), "sf_spfh_create"
+        )
+
+    def compute(self, self_nbrs: Neighbors) -> "Spfh":
+        _ffi.check(
+            self.engine.lib.sf_spfh_compute(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(self.edges)), "sf_spfh_compute"
+        )
+        return self
+
+    def allgather(self, rows_per_rank: int) -> None:
+        _ffi.check(self.engine.lib.sf_spfh_allgather(self.engine.h, self.h, int(rows_per_rank)), "sf_spfh_allgather")
+
+    def export(self) -> np.ndarray:
+        out = np.zeros((self.cloud.n, self.n_bins**3))
+        _ffi.check(self.engine.lib.sf_spfh_export(self.engine.h, self.cloud.h, self.h, _ptr(out), SF_HOST), "sf_spfh_export")
+        return out
+
+    def fpfh(self, self_nbrs: Neighbors, keypoints_indices=None, out: Optional[DeviceArray] = None):
+        nb3 = self.n_bins**3
+        if keypoints_indices is None:
+            m, kp = self_nbrs.m, None
+        else:
+            kp = np.ascontiguousarray(keypoints_indices, dtype=np.int64)
+            m = kp.shape[0]
+        if out is not None:
+            _ffi.check(
+                self.engine.lib.sf_fpfh(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(kp), m, out.ptr, SF_OUT_DEVICE),
+                "sf_fpfh",
+            )
+            return out
+        res = np.zeros((m, nb3))
+        _ffi.check(
+            self.engine.lib.sf_fpfh(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(kp), m, _ptr(res), SF_HOST), "sf_fpfh"
+        )
+        return res
+
+    def free(self) -> None:
+        if getattr(self, "h", None) and self.engine.h:
+            self.engine.lib.sf_spfh_free(self.engine.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+_default: Optional[Engine] = None
+_default_lock = threading.Lock()
+
+
+def default_engine() -> Engine:
+    """Process-wide engine on GPU LOCAL_RANK (or 0), created on first use.  A forked child must not
+    reuse its parent's HIP context ('HIP + fork'), so the engine is re-created per pid."""
+    global _default
+    with _default_lock:
+        if _default is None or _default.pid != os.getpid() or _default.h is None:
+            _default = Engine()
+        return _default

@@ -1,0 +1,83 @@
+"""Descriptor matching on the GPU -- drop-ins for shot_fpfh.matching.basic_matching and the 2-D
+(Euclidean) branch of match_descriptors (matching.py:39-74, 138-169).
+
+The M1 x M2 distance matrix of the reference (scipy cdist, 8 TB at 1M x 1M) is never formed: kernel
+K8 returns, per scan descriptor, the first arg-min over the reference descriptors and its distance,
+and per reference descriptor the arg-min over the scan side for the reciprocity test.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Callable, Optional
+
+import numpy as np
+import numpy.typing as npt
+
+from ..engine import Engine, default_engine
+
+__all__ = ["basic_matching", "match_descriptors", "double_matching_with_rejects"]
+
+
+def _non_empty_rows(desc: np.ndarray) -> np.ndarray:
+    # descriptors left at zero (too sparse a neighbourhood in SHOT) never take part (matching.py:43-44)
+    return np.flatnonzero(np.any(desc, axis=1))
+
+
+def basic_matching(
+    scan_descriptors: npt.NDArray[np.float64],
+    ref_descriptors: npt.NDArray[np.float64],
+    *,
+    engine: Optional[Engine] = None,
+) -> tuple[npt.NDArray[np.int64], npt.NDArray[np.int64]]:
+    """Nearest reference descriptor of every non-empty scan descriptor (matching.py:149-169).
+    Returns (scan row indices, matched ref row indices) in the original row numbering."""
+    eng = engine or default_engine()
+    scan_rows, ref_rows = _non_empty_rows(scan_descriptors), _non_empty_rows(ref_descriptors)
+    idx, _, _ = eng.match_argmin(scan_descriptors[scan_rows], ref_descriptors[ref_rows], want_dist=False)
+    return scan_rows, ref_rows[idx]
+
+
+def match_descriptors(
+    scan_descriptors: npt.NDArray[np.float64],
+    ref_descriptors: npt.NDArray[np.float64],
+    filter_callback: Callable[..., npt.NDArray[np.bool_]] | None = None,
+    filter_nonreciprocal: bool = False,
+    verbose: bool = True,
+    n_min_matches: int = 100,
+    *,
+    engine: Optional[Engine] = None,
+    **kwargs,
+) -> tuple[npt.NDArray[np.int64], npt.NDArray[np.int64]]:
+    """Arg-min matching with an optional distance filter and reciprocity test (matching.py:39-74).
+
+    `filter_callback(distances, **kwargs)` receives the winners' distances and returns a keep-mask.
+    With `filter_nonreciprocal`, a match i -> j is also required to satisfy argmin_i' d(i', j) == i,
+    but only if at least `n_min_matches` matches survive; otherwise the reciprocity test is dropped.
+    The 3-D "minimum over scales" input form (matching.py:77-136) is not on the device path yet.
+    """
+    if np.ndim(scan_descriptors) != 2:
+        raise NotImplementedError("multi-scale (3-D) descriptor stacks are not supported on the device path yet")
+    eng = engine or default_engine()
+    if verbose:
+        logging.info("")
+        logging.info("-- Matching descriptors based on Euclidian-norm proximity --")
+    scan_rows, ref_rows = _non_empty_rows(scan_descriptors), _non_empty_rows(ref_descriptors)
+    idx, dist, col = eng.match_argmin(
+        scan_descriptors[scan_rows], ref_descriptors[ref_rows], want_dist=True, want_col=filter_nonreciprocal
+    )
+    keep = filter_callback(dist, **kwargs) if filter_callback is not None else np.ones(dist.shape[0], dtype=bool)
+    if filter_nonreciprocal:
+        both = keep & (col[idx] == np.arange(idx.shape[0]))
+        if both.sum() >= n_min_matches:
+            keep = both
+        elif verbose:
+            logging.warning("Too few reciprocal matches, keeping non-reciprocal matches.")
+    if verbose:
+        logging.info(f"Kept {keep.sum()} matches out of {scan_descriptors.shape[-2]} descriptors.")
+    return scan_rows[keep], ref_rows[idx[keep]]
+
+
+def double_matching_with_rejects(scan_descriptors, ref_descriptors, threshold, verbose=True):
+    """Present in the reference's export list but broken there: it always raises IndexError
+    (matching.py:202/220).  Kept as an explicit non-feature."""
+    raise NotImplementedError("double_matching_with_rejects always raises in the reference implementation; not provided")

@@ -1,0 +1,62 @@
+"""RANSAC over descriptor matches -- drop-in for shot_fpfh.matching.ransac_on_matches
+(ransac.py:17-82).
+
+Host: the draws (same module-level np.random.default_rng(seed=72) stream as ransac.py:14, so draw
+k of a process equals the reference's draw k) and one Kabsch fit per draw.  Device (K9): the
+O(n_draws x n_matches) inlier count of every candidate transform in ONE launch, instead of one NumPy
+pass over all matches per draw.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import numpy as np
+import numpy.typing as npt
+
+from ..core import RigidTransform, solver_point_to_point
+from ..engine import Engine, default_engine
+
+__all__ = ["ransac_on_matches", "rng"]
+
+# same seed and same persistence across calls as the reference module's generator
+rng = np.random.default_rng(seed=72)
+
+
+def ransac_on_matches(
+    scan_descriptors_indices: npt.NDArray[np.integer],
+    ref_descriptors_indices: npt.NDArray[np.integer],
+    scan_keypoints: npt.NDArray[np.float64],
+    ref_keypoints: npt.NDArray[np.float64],
+    n_draws: int = 10000,
+    draw_size: int = 4,
+    distance_threshold: float = 1,
+    verbose: bool = False,
+    disable_progress_bar: bool = False,
+    *,
+    engine: Optional[Engine] = None,
+) -> tuple[float, RigidTransform]:
+    """Returns (inlier ratio of the best draw, its RigidTransform with a re-normalised rotation).
+
+    The best draw is the FIRST one reaching the maximal inlier count (strict `>` at ransac.py:68).
+    """
+    eng = engine or default_engine()
+    n_matches = scan_descriptors_indices.shape[0]
+    scan_pts = np.ascontiguousarray(scan_keypoints[scan_descriptors_indices], dtype=np.float64)
+    ref_pts = np.ascontiguousarray(ref_keypoints[ref_descriptors_indices], dtype=np.float64)
+
+    candidates: list[RigidTransform] = []
+    records = np.empty((n_draws, 12), dtype=np.float64)
+    for d in range(n_draws):
+        draw = rng.choice(n_matches, draw_size, replace=False, shuffle=False)  # ransac.py:50-55
+        tf = solver_point_to_point(scan_pts[draw], ref_pts[draw])
+        candidates.append(tf)
+        records[d] = tf.as_row12()
+
+    inliers = eng.ransac_score(scan_pts, ref_pts, records, distance_threshold)
+    best = int(np.argmax(inliers))  # first maximum == reference's strict-greater update rule
+    if verbose:
+        logging.info(f"Best draw {best}: {int(inliers[best])} inliers out of {n_matches}")
+    best_transform = candidates[best]
+    best_transform.normalize_rotation()
+    return inliers[best] / n_matches, best_transform
