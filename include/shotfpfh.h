@@ -78,6 +78,13 @@ int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *cloud, const double *normals, in
 int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *cloud, double cell);
 int64_t sf_cloud_size(const sf_cloud *cloud);
 void sf_cloud_free(sf_ctx *ctx, sf_cloud *cloud);
+/* cell-sorted position -> original index (n entries, host) */
+int sf_cloud_perm(sf_ctx *ctx, sf_cloud *cloud, int32_t *perm);
+/* Multi-GPU sharding helper: the smallest range [halo_begin, halo_end) of cell-sorted positions that
+ * contains every point within one grid cell (>= the search radius) of the block [begin, end).  The grid
+ * orders cells z-slowest, so a block is a z-slab and its halo is one contiguous run on each side. */
+int sf_cloud_halo_range(sf_ctx *ctx, sf_cloud *cloud, int64_t begin, int64_t end, int64_t *halo_begin,
+                        int64_t *halo_end);
 
 /* ---- radius search: replaces KDTree.query_radius (kernels K2 count / fill) --------------
  * Inclusion rule of sklearn's euclidean KDTree: ((dx*dx + dy*dy) + dz*dz) <= r*r in float64,
@@ -92,6 +99,8 @@ void sf_cloud_free(sf_ctx *ctx, sf_cloud *cloud);
 sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, double radius,
                           int flags);
 sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *cloud, double radius, int64_t begin, int64_t end);
+/* non-owning view of queries [first, first+count) of `nbrs` (free it before the parent) */
+sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nbrs, int64_t first, int64_t count);
 int64_t sf_nbrs_num_queries(const sf_nbrs *nbrs);
 int64_t sf_nbrs_total(const sf_nbrs *nbrs);
 int64_t sf_nbrs_max_count(const sf_nbrs *nbrs);
@@ -119,8 +128,9 @@ int sf_shot(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *lrf /* m 
  * the queries of `self_nbrs` (a sf_radius_search_self result); edges = 3 x (n_bins+1) histogram
  * edges exactly as np.histogramdd builds them (np.linspace; fpfh.py:82-87).
  * sf_fpfh (K7) reduces  spfh[kp] + sum_{j, d_j>0} spfh[j]/d_j / k  (fpfh.py:101-116) for keypoints
- * given either as original indices kp_idx (m) or, when kp_idx == NULL, for every query of
- * `self_nbrs` in cell-sorted order (m must equal its query count).
+ * given either as original indices kp_idx (m; needs lists of the whole cloud) or, when kp_idx == NULL,
+ * for every query of `self_nbrs` in cell-sorted order (m must equal its query count; with a
+ * sf_nbrs_slice view this is how a shard reduces only its own block).
  * sf_spfh_export writes the float64 SPFH table (n x n_bins^3, original numbering). */
 sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_count);
 int sf_spfh_compute(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const double *edges);

@@ -121,6 +121,7 @@ struct sf_nbrs {
     double radius = 0.0;
     int64_t total = 0;
     int64_t max_count = 0;
+    bool view = false;       // non-owning slice of another sf_nbrs
     bool self = false;       // queries are cloud points
     int64_t self_begin = 0;  // first sorted position when self
     double *qx = nullptr, *qy = nullptr, *qz = nullptr; // query coords in PROCESSING order (owned unless self)

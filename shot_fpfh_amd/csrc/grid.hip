@@ -264,6 +264,42 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
     return SF_OK;
 }
 
+extern "C" int sf_cloud_perm(sf_ctx *ctx, sf_cloud *c, int32_t *perm)
+{
+    if (!ctx || !c || !perm) { sf_set_error("sf_cloud_perm: null argument"); return SF_ERR_ARG; }
+    if (!c->perm) { sf_set_error("sf_cloud_perm: grid not built"); return SF_ERR_STATE; }
+    if (c->n) SF_HIP(hipMemcpyAsync(perm, c->perm, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_cloud_halo_range(sf_ctx *ctx, sf_cloud *c, int64_t begin, int64_t end, int64_t *hb, int64_t *he)
+{
+    if (!ctx || !c || !hb || !he || begin < 0 || end > c->n || begin > end) {
+        sf_set_error("sf_cloud_halo_range: bad arguments");
+        return SF_ERR_ARG;
+    }
+    if (!c->cell_start) { sf_set_error("sf_cloud_halo_range: grid not built"); return SF_ERR_STATE; }
+    if (begin == end) { *hb = begin; *he = end; return SF_OK; }
+    // z coordinates of the first and last point of the block give its z-layers of cells
+    double zz[2];
+    SF_HIP(hipMemcpyAsync(&zz[0], c->zs + begin, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipMemcpyAsync(&zz[1], c->zs + (end - 1), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    const int z0 = sf_cell_coord(zz[0], c->lo[2], c->inv_cell, c->dim[2]);
+    const int z1 = sf_cell_coord(zz[1], c->lo[2], c->inv_cell, c->dim[2]);
+    const int64_t layer = (int64_t)c->dim[0] * c->dim[1];
+    const int64_t c0 = (int64_t)std::max(z0 - 1, 0) * layer;
+    const int64_t c1 = (int64_t)std::min(z1 + 2, c->dim[2]) * layer;
+    int32_t v[2];
+    SF_HIP(hipMemcpyAsync(&v[0], c->cell_start + c0, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipMemcpyAsync(&v[1], c->cell_start + c1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    *hb = std::min<int64_t>(v[0], begin);
+    *he = std::max<int64_t>(v[1], end);
+    return SF_OK;
+}
+
 extern "C" int64_t sf_cloud_size(const sf_cloud *c) { return c ? c->n : -1; }
 
 extern "C" void sf_cloud_free(sf_ctx *ctx, sf_cloud *c)

@@ -284,6 +284,30 @@ extern "C" sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *c, const double *que
     return nb;
 }
 
+extern "C" sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nb, int64_t first, int64_t count)
+{
+    if (!ctx || !nb || first < 0 || count < 0 || first + count > nb->m) {
+        sf_set_error("sf_nbrs_slice: bad range");
+        return nullptr;
+    }
+    sf_nbrs *v = new sf_nbrs();
+    v->view = true;
+    v->m = count;
+    v->radius = nb->radius;
+    v->self = nb->self;
+    v->self_begin = nb->self_begin + first;
+    v->qx = nb->qx + first;
+    v->qy = nb->qy + first;
+    v->qz = nb->qz + first;
+    v->qrow = nb->qrow ? nb->qrow + first : nullptr;
+    v->count = nb->count + first;
+    v->offset = nb->offset + first; // offsets stay absolute into idx
+    v->idx = nb->idx;
+    v->max_count = nb->max_count;
+    v->total = -1; // unknown without a device read; views are for compute, not export
+    return v;
+}
+
 extern "C" int64_t sf_nbrs_num_queries(const sf_nbrs *nb) { return nb ? nb->m : -1; }
 extern "C" int64_t sf_nbrs_total(const sf_nbrs *nb) { return nb ? nb->total : -1; }
 extern "C" int64_t sf_nbrs_max_count(const sf_nbrs *nb) { return nb ? nb->max_count : -1; }
@@ -294,6 +318,7 @@ extern "C" int sf_nbrs_export(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t *of
     // numbering, order each list by ascending index and rows by the caller's query order.  For a self
     // search row i is the point at cell-sorted position self_begin + i.
     if (!ctx || !c || !nb || !offsets) { sf_set_error("sf_nbrs_export: null argument"); return SF_ERR_ARG; }
+    if (nb->view) { sf_set_error("sf_nbrs_export: not available on a slice view"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
     const int64_t m = nb->m, total = nb->total;
     std::vector<int64_t> off((size_t)m + 1);
@@ -355,6 +380,7 @@ extern "C" int sf_nbrs_export(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t *of
 extern "C" void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nb)
 {
     if (!nb) return;
+    if (nb->view) { delete nb; return; }
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (!nb->self) {
         if (nb->qx) (void)hipFree(nb->qx);

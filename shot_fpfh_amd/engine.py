@@ -224,6 +224,21 @@ class Cloud:
     def build_grid(self, cell: float) -> None:
         _ffi.check(self.engine.lib.sf_cloud_build_grid(self.engine.h, self.h, float(cell)), "sf_cloud_build_grid")
 
+    def perm(self) -> np.ndarray:
+        """cell-sorted position -> original point index (valid after a grid build / search)."""
+        out = np.zeros(self.n, dtype=np.int32)
+        _ffi.check(self.engine.lib.sf_cloud_perm(self.engine.h, self.h, _ptr(out)), "sf_cloud_perm")
+        return out
+
+    def halo_range(self, begin: int, end: int) -> tuple[int, int]:
+        """Range of cell-sorted positions holding every point within one grid cell of block [begin, end)."""
+        hb, he = C.c_int64(0), C.c_int64(0)
+        _ffi.check(
+            self.engine.lib.sf_cloud_halo_range(self.engine.h, self.h, begin, end, C.byref(hb), C.byref(he)),
+            "sf_cloud_halo_range",
+        )
+        return hb.value, he.value
+
     def radius_search(self, queries, radius: float) -> "Neighbors":
         q = _f64(queries, 3)
         h = _ffi.check_handle(
@@ -260,6 +275,13 @@ class Neighbors:
         self.m = lib.sf_nbrs_num_queries(handle)
         self.total = lib.sf_nbrs_total(handle)
         self.max_count = lib.sf_nbrs_max_count(handle)
+
+    def slice(self, first: int, count: int) -> "Neighbors":
+        """Non-owning view of queries [first, first+count); keep the parent alive while it is used."""
+        h = _ffi.check_handle(self.engine.lib.sf_nbrs_slice(self.engine.h, self.h, first, count), "sf_nbrs_slice")
+        v = Neighbors(self.cloud, h)
+        v._parent = self
+        return v
 
     def export(self, return_distance: bool = False):
         """(offsets[m+1], idx[total]) with ascending original indices inside each list

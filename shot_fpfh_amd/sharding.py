@@ -1,0 +1,132 @@
+"""Sharding of the descriptor path over the GPUs of one node (one process per GPU).
+
+The reference has no distributed path (its only parallelism is a multiprocessing.Pool,
+shot_parallelization.py:30-44).  Here the cloud is replicated on every GPU (an 8M-point cloud is
+384 MB of float64 -- nothing next to 288 GB of HBM) and the QUERY points are partitioned: the grid
+orders cells z-slowest, so rank g's contiguous block of cell-sorted positions is a z-slab.
+
+* SHOT, normals and SPFH of a block need only read access to the cloud: no exchange.
+* FPFH of a block needs the SPFH rows of the block's neighbours, some of which belong to the two
+  adjacent slabs.  Two ways to get them (`spfh_exchange`):
+    "halo"       recompute SPFH for the one-cell-thick halo on each side of the block -- a
+                 contiguous run of positions -- so the descriptor pass has NO data-path collective;
+    "allgather"  compute only the block and all-gather the integer SPFH table over RCCL/xGMI.
+* Matching needs every reference descriptor on every rank: one RCCL all-gather of descriptor rows
+  (`gather_rows`) before K8, whose row arg-min is then local to each rank's scan block.
+
+Results are bit-identical for any number of ranks: every kernel's arithmetic for a query depends only
+on the cloud and the query, never on the block boundaries.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .engine import Cloud, DeviceArray, Engine, Neighbors, Spfh
+
+__all__ = ["ShardPlan", "DescriptorJob"]
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Equal blocks of ceil(n / world) cell-sorted positions; trailing ranks may get a short or empty block."""
+
+    n: int
+    world: int = 1
+    rank: int = 0
+
+    def __post_init__(self):
+        if self.world < 1 or not 0 <= self.rank < self.world or self.n < 0:
+            raise ValueError(f"bad shard plan n={self.n} world={self.world} rank={self.rank}")
+
+    @property
+    def rows_per_rank(self) -> int:
+        return -(-self.n // self.world) if self.n else 0
+
+    def block(self, rank: Optional[int] = None) -> tuple[int, int]:
+        r = self.rank if rank is None else rank
+        b = min(r * self.rows_per_rank, self.n)
+        return b, min(b + self.rows_per_rank, self.n)
+
+    @property
+    def begin(self) -> int:
+        return self.block()[0]
+
+    @property
+    def end(self) -> int:
+        return self.block()[1]
+
+
+class DescriptorJob:
+    """FPFH + SHOT for this rank's block of a resident cloud, outputs kept in HBM.
+
+    One `step()` is one pass of the hot path: K1 grid build, K2 radius search (shared by both
+    descriptors, their radii being equal), K6 SPFH, K7 FPFH, K4 local frames, K5 SHOT.
+    Rows of the outputs follow cell-sorted order; `block_original_indices()` maps them back.
+    """
+
+    def __init__(self, engine: Engine, points, normals, radius: float, n_bins: int = 5, normalize: bool = True,
+                 min_neighborhood_size: int = 10, world: int = 1, rank: int = 0, spfh_exchange: str = "halo",
+                 do_fpfh: bool = True, do_shot: bool = True):
+        if spfh_exchange not in ("halo", "allgather"):
+            raise ValueError("spfh_exchange must be 'halo' or 'allgather'")
+        self.engine, self.radius, self.n_bins = engine, float(radius), int(n_bins)
+        self.normalize, self.min_nb = bool(normalize), int(min_neighborhood_size)
+        self.exchange, self.do_fpfh, self.do_shot = spfh_exchange, do_fpfh, do_shot
+        self.cloud: Cloud = engine.cloud(points, normals)
+        self.plan = ShardPlan(self.cloud.n, world, rank)
+        m = self.plan.end - self.plan.begin
+        self.m = m
+        self.fpfh_out: Optional[DeviceArray] = engine.empty((m, self.n_bins**3)) if do_fpfh else None
+        self.lrf_out: Optional[DeviceArray] = engine.empty((m, 9)) if do_shot else None
+        self.shot_out: Optional[DeviceArray] = engine.empty((m, 352)) if do_shot else None
+        self.spfh: Optional[Spfh] = None
+        self._spfh_wide = False
+        self.last_pairs = 0
+
+    def _spfh_table(self, max_count: int) -> Spfh:
+        wide = max_count > 65535
+        if self.spfh is None or wide != self._spfh_wide:
+            if self.spfh is not None:
+                self.spfh.free()
+            self.spfh = Spfh(self.cloud, self.n_bins, max_count)
+            self._spfh_wide = wide
+        return self.spfh
+
+    def step(self) -> None:
+        cloud, (b, e) = self.cloud, self.plan.block()
+        cloud.build_grid(self.radius)
+        if self.do_fpfh and self.exchange == "halo":
+            hb, he = cloud.halo_range(b, e)
+        else:
+            hb, he = b, e
+        nb: Neighbors = cloud.radius_search_self(self.radius, hb, he)
+        try:
+            self.last_pairs = nb.total
+            blk = nb if (hb, he) == (b, e) else nb.slice(b - hb, e - b)
+            try:
+                if self.do_fpfh:
+                    spfh = self._spfh_table(nb.max_count).compute(nb)
+                    if self.exchange == "allgather" and self.plan.world > 1:
+                        spfh.allgather(self.plan.rows_per_rank)
+                    spfh.fpfh(blk, None, out=self.fpfh_out)
+                if self.do_shot:
+                    blk.shot_lrf(out=self.lrf_out)
+                    blk.shot(self.lrf_out, self.normalize, self.min_nb, out=self.shot_out)
+            finally:
+                if blk is not nb:
+                    blk.free()
+        finally:
+            nb.free()
+
+    def block_original_indices(self) -> np.ndarray:
+        b, e = self.plan.block()
+        return self.cloud.perm()[b:e].astype(np.int64)
+
+    def close(self) -> None:
+        for obj in (self.spfh, self.fpfh_out, self.lrf_out, self.shot_out, self.cloud):
+            if obj is not None:
+                obj.free()
+        self.spfh = self.fpfh_out = self.lrf_out = self.shot_out = None
