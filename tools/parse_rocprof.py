@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_gpu.sh run (rocprofv3 CSVs under gpurun_out/prof_<tag>/) into
+profiles/<tag>_summary.md and profiles/traffic.json (HBM bytes per launch of each hot kernel).
+
+HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are collected in SEPARATE --pmc passes, are reported in KiB, and on gfx950 FETCH_SIZE counts
+128-B requests as 64 B for wide coalesced reads, so the read side is doubled:
+    traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes.
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHORT = [
+    ("k_shot_lrf", "k4_shot_lrf"), ("k_lrf_", "k4_shot_lrf"), ("k_shot", "k5_shot"), ("k_fpfh", "k7_fpfh"), ("k_spfh_export", "k6_spfh_export"),
+    ("k_spfh", "k6_spfh"), ("k_radius<true>", "k2_radius_fill"), ("k_radius<false>", "k2_radius_count"),
+    ("k_radius", "k2_radius"), ("k_normals", "k3_normals"), ("k_match_tile", "k8_match_tile"), ("k_ransac", "k9_ransac_score"),
+    ("k_gather_sorted", "k1_gather_sorted"), ("k_cell_ids", "k1_cell_ids"), ("k_cell_start", "k1_cell_start"),
+    ("k_bbox", "k1_bbox"), ("radix_sort", "rocprim_radix_sort"), ("merge_sort", "rocprim_radix_sort"),
+    ("scan", "rocprim_scan"), ("reduce", "rocprim_reduce"), ("copyBuffer", "hip_copy"), ("fillBuffer", "hip_fill"),
+]
+
+
+def short(name):
+    for pat, s in SHORT:
+        if pat in name:
+            return s
+    return re.sub(r"\(.*", "", name)[:40]
+
+
+def read_counter(path, counter):
+    agg = defaultdict(list)
+    if not os.path.exists(path):
+        return agg
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == counter:
+            agg[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    stats = defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(os.path.join(base, "trace", "trace_kernel_stats.csv"))):
+        s = stats[short(row["Name"])]
+        s[0] += int(row["Calls"])
+        s[1] += float(row["TotalDurationNs"])
+    total = sum(v[1] for v in stats.values())
+    fetch = read_counter(os.path.join(base, "pmc_fetch", "pmc_counter_collection.csv"), "FETCH_SIZE")
+    write = read_counter(os.path.join(base, "pmc_write", "pmc_counter_collection.csv"), "WRITE_SIZE")
+    hit = read_counter(os.path.join(base, "pmc_l2", "pmc_counter_collection.csv"), "TCC_HIT_sum")
+    miss = read_counter(os.path.join(base, "pmc_l2", "pmc_counter_collection.csv"), "TCC_MISS_sum")
+    lines = [f"# rocprofv3 summary `{tag}`", "",
+             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
+             "(+ separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc TCC_HIT_sum TCC_MISS_sum` passes).", "",
+             "HBM traffic/launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md).", "",
+             "| kernel | calls | avg us | % of GPU time | FETCH_SIZE KiB/launch (raw) | WRITE_SIZE KiB/launch | HBM MB/launch (corrected) | L2 hit rate |",
+             "|---|---|---|---|---|---|---|---|"]
+    traffic = {}
+    for name, (calls, ns) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+        f = sum(fetch[name]) / len(fetch[name]) if fetch.get(name) else None
+        w = sum(write[name]) / len(write[name]) if write.get(name) else None
+        hr = None
+        if hit.get(name) and miss.get(name):
+            h, m = sum(hit[name]), sum(miss[name])
+            hr = h / (h + m) if h + m else None
+        tb = (2 * f + w) * 1024 if f is not None and w is not None else None
+        if tb is not None and name.startswith("k"):
+            traffic[name] = tb
+        lines.append(f"| {name} | {calls} | {ns / calls / 1e3:.1f} | {100 * ns / total:.2f} | "
+                     f"{'' if f is None else f'{f:.0f}'} | {'' if w is None else f'{w:.0f}'} | "
+                     f"{'' if tb is None else f'{tb / 1e6:.1f}'} | {'' if hr is None else f'{hr:.3f}'} |")
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
