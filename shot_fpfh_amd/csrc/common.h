@@ -57,7 +57,24 @@ struct sf_ctx {
     // small reusable device scratch (bbox partials etc.)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // stream-ordered caching allocator: freed blocks are reused by later launches on the SAME stream,
+    // so neither hipMalloc nor the implicit device sync of hipFree sits inside a step of the path
+    std::multimap<size_t, void *> pool_free;
+    std::map<void *, size_t> pool_size;
+    size_t pool_cached = 0;
 };
+
+int sf_pool_alloc(sf_ctx *ctx, size_t bytes, void **out);
+void sf_pool_release(sf_ctx *ctx, void *p);
+void sf_pool_trim(sf_ctx *ctx);
+template <typename T>
+static inline int sf_palloc(sf_ctx *ctx, T **out, size_t count)
+{
+    void *p = nullptr;
+    int rc = sf_pool_alloc(ctx, (count ? count : 1) * sizeof(T), &p);
+    *out = (T *)p;
+    return rc;
+}
 
 int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out);
 hipEvent_t sf_ctx_event(sf_ctx *ctx);

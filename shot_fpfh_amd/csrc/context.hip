@@ -59,6 +59,8 @@ extern "C" void sf_destroy(sf_ctx *ctx)
         }
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    sf_pool_trim(ctx);
+    for (auto &kv : ctx->pool_size) (void)hipFree(kv.first); // blocks still held by live handles
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -123,6 +125,53 @@ int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out)
     }
     *out = ctx->scratch;
     return SF_OK;
+}
+
+int sf_pool_alloc(sf_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes < 256) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = ctx->pool_free.lower_bound(bytes);
+    if (it != ctx->pool_free.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+        *out = it->second;
+        ctx->pool_cached -= it->first;
+        ctx->pool_free.erase(it);
+        return SF_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { // give cached blocks back and retry once
+        sf_pool_trim(ctx);
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        sf_set_error("out of device memory allocating %zu bytes: %s", bytes, hipGetErrorString(e));
+        return SF_ERR_NOMEM;
+    }
+    ctx->pool_size[p] = bytes;
+    *out = p;
+    return SF_OK;
+}
+
+void sf_pool_release(sf_ctx *ctx, void *p)
+{
+    if (!p) return;
+    auto it = ctx->pool_size.find(p);
+    if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
+    ctx->pool_free.emplace(it->second, p);
+    ctx->pool_cached += it->second;
+    if (ctx->pool_cached > ((size_t)96 << 30)) sf_pool_trim(ctx);
+}
+
+void sf_pool_trim(sf_ctx *ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool_free) {
+        (void)hipFree(kv.second);
+        ctx->pool_size.erase(kv.second);
+    }
+    ctx->pool_free.clear();
+    ctx->pool_cached = 0;
 }
 
 hipEvent_t sf_ctx_event(sf_ctx *ctx)

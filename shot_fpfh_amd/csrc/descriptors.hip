@@ -15,9 +15,18 @@
 namespace {
 
 // --------------------------------------------------------------------------------------------------
+// K3 / K4 share one structure: a wave owns 64 consecutive queries.
+//   phase A  for each of its queries in turn, all 64 lanes sweep that query's neighbour list and
+//            wave-reduce the moment sums; lane t keeps the sums of query t (no LDS, no scratch);
+//   phase B  every lane runs the LAPACK-compatible 3x3 eigensolver on ITS query (one solve per lane
+//            instead of one redundant solve per wave);
+//   phase C  (K4 only) the sign votes: lane t's axes are broadcast with v_readlane, the wave sweeps
+//            query t's list again and ballots the projections.
+// --------------------------------------------------------------------------------------------------
+__device__ inline double lane_bcast(double v, int src) { return __shfl(v, src); }
+
 // K3: normals.  cov = centered^T centered / k about the barycentre (pca_based_descriptors.py:21-23),
 // eigh, eigenvector of the smallest eigenvalue (:51), optional re-orientation (:53-57).
-// --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, const double *__restrict__ ys,
                                                  const double *__restrict__ zs, const double *__restrict__ qx,
                                                  const double *__restrict__ qy, const double *__restrict__ qz,
@@ -26,56 +35,61 @@ __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, 
                                                  const double *__restrict__ pre, double *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (q >= m) return;
-    const int64_t s = offset[q];
-    const int k = (int)(offset[q + 1] - s);
-    const int64_t row = qrow ? qrow[q] : q;
-    const double px = qx[q], py = qy[q], pz = qz[q];
-    // pass 1: barycentre, accumulated relative to the query to keep the sums small
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int t = lane; t < k; t += 64) {
-        const int j = idx[s + t];
-        sx += xs[j] - px;
-        sy += ys[j] - py;
-        sz += zs[j] - pz;
-    }
-    const double kk = (double)k;
-    const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
-    // pass 2: lower triangle of the centred second moments
+    const int64_t q0 = sf_uniform64(((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64);
+    if (q0 >= m) return;
+    const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
-    for (int t = lane; t < k; t += 64) {
-        const int j = idx[s + t];
-        const double ax = (xs[j] - px) - mx, ay = (ys[j] - py) - my, az = (zs[j] - pz) - mz;
-        c11 += ax * ax;
-        c21 += ay * ax;
-        c31 += az * ax;
-        c22 += ay * ay;
-        c32 += az * ay;
-        c33 += az * az;
+    for (int t = 0; t < nq; ++t) {
+        const int64_t q = q0 + t;
+        const int64_t s = offset[q];
+        const int k = (int)(offset[q + 1] - s);
+        const double px = qx[q], py = qy[q], pz = qz[q];
+        // pass 1: barycentre, accumulated relative to the query to keep the sums small
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int u = lane; u < k; u += 64) {
+            const int j = idx[s + u];
+            sx += xs[j] - px;
+            sy += ys[j] - py;
+            sz += zs[j] - pz;
+        }
+        const double kk = (double)k;
+        const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
+        // pass 2: lower triangle of the centred second moments
+        double a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
+        for (int u = lane; u < k; u += 64) {
+            const int j = idx[s + u];
+            const double ax = (xs[j] - px) - mx, ay = (ys[j] - py) - my, az = (zs[j] - pz) - mz;
+            a11 += ax * ax;
+            a21 += ay * ax;
+            a31 += az * ax;
+            a22 += ay * ay;
+            a32 += az * ay;
+            a33 += az * az;
+        }
+        a11 = sf_wave_sum(a11) / kk;
+        a21 = sf_wave_sum(a21) / kk;
+        a31 = sf_wave_sum(a31) / kk;
+        a22 = sf_wave_sum(a22) / kk;
+        a32 = sf_wave_sum(a32) / kk;
+        a33 = sf_wave_sum(a33) / kk;
+        if (lane == t) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; }
     }
-    c11 = sf_wave_sum(c11) / kk;
-    c21 = sf_wave_sum(c21) / kk;
-    c31 = sf_wave_sum(c31) / kk;
-    c22 = sf_wave_sum(c22) / kk;
-    c32 = sf_wave_sum(c32) / kk;
-    c33 = sf_wave_sum(c33) / kk;
-    const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33);
-    double nx = e.v11, ny = e.v21, nz = e.v31;
-    if (pre) {
-        const double dot = (nx * pre[3 * row] + ny * pre[3 * row + 1]) + nz * pre[3 * row + 2];
-        if (dot < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
-    }
-    if (lane == 0) {
+    if (lane < nq) {
+        const int64_t q = q0 + lane;
+        const int64_t row = qrow ? qrow[q] : q;
+        const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33);
+        double nx = e.v11, ny = e.v21, nz = e.v31;
+        if (pre) {
+            const double dot = (nx * pre[3 * row] + ny * pre[3 * row + 1]) + nz * pre[3 * row + 2];
+            if (dot < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+        }
         out[3 * row + 0] = nx;
         out[3 * row + 1] = ny;
         out[3 * row + 2] = nz;
     }
 }
 
-// --------------------------------------------------------------------------------------------------
 // K4: SHOT local reference frame (shot.py:16-48), query included in its own support.
-// --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs, const double *__restrict__ ys,
                                                   const double *__restrict__ zs, const double *__restrict__ qx,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
@@ -84,65 +98,89 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
                                                   double *__restrict__ lrf)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (q >= m) return;
-    const int64_t s = offset[q];
-    const int k = (int)(offset[q + 1] - s);
-    const int64_t row = qrow ? qrow[q] : q;
-    double *o = lrf + 9 * row;
-    if (k == 0) { // shot.py:24-25
-        if (lane < 9) o[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
-        return;
-    }
-    const double px = qx[q], py = qy[q], pz = qz[q];
-    // weighted covariance, w = r - ||c|| (shot.py:27-35)
-    double ws = 0, c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
-    for (int t = lane; t < k; t += 64) {
-        const int j = idx[s + t];
-        const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
-        const double w = radius - sqrt((cx * cx + cy * cy) + cz * cz);
-        ws += w;
-        const double wx = cx * w, wy = cy * w, wz = cz * w;
-        c11 += cx * wx;
-        c21 += cy * wx;
-        c31 += cz * wx;
-        c22 += cy * wy;
-        c32 += cz * wy;
-        c33 += cz * wz;
-    }
-    ws = sf_wave_sum(ws);
-    c11 = sf_wave_sum(c11) / ws;
-    c21 = sf_wave_sum(c21) / ws;
-    c31 = sf_wave_sum(c31) / ws;
-    c22 = sf_wave_sum(c22) / ws;
-    c32 = sf_wave_sum(c32) / ws;
-    c33 = sf_wave_sum(c33) / ws;
-    const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33); // shot.py:36
-    double x0 = e.v13, x1 = e.v23, x2 = e.v33; // eigenvectors[:, 2]
-    double z0 = e.v11, z1 = e.v21, z2 = e.v31; // eigenvectors[:, 0]
-    // sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
-    int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
-    for (int t0 = 0; t0 < k; t0 += 64) {
-        const int t = t0 + lane;
-        bool xn = false, xp = false, zn = false, zp = false;
-        if (t < k) {
-            const int j = idx[s + t];
+    const int64_t q0 = sf_uniform64(((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64);
+    if (q0 >= m) return;
+    const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
+    // phase A: weighted covariance, w = r - ||c|| (shot.py:27-35)
+    double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
+    for (int t = 0; t < nq; ++t) {
+        const int64_t q = q0 + t;
+        const int64_t s = offset[q];
+        const int k = (int)(offset[q + 1] - s);
+        const double px = qx[q], py = qy[q], pz = qz[q];
+        double ws = 0, a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
+        for (int u = lane; u < k; u += 64) {
+            const int j = idx[s + u];
             const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
-            const double xo = (cx * x0 + cy * x1) + cz * x2;
-            const double zo = (cx * z0 + cy * z1) + cz * z2;
-            xn = xo < 0.0; xp = xo >= 0.0;
-            zn = zo < 0.0; zp = zo >= 0.0;
+            const double w = radius - sqrt((cx * cx + cy * cy) + cz * cz);
+            ws += w;
+            const double wx = cx * w, wy = cy * w, wz = cz * w;
+            a11 += cx * wx;
+            a21 += cy * wx;
+            a31 += cz * wx;
+            a22 += cy * wy;
+            a32 += cz * wy;
+            a33 += cz * wz;
         }
-        xneg += __popcll(__ballot(xn)); xpos += __popcll(__ballot(xp));
-        zneg += __popcll(__ballot(zn)); zpos += __popcll(__ballot(zp));
+        ws = sf_wave_sum(ws);
+        a11 = sf_wave_sum(a11) / ws;
+        a21 = sf_wave_sum(a21) / ws;
+        a31 = sf_wave_sum(a31) / ws;
+        a22 = sf_wave_sum(a22) / ws;
+        a32 = sf_wave_sum(a32) / ws;
+        a33 = sf_wave_sum(a33) / ws;
+        if (lane == t) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; }
     }
-    if (xneg > xpos) { x0 = -x0; x1 = -x1; x2 = -x2; }
-    if (zneg > zpos) { z0 = -z0; z1 = -z1; z2 = -z2; }
-    const double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0; // cross(z, x) :46
-    if (lane == 0) { // columns [x y z] (:48)
-        o[0] = x0; o[1] = y0; o[2] = z0;
-        o[3] = x1; o[4] = y1; o[5] = z1;
-        o[6] = x2; o[7] = y2; o[8] = z2;
+    // phase B: one eigen-decomposition per lane (shot.py:36)
+    double x0 = 0, x1 = 0, x2 = 0, z0 = 0, z1 = 0, z2 = 0;
+    if (lane < nq) {
+        const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33);
+        x0 = e.v13; x1 = e.v23; x2 = e.v33; // eigenvectors[:, 2]
+        z0 = e.v11; z1 = e.v21; z2 = e.v31; // eigenvectors[:, 0]
+    }
+    // phase C: sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
+    bool flipx = false, flipz = false;
+    int kmine = 0;
+    for (int t = 0; t < nq; ++t) {
+        const int64_t q = q0 + t;
+        const int64_t s = offset[q];
+        const int k = (int)(offset[q + 1] - s);
+        const double px = qx[q], py = qy[q], pz = qz[q];
+        const double bx0 = lane_bcast(x0, t), bx1 = lane_bcast(x1, t), bx2 = lane_bcast(x2, t);
+        const double bz0 = lane_bcast(z0, t), bz1 = lane_bcast(z1, t), bz2 = lane_bcast(z2, t);
+        int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
+        for (int u0 = 0; u0 < k; u0 += 64) {
+            const int u = u0 + lane;
+            bool xn = false, xp = false, zn = false, zp = false;
+            if (u < k) {
+                const int j = idx[s + u];
+                const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+                const double xo = (cx * bx0 + cy * bx1) + cz * bx2;
+                const double zo = (cx * bz0 + cy * bz1) + cz * bz2;
+                xn = xo < 0.0; xp = xo >= 0.0;
+                zn = zo < 0.0; zp = zo >= 0.0;
+            }
+            xneg += __popcll(__ballot(xn)); xpos += __popcll(__ballot(xp));
+            zneg += __popcll(__ballot(zn)); zpos += __popcll(__ballot(zp));
+        }
+        if (lane == t) { flipx = xneg > xpos; flipz = zneg > zpos; kmine = k; }
+    }
+    if (lane < nq) {
+        const int64_t q = q0 + lane;
+        const int64_t row = qrow ? qrow[q] : q;
+        double *o = lrf + 9 * row;
+        if (kmine == 0) { // shot.py:24-25
+            o[0] = 1.0; o[1] = 0.0; o[2] = 0.0;
+            o[3] = 0.0; o[4] = 1.0; o[5] = 0.0;
+            o[6] = 0.0; o[7] = 0.0; o[8] = 1.0;
+        } else {
+            if (flipx) { x0 = -x0; x1 = -x1; x2 = -x2; }
+            if (flipz) { z0 = -z0; z1 = -z1; z2 = -z2; }
+            const double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0; // cross(z, x) :46
+            o[0] = x0; o[1] = y0; o[2] = z0; // columns [x y z] (:48)
+            o[3] = x1; o[4] = y1; o[5] = z1;
+            o[6] = x2; o[7] = y2; o[8] = z2;
+        }
     }
 }
 
@@ -403,7 +441,7 @@ extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *p
     SF_CHECK(stage_in(ctx, pre, (size_t)m * 3, flags, &dpre, &opre));
     SF_CHECK(stage_out(ctx, out, (size_t)m * 3, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs, nb->qx,
+        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3((unsigned)sf_div_up(m, 256)), dim3(256), c->xs, c->ys, c->zs, nb->qx,
                   nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, dpre, dout);
     }
     SF_CHECK(finish_out(ctx, out, (size_t)m * 3, dout, oout));
@@ -419,7 +457,7 @@ extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, i
     double *dout, *oout;
     SF_CHECK(stage_out(ctx, lrf, (size_t)m * 9, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs,
+        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3((unsigned)sf_div_up(m, 256)), dim3(256), c->xs, c->ys, c->zs,
                   nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, nb->radius, dout);
     }
     return finish_out(ctx, lrf, (size_t)m * 9, dout, oout);

@@ -105,8 +105,20 @@ struct tri3 {
             t = z33; z33 = ct * t - st * z32; z32 = st * t + ct * z32;
         }
     }
-    __device__ inline double &D(int i) { return i == 1 ? d1 : (i == 2 ? d2 : d3); }
-    __device__ inline double &E(int i) { return i == 1 ? e1 : e2; }
+    // select-based accessors: a run-time index into a register array would be spilled to scratch
+    __device__ inline double D(int i) const { return i == 1 ? d1 : (i == 2 ? d2 : d3); }
+    __device__ inline double E(int i) const { return i == 1 ? e1 : e2; }
+    __device__ inline void setD(int i, double v)
+    {
+        d1 = i == 1 ? v : d1;
+        d2 = i == 2 ? v : d2;
+        d3 = i == 3 ? v : d3;
+    }
+    __device__ inline void setE(int i, double v)
+    {
+        e1 = i == 1 ? v : e1;
+        e2 = i == 2 ? v : e2;
+    }
     __device__ inline void swap_cols(int i, int k)
     {
         // only (1,2), (1,3), (2,3) occur
@@ -128,12 +140,12 @@ __device__ inline void steqr3(tri3 &T)
     const int n = 3, nmaxit = 90;
     int jtot = 0, l1 = 1;
     while (l1 <= n) { // label 10
-        if (l1 > 1) T.E(l1 - 1) = 0.0;
+        if (l1 > 1) T.setE(l1 - 1, 0.0);
         int m = n;
         for (int mm = l1; mm <= n - 1; ++mm) {
             double tst = fabs(T.E(mm));
             if (tst == 0.0) { m = mm; break; }
-            if (tst <= (sqrt(fabs(T.D(mm))) * sqrt(fabs(T.D(mm + 1)))) * eps) { T.E(mm) = 0.0; m = mm; break; }
+            if (tst <= (sqrt(fabs(T.D(mm))) * sqrt(fabs(T.D(mm + 1)))) * eps) { T.setE(mm, 0.0); m = mm; break; }
         }
         int l = l1, lsv = l, lend = m, lendsv = lend;
         l1 = m + 1;
@@ -145,12 +157,12 @@ __device__ inline void steqr3(tri3 &T)
         if (anorm == 0.0) continue;
         if (anorm > ssfmax) {
             iscale = 1;
-            for (int i = l; i <= lend; ++i) T.D(i) = T.D(i) / anorm * ssfmax;
-            for (int i = l; i <= lend - 1; ++i) T.E(i) = T.E(i) / anorm * ssfmax;
+            for (int i = l; i <= lend; ++i) T.setD(i, T.D(i) / anorm * ssfmax);
+            for (int i = l; i <= lend - 1; ++i) T.setE(i, T.E(i) / anorm * ssfmax);
         } else if (anorm < ssfmin) {
             iscale = 2;
-            for (int i = l; i <= lend; ++i) T.D(i) = T.D(i) / anorm * ssfmin;
-            for (int i = l; i <= lend - 1; ++i) T.E(i) = T.E(i) / anorm * ssfmin;
+            for (int i = l; i <= lend; ++i) T.setD(i, T.D(i) / anorm * ssfmin);
+            for (int i = l; i <= lend - 1; ++i) T.setE(i, T.E(i) / anorm * ssfmin);
         }
         if (fabs(T.D(lend)) < fabs(T.D(l))) { lend = lsv; l = lendsv; }
         if (lend > l) {
@@ -162,7 +174,7 @@ __device__ inline void steqr3(tri3 &T)
                         double a = fabs(T.E(mm));
                         if (a * a <= (eps2 * fabs(T.D(mm))) * fabs(T.D(mm + 1)) + safmin) { m = mm; break; }
                     }
-                if (m < lend) T.E(m) = 0.0;
+                if (m < lend) T.setE(m, 0.0);
                 double p = T.D(l);
                 if (m == l) { // label 80
                     l = l + 1;
@@ -173,7 +185,7 @@ __device__ inline void steqr3(tri3 &T)
                     double rt1, rt2, c, s;
                     sym2x2(T.D(l), T.E(l), T.D(l + 1), rt1, rt2, c, s);
                     T.rot(l, c, s);
-                    T.D(l) = rt1; T.D(l + 1) = rt2; T.E(l) = 0.0;
+                    T.setD(l, rt1); T.setD(l + 1, rt2); T.setE(l, 0.0);
                     l = l + 2;
                     if (l <= lend) continue;
                     break;
@@ -190,19 +202,19 @@ __device__ inline void steqr3(tri3 &T)
                 for (int i = m - 1; i >= l; --i) {
                     double f = s * T.E(i), b = c * T.E(i);
                     givens(g, f, c, s, r);
-                    if (i != m - 1) T.E(i + 1) = r;
+                    if (i != m - 1) T.setE(i + 1, r);
                     g = T.D(i + 1) - p;
                     r = (T.D(i) - g) * s + 2.0 * c * b;
                     p = s * r;
-                    T.D(i + 1) = g + p;
+                    T.setD(i + 1, g + p);
                     g = c * r - b;
                     if (i == l) { c_lo = c; s_lo = -s; } else { c_hi = c; s_hi = -s; }
                 }
                 // dlasr('R','V','B') over columns l..m: j = m-1 first, then down to l
                 if (m - l == 2) { T.rot(l + 1, c_hi, s_hi); T.rot(l, c_lo, s_lo); }
                 else T.rot(l, c_lo, s_lo);
-                T.D(l) = T.D(l) - p;
-                T.E(l) = g;
+                T.setD(l, T.D(l) - p);
+                T.setE(l, g);
             }
         } else {
             // ---- QR iteration ----
@@ -213,7 +225,7 @@ __device__ inline void steqr3(tri3 &T)
                         double a = fabs(T.E(mm - 1));
                         if (a * a <= (eps2 * fabs(T.D(mm))) * fabs(T.D(mm - 1)) + safmin) { m = mm; break; }
                     }
-                if (m > lend) T.E(m - 1) = 0.0;
+                if (m > lend) T.setE(m - 1, 0.0);
                 double p = T.D(l);
                 if (m == l) { // label 130
                     l = l - 1;
@@ -224,7 +236,7 @@ __device__ inline void steqr3(tri3 &T)
                     double rt1, rt2, c, s;
                     sym2x2(T.D(l - 1), T.E(l - 1), T.D(l), rt1, rt2, c, s);
                     T.rot(l - 1, c, s);
-                    T.D(l - 1) = rt1; T.D(l) = rt2; T.E(l - 1) = 0.0;
+                    T.setD(l - 1, rt1); T.setD(l, rt2); T.setE(l - 1, 0.0);
                     l = l - 2;
                     if (l >= lend) continue;
                     break;
@@ -240,27 +252,27 @@ __device__ inline void steqr3(tri3 &T)
                 for (int i = m; i <= l - 1; ++i) {
                     double f = s * T.E(i), b = c * T.E(i);
                     givens(g, f, c, s, r);
-                    if (i != m) T.E(i - 1) = r;
+                    if (i != m) T.setE(i - 1, r);
                     g = T.D(i) - p;
                     r = (T.D(i + 1) - g) * s + 2.0 * c * b;
                     p = s * r;
-                    T.D(i) = g + p;
+                    T.setD(i, g + p);
                     g = c * r - b;
                     if (i == m) { c_lo = c; s_lo = s; } else { c_hi = c; s_hi = s; }
                 }
                 // dlasr('R','V','F') over columns m..l: j = m first, then up
                 T.rot(m, c_lo, s_lo);
                 if (l - m == 2) T.rot(m + 1, c_hi, s_hi);
-                T.D(l) = T.D(l) - p;
-                T.E(l - 1) = g;
+                T.setD(l, T.D(l) - p);
+                T.setE(l - 1, g);
             }
         }
         if (iscale == 1) {
-            for (int i = lsv; i <= lendsv; ++i) T.D(i) = T.D(i) / ssfmax * anorm;
-            for (int i = lsv; i <= lendsv - 1; ++i) T.E(i) = T.E(i) / ssfmax * anorm;
+            for (int i = lsv; i <= lendsv; ++i) T.setD(i, T.D(i) / ssfmax * anorm);
+            for (int i = lsv; i <= lendsv - 1; ++i) T.setE(i, T.E(i) / ssfmax * anorm);
         } else if (iscale == 2) {
-            for (int i = lsv; i <= lendsv; ++i) T.D(i) = T.D(i) / ssfmin * anorm;
-            for (int i = lsv; i <= lendsv - 1; ++i) T.E(i) = T.E(i) / ssfmin * anorm;
+            for (int i = lsv; i <= lendsv; ++i) T.setD(i, T.D(i) / ssfmin * anorm);
+            for (int i = lsv; i <= lendsv - 1; ++i) T.setE(i, T.E(i) / ssfmin * anorm);
         }
         if (jtot >= nmaxit) break;
     }
@@ -271,8 +283,8 @@ __device__ inline void steqr3(tri3 &T)
         for (int j = ii; j <= n; ++j)
             if (T.D(j) < p) { k = j; p = T.D(j); }
         if (k != i) {
-            T.D(k) = T.D(i);
-            T.D(i) = p;
+            T.setD(k, T.D(i));
+            T.setD(i, p);
             T.swap_cols(i, k);
         }
     }

@@ -113,9 +113,13 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
             if (d2 > 0.0) w = (1.0 / (double)kk[j]) / sqrt(d2);
         }
         const int cnt = min(64, k - t0);
+        // tt is wave-uniform: v_readlane gives the neighbour index / weight as scalars, the row base is a
+        // scalar address and the 8-deep unroll keeps several independent row loads in flight
+#pragma unroll 8
         for (int tt = 0; tt < cnt; ++tt) {
-            const int jj = __shfl(j, tt);
-            const double ww = __shfl(w, tt);
+            const int jj = __builtin_amdgcn_readlane(j, tt);
+            const double ww = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(w), tt),
+                                               __builtin_amdgcn_readlane(__double2loint(w), tt));
             const CT *rowp = counts + (int64_t)jj * stride;
 #pragma unroll
             for (int u = 0; u < NB2; ++u) {
@@ -359,7 +363,7 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
     if (rc == SF_OK && owned) {
         if (tot) SF_HIP(hipMemcpyAsync(out, owned, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
-    SF_HIP(hipStreamSynchronize(ctx->stream));
+    if (owned || pos) SF_HIP(hipStreamSynchronize(ctx->stream));
     if (owned) SF_HIP(hipFree(owned));
     if (pos) SF_HIP(hipFree(pos));
     return rc;

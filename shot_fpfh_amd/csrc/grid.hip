@@ -93,11 +93,13 @@ __global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t n, 
 
 } // namespace
 
-static void cloud_release_grid(sf_cloud *c)
+static void cloud_release_grid(sf_ctx *ctx, sf_cloud *c)
 {
     void *ptrs[] = {c->cell_start, c->perm, c->inv_perm, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (ctx) sf_pool_release(ctx, p); else (void)hipFree(p);
+        }
     c->cell_start = c->perm = c->inv_perm = nullptr;
     c->xs = c->ys = c->zs = c->nxs = c->nys = c->nzs = nullptr;
     c->normals_sorted = false;
@@ -156,9 +158,9 @@ int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
     if (!c->perm) { sf_set_error("grid not built"); return SF_ERR_STATE; }
     size_t bytes = (size_t)(c->n ? c->n : 1) * sizeof(double);
     if (!c->nxs) {
-        SF_HIP(hipMalloc(&c->nxs, bytes));
-        SF_HIP(hipMalloc(&c->nys, bytes));
-        SF_HIP(hipMalloc(&c->nzs, bytes));
+        SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nxs));
+        SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nys));
+        SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nzs));
     }
     if (c->n) {
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(c->n, 256)), dim3(256),
@@ -175,7 +177,7 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
         return SF_ERR_ARG;
     }
     SF_HIP(hipSetDevice(ctx->device));
-    cloud_release_grid(c);
+    cloud_release_grid(ctx, c);
     const int64_t n = c->n;
     // ---- bounding box -------------------------------------------------------------------------
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -221,12 +223,12 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
     for (int a = 0; a < 3; ++a) c->lo[a] = lo[a];
 
     size_t nn = (size_t)(n ? n : 1);
-    SF_HIP(hipMalloc(&c->cell_start, (size_t)(ncell + 1) * sizeof(int32_t)));
-    SF_HIP(hipMalloc(&c->perm, nn * sizeof(int32_t)));
-    SF_HIP(hipMalloc(&c->inv_perm, nn * sizeof(int32_t)));
-    SF_HIP(hipMalloc(&c->xs, nn * sizeof(double)));
-    SF_HIP(hipMalloc(&c->ys, nn * sizeof(double)));
-    SF_HIP(hipMalloc(&c->zs, nn * sizeof(double)));
+    SF_CHECK(sf_palloc(ctx, &c->cell_start, (size_t)(ncell + 1)));
+    SF_CHECK(sf_palloc(ctx, &c->perm, nn));
+    SF_CHECK(sf_palloc(ctx, &c->inv_perm, nn));
+    SF_CHECK(sf_palloc(ctx, &c->xs, nn));
+    SF_CHECK(sf_palloc(ctx, &c->ys, nn));
+    SF_CHECK(sf_palloc(ctx, &c->zs, nn));
     if (!n) {
         SF_HIP(hipMemsetAsync(c->cell_start, 0, (size_t)(ncell + 1) * sizeof(int32_t), ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
@@ -234,9 +236,9 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
     }
     // ---- cell ids, stable radix sort (ties keep ascending original index), SoA gather ---------
     int32_t *cid = nullptr, *cid_sorted = nullptr, *val = nullptr;
-    SF_HIP(hipMalloc(&cid, nn * sizeof(int32_t)));
-    SF_HIP(hipMalloc(&cid_sorted, nn * sizeof(int32_t)));
-    SF_HIP(hipMalloc(&val, nn * sizeof(int32_t)));
+    SF_CHECK(sf_palloc(ctx, &cid, nn));
+    SF_CHECK(sf_palloc(ctx, &cid_sorted, nn));
+    SF_CHECK(sf_palloc(ctx, &val, nn));
     sf_grid_desc g = sf_make_grid_desc(c);
     SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, g, cid,
               val);
@@ -246,7 +248,7 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
     SF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, cid, cid_sorted, val, c->perm, (size_t)n, 0, bits,
                                      ctx->stream));
     void *tmp = nullptr;
-    SF_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    SF_CHECK(sf_pool_alloc(ctx, tmp_bytes ? tmp_bytes : 8, &tmp));
     {
         sf_launch_timer t_(ctx, "k1_radix_sort");
         SF_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cid, cid_sorted, val, c->perm, (size_t)n, 0, bits,
@@ -256,11 +258,10 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
               c->perm, n, c->xs, c->ys, c->zs, c->inv_perm);
     SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, n,
               ncell, c->cell_start);
-    SF_HIP(hipStreamSynchronize(ctx->stream));
-    SF_HIP(hipFree(tmp));
-    SF_HIP(hipFree(cid));
-    SF_HIP(hipFree(cid_sorted));
-    SF_HIP(hipFree(val));
+    sf_pool_release(ctx, tmp);
+    sf_pool_release(ctx, cid);
+    sf_pool_release(ctx, cid_sorted);
+    sf_pool_release(ctx, val);
     return SF_OK;
 }
 
@@ -306,7 +307,7 @@ extern "C" void sf_cloud_free(sf_ctx *ctx, sf_cloud *c)
 {
     if (!c) return;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    cloud_release_grid(c);
+    cloud_release_grid(ctx, c);
     if (c->xyz_orig) (void)hipFree(c->xyz_orig);
     if (c->nrm_orig) (void)hipFree(c->nrm_orig);
     delete c;

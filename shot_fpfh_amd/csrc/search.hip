@@ -137,8 +137,8 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
 {
     const int64_t m = nb->m;
     const double r2 = nb->radius * nb->radius;
-    SF_HIP(hipMalloc(&nb->count, (size_t)(m + 1) * sizeof(int32_t)));
-    SF_HIP(hipMalloc(&nb->offset, (size_t)(m + 1) * sizeof(int64_t)));
+    SF_CHECK(sf_palloc(ctx, &nb->count, (size_t)(m + 1)));
+    SF_CHECK(sf_palloc(ctx, &nb->offset, (size_t)(m + 1)));
     SF_HIP(hipMemsetAsync(nb->count, 0, (size_t)(m + 1) * sizeof(int32_t), ctx->stream));
     sf_grid_desc g = sf_make_grid_desc(c);
     const dim3 grid((unsigned)sf_div_up(m ? m : 1, 4)), block(256);
@@ -156,7 +156,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
                            ctx->stream));
     void *tmp = nullptr;
     size_t tb = std::max(tb1, tb2);
-    SF_HIP(hipMalloc(&tmp, (tb ? tb : 8) + 16));
+    SF_CHECK(sf_pool_alloc(ctx, (tb ? tb : 8) + 16, &tmp));
     d_max = (int32_t *)((char *)tmp + ((tb + 7) / 8) * 8);
     {
         sf_launch_timer t_(ctx, "k2_scan");
@@ -170,10 +170,10 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     SF_HIP(hipMemcpyAsync(&total, nb->offset + m, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipMemcpyAsync(&mx, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    SF_HIP(hipFree(tmp));
+    sf_pool_release(ctx, tmp);
     nb->total = total;
     nb->max_count = mx;
-    SF_HIP(hipMalloc(&nb->idx, (size_t)(total ? total : 1) * sizeof(int32_t)));
+    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)total));
     if (m && total) {
         SF_LAUNCH(ctx, "k2_radius_fill", k_radius<true>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
                   nb->qy, nb->qz, m, r2, (int32_t *)nullptr, (const int64_t *)nb->offset, nb->idx);
@@ -226,19 +226,19 @@ static int prepare_queries(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *
     if (flags & SF_IN_DEVICE) {
         dq = const_cast<double *>(queries);
     } else {
-        SF_HIP(hipMalloc(&dq, mm * 24));
+        SF_CHECK(sf_palloc(ctx, &dq, mm * 3));
         own_dq = true;
         if (m) SF_HIP(hipMemcpyAsync(dq, queries, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
     }
-    SF_HIP(hipMalloc(&nb->qx, mm * sizeof(double)));
-    SF_HIP(hipMalloc(&nb->qy, mm * sizeof(double)));
-    SF_HIP(hipMalloc(&nb->qz, mm * sizeof(double)));
-    SF_HIP(hipMalloc(&nb->qrow, mm * sizeof(int32_t)));
+    SF_CHECK(sf_palloc(ctx, &nb->qx, mm));
+    SF_CHECK(sf_palloc(ctx, &nb->qy, mm));
+    SF_CHECK(sf_palloc(ctx, &nb->qz, mm));
+    SF_CHECK(sf_palloc(ctx, &nb->qrow, mm));
     if (m) {
         int32_t *cid = nullptr, *cid_s = nullptr, *val = nullptr;
-        SF_HIP(hipMalloc(&cid, mm * sizeof(int32_t)));
-        SF_HIP(hipMalloc(&cid_s, mm * sizeof(int32_t)));
-        SF_HIP(hipMalloc(&val, mm * sizeof(int32_t)));
+        SF_CHECK(sf_palloc(ctx, &cid, mm));
+        SF_CHECK(sf_palloc(ctx, &cid_s, mm));
+        SF_CHECK(sf_palloc(ctx, &val, mm));
         sf_grid_desc g = sf_make_grid_desc(c);
         SF_LAUNCH(ctx, "k2_query_cells", k_query_cells, dim3((unsigned)sf_div_up(m, 256)), dim3(256), dq, m, g, cid,
                   val);
@@ -247,20 +247,22 @@ static int prepare_queries(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *
         size_t tb = 0;
         SF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
         void *tmp = nullptr;
-        SF_HIP(hipMalloc(&tmp, tb ? tb : 8));
+        SF_CHECK(sf_pool_alloc(ctx, tb ? tb : 8, &tmp));
         {
             sf_launch_timer t_(ctx, "k2_query_sort");
             SF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
         }
         SF_LAUNCH(ctx, "k2_gather_queries", k_gather_queries, dim3((unsigned)sf_div_up(m, 256)), dim3(256), dq,
                   nb->qrow, m, nb->qx, nb->qy, nb->qz);
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(tmp));
-        SF_HIP(hipFree(cid));
-        SF_HIP(hipFree(cid_s));
-        SF_HIP(hipFree(val));
+        sf_pool_release(ctx, tmp);
+        sf_pool_release(ctx, cid);
+        sf_pool_release(ctx, cid_s);
+        sf_pool_release(ctx, val);
     }
-    if (own_dq) SF_HIP(hipFree(dq));
+    if (own_dq) {
+        SF_HIP(hipStreamSynchronize(ctx->stream)); // the host source buffer of the async copy is the caller's
+        sf_pool_release(ctx, dq);
+    }
     return SF_OK;
 }
 
@@ -347,13 +349,13 @@ extern "C" int sf_nbrs_export(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t *of
                                     ctx->stream));
     if (dist && total) {
         double *dd = nullptr;
-        SF_HIP(hipMalloc(&dd, (size_t)total * sizeof(double)));
+        SF_CHECK(sf_palloc(ctx, &dd, (size_t)total));
         SF_LAUNCH(ctx, "k2_pair_dist", k_pair_dist, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs,
                   nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, m, dd);
         rawd.resize((size_t)total);
         SF_HIP(hipMemcpyAsync(rawd.data(), dd, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(dd));
+        sf_pool_release(ctx, dd);
     }
     SF_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<std::pair<int32_t, double>> tmp;
@@ -381,15 +383,15 @@ extern "C" void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nb)
 {
     if (!nb) return;
     if (nb->view) { delete nb; return; }
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (!ctx) { delete nb; return; } // leaked on purpose: no context to return the blocks to
     if (!nb->self) {
-        if (nb->qx) (void)hipFree(nb->qx);
-        if (nb->qy) (void)hipFree(nb->qy);
-        if (nb->qz) (void)hipFree(nb->qz);
+        sf_pool_release(ctx, nb->qx);
+        sf_pool_release(ctx, nb->qy);
+        sf_pool_release(ctx, nb->qz);
     }
-    if (nb->qrow) (void)hipFree(nb->qrow);
-    if (nb->count) (void)hipFree(nb->count);
-    if (nb->offset) (void)hipFree(nb->offset);
-    if (nb->idx) (void)hipFree(nb->idx);
+    sf_pool_release(ctx, nb->qrow);
+    sf_pool_release(ctx, nb->count);
+    sf_pool_release(ctx, nb->offset);
+    sf_pool_release(ctx, nb->idx);
     delete nb;
 }
