@@ -121,6 +121,9 @@ class Engine:
     def cloud(self, points, normals=None) -> "Cloud":
         return Cloud(self, points, normals)
 
+    def spfh(self, cloud: "Cloud", n_bins: int, max_count: int) -> "Spfh":
+        return Spfh(cloud, n_bins, max_count)
+
     # ---- matching (K8) / RANSAC scoring (K9) ------------------------------------------------------
     def match_argmin(self, a, b, want_dist=True, want_col=False):
         """Row arg-min of cdist(a, b) (first minimum), winners' distances, optional column arg-min."""

@@ -91,7 +91,7 @@ class DescriptorJob:
         if self.spfh is None or wide != self._spfh_wide:
             if self.spfh is not None:
                 self.spfh.free()
-            self.spfh = Spfh(self.cloud, self.n_bins, max_count)
+            self.spfh = self.engine.spfh(self.cloud, self.n_bins, max_count)
             self._spfh_wide = wide
         return self.spfh
 

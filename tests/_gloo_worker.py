@@ -1,0 +1,41 @@
+"""Worker of tests/test_multi_gpu_gloo.py: one rank of a world_size-2 gloo job running DescriptorJob on
+the oracle-backed FakeEngine, then handing its block to rank 0."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import synth_cloud  # noqa: E402
+from fake_engine import FakeEngine  # noqa: E402
+from shot_fpfh_amd.sharding import DescriptorJob  # noqa: E402
+
+
+def main():
+    out_path, mode = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p, nr, _ = synth_cloud(1500, 41)
+    job = DescriptorJob(FakeEngine(), p, nr, 0.15, n_bins=5, normalize=True, min_neighborhood_size=5, world=world,
+                        rank=rank, spfh_exchange=mode)
+    job.step()
+    mine = (job.block_original_indices(), job.fpfh_out.to_host(), job.shot_out.to_host())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        n = p.shape[0]
+        fpfh, shot, seen = np.full((n, 125), np.nan), np.full((n, 352), np.nan), np.zeros(n, dtype=int)
+        for rows, f, s in gathered:
+            fpfh[rows], shot[rows] = f, s
+            seen[rows] += 1
+        np.savez(out_path, fpfh=fpfh, shot=shot, seen=seen)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""Oracle-backed stand-in for shot_fpfh_amd.engine.Engine -- TEST INFRASTRUCTURE ONLY.
+
+It lets the multi-process sharding logic (shot_fpfh_amd/sharding.py: block planning, halo ranges, list
+slicing, SPFH exchange) run under world_size-2 gloo on a machine without GPUs.  It implements exactly
+the calls DescriptorJob makes, with NumPy + the CPU oracle, and deliberately poisons (NaN) every SPFH
+row a rank did not compute so that a wrong halo or a missing exchange cannot go unnoticed.
+"""
+import numpy as np
+
+from oracle import oracle as O
+
+
+class FakeArray:
+    def __init__(self, shape):
+        self.a = np.full(shape, np.nan)
+
+    def to_host(self):
+        return self.a.copy()
+
+    def free(self):
+        pass
+
+
+class FakeNbrs:
+    def __init__(self, cloud, radius, begin, off, idx_sorted):
+        self.cloud, self.radius, self.begin = cloud, radius, begin
+        self.off, self.idx = off, idx_sorted
+        self.m = len(off) - 1
+        self.total = int(off[-1] - off[0])
+        self.max_count = int(np.diff(off).max()) if self.m else 0
+
+    def slice(self, first, count):
+        return FakeNbrs(self.cloud, self.radius, self.begin + first, self.off[first:first + count + 1], self.idx)
+
+    def _queries(self):
+        return self.cloud.ps[self.begin:self.begin + self.m]
+
+    def shot_lrf(self, out=None):
+        out.a[:] = O.shot_lrf(self.cloud.ps, self._queries(), self.radius).reshape(self.m, 9)
+        return out
+
+    def shot(self, lrf, normalize, min_nb, out=None):
+        out.a[:] = O.shot(self.cloud.ps, self.cloud.ns, self._queries(), self.radius, lrf.a, normalize, min_nb)
+        return out
+
+    def free(self):
+        pass
+
+
+class FakeSpfh:
+    def __init__(self, cloud, n_bins):
+        self.cloud, self.n_bins = cloud, n_bins
+        self.table = np.full((cloud.n, n_bins**3), np.nan)
+        self.k = np.zeros(cloud.n, dtype=np.int64)
+        self._full = None
+
+    def compute(self, nb):
+        if self._full is None:  # the oracle's SPFH of the whole cloud, by sorted position
+            _, sp = O.compute_fpfh_descriptor(np.zeros(0, dtype=np.int64), self.cloud.ps, self.cloud.ns, nb.radius,
+                                              self.n_bins, return_spfh=True)
+            self._full = sp
+        self.table[:] = np.nan
+        rows = slice(nb.begin, nb.begin + nb.m)
+        self.table[rows] = self._full[rows]
+        self.k[rows] = np.diff(nb.off)
+        return self
+
+    def allgather(self, rows_per_rank):
+        import torch
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(), dist.get_rank()
+        pad = rows_per_rank * world
+        buf = np.zeros((pad, self.table.shape[1]))
+        buf[: self.cloud.n] = np.nan_to_num(self.table, nan=-7.0)
+        mine = torch.from_numpy(buf[rank * rows_per_rank:(rank + 1) * rows_per_rank].copy())
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        full = torch.cat(parts).numpy()[: self.cloud.n]
+        self.table = np.where(full == -7.0, np.nan, full)
+
+    def fpfh(self, blk, kp, out=None):
+        ps = self.cloud.ps
+        for q in range(blk.m):
+            i = blk.begin + q
+            js = blk.idx[blk.off[q]:blk.off[q + 1]]
+            d = np.sqrt(((ps[js] - ps[i]) ** 2).sum(axis=1))
+            keep = d > 0
+            acc = (self.table[js[keep]] / d[keep, None]).sum(axis=0) if keep.any() else 0.0
+            out.a[q] = self.table[i] + acc / len(js)
+        return out
+
+    def free(self):
+        pass
+
+
+class FakeCloud:
+    def __init__(self, points, normals):
+        self.p, self.nr = np.asarray(points, dtype=np.float64), np.asarray(normals, dtype=np.float64)
+        self.n = self.p.shape[0]
+
+    def build_grid(self, cell):
+        edge = cell * (1.0 + 2.0**-20)
+        self.lo = self.p.min(axis=0)
+        c = np.floor((self.p - self.lo) / edge).astype(np.int64)
+        self.dim = c.max(axis=0) + 1
+        cid = (c[:, 2] * self.dim[1] + c[:, 1]) * self.dim[0] + c[:, 0]
+        self._perm = np.argsort(cid, kind="stable")
+        self.ps, self.ns = np.ascontiguousarray(self.p[self._perm]), np.ascontiguousarray(self.nr[self._perm])
+        self.cz = c[self._perm, 2]
+
+    def perm(self):
+        return self._perm.astype(np.int32)
+
+    def halo_range(self, b, e):
+        if b == e:
+            return b, e
+        z0, z1 = self.cz[b], self.cz[e - 1]
+        inside = np.flatnonzero((self.cz >= z0 - 1) & (self.cz <= z1 + 1))
+        return int(min(inside[0], b)), int(max(inside[-1] + 1, e))
+
+    def radius_search_self(self, radius, begin=0, end=None):
+        end = self.n if end is None else end
+        off, idx = O.radius_search(self.ps, self.ps[begin:end], radius)
+        return FakeNbrs(self, radius, begin, off, idx.astype(np.int64))
+
+    def free(self):
+        pass
+
+
+class FakeEngine:
+    def cloud(self, points, normals=None):
+        return FakeCloud(points, normals)
+
+    def empty(self, shape, dtype=np.float64):
+        return FakeArray(shape)
+
+    def spfh(self, cloud, n_bins, max_count):
+        return FakeSpfh(cloud, n_bins)

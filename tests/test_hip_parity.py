@@ -235,3 +235,31 @@ def test_ransac_golden(eng):
                                     draw_size=4, distance_threshold=float(g["thr"]), disable_progress_bar=True)
     assert ratio == float(g["ratio"])
     assert np.array_equal(tf.rotation, g["rotation"]) and np.array_equal(tf.translation, g["translation"])
+
+
+# ---- sharding on one device: G shards run one after the other must reproduce the single-shard result -------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_blocks_bit_identical_to_single(eng, O, world):
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    p, nr, _ = synth_cloud(20000, 51)
+    r = 0.08
+
+    def run(w):
+        f, s = np.zeros((20000, 125)), np.zeros((20000, 352))
+        seen = np.zeros(20000, dtype=int)
+        for rank in range(w):
+            job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=w, rank=rank)
+            job.step()
+            rows = job.block_original_indices()
+            f[rows], s[rows] = job.fpfh_out.to_host(), job.shot_out.to_host()
+            seen[rows] += 1
+            job.close()
+        assert (seen == 1).all()
+        return f, s
+
+    f1, s1 = run(1)
+    fw, sw = run(world)
+    assert np.array_equal(f1, fw) and np.array_equal(s1, sw)
+    fo = O.compute_fpfh_descriptor(np.arange(20000), p, nr, r, 5)
+    assert close(f1, fo).all()

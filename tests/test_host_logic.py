@@ -1,0 +1,98 @@
+"""Host-side pieces of the drop-in (no GPU): filters, voxel subsampling, Kabsch solver / RigidTransform,
+histogram edges, shard planning."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, synth_cloud
+
+
+def test_grid_subsampling_matches_reference_golden():
+    from shot_fpfh_amd.core import grid_subsampling
+
+    g = load_golden("grid_sub_20k.npz")
+    p, _, _ = synth_cloud(int(g["n"]), int(g["seed"]))
+    assert np.array_equal(grid_subsampling(p, float(g["voxel"])), g["idx"])
+    s = load_golden("shot_150.npz")
+    assert np.array_equal(grid_subsampling(s["cloud"], float(s["voxel"])), s["support"])
+    assert np.array_equal(grid_subsampling(s["cloud"], 0.008), s["support_008"])
+
+
+def test_kabsch_and_rigid_transform_match_golden_draws():
+    from shot_fpfh_amd.core import RigidTransform, solver_point_to_point
+
+    g = load_golden("ransac_500.npz")
+    a, b = g["scan_kp"][g["scan_idx"]], g["ref_kp"][g["ref_idx"]]
+    for d, rt in list(zip(g["draws"], g["draw_rt"]))[:50]:
+        tf = solver_point_to_point(a[d], b[d])
+        assert np.array_equal(tf.as_row12(), rt)
+        assert abs(np.linalg.det(tf.rotation) - 1.0) < 1e-9
+    tf = RigidTransform(g["rotation"], g["translation"])
+    assert np.allclose(tf[a[:5]], a[:5] @ g["rotation"].T + g["translation"])
+    inv = ~tf
+    assert np.array_equal(inv.rotation, g["rotation"].T) and np.array_equal(inv.translation, -g["translation"])
+    assert "\n" in repr(tf)
+
+
+def test_ransac_draw_stream_is_the_reference_stream():
+    g = load_golden("ransac_500.npz")
+    gen = np.random.default_rng(seed=72)
+    mine = np.stack([gen.choice(500, 4, replace=False, shuffle=False) for _ in range(len(g["draws"]))])
+    assert np.array_equal(mine, g["draws"])
+
+
+def test_filters():
+    from shot_fpfh_amd.matching import left_median_filter, quantile_filter, threshold_filter
+
+    d = np.array([0.0, 0.5, 1.0, 2.0, 8.0, 0.25])
+    assert threshold_filter(d, 4).tolist() == [True, True, True, False, False, True]
+    assert quantile_filter(d, (0.2, 0.8)).tolist() == [False, True, True, True, False, True]
+    # (median + index of the first non-zero distance) / 2 -- the reference's own formula
+    assert left_median_filter(d).tolist() == [(x <= 0.75) and (x >= (0.75 + 1) / 2) for x in d]
+
+
+def test_fpfh_edges_are_histogramdd_edges():
+    from shot_fpfh_amd.engine import fpfh_edges
+
+    rng = np.random.default_rng(0)
+    sample = rng.random((50, 3)) * 2 - 1
+    for nb in (3, 4, 5, 8):
+        _, edges = np.histogramdd(sample, bins=nb, range=[(-1, 1), (-1, 1), (-np.pi / 2, np.pi / 2)])
+        e = fpfh_edges(nb)
+        assert e.shape == (3, nb + 1)
+        for a in range(3):
+            assert np.array_equal(e[a], edges[a])
+
+
+def test_shard_plan_partitions_exactly():
+    from shot_fpfh_amd.sharding import ShardPlan
+
+    for n in (0, 1, 7, 1000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            blocks = [ShardPlan(n, world, r).block() for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            assert all(e - b <= ShardPlan(n, world, 0).rows_per_rank for b, e in blocks)
+    with pytest.raises(ValueError):
+        ShardPlan(10, 2, 2)
+
+
+def test_api_surface_matches_reference_signatures():
+    import inspect
+
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor, compute_fpfh_descriptor, compute_normals
+    from shot_fpfh_amd.matching import basic_matching, match_descriptors, ransac_on_matches
+
+    p = list(inspect.signature(compute_fpfh_descriptor).parameters)
+    assert p[:8] == ["keypoints_indices", "cloud_points", "normals", "radius", "n_bins", "decorrelated", "verbose",
+                     "disable_progress_bars"]
+    p = inspect.signature(compute_normals).parameters
+    assert list(p)[:2] == ["query_points", "cloud_points"] and p["k"].kind is inspect.Parameter.KEYWORD_ONLY
+    sm = ShotMultiprocessor()
+    assert (sm.normalize, sm.share_local_rfs, sm.min_neighborhood_size, sm.n_procs) == (True, True, 100, 8)
+    p = list(inspect.signature(sm.compute_descriptor_single_scale).parameters)
+    assert p == ["point_cloud", "normals", "keypoints", "radius", "subsampling_voxel_size"]
+    p = list(inspect.signature(match_descriptors).parameters)
+    assert p[:6] == ["scan_descriptors", "ref_descriptors", "filter_callback", "filter_nonreciprocal", "verbose", "n_min_matches"]
+    p = inspect.signature(ransac_on_matches).parameters
+    assert (p["n_draws"].default, p["draw_size"].default, p["distance_threshold"].default) == (10000, 4, 1)
+    assert list(inspect.signature(basic_matching).parameters)[:2] == ["scan_descriptors", "ref_descriptors"]
