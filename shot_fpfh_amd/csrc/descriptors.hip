@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, 
                                                  const double *__restrict__ pre, double *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t q0 = sf_uniform64(((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64);
+    const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
     if (q0 >= m) return;
     const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
                                                   double *__restrict__ lrf)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t q0 = sf_uniform64(((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64);
+    const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
     if (q0 >= m) return;
     const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
     // phase A: weighted covariance, w = r - ||c|| (shot.py:27-35)
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, cons
     __shared__ unsigned long long sA[352], sB[352], sG[352], sCD[176], sEF[176];
     __shared__ double sD[176], sF[176];
     const int lane = threadIdx.x;
-    const int64_t q = blockIdx.x;
+    const int64_t q = sf_xcd_block();
     if (q >= m) return;
     const int64_t s = offset[q];
     const int k = (int)(offset[q + 1] - s);
@@ -441,7 +441,7 @@ extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *p
     SF_CHECK(stage_in(ctx, pre, (size_t)m * 3, flags, &dpre, &opre));
     SF_CHECK(stage_out(ctx, out, (size_t)m * 3, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3((unsigned)sf_div_up(m, 256)), dim3(256), c->xs, c->ys, c->zs, nb->qx,
+        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->xs, c->ys, c->zs, nb->qx,
                   nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, dpre, dout);
     }
     SF_CHECK(finish_out(ctx, out, (size_t)m * 3, dout, oout));
@@ -457,7 +457,7 @@ extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, i
     double *dout, *oout;
     SF_CHECK(stage_out(ctx, lrf, (size_t)m * 9, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3((unsigned)sf_div_up(m, 256)), dim3(256), c->xs, c->ys, c->zs,
+        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->xs, c->ys, c->zs,
                   nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, nb->radius, dout);
     }
     return finish_out(ctx, lrf, (size_t)m * 9, dout, oout);
@@ -475,7 +475,7 @@ extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf,
     SF_CHECK(stage_in(ctx, lrf, (size_t)m * 9, flags, &dlrf, &olrf));
     SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k5_shot", k_shot, dim3((unsigned)m), dim3(64), c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs,
+        SF_LAUNCH(ctx, "k5_shot", k_shot, dim3(sf_xcd_grid(m)), dim3(64), c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs,
                   nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, nb->radius, dlrf, normalize, min_nb, dout);
     }
     SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));

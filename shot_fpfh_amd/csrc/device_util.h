@@ -40,6 +40,18 @@ __device__ inline double sf_wave_sum(double v)
     return v;
 }
 
+// XCD-aware block remap.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks
+// share an XCD / an L2).  Consecutive queries are spatial neighbours (cell-sorted order), so giving each
+// XCD ONE contiguous eighth of the queries makes the cells a query needs hot in that XCD's own 4 MB L2
+// instead of replicating the whole moving working set in all eight.  Launch grids padded with
+// sf_xcd_grid(); the returned virtual block id may be >= the real block count (the caller's bound check
+// on the query index covers it).  Placement only changes speed, never results.
+__device__ inline long long sf_xcd_block()
+{
+    const unsigned b = blockIdx.x, chunk = gridDim.x >> 3; // gridDim.x is a multiple of 8
+    return (long long)(b & 7u) * chunk + (b >> 3);
+}
+
 __device__ inline int sf_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ inline long long sf_uniform64(long long v)
@@ -49,6 +61,8 @@ __device__ inline long long sf_uniform64(long long v)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 #endif
+
+static inline unsigned sf_xcd_grid(long long blocks) { return (unsigned)(((blocks + 7) / 8) * 8); }
 
 sf_grid_desc sf_make_grid_desc(const sf_cloud *c);
 int sf_cloud_ensure_sorted_normals(struct sf_ctx *ctx, sf_cloud *c);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
 {
     __shared__ unsigned int hist[4][SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + wave);
+    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + wave);
     if (q >= m) return; // whole wave exits together; no block-wide barrier below
     unsigned int *h = hist[wave];
     for (int b = lane; b < nb3; b += 64) h[b] = 0;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
                                               double *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
     if (q >= m) return;
     // keypoint's cell-sorted position and its slot in the neighbour lists
     const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
@@ -113,28 +113,56 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
             if (d2 > 0.0) w = (1.0 / (double)kk[j]) / sqrt(d2);
         }
         const int cnt = min(64, k - t0);
-        // tt is wave-uniform: v_readlane gives the neighbour index / weight as scalars, the row base is a
-        // scalar address and the 8-deep unroll keeps several independent row loads in flight
-#pragma unroll 8
-        for (int tt = 0; tt < cnt; ++tt) {
-            const int jj = __builtin_amdgcn_readlane(j, tt);
-            const double ww = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(w), tt),
-                                               __builtin_amdgcn_readlane(__double2loint(w), tt));
-            const CT *rowp = counts + (int64_t)jj * stride;
+        // tt is wave-uniform: v_readlane hands the neighbour index / weight over as scalars, the row base is
+        // a scalar address, and rows are fetched in batches of 8 independent loads before any is consumed
+        auto row_word = [&](int tt, int u) -> uint2 {
+            // unconditional load (lanes past the row end re-read its first word and are masked by select):
+            // a branch around the load would make hipcc wait for each row before issuing the next
+            const unsigned jj = (unsigned)__builtin_amdgcn_readlane(j, tt);
+            const char *rowp = reinterpret_cast<const char *>(counts) + (size_t)jj * ((size_t)stride * sizeof(CT));
+            const int b = 2 * (lane + 64 * u);
+            const bool ok = b < stride; // stride is even and >= nb3; padding counts are zero
+            const int bb = ok ? b : 0;
+            uint2 pk;
+            if (sizeof(CT) == 2) {
+                const unsigned int v = *reinterpret_cast<const unsigned int *>(rowp + (size_t)bb * 2);
+                pk.x = v & 0xffffu;
+                pk.y = v >> 16;
+            } else {
+                pk = *reinterpret_cast<const uint2 *>(rowp + (size_t)bb * 4);
+            }
+            pk.x = ok ? pk.x : 0u;
+            pk.y = ok ? pk.y : 0u;
+            return pk;
+        };
+        auto weight = [&](int tt) -> double {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(w), tt),
+                                    __builtin_amdgcn_readlane(__double2loint(w), tt));
+        };
+        int tt = 0;
+        for (; tt + 8 <= cnt; tt += 8) {
+            uint2 pk[8][NB2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int u = 0; u < NB2; ++u) pk[e][u] = row_word(tt + e, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double ww = weight(tt + e);
+#pragma unroll
+                for (int u = 0; u < NB2; ++u) {
+                    acc0[u] = __builtin_fma((double)pk[e][u].x, ww, acc0[u]);
+                    acc1[u] = __builtin_fma((double)pk[e][u].y, ww, acc1[u]);
+                }
+            }
+        }
+        for (; tt < cnt; ++tt) {
+            const double ww = weight(tt);
 #pragma unroll
             for (int u = 0; u < NB2; ++u) {
-                const int b = 2 * (lane + 64 * u);
-                if (b < stride) { // stride is even and >= nb3; padding counts are zero
-                    if (sizeof(CT) == 2) {
-                        const unsigned int pk = *reinterpret_cast<const unsigned int *>(rowp + b);
-                        acc0[u] += (double)(pk & 0xffffu) * ww;
-                        acc1[u] += (double)(pk >> 16) * ww;
-                    } else {
-                        const uint2 pk = *reinterpret_cast<const uint2 *>(rowp + b);
-                        acc0[u] += (double)pk.x * ww;
-                        acc1[u] += (double)pk.y * ww;
-                    }
-                }
+                const uint2 pk = row_word(tt, u);
+                acc0[u] = __builtin_fma((double)pk.x, ww, acc0[u]);
+                acc1[u] = __builtin_fma((double)pk.y, ww, acc1[u]);
             }
         }
     }
@@ -231,7 +259,7 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     }
     const int64_t m = nb->m;
     if (!m) return SF_OK;
-    const dim3 grid((unsigned)sf_div_up(m, 4)), block(256);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
     if (sp->elem_bytes == 2) {
         SF_LAUNCH(ctx, "k6_spfh", k_spfh<uint16_t>, grid, block, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->offset,
                   nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (uint16_t *)sp->counts, sp->k);
@@ -293,7 +321,7 @@ template <typename CT>
 static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const int32_t *kp_pos, int64_t m,
                        double *dout)
 {
-    const dim3 grid((unsigned)sf_div_up(m, 4)), block(256);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
     const int pairs = sp->stride / 2;                 // bin pairs per row
     const int nb2 = (int)sf_div_up(pairs, 64);        // pairs per lane
 #define SF_FPFH_CASE(NB2)                                                                                           \

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
                                                 const int64_t *__restrict__ offset, int32_t *__restrict__ idx)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
     if (q >= m) return;
     const double px = qx[q], py = qy[q], pz = qz[q];
     int x0, x1, y0, y1, z0, z1;
@@ -141,7 +141,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     SF_CHECK(sf_palloc(ctx, &nb->offset, (size_t)(m + 1)));
     SF_HIP(hipMemsetAsync(nb->count, 0, (size_t)(m + 1) * sizeof(int32_t), ctx->stream));
     sf_grid_desc g = sf_make_grid_desc(c);
-    const dim3 grid((unsigned)sf_div_up(m ? m : 1, 4)), block(256);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4))), block(256);
     if (m) {
         SF_LAUNCH(ctx, "k2_radius_count", k_radius<false>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
                   nb->qy, nb->qz, m, r2, nb->count, (const int64_t *)nullptr, (int32_t *)nullptr);
