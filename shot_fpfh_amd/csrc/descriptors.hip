@@ -390,6 +390,220 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, cons
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// K5, register-cached form for neighbourhoods of at most 64*NCH points (the common case; the streaming
+// kernel above stays as the fallback for larger ones).  The neighbour coordinates are gathered ONCE,
+// all NCH chunks in flight together; sweep 1 does the geometry (local coordinates, bins, rho) and keeps
+// the five numbers sweep 2 needs per neighbour in VGPRs, so sweep 2 is only the transcendental /
+// interpolation part.  The azimuth-neighbour decision in sweep 1 uses the sign of the cross product with
+// the octant's centre direction (no atan2); when that is not clearly non-zero it falls back to the
+// reference's own expression, so the decision equals shot.py:283-288 in every case.
+// --------------------------------------------------------------------------------------------------
+struct shot_kept {
+    double rho, dc, lx, ly, lz;
+    unsigned bins0, bins1; // base | bcos << 9 | bth << 18 ; cd | ef << 8 ; bins1 bit 31 = valid
+};
+
+__device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
+                                     const double *E, double radius, shot_kept &o)
+{
+    const double rho = sqrt(d2);
+    const double lx = (cx * E[0] + cy * E[3]) + cz * E[6];
+    const double ly = (cx * E[1] + cy * E[4]) + cz * E[7];
+    const double lz = (cx * E[2] + cy * E[5]) + cz * E[8];
+    double cosine = (nx * E[2] + ny * E[5]) + nz * E[8];
+    cosine = fmin(fmax(cosine, -1.0), 1.0);
+    const double cpos = (cosine + 1.0) * 11.0 / 2.0 - 0.5;
+    const double cf = rint(cpos);
+    const int ci = (int)cf;
+    const int ti = azimuth_octant(lx, ly);
+    const int pi_ = lz > 0.0 ? 1 : 0;
+    const int ri = rho > radius / 2 ? 1 : 0;
+    const double dc = cpos - cf;
+    const int sc = (dc > 0.0) - (dc < 0.0);
+    int cin = (ci + sc) % 11;
+    if (cin < 0) cin += 11;
+    // sign of the azimuth offset from the octant centre -pi + (ti + 1/2) pi/4
+    const double C8 = 0.9238795325112867, S8 = 0.3826834323650898; // cos, sin of pi/8
+    const bool cos_is_c = (((ti ^ (ti >> 1)) & 1) == 0);
+    const double ac = cos_is_c ? C8 : S8, as = cos_is_c ? S8 : C8;
+    const double ctr_x = ((ti + 2) & 4) ? ac : -ac, ctr_y = ti >= 4 ? as : -as;
+    const double cross = ctr_x * ly - ctr_y * lx;
+    int sth;
+    if (fabs(cross) > 1e-9 * (fabs(lx) + fabs(ly))) {
+        sth = cross > 0.0 ? 1 : -1;
+    } else { // on (or within rounding of) the centre ray, or lx = ly = 0: the reference's expression decides
+        const double tsz = 2 * SHOT_PI / 8;
+        double dth = (atan2(ly, lx) - (-SHOT_PI + ti * tsz)) / tsz - 0.5;
+        dth = fmin(fmax(dth, -0.5), 0.5);
+        sth = (dth > 0.0) - (dth < 0.0);
+    }
+    const int tin = (ti + sth) & 7;
+    const unsigned cd = (unsigned)((ci * 8 + ti) * 2 + pi_), ef = (unsigned)((ci * 8 + ti) * 2 + ri);
+    const unsigned base = cd * 2 + ri;
+    const unsigned bcos = (unsigned)(((cin * 8 + ti) * 2 + pi_) * 2 + ri);
+    const unsigned bth = (unsigned)(((ci * 8 + tin) * 2 + pi_) * 2 + ri);
+    o.rho = rho; o.dc = dc; o.lx = lx; o.ly = ly; o.lz = lz;
+    o.bins0 = base | (bcos << 9) | (bth << 18);
+    o.bins1 = cd | (ef << 8) | 0x80000000u;
+}
+
+struct shot_values { double vA, vB, vG, vC, vD, vE, vF; };
+
+__device__ inline void shot_interp(const shot_kept &g, double radius, shot_values &o)
+{
+    const unsigned base = g.bins0 & 511u;
+    const int ri = base & 1, pi_ = (base >> 1) & 1, ti = (base >> 2) & 7;
+    const double rho = g.rho;
+    const double adc = fabs(g.dc);
+    const double theta = atan2(g.ly, g.lx);
+    const double tsz = 2 * SHOT_PI / 8;
+    double dth = (theta - (-SHOT_PI + ti * tsz)) / tsz - 0.5;
+    dth = fmin(fmax(dth, -0.5), 0.5);
+    const double adth = fabs(dth);
+    const double half_r = radius / 2, q1 = radius / 4, q3 = radius * 3 / 4;
+    const double inner = (double)((rho > half_r) && (rho < q3)) * (q3 - rho) / half_r;
+    const double outer = (double)((rho < half_r) && (rho > q1)) * (rho - q1) / half_r;
+    const double cur = (double)(rho < half_r) * (1 - fabs(rho - q1) / half_r) +
+                       (double)(rho > half_r) * (1 - fabs(rho - q3) / half_r);
+    double lzr = g.lz / rho;
+    lzr = fmin(fmax(lzr, -1.0), 1.0);
+    const double phi = acos(lzr);
+    const double hpi = SHOT_PI / 2, pi34 = SHOT_PI * 3 / 4, pi4 = SHOT_PI / 4;
+    const double upper =
+        (double)(((phi > hpi) || ((fabs(phi - hpi) < 1e-10) && (g.lz <= 0.0))) && (phi <= pi34)) * (pi34 - phi) / hpi;
+    const double lower =
+        (double)(((phi < hpi) && ((fabs(phi - hpi) >= 1e-10) || (g.lz > 0.0))) && (phi >= pi4)) * (phi - pi4) / hpi;
+    const double curv = (double)(phi < hpi) * (1 - fabs(phi - pi4) / hpi) +
+                        (double)(phi >= hpi) * (1 - fabs(phi - pi34) / hpi);
+    o.vB = adc; // the reference's mask (cf > -0.5) & (cf < 10.5) is always true for cf in 0..10
+    o.vA = (((1 - adc) + cur) + curv) + (1 - adth);
+    o.vC = outer * (double)(ri == 0);
+    o.vD = inner * (double)(ri == 1);
+    o.vE = upper * (double)(pi_ == 0);
+    o.vF = lower * (double)(pi_ == 1);
+    o.vG = adth;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                    const double *__restrict__ zs, const double *__restrict__ nxs,
+                                                    const double *__restrict__ nys, const double *__restrict__ nzs,
+                                                    const double *__restrict__ qx, const double *__restrict__ qy,
+                                                    const double *__restrict__ qz, const int64_t *__restrict__ offset,
+                                                    const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
+                                                    int64_t m, double radius, const double *__restrict__ lrf,
+                                                    int normalize, int64_t min_nb, double *__restrict__ out)
+{
+    __shared__ unsigned long long sA[352], sB[352], sG[352], sCD[176], sEF[176];
+    __shared__ double sD[176], sF[176];
+    const int lane = threadIdx.x;
+    const int64_t q = sf_xcd_block();
+    if (q >= m) return;
+    const int64_t s = offset[q];
+    const int k = (int)(offset[q + 1] - s);
+    const int64_t row = qrow ? qrow[q] : q;
+    double *o = out + (int64_t)SF_SHOT_LEN * row;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+
+    for (int b = lane; b < 352; b += 64) { sA[b] = 0; sB[b] = 0; sG[b] = 0; }
+    for (int b = lane; b < 176; b += 64) { sCD[b] = 0; sEF[b] = 0; sD[b] = 0.0; sF[b] = 0.0; }
+
+    // one gather for all chunks
+    double cx[NCH], cy[NCH], cz[NCH], nx[NCH], ny[NCH], nz[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = c * 64 + lane;
+        const int j = t < k ? idx[s + t] : -1;
+        const int jj = j < 0 ? 0 : j;
+        cx[c] = j < 0 ? 0.0 : xs[jj] - px;
+        cy[c] = j < 0 ? 0.0 : ys[jj] - py;
+        cz[c] = j < 0 ? 0.0 : zs[jj] - pz;
+        nx[c] = nxs[jj];
+        ny[c] = nys[jj];
+        nz[c] = nzs[jj];
+    }
+    double E[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+
+    // gate (shot.py:212): neighbours at non-zero distance; padding lanes have c = 0 -> d2 = 0
+    double d2[NCH];
+    int npos = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        d2[c] = (cx[c] * cx[c] + cy[c] * cy[c]) + cz[c] * cz[c];
+        npos += __popcll(__ballot(d2[c] > 0.0));
+    }
+    if (!((int64_t)npos > min_nb)) {
+        for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
+        return;
+    }
+    __syncthreads();
+    // sweep 1: geometry + election of the max-rho writer of every (key, bin)
+    shot_kept g[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        g[c].bins1 = 0u;
+        if (d2[c] > 0.0) {
+            shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, radius, g[c]);
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            atomicMax(&sA[g[c].bins0 & 511u], key);
+            atomicMax(&sB[(g[c].bins0 >> 9) & 511u], key);
+            atomicMax(&sG[(g[c].bins0 >> 18) & 511u], key);
+            atomicMax(&sCD[g[c].bins1 & 255u], key);
+            atomicMax(&sEF[(g[c].bins1 >> 8) & 255u], key);
+        }
+    }
+    __syncthreads();
+    // sweep 2: winners replace their key by their (tagged) value
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (g[c].bins1 >> 31) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            const unsigned iA = g[c].bins0 & 511u, iB = (g[c].bins0 >> 9) & 511u, iG = (g[c].bins0 >> 18) & 511u;
+            const unsigned iCD = g[c].bins1 & 255u, iEF = (g[c].bins1 >> 8) & 255u;
+            const bool wA = sA[iA] == key, wB = sB[iB] == key, wG = sG[iG] == key, wCD = sCD[iCD] == key,
+                       wEF = sEF[iEF] == key;
+            if (wA | wB | wG | wCD | wEF) { // a neighbour that won nothing needs no values
+                shot_values v;
+                shot_interp(g[c], radius, v);
+                if (wA) sA[iA] = tag_value(v.vA);
+                if (wB) sB[iB] = tag_value(v.vB);
+                if (wG) sG[iG] = tag_value(v.vG);
+                if (wCD) { sCD[iCD] = tag_value(v.vC); sD[iCD] = v.vD; }
+                if (wEF) { sEF[iEF] = tag_value(v.vE); sF[iEF] = v.vF; }
+            }
+        }
+    }
+    __syncthreads();
+    double vals[6];
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int b = lane + 64 * u;
+        double v = 0.0;
+        if (b < 352) {
+            const int cdi = b >> 1, efi = ((b >> 2) << 1) | (b & 1);
+            const int rb = b & 1, pb = (b >> 1) & 1;
+            v = untag_value(sB[b]);
+            v += untag_value(sA[b]);
+            v += rb ? untag_value(sCD[cdi]) : sD[cdi];
+            v += pb ? untag_value(sEF[efi]) : sF[efi];
+            v += untag_value(sG[b]);
+        }
+        vals[u] = v;
+        ss += v * v;
+    }
+    const double nrm = sqrt(sf_wave_sum(ss));
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int b = lane + 64 * u;
+        if (b < 352) o[b] = nrm > 0.0 ? (normalize ? vals[u] / nrm : vals[u]) : 0.0;
+    }
+}
+
 } // namespace
 
 static int check_nbrs(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const char *who)
@@ -475,8 +689,16 @@ extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf,
     SF_CHECK(stage_in(ctx, lrf, (size_t)m * 9, flags, &dlrf, &olrf));
     SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k5_shot", k_shot, dim3(sf_xcd_grid(m)), dim3(64), c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs,
-                  nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, nb->radius, dlrf, normalize, min_nb, dout);
+        const dim3 grid(sf_xcd_grid(m)), block(64);
+#define SF_SHOT_ARGS c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, \
+                     nb->radius, dlrf, normalize, min_nb, dout
+        const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+        if (chunks <= 1) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<1>, grid, block, SF_SHOT_ARGS); }
+        else if (chunks == 2) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<2>, grid, block, SF_SHOT_ARGS); }
+        else if (chunks == 3) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<3>, grid, block, SF_SHOT_ARGS); }
+        else if (chunks == 4) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<4>, grid, block, SF_SHOT_ARGS); }
+        else { SF_LAUNCH(ctx, "k5_shot", k_shot, grid, block, SF_SHOT_ARGS); } // streaming fallback, any size
+#undef SF_SHOT_ARGS
     }
     SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
     if (olrf) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(olrf)); }

@@ -263,3 +263,16 @@ def test_sharded_blocks_bit_identical_to_single(eng, O, world):
     assert np.array_equal(f1, fw) and np.array_equal(s1, sw)
     fo = O.compute_fpfh_descriptor(np.arange(20000), p, nr, r, 5)
     assert close(f1, fo).all()
+
+
+def test_shot_large_neighbourhoods_streaming_kernel(O):
+    """k > 256 neighbours per keypoint takes the streaming K5 kernel instead of the register-cached one."""
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    p, nr, rng = synth_cloud(4000, 61)
+    kp = p[rng.choice(4000, 200, replace=False)]
+    for r in (0.3, 0.17):  # ~450 and ~80 neighbours
+        with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+            d = sm.compute_descriptor_single_scale(p, nr, kp, r)
+        do = O.shot_single_scale(p, nr, kp, r, True, 10)
+        assert close(d, do).all(), f"r={r}: max err {np.abs(d - do).max()}"
