@@ -15,6 +15,7 @@
 // HBM roofline, algorithmic bytes (float64 API widths): 48 in + 1000 SPFH write + 1000 SPFH
 // read + 1000 FPFH write = 3048 B per descriptor when every point is a keypoint.
 #include <algorithm>
+#include <cmath>
 
 #include "common.h"
 #include "device_util.h"
@@ -23,6 +24,7 @@ namespace {
 
 struct fpfh_edges {
     double a[SF_MAX_FPFH_BINS + 1], p[SF_MAX_FPFH_BINS + 1], t[SF_MAX_FPFH_BINS + 1];
+    double tan_t[SF_MAX_FPFH_BINS + 1]; // tan of the interior theta edges (index 1..nb-1)
 };
 
 // np.histogramdd bin of x: searchsorted(edges, x, 'right') - 1, x == last edge -> last bin, out of
@@ -37,7 +39,35 @@ __device__ inline int hist_bin(const double *e, int nb, double x)
     return b;
 }
 
-template <typename CT>
+// Bin of theta = atan2(a, b) over the theta edges WITHOUT evaluating atan2: inside (-pi/2, pi/2) (b > 0)
+// theta >= e_i  <=>  a >= tan(e_i) * b.  Whenever a comparison is within a 1e-13 relative band of
+// equality, or b is within that band of 0 (theta near +-pi/2, the outer edges), the reference's own
+// expression -- atan2 then the histogramdd rule -- decides, so the result is the reference's in all cases.
+__device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b)
+{
+    const double band = 1e-13;
+    const double aa = fabs(a);
+    if (b > band * aa) {
+        int bin = 0;
+        bool near = false;
+#pragma unroll
+        for (int i = 1; i < SF_MAX_FPFH_BINS; ++i)
+            if (i < nb) {
+                const double tb = ed.tan_t[i] * b;
+                bin += a >= tb ? 1 : 0;
+                near |= fabs(a - tb) <= band * (aa + fabs(tb));
+            }
+        if (!near) return bin;
+    } else if (b < -band * aa) {
+        return -1; // |theta| > pi/2: outside the histogram range, dropped (fpfh.py:86)
+    }
+    return hist_bin(ed.t, nb, atan2(a, b));
+}
+
+// NCH > 0: neighbourhoods of at most 64*NCH points -- every chunk's indices, then every chunk's
+// coordinates / normals, are requested before any is used, so a wave pays ONE index round trip and ONE
+// gather round trip instead of one per chunk.  NCH == 0: streaming loop for any size.
+template <typename CT, int NCH>
 __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, const double *__restrict__ ys,
                                               const double *__restrict__ zs, const double *__restrict__ nxs,
                                               const double *__restrict__ nys, const double *__restrict__ nzs,
@@ -57,20 +87,41 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
     const double px = xs[i], py = ys[i], pz = zs[i];
     const double ux = nxs[i], uy = nys[i], uz = nzs[i];
     __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < k; t += 64) {
-        const int j = idx[s + t];
-        const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+    auto pair = [&](double cx, double cy, double cz, double njx, double njy, double njz) {
         const double d2 = (cx * cx + cy * cy) + cz * cz;
         if (d2 > 0.0) { // dist > 0 (fpfh.py:50-57)
             const double dist = sqrt(d2);
-            const double njx = nxs[j], njy = nys[j], njz = nzs[j];
             const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
             const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
             const double alpha = (vx * njx + vy * njy) + vz * njz;
             const double phi = ((cx * ux + cy * uy) + cz * uz) / dist;
-            const double theta = atan2((njx * wx + njy * wy) + njz * wz, (njx * ux + njy * uy) + njz * uz);
-            const int ba = hist_bin(ed.a, nb, alpha), bp = hist_bin(ed.p, nb, phi), bt = hist_bin(ed.t, nb, theta);
+            const int bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, (njx * ux + njy * uy) + njz * uz);
+            const int ba = hist_bin(ed.a, nb, alpha), bp = hist_bin(ed.p, nb, phi);
             if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt], 1u);
+        }
+    };
+    if (NCH > 0) {
+        constexpr int NC = NCH > 0 ? NCH : 1;
+        int jj[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int t = c * 64 + lane;
+            jj[c] = t < k ? idx[s + t] : -1;
+        }
+        double cx[NC], cy[NC], cz[NC], ax[NC], ay[NC], az[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = jj[c] < 0 ? 0 : jj[c];
+            cx[c] = xs[j]; cy[c] = ys[j]; cz[c] = zs[j];
+            ax[c] = nxs[j]; ay[c] = nys[j]; az[c] = nzs[j];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (jj[c] >= 0) pair(cx[c] - px, cy[c] - py, cz[c] - pz, ax[c], ay[c], az[c]);
+    } else {
+        for (int t = lane; t < k; t += 64) {
+            const int j = idx[s + t];
+            pair(xs[j] - px, ys[j] - py, zs[j] - pz, nxs[j], nys[j], nzs[j]);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -80,15 +131,21 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
     if (lane == 0) kout[i] = k;
 }
 
-// K7.  NB2 = number of (bin pair)s per lane: lane l owns bins 2*(l + 64*u) and +1, u < NB2.
-template <typename CT, int NB2>
+// K7.  The vector-memory pipe of a CU takes 16 cycles per wave instruction whatever the width per lane, so
+// the neighbour rows are fetched 16 B per lane (dwordx4): a row of RB bytes occupies LPR = RB/16 lanes and
+// ONE load instruction brings in 64/LPR rows (4 rows of 125 uint16 bins).  Each lane accumulates the
+// 16/sizeof(CT) bins of its 16-byte piece (NP pieces when a row is longer than 1 KiB) in float64 and the
+// lane groups are summed with shuffles at the end.  NCH as in K6 (0 = any list length).
+template <typename CT, int LPR, int NP, int NCH>
 __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, const double *__restrict__ ys,
                                               const double *__restrict__ zs, const int64_t *__restrict__ offset,
                                               const int32_t *__restrict__ idx, int64_t nbrs_begin,
                                               const int32_t *__restrict__ kp_pos, int64_t m, int nb3, int stride,
-                                              const CT *__restrict__ counts, const int32_t *__restrict__ kk,
-                                              double *__restrict__ out)
+                                              const CT *__restrict__ counts, unsigned table_bytes,
+                                              const int32_t *__restrict__ kk, double *__restrict__ out)
 {
+    constexpr int BPP = 16 / (int)sizeof(CT); // bins per 16-byte piece
+    constexpr int RPI = 64 / LPR;             // rows per load instruction
     const int lane = threadIdx.x & 63;
     const int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
     if (q >= m) return;
@@ -98,82 +155,124 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
     const int64_t s = offset[slot];
     const int k = (int)(offset[slot + 1] - s);
     const double px = xs[i], py = ys[i], pz = zs[i];
-    double acc0[NB2], acc1[NB2];
+    const int grp = lane / LPR, piece = lane % LPR;
+    const unsigned row_bytes = (unsigned)stride * (unsigned)sizeof(CT);
+    double acc[NP][BPP];
 #pragma unroll
-    for (int u = 0; u < NB2; ++u) { acc0[u] = 0.0; acc1[u] = 0.0; }
-    for (int t0 = 0; t0 < k; t0 += 64) {
-        const int t = t0 + lane;
-        int j = 0;
-        double w = 0.0;
-        if (t < k) {
-            j = idx[s + t];
-            const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
-            const double d2 = (cx * cx + cy * cy) + cz * cz;
-            // weight of neighbour j: spfh[j] / d_j with spfh[j] = count_j / k_j ; d == 0 is masked out
-            if (d2 > 0.0) w = (1.0 / (double)kk[j]) / sqrt(d2);
+    for (int u = 0; u < NP; ++u)
+#pragma unroll
+        for (int e = 0; e < BPP; ++e) acc[u][e] = 0.0;
+    // descriptor of the whole SPFH table (wave-uniform); table_bytes < 4 GiB is checked by the host
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT *>(counts), 0, (int)table_bytes, 0x00020000);
+
+    // exact uint32 -> double without v_cvt_f64_u32: the bit pattern {hi = 0x43300000, lo = c} is the double
+    // 2^52 + c, and subtracting 2^52 is exact for c < 2^32
+    auto u2d = [](unsigned c) -> double { return __hiloint2double(0x43300000, (int)c) - 4503599627370496.0; };
+    // weight of neighbour j: spfh[j] / d_j with spfh[j] = count_j / k_j ; d == 0 is masked out (fpfh.py:110-114)
+    auto weight_of = [&](double x, double y, double z, int kj) -> double {
+        const double cx = x - px, cy = y - py, cz = z - pz;
+        const double d2 = (cx * cx + cy * cy) + cz * cz;
+        return d2 > 0.0 ? (1.0 / (double)kj) / sqrt(d2) : 0.0;
+    };
+    auto accumulate = [&](const uint4 &v, double ww, int u) {
+        if (sizeof(CT) == 2) {
+            acc[u][0] = __builtin_fma(u2d(v.x & 0xffffu), ww, acc[u][0]);
+            acc[u][1] = __builtin_fma(u2d(v.x >> 16), ww, acc[u][1]);
+            acc[u][2] = __builtin_fma(u2d(v.y & 0xffffu), ww, acc[u][2]);
+            acc[u][3] = __builtin_fma(u2d(v.y >> 16), ww, acc[u][3]);
+            acc[u][4 % BPP] = __builtin_fma(u2d(v.z & 0xffffu), ww, acc[u][4 % BPP]);
+            acc[u][5 % BPP] = __builtin_fma(u2d(v.z >> 16), ww, acc[u][5 % BPP]);
+            acc[u][6 % BPP] = __builtin_fma(u2d(v.w & 0xffffu), ww, acc[u][6 % BPP]);
+            acc[u][7 % BPP] = __builtin_fma(u2d(v.w >> 16), ww, acc[u][7 % BPP]);
+        } else {
+            acc[u][0] = __builtin_fma(u2d(v.x), ww, acc[u][0]);
+            acc[u][1] = __builtin_fma(u2d(v.y), ww, acc[u][1]);
+            acc[u][2] = __builtin_fma(u2d(v.z), ww, acc[u][2]);
+            acc[u][3] = __builtin_fma(u2d(v.w), ww, acc[u][3]);
         }
-        const int cnt = min(64, k - t0);
-        // tt is wave-uniform: v_readlane hands the neighbour index / weight over as scalars, the row base is
-        // a scalar address, and rows are fetched in batches of 8 independent loads before any is consumed
-        auto row_word = [&](int tt, int u) -> uint2 {
-            // unconditional load (lanes past the row end re-read its first word and are masked by select):
-            // a branch around the load would make hipcc wait for each row before issuing the next
-            const unsigned jj = (unsigned)__builtin_amdgcn_readlane(j, tt);
-            const char *rowp = reinterpret_cast<const char *>(counts) + (size_t)jj * ((size_t)stride * sizeof(CT));
-            const int b = 2 * (lane + 64 * u);
-            const bool ok = b < stride; // stride is even and >= nb3; padding counts are zero
-            const int bb = ok ? b : 0;
-            uint2 pk;
-            if (sizeof(CT) == 2) {
-                const unsigned int v = *reinterpret_cast<const unsigned int *>(rowp + (size_t)bb * 2);
-                pk.x = v & 0xffffu;
-                pk.y = v >> 16;
-            } else {
-                pk = *reinterpret_cast<const uint2 *>(rowp + (size_t)bb * 4);
-            }
-            pk.x = ok ? pk.x : 0u;
-            pk.y = ok ? pk.y : 0u;
-            return pk;
-        };
-        auto weight = [&](int tt) -> double {
-            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(w), tt),
-                                    __builtin_amdgcn_readlane(__double2loint(w), tt));
-        };
-        int tt = 0;
-        for (; tt + 8 <= cnt; tt += 8) {
-            uint2 pk[8][NB2];
+    };
+    // stream the rows of one chunk (lane t holds neighbour t's row index j and weight w; w = 0 past the end):
+    // per step, lane group g takes neighbour tt + g; 4 steps' loads are issued before any is consumed
+    auto stream_rows = [&](int j, double w, int cnt) {
+        constexpr int UNR = 4;
+        for (int tt = 0; tt < cnt; tt += RPI * UNR) {
+            uint4 v[UNR][NP];
+            double ww[UNR];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
+            for (int e = 0; e < UNR; ++e) {
+                const int src = tt + e * RPI + grp; // < 64 whenever tt + e*RPI < 64; beyond cnt the weight is 0
+                const int jj = __shfl(j, src & 63);
+                ww[e] = (tt + e * RPI < cnt) ? __shfl(w, src & 63) : 0.0;
+                const unsigned voff = (unsigned)jj * row_bytes + (unsigned)piece * 16u;
 #pragma unroll
-                for (int u = 0; u < NB2; ++u) pk[e][u] = row_word(tt + e, u);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const double ww = weight(tt + e);
-#pragma unroll
-                for (int u = 0; u < NB2; ++u) {
-                    acc0[u] = __builtin_fma((double)pk[e][u].x, ww, acc0[u]);
-                    acc1[u] = __builtin_fma((double)pk[e][u].y, ww, acc1[u]);
+                for (int u = 0; u < NP; ++u) {
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)u * 1024u, 0, 0);
+                    v[e][u] = make_uint4(r[0], r[1], r[2], r[3]);
                 }
             }
-        }
-        for (; tt < cnt; ++tt) {
-            const double ww = weight(tt);
 #pragma unroll
-            for (int u = 0; u < NB2; ++u) {
-                const uint2 pk = row_word(tt, u);
-                acc0[u] = __builtin_fma((double)pk.x, ww, acc0[u]);
-                acc1[u] = __builtin_fma((double)pk.y, ww, acc1[u]);
+            for (int e = 0; e < UNR; ++e)
+#pragma unroll
+                for (int u = 0; u < NP; ++u) accumulate(v[e][u], ww[e], u);
+        }
+    };
+    if (NCH > 0) {
+        constexpr int NC = NCH > 0 ? NCH : 1;
+        int jv[NC];
+        double wv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int t = c * 64 + lane;
+            jv[c] = t < k ? idx[s + t] : -1;
+        }
+        double gx[NC], gy[NC], gz[NC];
+        int gk[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = jv[c] < 0 ? 0 : jv[c];
+            gx[c] = xs[j]; gy[c] = ys[j]; gz[c] = zs[j];
+            gk[c] = kk[j];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            wv[c] = jv[c] < 0 ? 0.0 : weight_of(gx[c], gy[c], gz[c], gk[c]);
+            jv[c] = jv[c] < 0 ? 0 : jv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cnt = min(64, k - c * 64);
+            if (cnt > 0) stream_rows(jv[c], wv[c], cnt);
+        }
+    } else {
+        for (int t0 = 0; t0 < k; t0 += 64) {
+            const int t = t0 + lane;
+            int j = 0;
+            double w = 0.0;
+            if (t < k) {
+                j = idx[s + t];
+                w = weight_of(xs[j], ys[j], zs[j], kk[j]);
             }
+            stream_rows(j, w, min(64, k - t0));
         }
     }
-    const double kd = (double)k;
-    const CT *own = counts + i * (int64_t)stride;
-    double *o = out + q * (int64_t)nb3;
+    // sum the lane groups (each holds a partial sum over its share of the neighbours)
 #pragma unroll
-    for (int u = 0; u < NB2; ++u) {
-        const int b = 2 * (lane + 64 * u);
-        if (b < nb3) o[b] = (double)own[b] / kd + acc0[u] / kd;
-        if (b + 1 < nb3) o[b + 1] = (double)own[b + 1] / kd + acc1[u] / kd;
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+#pragma unroll
+            for (int e = 0; e < BPP; ++e) acc[u][e] += __shfl_xor(acc[u][e], off);
+    if (grp == 0) {
+        const double kd = (double)k;
+        const CT *own = counts + i * (int64_t)stride;
+        double *o = out + q * (int64_t)nb3;
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+#pragma unroll
+            for (int e = 0; e < BPP; ++e) {
+                const int b = (u * 64 + piece) * BPP + e; // == byte offset (u*1024 + piece*16) / sizeof(CT) + e
+                if (b < nb3) o[b] = (double)own[b] / kd + acc[u][e] / kd;
+            }
     }
 }
 
@@ -214,8 +313,9 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     sp->n_bins = n_bins;
     sp->nb3 = n_bins * n_bins * n_bins;
     sp->elem_bytes = max_count > 65535 ? 4 : 2;
-    int per128 = 128 / sp->elem_bytes; // rows padded to a multiple of 128 B
-    sp->stride = (int)sf_div_up(sp->nb3, per128) * per128;
+    // rows padded to a multiple of 128 elements: lane l of a wave owns elements 2l, 2l+1 of each 128-element
+    // slice, so no lane of the K7 row loads ever falls outside its row (256 B rows for 125 uint16 bins)
+    sp->stride = (int)sf_div_up(sp->nb3, 128) * 128;
     // room for ceil(n / nranks) rows per rank so the table can be all-gathered in place
     const int64_t nr = ctx->nranks > 0 ? ctx->nranks : 1;
     sp->rows_alloc = std::max<int64_t>(sf_div_up(c->n, nr) * nr, 1);
@@ -256,17 +356,31 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
         ed.a[i] = edges[i <= nbn ? i : nbn];
         ed.p[i] = edges[(nbn + 1) + (i <= nbn ? i : nbn)];
         ed.t[i] = edges[2 * (nbn + 1) + (i <= nbn ? i : nbn)];
+        ed.tan_t[i] = std::tan(ed.t[i]);
     }
     const int64_t m = nb->m;
     if (!m) return SF_OK;
     const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
-    if (sp->elem_bytes == 2) {
-        SF_LAUNCH(ctx, "k6_spfh", k_spfh<uint16_t>, grid, block, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->offset,
-                  nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (uint16_t *)sp->counts, sp->k);
-    } else {
-        SF_LAUNCH(ctx, "k6_spfh", k_spfh<uint32_t>, grid, block, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->offset,
-                  nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (uint32_t *)sp->counts, sp->k);
+    int chunks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+    if (chunks > 4) chunks = 0; // streaming kernel
+#define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
+    SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH>), grid, block, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->offset,  \
+              nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k)
+#define SF_SPFH_DISPATCH(CT)                                     \
+    switch (chunks) {                                            \
+    case 1: { SF_SPFH_LAUNCH(CT, 1); } break;                    \
+    case 2: { SF_SPFH_LAUNCH(CT, 2); } break;                    \
+    case 3: { SF_SPFH_LAUNCH(CT, 3); } break;                    \
+    case 4: { SF_SPFH_LAUNCH(CT, 4); } break;                    \
+    default: { SF_SPFH_LAUNCH(CT, 0); } break;                   \
     }
+    if (sp->elem_bytes == 2) {
+        SF_SPFH_DISPATCH(uint16_t)
+    } else {
+        SF_SPFH_DISPATCH(uint32_t)
+    }
+#undef SF_SPFH_DISPATCH
+#undef SF_SPFH_LAUNCH
     return SF_OK;
 }
 
@@ -322,23 +436,37 @@ static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
                        double *dout)
 {
     const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
-    const int pairs = sp->stride / 2;                 // bin pairs per row
-    const int nb2 = (int)sf_div_up(pairs, 64);        // pairs per lane
-#define SF_FPFH_CASE(NB2)                                                                                           \
-    case NB2: {                                                                                                     \
-        SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh<CT, NB2>), grid, block, c->xs, c->ys, c->zs, nb->offset, nb->idx,          \
-                  nb->self_begin, kp_pos, m, sp->nb3, sp->stride, (const CT *)sp->counts, sp->k, dout);             \
-    } break;
-    switch (nb2) {
-        SF_FPFH_CASE(1)
-        SF_FPFH_CASE(2)
-        SF_FPFH_CASE(3)
-        SF_FPFH_CASE(4)
-    default:
-        sf_set_error("sf_fpfh: %d histogram cells per point unsupported", sp->nb3);
+    const size_t tb = (size_t)sp->rows_alloc * sp->stride * sizeof(CT);
+    if (tb >= ((size_t)1 << 32)) {
+        sf_set_error("sf_fpfh: SPFH table of %zu bytes exceeds the 4 GiB buffer-addressing limit of the K7 kernel", tb);
         return SF_ERR_UNSUPPORTED;
     }
-#undef SF_FPFH_CASE
+    const unsigned table_bytes = (unsigned)tb;
+    const int row_bytes = sp->stride * (int)sizeof(CT); // a multiple of 256
+    int nch = 0;
+    if (sizeof(CT) == 2) {
+        const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+        nch = chunks <= 2 ? 2 : (chunks <= 4 ? 4 : 0);
+    }
+#define SF_FPFH_LAUNCH(LPR, NP, NCH)                                                                                 \
+    SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh<CT, LPR, NP, NCH>), grid, block, c->xs, c->ys, c->zs, nb->offset, nb->idx,      \
+              nb->self_begin, kp_pos, m, sp->nb3, sp->stride, (const CT *)sp->counts, table_bytes, sp->k, dout)
+#define SF_FPFH_SHAPE(LPR, NP)                                                 \
+    {                                                                          \
+        if (sizeof(CT) == 2 && nch == 2) { SF_FPFH_LAUNCH(LPR, NP, 2); }       \
+        else if (sizeof(CT) == 2 && nch == 4) { SF_FPFH_LAUNCH(LPR, NP, 4); }  \
+        else { SF_FPFH_LAUNCH(LPR, NP, 0); }                                   \
+    }
+    if (row_bytes == 256) SF_FPFH_SHAPE(16, 1)
+    else if (row_bytes == 512) SF_FPFH_SHAPE(32, 1)
+    else if (row_bytes == 1024) SF_FPFH_SHAPE(64, 1)
+    else if (row_bytes == 2048) SF_FPFH_SHAPE(64, 2)
+    else {
+        sf_set_error("sf_fpfh: SPFH rows of %d bytes unsupported", row_bytes);
+        return SF_ERR_UNSUPPORTED;
+    }
+#undef SF_FPFH_SHAPE
+#undef SF_FPFH_LAUNCH
     return SF_OK;
 }
 
