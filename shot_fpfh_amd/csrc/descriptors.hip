@@ -30,7 +30,8 @@ __device__ inline double lane_bcast(double v, int src) { return __shfl(v, src); 
 __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, const double *__restrict__ ys,
                                                  const double *__restrict__ zs, const double *__restrict__ qx,
                                                  const double *__restrict__ qy, const double *__restrict__ qz,
-                                                 const int64_t *__restrict__ offset, const int32_t *__restrict__ idx,
+                                                 const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ idx,
                                                  const int32_t *__restrict__ qrow, int64_t m,
                                                  const double *__restrict__ pre, double *__restrict__ out)
 {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, 
     for (int t = 0; t < nq; ++t) {
         const int64_t q = q0 + t;
         const int64_t s = offset[q];
-        const int k = (int)(offset[q + 1] - s);
+        const int k = cnt[q];
         const double px = qx[q], py = qy[q], pz = qz[q];
         // pass 1: barycentre, accumulated relative to the query to keep the sums small
         double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, 
 __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs, const double *__restrict__ ys,
                                                   const double *__restrict__ zs, const double *__restrict__ qx,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
-                                                  const int64_t *__restrict__ offset, const int32_t *__restrict__ idx,
+                                                  const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ idx,
                                                   const int32_t *__restrict__ qrow, int64_t m, double radius,
                                                   double *__restrict__ lrf)
 {
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
     for (int t = 0; t < nq; ++t) {
         const int64_t q = q0 + t;
         const int64_t s = offset[q];
-        const int k = (int)(offset[q + 1] - s);
+        const int k = cnt[q];
         const double px = qx[q], py = qy[q], pz = qz[q];
         double ws = 0, a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
         for (int u = lane; u < k; u += 64) {
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
     for (int t = 0; t < nq; ++t) {
         const int64_t q = q0 + t;
         const int64_t s = offset[q];
-        const int k = (int)(offset[q + 1] - s);
+        const int k = cnt[q];
         const double px = qx[q], py = qy[q], pz = qz[q];
         const double bx0 = lane_bcast(x0, t), bx1 = lane_bcast(x1, t), bx2 = lane_bcast(x2, t);
         const double bz0 = lane_bcast(z0, t), bz1 = lane_bcast(z1, t), bz2 = lane_bcast(z2, t);
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, cons
                                              const double *__restrict__ nys, const double *__restrict__ nzs,
                                              const double *__restrict__ qx, const double *__restrict__ qy,
                                              const double *__restrict__ qz, const int64_t *__restrict__ offset,
-                                             const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
+                                             const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                             const int32_t *__restrict__ qrow,
                                              int64_t m, double radius, const double *__restrict__ lrf, int normalize,
                                              int64_t min_nb, double *__restrict__ out)
 {
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, cons
     const int64_t q = sf_xcd_block();
     if (q >= m) return;
     const int64_t s = offset[q];
-    const int k = (int)(offset[q + 1] - s);
+    const int k = cnt[q];
     const int64_t row = qrow ? qrow[q] : q;
     double *o = out + (int64_t)SF_SHOT_LEN * row;
     const double px = qx[q], py = qy[q], pz = qz[q];
@@ -492,7 +495,8 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
                                                     const double *__restrict__ nys, const double *__restrict__ nzs,
                                                     const double *__restrict__ qx, const double *__restrict__ qy,
                                                     const double *__restrict__ qz, const int64_t *__restrict__ offset,
-                                                    const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
+                                                    const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                    const int32_t *__restrict__ qrow,
                                                     int64_t m, double radius, const double *__restrict__ lrf,
                                                     int normalize, int64_t min_nb, double *__restrict__ out)
 {
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
     const int64_t q = sf_xcd_block();
     if (q >= m) return;
     const int64_t s = offset[q];
-    const int k = (int)(offset[q + 1] - s);
+    const int k = cnt[q];
     const int64_t row = qrow ? qrow[q] : q;
     double *o = out + (int64_t)SF_SHOT_LEN * row;
     const double px = qx[q], py = qy[q], pz = qz[q];
@@ -656,7 +660,7 @@ extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *p
     SF_CHECK(stage_out(ctx, out, (size_t)m * 3, flags, &dout, &oout));
     if (m) {
         SF_LAUNCH(ctx, "k3_normals", k_normals, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->xs, c->ys, c->zs, nb->qx,
-                  nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, dpre, dout);
+                  nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, dpre, dout);
     }
     SF_CHECK(finish_out(ctx, out, (size_t)m * 3, dout, oout));
     if (opre) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(opre)); }
@@ -672,7 +676,7 @@ extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, i
     SF_CHECK(stage_out(ctx, lrf, (size_t)m * 9, flags, &dout, &oout));
     if (m) {
         SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->xs, c->ys, c->zs,
-                  nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, nb->radius, dout);
+                  nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, dout);
     }
     return finish_out(ctx, lrf, (size_t)m * 9, dout, oout);
 }
@@ -690,7 +694,7 @@ extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf,
     SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
     if (m) {
         const dim3 grid(sf_xcd_grid(m)), block(64);
-#define SF_SHOT_ARGS c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, nb->qrow, m, \
+#define SF_SHOT_ARGS c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, \
                      nb->radius, dlrf, normalize, min_nb, dout
         const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
         if (chunks <= 1) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<1>, grid, block, SF_SHOT_ARGS); }

@@ -71,7 +71,8 @@ template <typename CT, int NCH>
 __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, const double *__restrict__ ys,
                                               const double *__restrict__ zs, const double *__restrict__ nxs,
                                               const double *__restrict__ nys, const double *__restrict__ nzs,
-                                              const int64_t *__restrict__ offset, const int32_t *__restrict__ idx,
+                                              const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb, int nb3, int stride,
                                               CT *__restrict__ counts, int32_t *__restrict__ kout)
 {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
     for (int b = lane; b < nb3; b += 64) h[b] = 0;
     const int64_t i = self_begin + q; // cell-sorted position of this point
     const int64_t s = offset[q];
-    const int k = (int)(offset[q + 1] - s);
+    const int k = cnt[q];
     const double px = xs[i], py = ys[i], pz = zs[i];
     const double ux = nxs[i], uy = nys[i], uz = nzs[i];
     __builtin_amdgcn_wave_barrier();
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
 template <typename CT, int LPR, int NP, int NCH>
 __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, const double *__restrict__ ys,
                                               const double *__restrict__ zs, const int64_t *__restrict__ offset,
-                                              const int32_t *__restrict__ idx, int64_t nbrs_begin,
+                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                              int64_t nbrs_begin,
                                               const int32_t *__restrict__ kp_pos, int64_t m, int nb3, int stride,
                                               const CT *__restrict__ counts, unsigned table_bytes,
                                               const int32_t *__restrict__ kk, double *__restrict__ out)
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
     const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
     const int64_t slot = i - nbrs_begin;
     const int64_t s = offset[slot];
-    const int k = (int)(offset[slot + 1] - s);
+    const int k = cnt[slot];
     const double px = xs[i], py = ys[i], pz = zs[i];
     const int grp = lane / LPR, piece = lane % LPR;
     const unsigned row_bytes = (unsigned)stride * (unsigned)sizeof(CT);
@@ -365,7 +367,7 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH>), grid, block, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->offset,  \
-              nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k)
+              nb->count, nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k)
 #define SF_SPFH_DISPATCH(CT)                                     \
     switch (chunks) {                                            \
     case 1: { SF_SPFH_LAUNCH(CT, 1); } break;                    \
@@ -449,7 +451,7 @@ static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
         nch = chunks <= 2 ? 2 : (chunks <= 4 ? 4 : 0);
     }
 #define SF_FPFH_LAUNCH(LPR, NP, NCH)                                                                                 \
-    SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh<CT, LPR, NP, NCH>), grid, block, c->xs, c->ys, c->zs, nb->offset, nb->idx,      \
+    SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh<CT, LPR, NP, NCH>), grid, block, c->xs, c->ys, c->zs, nb->offset, nb->count, nb->idx,      \
               nb->self_begin, kp_pos, m, sp->nb3, sp->stride, (const CT *)sp->counts, table_bytes, sp->k, dout)
 #define SF_FPFH_SHAPE(LPR, NP)                                                 \
     {                                                                          \

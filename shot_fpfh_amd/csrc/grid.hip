@@ -226,9 +226,9 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
     SF_CHECK(sf_palloc(ctx, &c->cell_start, (size_t)(ncell + 1)));
     SF_CHECK(sf_palloc(ctx, &c->perm, nn));
     SF_CHECK(sf_palloc(ctx, &c->inv_perm, nn));
-    SF_CHECK(sf_palloc(ctx, &c->xs, nn));
-    SF_CHECK(sf_palloc(ctx, &c->ys, nn));
-    SF_CHECK(sf_palloc(ctx, &c->zs, nn));
+    SF_CHECK(sf_palloc(ctx, &c->xs, nn + 2)); // +2: K2 reads candidates in pairs (one element past the end)
+    SF_CHECK(sf_palloc(ctx, &c->ys, nn + 2));
+    SF_CHECK(sf_palloc(ctx, &c->zs, nn + 2));
     if (!n) {
         SF_HIP(hipMemsetAsync(c->cell_start, 0, (size_t)(ncell + 1) * sizeof(int32_t), ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));

@@ -51,13 +51,24 @@ __device__ inline void stencil_bounds(double v, double lo, double inv_cell, int 
     c1 = (int)b;
 }
 
-template <bool FILL>
+// Two consecutive doubles fetched with ONE 16-byte load.  The vector-memory pipe of a CU accepts one wave
+// instruction per 16 cycles whatever its width per lane, so K2 tests two candidates per lane: 3 loads per
+// 128 candidates instead of 3 per 64.  (8-byte alignment only; global dwordx4 loads need dword alignment.)
+struct __attribute__((aligned(8))) sf_dbl2 {
+    double a, b;
+};
+
+// MODE 0: count only.  MODE 1: fill at the exact CSR offsets of a previous count + scan.
+// MODE 2: optimistic single pass -- query q owns the fixed slot [q*cap, (q+1)*cap) of idx; hits beyond cap
+//         are counted but not stored, and the host falls back to the exact two-pass scheme if any list
+//         overflowed (HBM is plentiful: slots cost cap*4 B per query).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *__restrict__ cell_start,
                                                 const double *__restrict__ xs, const double *__restrict__ ys,
                                                 const double *__restrict__ zs, const double *__restrict__ qx,
                                                 const double *__restrict__ qy, const double *__restrict__ qz,
-                                                int64_t m, double r2, int32_t *__restrict__ count,
-                                                const int64_t *__restrict__ offset, int32_t *__restrict__ idx)
+                                                int64_t m, double r2, int cap, int32_t *__restrict__ count,
+                                                int64_t *__restrict__ offset, int32_t *__restrict__ idx)
 {
     const int lane = threadIdx.x & 63;
     const int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
@@ -68,25 +79,40 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
     stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
     stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
     int total = 0;
-    int64_t out = FILL ? offset[q] : 0;
+    const int64_t out = MODE == 1 ? offset[q] : q * (int64_t)cap;
+    const int room = MODE == 2 ? cap : 0x7fffffff;
     for (int cz = z0; cz <= z1; ++cz)
         for (int cy = y0; cy <= y1; ++cy) {
             const int64_t row = ((int64_t)cz * g.dim[1] + cy) * g.dim[0];
             const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
-            for (int j0 = s; j0 < e; j0 += 64) {
-                const int j = j0 + lane;
-                bool hit = false;
-                if (j < e) {
-                    const double dx = xs[j] - px, dy = ys[j] - py, dz = zs[j] - pz;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    hit = d2 <= r2;
+            for (int j0 = s; j0 < e; j0 += 128) {
+                const int j = j0 + 2 * lane;
+                const bool in0 = j < e, in1 = j + 1 < e;
+                const int jj = in0 ? j : s; // unconditional loads (the arrays carry one padding element)
+                const sf_dbl2 X = *reinterpret_cast<const sf_dbl2 *>(xs + jj);
+                const sf_dbl2 Y = *reinterpret_cast<const sf_dbl2 *>(ys + jj);
+                const sf_dbl2 Z = *reinterpret_cast<const sf_dbl2 *>(zs + jj);
+                const double dxa = X.a - px, dya = Y.a - py, dza = Z.a - pz;
+                const double dxb = X.b - px, dyb = Y.b - py, dzb = Z.b - pz;
+                const bool hit0 = in0 && ((dxa * dxa + dya * dya) + dza * dza) <= r2;
+                const bool hit1 = in1 && ((dxb * dxb + dyb * dyb) + dzb * dzb) <= r2;
+                const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+                if (MODE != 0) {
+                    const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
+                    if (hit0 && pos < room) idx[out + pos] = j;
+                    const int pos1 = pos + (hit0 ? 1 : 0);
+                    if (hit1 && pos1 < room) idx[out + pos1] = j + 1;
                 }
-                const unsigned long long mask = __ballot(hit);
-                if (FILL && hit) idx[out + total + sf_prefix_count(mask)] = j;
-                total += __popcll(mask);
+                total += __popcll(m0) + __popcll(m1);
             }
         }
-    if (!FILL && lane == 0) count[q] = total;
+    if (lane == 0) {
+        if (MODE != 1) count[q] = total;
+        if (MODE == 2) {
+            offset[q] = out;
+            if (q == m - 1) offset[m] = out + cap;
+        }
+    }
 }
 
 __global__ void k_query_cells(const double *__restrict__ q, int64_t m, sf_grid_desc g, int32_t *__restrict__ cid,
@@ -112,26 +138,69 @@ __global__ void k_gather_queries(const double *__restrict__ q, const int32_t *__
     qz[i] = q[3 * o + 2];
 }
 
-// sqrt(d2) of every stored pair, in list order (KDTree.query_radius(..., return_distance=True))
-__global__ __launch_bounds__(256) void k_pair_dist(const double *__restrict__ xs, const double *__restrict__ ys,
-                                                   const double *__restrict__ zs, const double *__restrict__ qx,
-                                                   const double *__restrict__ qy, const double *__restrict__ qz,
-                                                   const int64_t *__restrict__ offset, const int32_t *__restrict__ idx,
-                                                   int64_t m, double *__restrict__ dist)
+// Export helper: copy every list from its (slot or CSR) position to the exact CSR position eoff[q], mapping
+// cell-sorted positions to the caller's point numbering, optionally with sqrt(d2) of each pair
+// (KDTree.query_radius(..., return_distance=True)).
+__global__ __launch_bounds__(256) void k_export_lists(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                      const double *__restrict__ zs, const double *__restrict__ qx,
+                                                      const double *__restrict__ qy, const double *__restrict__ qz,
+                                                      const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+                                                      const int32_t *__restrict__ idx, const int64_t *__restrict__ eoff,
+                                                      const int32_t *__restrict__ perm, int64_t m,
+                                                      int32_t *__restrict__ out_idx, double *__restrict__ out_dist)
 {
     const int lane = threadIdx.x & 63;
     const int64_t q = sf_uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
     if (q >= m) return;
-    const int64_t s = offset[q], e = offset[q + 1];
+    const int64_t s = offset[q], d = eoff[q];
+    const int k = cnt[q];
     const double px = qx[q], py = qy[q], pz = qz[q];
-    for (int64_t t = s + lane; t < e; t += 64) {
-        const int j = idx[t];
-        const double dx = xs[j] - px, dy = ys[j] - py, dz = zs[j] - pz;
-        dist[t] = sqrt((dx * dx + dy * dy) + dz * dz);
+    for (int t = lane; t < k; t += 64) {
+        const int j = idx[s + t];
+        out_idx[d + t] = perm[j];
+        if (out_dist) {
+            const double dx = xs[j] - px, dy = ys[j] - py, dz = zs[j] - pz;
+            out_dist[d + t] = sqrt((dx * dx + dy * dy) + dz * dz);
+        }
     }
 }
 
 } // namespace
+
+struct to_i64_sum {
+    __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
+};
+
+// max and sum of the per-query counts (two small rocPRIM reductions), read back with one sync
+static int count_stats(sf_ctx *ctx, sf_nbrs *nb, int64_t *total, int32_t *mx)
+{
+    const int64_t m = nb->m;
+    auto in64 = rocprim::make_transform_iterator(nb->count, to_i64());
+    size_t tb1 = 0, tb2 = 0;
+    int32_t *d_max = nullptr;
+    int64_t *d_sum = nullptr;
+    SF_HIP(rocprim::reduce(nullptr, tb1, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
+                           ctx->stream));
+    SF_HIP(rocprim::reduce(nullptr, tb2, in64, d_sum, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
+                           ctx->stream));
+    size_t tb = ((std::max(tb1, tb2) + 15) / 16) * 16;
+    void *tmp = nullptr;
+    SF_CHECK(sf_pool_alloc(ctx, tb + 32, &tmp));
+    d_sum = (int64_t *)((char *)tmp + tb);
+    d_max = (int32_t *)((char *)tmp + tb + 16);
+    {
+        sf_launch_timer t_(ctx, "k2_reduce");
+        SF_HIP(rocprim::reduce(tmp, tb1, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
+                               ctx->stream));
+        SF_HIP(rocprim::reduce(tmp, tb2, in64, d_sum, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
+                               ctx->stream));
+    }
+    SF_HIP(hipMemcpyAsync(total, d_sum, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipMemcpyAsync(mx, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    sf_pool_release(ctx, tmp);
+    return SF_OK;
+}
 
 static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
 {
@@ -140,43 +209,60 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     SF_CHECK(sf_palloc(ctx, &nb->count, (size_t)(m + 1)));
     SF_CHECK(sf_palloc(ctx, &nb->offset, (size_t)(m + 1)));
     SF_HIP(hipMemsetAsync(nb->count, 0, (size_t)(m + 1) * sizeof(int32_t), ctx->stream));
+    SF_HIP(hipMemsetAsync(nb->offset, 0, (size_t)(m + 1) * sizeof(int64_t), ctx->stream));
     sf_grid_desc g = sf_make_grid_desc(c);
     const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4))), block(256);
-    if (m) {
-        SF_LAUNCH(ctx, "k2_radius_count", k_radius<false>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
-                  nb->qy, nb->qz, m, r2, nb->count, (const int64_t *)nullptr, (int32_t *)nullptr);
+    if (!m) {
+        SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)1));
+        return SF_OK;
     }
-    // exclusive scan of m+1 counts (last is 0) -> offset[m] = total; max over counts
+    // ---- optimistic single pass into fixed-capacity slots -----------------------------------------
+    // capacity from the mean density of the bounding box (x2.25 + 32, multiple of 32); skipped when the slots
+    // would take more than 24 GiB or the estimate is meaningless
+    double vol = 1.0;
+    for (int a = 0; a < 3; ++a) vol *= std::max((double)c->dim[a] * c->cell, 1e-300);
+    const double expect = (double)c->n * 4.18879020478639 * nb->radius * nb->radius * nb->radius / vol;
+    int64_t cap = (int64_t)(expect * 2.25) + 32;
+    cap = std::min<int64_t>(((cap + 31) / 32) * 32, std::max<int64_t>(c->n, 32));
+    const bool optimistic = std::isfinite(expect) && cap * m * 4 <= ((int64_t)24 << 30) && cap < 0x7fffffff;
+    if (optimistic) {
+        SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)(cap * m)));
+        SF_LAUNCH(ctx, "k2_radius_slots", k_radius<2>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
+                  nb->qz, m, r2, (int)cap, nb->count, nb->offset, nb->idx);
+        int64_t total = 0;
+        int32_t mx = 0;
+        SF_CHECK(count_stats(ctx, nb, &total, &mx));
+        nb->total = total;
+        nb->max_count = mx;
+        if (mx <= cap) return SF_OK;
+        sf_pool_release(ctx, nb->idx); // some list overflowed its slot: redo exactly
+        nb->idx = nullptr;
+    } else {
+        SF_LAUNCH(ctx, "k2_radius_count", k_radius<0>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
+                  nb->qz, m, r2, 0, nb->count, nb->offset, (int32_t *)nullptr);
+        int64_t total = 0;
+        int32_t mx = 0;
+        SF_CHECK(count_stats(ctx, nb, &total, &mx));
+        nb->total = total;
+        nb->max_count = mx;
+    }
+    // ---- exact two-pass scheme: counts are known, scan them, fill ---------------------------------------
     auto in = rocprim::make_transform_iterator(nb->count, to_i64());
-    size_t tb1 = 0, tb2 = 0;
-    int32_t *d_max = nullptr;
+    size_t tb1 = 0;
     SF_HIP(rocprim::exclusive_scan(nullptr, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
                                    ctx->stream));
-    SF_HIP(rocprim::reduce(nullptr, tb2, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
-                           ctx->stream));
     void *tmp = nullptr;
-    size_t tb = std::max(tb1, tb2);
-    SF_CHECK(sf_pool_alloc(ctx, (tb ? tb : 8) + 16, &tmp));
-    d_max = (int32_t *)((char *)tmp + ((tb + 7) / 8) * 8);
+    SF_CHECK(sf_pool_alloc(ctx, tb1 ? tb1 : 8, &tmp));
     {
         sf_launch_timer t_(ctx, "k2_scan");
         SF_HIP(rocprim::exclusive_scan(tmp, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
                                        ctx->stream));
-        SF_HIP(rocprim::reduce(tmp, tb2, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
-                               ctx->stream));
     }
-    int64_t total = 0;
-    int32_t mx = 0;
-    SF_HIP(hipMemcpyAsync(&total, nb->offset + m, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipMemcpyAsync(&mx, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipStreamSynchronize(ctx->stream));
     sf_pool_release(ctx, tmp);
-    nb->total = total;
-    nb->max_count = mx;
-    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)total));
-    if (m && total) {
-        SF_LAUNCH(ctx, "k2_radius_fill", k_radius<true>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
-                  nb->qy, nb->qz, m, r2, (int32_t *)nullptr, (const int64_t *)nb->offset, nb->idx);
+    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)nb->total));
+    if (nb->total) {
+        SF_LAUNCH(ctx, "k2_radius_fill", k_radius<1>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
+                  nb->qz, m, r2, 0, nb->count, nb->offset, nb->idx);
     }
     return SF_OK;
 }
@@ -316,59 +402,62 @@ extern "C" int64_t sf_nbrs_max_count(const sf_nbrs *nb) { return nb ? nb->max_co
 
 extern "C" int sf_nbrs_export(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t *offsets, int32_t *idx, double *dist)
 {
-    // Host-side plumbing only: copy the device CSR back, map cell-sorted positions to the caller's point
-    // numbering, order each list by ascending index and rows by the caller's query order.  For a self
-    // search row i is the point at cell-sorted position self_begin + i.
+    // The device compacts the lists into an exact CSR in the caller's point numbering (k_export_lists); the host
+    // only orders each list by ascending index and the rows by the caller's query order.  For a self search
+    // row i is the point at cell-sorted position self_begin + i.
     if (!ctx || !c || !nb || !offsets) { sf_set_error("sf_nbrs_export: null argument"); return SF_ERR_ARG; }
     if (nb->view) { sf_set_error("sf_nbrs_export: not available on a slice view"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
     const int64_t m = nb->m, total = nb->total;
-    std::vector<int64_t> off((size_t)m + 1);
-    std::vector<int32_t> qrow;
-    SF_HIP(hipMemcpyAsync(off.data(), nb->offset, (size_t)(m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    std::vector<int32_t> cnt((size_t)m + 1), qrow;
+    SF_HIP(hipMemcpyAsync(cnt.data(), nb->count, (size_t)(m + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nb->qrow && m) {
         qrow.resize((size_t)m);
         SF_HIP(hipMemcpyAsync(qrow.data(), nb->qrow, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int64_t> cnt_by_row((size_t)m), slot_of_row((size_t)m);
+    std::vector<int64_t> eoff((size_t)m + 1), slot_of_row((size_t)m);
+    eoff[0] = 0;
     for (int64_t s = 0; s < m; ++s) {
-        int64_t row = nb->qrow ? qrow[(size_t)s] : s;
-        cnt_by_row[(size_t)row] = off[(size_t)s + 1] - off[(size_t)s];
-        slot_of_row[(size_t)row] = s;
+        eoff[(size_t)s + 1] = eoff[(size_t)s] + cnt[(size_t)s];
+        slot_of_row[(size_t)(nb->qrow ? qrow[(size_t)s] : s)] = s;
     }
     offsets[0] = 0;
-    for (int64_t r = 0; r < m; ++r) offsets[r + 1] = offsets[r] + cnt_by_row[(size_t)r];
+    for (int64_t r = 0; r < m; ++r) offsets[r + 1] = offsets[r] + cnt[(size_t)slot_of_row[(size_t)r]];
     if (!idx) return SF_OK;
-    std::vector<int32_t> raw((size_t)(total ? total : 1)), perm((size_t)(c->n ? c->n : 1));
+    if (eoff[(size_t)m] != total) { sf_set_error("sf_nbrs_export: inconsistent counts"); return SF_ERR_STATE; }
+    int64_t *d_eoff = nullptr;
+    int32_t *d_idx = nullptr;
+    double *d_dist = nullptr;
+    SF_CHECK(sf_palloc(ctx, &d_eoff, (size_t)m + 1));
+    SF_CHECK(sf_palloc(ctx, &d_idx, (size_t)total));
+    if (dist) SF_CHECK(sf_palloc(ctx, &d_dist, (size_t)total));
+    SF_HIP(hipMemcpyAsync(d_eoff, eoff.data(), (size_t)(m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int32_t> raw((size_t)(total ? total : 1));
     std::vector<double> rawd;
-    if (total) SF_HIP(hipMemcpyAsync(raw.data(), nb->idx, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                     ctx->stream));
-    if (c->n) SF_HIP(hipMemcpyAsync(perm.data(), c->perm, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                    ctx->stream));
-    if (dist && total) {
-        double *dd = nullptr;
-        SF_CHECK(sf_palloc(ctx, &dd, (size_t)total));
-        SF_LAUNCH(ctx, "k2_pair_dist", k_pair_dist, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs,
-                  nb->qx, nb->qy, nb->qz, nb->offset, nb->idx, m, dd);
-        rawd.resize((size_t)total);
-        SF_HIP(hipMemcpyAsync(rawd.data(), dd, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        sf_pool_release(ctx, dd);
+    if (m && total) {
+        SF_LAUNCH(ctx, "k2_export_lists", k_export_lists, dim3((unsigned)sf_div_up(m, 4)), dim3(256), c->xs, c->ys, c->zs,
+                  nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, d_eoff, c->perm, m, d_idx, d_dist);
+        SF_HIP(hipMemcpyAsync(raw.data(), d_idx, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (dist) {
+            rawd.resize((size_t)total);
+            SF_HIP(hipMemcpyAsync(rawd.data(), d_dist, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
     SF_HIP(hipStreamSynchronize(ctx->stream));
+    sf_pool_release(ctx, d_eoff);
+    sf_pool_release(ctx, d_idx);
+    if (d_dist) sf_pool_release(ctx, d_dist);
     std::vector<std::pair<int32_t, double>> tmp;
     for (int64_t r = 0; r < m; ++r) {
-        const int64_t s = slot_of_row[(size_t)r], k = cnt_by_row[(size_t)r], base = off[(size_t)s];
+        const int64_t s = slot_of_row[(size_t)r], k = cnt[(size_t)s], base = eoff[(size_t)s];
         int32_t *dst = idx + offsets[r];
         if (!dist) {
-            for (int64_t t = 0; t < k; ++t) dst[t] = perm[(size_t)raw[(size_t)(base + t)]];
+            for (int64_t t = 0; t < k; ++t) dst[t] = raw[(size_t)(base + t)];
             std::sort(dst, dst + k);
         } else {
             tmp.resize((size_t)k);
-            for (int64_t t = 0; t < k; ++t)
-                tmp[(size_t)t] = {perm[(size_t)raw[(size_t)(base + t)]], rawd[(size_t)(base + t)]};
+            for (int64_t t = 0; t < k; ++t) tmp[(size_t)t] = {raw[(size_t)(base + t)], rawd[(size_t)(base + t)]};
             std::sort(tmp.begin(), tmp.end());
             for (int64_t t = 0; t < k; ++t) {
                 dst[t] = tmp[(size_t)t].first;
