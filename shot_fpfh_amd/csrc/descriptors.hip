@@ -278,13 +278,15 @@ __device__ inline void shot_eval(double cx, double cy, double cz, double d2, dou
     }
 }
 
+// A resolved slot holds the NEGATED value (values are >= 0, so the sign bit marks it); an unresolved key is
+// the bit pattern of rho > 0 and an empty slot is +0.  Decoding is therefore max(-x, 0): one instruction.
 __device__ inline unsigned long long tag_value(double v)
 {
     return (unsigned long long)__double_as_longlong(v) | 0x8000000000000000ull;
 }
 __device__ inline double untag_value(unsigned long long s)
 {
-    return (s >> 63) ? __longlong_as_double((long long)(s & 0x7fffffffffffffffull)) : 0.0;
+    return fmax(-__longlong_as_double((long long)s), 0.0);
 }
 
 __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, const double *__restrict__ ys,
@@ -456,6 +458,8 @@ struct shot_values { double vA, vB, vG, vC, vD, vE, vF; };
 
 __device__ inline void shot_interp(const shot_kept &g, double radius, shot_values &o)
 {
+    // Same interpolation weights as shot_eval<true> (shot.py:73-171, 282-298); the divisions by the two
+    // constant bin sizes (r/2 and pi/2) are multiplications by their reciprocals here (<= 1 ulp apart).
     const unsigned base = g.bins0 & 511u;
     const int ri = base & 1, pi_ = (base >> 1) & 1, ti = (base >> 2) & 7;
     const double rho = g.rho;
@@ -466,26 +470,26 @@ __device__ inline void shot_interp(const shot_kept &g, double radius, shot_value
     dth = fmin(fmax(dth, -0.5), 0.5);
     const double adth = fabs(dth);
     const double half_r = radius / 2, q1 = radius / 4, q3 = radius * 3 / 4;
-    const double inner = (double)((rho > half_r) && (rho < q3)) * (q3 - rho) / half_r;
-    const double outer = (double)((rho < half_r) && (rho > q1)) * (rho - q1) / half_r;
-    const double cur = (double)(rho < half_r) * (1 - fabs(rho - q1) / half_r) +
-                       (double)(rho > half_r) * (1 - fabs(rho - q3) / half_r);
+    const double inv_hr = 1.0 / half_r; // wave-uniform
+    const double inner = ((rho > half_r) && (rho < q3)) ? (q3 - rho) * inv_hr : 0.0;
+    const double outer = ((rho < half_r) && (rho > q1)) ? (rho - q1) * inv_hr : 0.0;
+    const double cur = rho < half_r ? 1 - fabs(rho - q1) * inv_hr : (rho > half_r ? 1 - fabs(rho - q3) * inv_hr : 0.0);
     double lzr = g.lz / rho;
     lzr = fmin(fmax(lzr, -1.0), 1.0);
     const double phi = acos(lzr);
     const double hpi = SHOT_PI / 2, pi34 = SHOT_PI * 3 / 4, pi4 = SHOT_PI / 4;
+    const double inv_hpi = 0.6366197723675814; // 1 / (pi/2)
     const double upper =
-        (double)(((phi > hpi) || ((fabs(phi - hpi) < 1e-10) && (g.lz <= 0.0))) && (phi <= pi34)) * (pi34 - phi) / hpi;
+        (((phi > hpi) || ((fabs(phi - hpi) < 1e-10) && (g.lz <= 0.0))) && (phi <= pi34)) ? (pi34 - phi) * inv_hpi : 0.0;
     const double lower =
-        (double)(((phi < hpi) && ((fabs(phi - hpi) >= 1e-10) || (g.lz > 0.0))) && (phi >= pi4)) * (phi - pi4) / hpi;
-    const double curv = (double)(phi < hpi) * (1 - fabs(phi - pi4) / hpi) +
-                        (double)(phi >= hpi) * (1 - fabs(phi - pi34) / hpi);
+        (((phi < hpi) && ((fabs(phi - hpi) >= 1e-10) || (g.lz > 0.0))) && (phi >= pi4)) ? (phi - pi4) * inv_hpi : 0.0;
+    const double curv = phi < hpi ? 1 - fabs(phi - pi4) * inv_hpi : 1 - fabs(phi - pi34) * inv_hpi;
     o.vB = adc; // the reference's mask (cf > -0.5) & (cf < 10.5) is always true for cf in 0..10
     o.vA = (((1 - adc) + cur) + curv) + (1 - adth);
-    o.vC = outer * (double)(ri == 0);
-    o.vD = inner * (double)(ri == 1);
-    o.vE = upper * (double)(pi_ == 0);
-    o.vF = lower * (double)(pi_ == 1);
+    o.vC = ri == 0 ? outer : 0.0;
+    o.vD = ri == 1 ? inner : 0.0;
+    o.vE = pi_ == 0 ? upper : 0.0;
+    o.vF = pi_ == 1 ? lower : 0.0;
     o.vG = adth;
 }
 
@@ -601,10 +605,11 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
         ss += v * v;
     }
     const double nrm = sqrt(sf_wave_sum(ss));
+    const double scale = nrm > 0.0 ? (normalize ? 1.0 / nrm : 1.0) : 0.0; // shot.py:301-305
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int b = lane + 64 * u;
-        if (b < 352) o[b] = nrm > 0.0 ? (normalize ? vals[u] / nrm : vals[u]) : 0.0;
+        if (b < 352) o[b] = vals[u] * scale;
     }
 }
 

@@ -33,11 +33,28 @@ __device__ inline int sf_prefix_count(unsigned long long mask)
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// Sum over the 64 lanes of a wave, result in every lane.  Built from DPP row operations (register-to-
+// register, a few cycles each) instead of ds_bpermute shuffles, whose LDS round trips made the six-step
+// dependency chain of a reduction the dominant latency of the list-sweeping kernels.
+//   quad_perm xor1, xor2 -> row_half_mirror -> row_mirror : every lane holds its 16-lane row's sum
+//   row_bcast15 (rows 1,3) -> row_bcast31 (rows 2,3)      : lane 63 holds the wave's sum -> v_readlane
 __device__ inline double sf_wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+#define SF_DPP_ADD(ctrl, row_mask)                                                                              \
+    {                                                                                                           \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, row_mask, 0xf, false);           \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, row_mask, 0xf, false);           \
+        v += __hiloint2double(hi, lo);                                                                          \
+    }
+    SF_DPP_ADD(0xB1, 0xf)  // quad_perm [1,0,3,2]
+    SF_DPP_ADD(0x4E, 0xf)  // quad_perm [2,3,0,1]
+    SF_DPP_ADD(0x141, 0xf) // row_half_mirror
+    SF_DPP_ADD(0x140, 0xf) // row_mirror
+    SF_DPP_ADD(0x142, 0xa) // row_bcast15 into rows 1 and 3 (other rows add the old value 0)
+    SF_DPP_ADD(0x143, 0xc) // row_bcast31 into rows 2 and 3
+#undef SF_DPP_ADD
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // XCD-aware block remap.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks

@@ -213,7 +213,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     sf_grid_desc g = sf_make_grid_desc(c);
     const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4))), block(256);
     if (!m) {
-        SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)1));
+        SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)8));
         return SF_OK;
     }
     // ---- optimistic single pass into fixed-capacity slots -----------------------------------------
@@ -226,7 +226,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     cap = std::min<int64_t>(((cap + 31) / 32) * 32, std::max<int64_t>(c->n, 32));
     const bool optimistic = std::isfinite(expect) && cap * m * 4 <= ((int64_t)24 << 30) && cap < 0x7fffffff;
     if (optimistic) {
-        SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)(cap * m)));
+        SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)(cap * m) + 4)); // +4: consumers read indices 16 B at a time
         SF_LAUNCH(ctx, "k2_radius_slots", k_radius<2>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
                   nb->qz, m, r2, (int)cap, nb->count, nb->offset, nb->idx);
         int64_t total = 0;
@@ -259,7 +259,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
                                        ctx->stream));
     }
     sf_pool_release(ctx, tmp);
-    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)nb->total));
+    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)nb->total + 4));
     if (nb->total) {
         SF_LAUNCH(ctx, "k2_radius_fill", k_radius<1>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
                   nb->qz, m, r2, 0, nb->count, nb->offset, nb->idx);
