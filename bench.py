@@ -101,7 +101,12 @@ def main() -> None:
     import shot_fpfh_amd as s
     from shot_fpfh_amd.sharding import DescriptorJob
 
-    eng = s.Engine(local_rank)
+    from shot_fpfh_amd import _ffi
+
+    n_dev = max(_ffi.load().sf_device_count(), 1)
+    if local_rank >= n_dev and rank == 0:
+        print(f"# warning: {world} ranks share {n_dev} GPU(s) (functional test only, timings are not a scaling result)", file=sys.stderr)
+    eng = s.Engine(local_rank % n_dev)
     if world > 1 and args.spfh_exchange == "allgather":
         ids = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
