@@ -91,13 +91,43 @@ __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, 
 }
 
 // K4: SHOT local reference frame (shot.py:16-48), query included in its own support.
+// The wave walks its queries one after the other; the first two chunks (128 neighbours) of the NEXT query
+// are requested before the current one is reduced, so the index -> coordinate round trips overlap the
+// arithmetic instead of serialising with it.
+struct lrf_fetch {
+    double x[2], y[2], z[2]; // raw neighbour coordinates of chunks 0 and 1 (garbage where t >= k)
+    double px, py, pz;
+    int64_t s;
+    int k;
+};
+
+__device__ inline lrf_fetch lrf_prefetch(const double *__restrict__ xs, const double *__restrict__ ys,
+                                         const double *__restrict__ zs, const double *__restrict__ qx,
+                                         const double *__restrict__ qy, const double *__restrict__ qz,
+                                         const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+                                         const int32_t *__restrict__ idx, int64_t q, int lane)
+{
+    lrf_fetch f;
+    f.s = offset[q];
+    f.k = cnt[q];
+    f.px = qx[q]; f.py = qy[q]; f.pz = qz[q];
+    int j[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int t = c * 64 + lane;
+        j[c] = t < f.k ? idx[f.s + t] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { f.x[c] = xs[j[c]]; f.y[c] = ys[j[c]]; f.z[c] = zs[j[c]]; }
+    return f;
+}
+
 __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs, const double *__restrict__ ys,
                                                   const double *__restrict__ zs, const double *__restrict__ qx,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
                                                   const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
-    const int32_t *__restrict__ idx,
-                                                  const int32_t *__restrict__ qrow, int64_t m, double radius,
-                                                  double *__restrict__ lrf)
+                                                  const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
+                                                  int64_t m, double radius, double *__restrict__ lrf)
 {
     const int lane = threadIdx.x & 63;
     const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
@@ -105,24 +135,24 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
     const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
     // phase A: weighted covariance, w = r - ||c|| (shot.py:27-35)
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
+    lrf_fetch cur = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0, lane);
     for (int t = 0; t < nq; ++t) {
-        const int64_t q = q0 + t;
-        const int64_t s = offset[q];
-        const int k = cnt[q];
-        const double px = qx[q], py = qy[q], pz = qz[q];
+        const lrf_fetch nxt = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
         double ws = 0, a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
-        for (int u = lane; u < k; u += 64) {
-            const int j = idx[s + u];
-            const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+        auto add = [&](double x, double y, double z) {
+            const double cx = x - cur.px, cy = y - cur.py, cz = z - cur.pz;
             const double w = radius - sqrt((cx * cx + cy * cy) + cz * cz);
             ws += w;
             const double wx = cx * w, wy = cy * w, wz = cz * w;
-            a11 += cx * wx;
-            a21 += cy * wx;
-            a31 += cz * wx;
-            a22 += cy * wy;
-            a32 += cz * wy;
-            a33 += cz * wz;
+            a11 += cx * wx; a21 += cy * wx; a31 += cz * wx;
+            a22 += cy * wy; a32 += cz * wy; a33 += cz * wz;
+        };
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c * 64 + lane < cur.k) add(cur.x[c], cur.y[c], cur.z[c]);
+        for (int u = 128 + lane; u < cur.k; u += 64) { // neighbourhoods beyond 128 points: streamed
+            const int j = idx[cur.s + u];
+            add(xs[j], ys[j], zs[j]);
         }
         ws = sf_wave_sum(ws);
         a11 = sf_wave_sum(a11) / ws;
@@ -132,6 +162,7 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
         a32 = sf_wave_sum(a32) / ws;
         a33 = sf_wave_sum(a33) / ws;
         if (lane == t) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; }
+        cur = nxt;
     }
     // phase B: one eigen-decomposition per lane (shot.py:36)
     double x0 = 0, x1 = 0, x2 = 0, z0 = 0, z1 = 0, z2 = 0;
@@ -143,29 +174,29 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
     // phase C: sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
     bool flipx = false, flipz = false;
     int kmine = 0;
+    cur = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0, lane);
     for (int t = 0; t < nq; ++t) {
-        const int64_t q = q0 + t;
-        const int64_t s = offset[q];
-        const int k = cnt[q];
-        const double px = qx[q], py = qy[q], pz = qz[q];
+        const lrf_fetch nxt = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
         const double bx0 = lane_bcast(x0, t), bx1 = lane_bcast(x1, t), bx2 = lane_bcast(x2, t);
         const double bz0 = lane_bcast(z0, t), bz1 = lane_bcast(z1, t), bz2 = lane_bcast(z2, t);
         int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
-        for (int u0 = 0; u0 < k; u0 += 64) {
+        auto vote = [&](bool on, double x, double y, double z) {
+            const double cx = x - cur.px, cy = y - cur.py, cz = z - cur.pz;
+            const double xo = (cx * bx0 + cy * bx1) + cz * bx2;
+            const double zo = (cx * bz0 + cy * bz1) + cz * bz2;
+            xneg += __popcll(__ballot(on && xo < 0.0)); xpos += __popcll(__ballot(on && xo >= 0.0));
+            zneg += __popcll(__ballot(on && zo < 0.0)); zpos += __popcll(__ballot(on && zo >= 0.0));
+        };
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c * 64 < cur.k) vote(c * 64 + lane < cur.k, cur.x[c], cur.y[c], cur.z[c]);
+        for (int u0 = 128; u0 < cur.k; u0 += 64) {
             const int u = u0 + lane;
-            bool xn = false, xp = false, zn = false, zp = false;
-            if (u < k) {
-                const int j = idx[s + u];
-                const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
-                const double xo = (cx * bx0 + cy * bx1) + cz * bx2;
-                const double zo = (cx * bz0 + cy * bz1) + cz * bz2;
-                xn = xo < 0.0; xp = xo >= 0.0;
-                zn = zo < 0.0; zp = zo >= 0.0;
-            }
-            xneg += __popcll(__ballot(xn)); xpos += __popcll(__ballot(xp));
-            zneg += __popcll(__ballot(zn)); zpos += __popcll(__ballot(zp));
+            const int j = u < cur.k ? idx[cur.s + u] : 0;
+            vote(u < cur.k, xs[j], ys[j], zs[j]);
         }
-        if (lane == t) { flipx = xneg > xpos; flipz = zneg > zpos; kmine = k; }
+        if (lane == t) { flipx = xneg > xpos; flipz = zneg > zpos; kmine = cur.k; }
+        cur = nxt;
     }
     if (lane < nq) {
         const int64_t q = q0 + lane;
@@ -504,8 +535,10 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
                                                     int64_t m, double radius, const double *__restrict__ lrf,
                                                     int normalize, int64_t min_nb, double *__restrict__ out)
 {
+    // 11 KB of LDS per wave (14 waves per CU).  sCD / sEF carry ONE value per slot plus a flag in bit 62
+    // (unused by doubles below 2.0): the S3/S4 pair of a winner has a single non-zero member, selected by
+    // the winner's radial bin, and likewise S6/S7 by its elevation bin.
     __shared__ unsigned long long sA[352], sB[352], sG[352], sCD[176], sEF[176];
-    __shared__ double sD[176], sF[176];
     const int lane = threadIdx.x;
     const int64_t q = sf_xcd_block();
     if (q >= m) return;
@@ -516,7 +549,7 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
     const double px = qx[q], py = qy[q], pz = qz[q];
 
     for (int b = lane; b < 352; b += 64) { sA[b] = 0; sB[b] = 0; sG[b] = 0; }
-    for (int b = lane; b < 176; b += 64) { sCD[b] = 0; sEF[b] = 0; sD[b] = 0.0; sF[b] = 0.0; }
+    for (int b = lane; b < 176; b += 64) { sCD[b] = 0; sEF[b] = 0; }
 
     // one gather for all chunks
     double cx[NCH], cy[NCH], cz[NCH], nx[NCH], ny[NCH], nz[NCH];
@@ -580,8 +613,9 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
                 if (wA) sA[iA] = tag_value(v.vA);
                 if (wB) sB[iB] = tag_value(v.vB);
                 if (wG) sG[iG] = tag_value(v.vG);
-                if (wCD) { sCD[iCD] = tag_value(v.vC); sD[iCD] = v.vD; }
-                if (wEF) { sEF[iEF] = tag_value(v.vE); sF[iEF] = v.vF; }
+                const unsigned long long ri_w = iA & 1u, pi_w = (iA >> 1) & 1u; // the winner's own radial / elevation bin
+                if (wCD) sCD[iCD] = tag_value(ri_w ? v.vD : v.vC) | (ri_w << 62);
+                if (wEF) sEF[iEF] = tag_value(pi_w ? v.vF : v.vE) | (pi_w << 62);
             }
         }
     }
@@ -595,10 +629,14 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
         if (b < 352) {
             const int cdi = b >> 1, efi = ((b >> 2) << 1) | (b & 1);
             const int rb = b & 1, pb = (b >> 1) & 1;
+            // S3 lands in radial bin 1 and comes from a winner in radial bin 0 (flag 0); S4 the other way round
+            const unsigned long long cd = sCD[cdi], ef = sEF[efi];
+            const bool cd_on = (cd >> 63) && (((cd >> 62) & 1ull) != (unsigned long long)rb);
+            const bool ef_on = (ef >> 63) && (((ef >> 62) & 1ull) != (unsigned long long)pb);
             v = untag_value(sB[b]);
             v += untag_value(sA[b]);
-            v += rb ? untag_value(sCD[cdi]) : sD[cdi];
-            v += pb ? untag_value(sEF[efi]) : sF[efi];
+            v += cd_on ? __longlong_as_double((long long)(cd & 0x3fffffffffffffffull)) : 0.0;
+            v += ef_on ? __longlong_as_double((long long)(ef & 0x3fffffffffffffffull)) : 0.0;
             v += untag_value(sG[b]);
         }
         vals[u] = v;
