@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
     auto weight_of = [&](double x, double y, double z, int kj) -> double {
         const double cx = x - px, cy = y - py, cz = z - pz;
         const double d2 = (cx * cx + cy * cy) + cz * cz;
-        return d2 > 0.0 ? (1.0 / (double)kj) / sqrt(d2) : 0.0;
+        return d2 > 0.0 ? 1.0 / ((double)kj * sqrt(d2)) : 0.0; // = (1/k_j)/d_j up to one rounding
     };
     auto accumulate = [&](const uint4 &v, double ww, int u) {
         if (sizeof(CT) == 2) {
@@ -231,19 +231,22 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
         int gk[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int j = jv[c] < 0 ? 0 : jv[c];
-            gx[c] = xs[j]; gy[c] = ys[j]; gz[c] = zs[j];
-            gk[c] = kk[j];
+            if (c * 64 < k) { // wave-uniform: chunks beyond the list cost nothing
+                const int j = jv[c] < 0 ? 0 : jv[c];
+                gx[c] = xs[j]; gy[c] = ys[j]; gz[c] = zs[j];
+                gk[c] = kk[j];
+            } else {
+                gx[c] = gy[c] = gz[c] = 0.0;
+                gk[c] = 1;
+            }
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            wv[c] = jv[c] < 0 ? 0.0 : weight_of(gx[c], gy[c], gz[c], gk[c]);
-            jv[c] = jv[c] < 0 ? 0 : jv[c];
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int cnt = min(64, k - c * 64);
-            if (cnt > 0) stream_rows(jv[c], wv[c], cnt);
+            if (c * 64 < k) {
+                wv[c] = jv[c] < 0 ? 0.0 : weight_of(gx[c], gy[c], gz[c], gk[c]);
+                jv[c] = jv[c] < 0 ? 0 : jv[c];
+                stream_rows(jv[c], wv[c], min(64, k - c * 64));
+            }
         }
     } else {
         for (int t0 = 0; t0 < k; t0 += 64) {
@@ -264,16 +267,24 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
         for (int u = 0; u < NP; ++u)
 #pragma unroll
             for (int e = 0; e < BPP; ++e) acc[u][e] += __shfl_xor(acc[u][e], off);
-    if (grp == 0) {
+    // every lane group now holds the complete sums; group g writes bins e = g, g + RPI, ... of each piece so the
+    // divisions are shared out instead of being executed (predicated) by the whole wave for group 0 alone
+    {
         const double kd = (double)k;
         const CT *own = counts + i * (int64_t)stride;
         double *o = out + q * (int64_t)nb3;
 #pragma unroll
         for (int u = 0; u < NP; ++u)
 #pragma unroll
-            for (int e = 0; e < BPP; ++e) {
+            for (int e0 = 0; e0 < BPP; e0 += RPI) {
+                // select acc[u][e0 + grp] without a run-time register index
+                double a = acc[u][e0];
+#pragma unroll
+                for (int g = 1; g < RPI; ++g)
+                    if (e0 + g < BPP) a = grp == g ? acc[u][e0 + g] : a;
+                const int e = e0 + grp;
                 const int b = (u * 64 + piece) * BPP + e; // == byte offset (u*1024 + piece*16) / sizeof(CT) + e
-                if (b < nb3) o[b] = (double)own[b] / kd + acc[u][e] / kd;
+                if (e < BPP && b < nb3) o[b] = (double)own[b] / kd + a / kd;
             }
     }
 }

@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
     stencil_bounds(px, g.lo[0], g.inv_cell, g.dim[0], x0, x1);
     stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
     stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
+    // the bounds are wave-uniform but were computed with (vector) float64 instructions: hand them to the
+    // scalar unit so the cell_start look-ups below are scalar loads, not 64-lane vector loads of one address
+    x0 = sf_uniform(x0); x1 = sf_uniform(x1);
+    y0 = sf_uniform(y0); y1 = sf_uniform(y1);
+    z0 = sf_uniform(z0); z1 = sf_uniform(z1);
     int total = 0;
     const int64_t out = MODE == 1 ? offset[q] : q * (int64_t)cap;
     const int room = MODE == 2 ? cap : 0x7fffffff;
@@ -85,17 +90,22 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
         for (int cy = y0; cy <= y1; ++cy) {
             const int64_t row = ((int64_t)cz * g.dim[1] + cy) * g.dim[0];
             const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
-            for (int j0 = s; j0 < e; j0 += 128) {
+            // pairs start at an EVEN position so that every 16-byte load is naturally aligned (the arrays
+            // are 256-byte aligned); the element before the run, if any, is masked out by `j >= s`
+            for (int j0 = s & ~1; j0 < e; j0 += 128) {
                 const int j = j0 + 2 * lane;
-                const bool in0 = j < e, in1 = j + 1 < e;
-                const int jj = in0 ? j : s; // unconditional loads (the arrays carry one padding element)
-                const sf_dbl2 X = *reinterpret_cast<const sf_dbl2 *>(xs + jj);
-                const sf_dbl2 Y = *reinterpret_cast<const sf_dbl2 *>(ys + jj);
-                const sf_dbl2 Z = *reinterpret_cast<const sf_dbl2 *>(zs + jj);
-                const double dxa = X.a - px, dya = Y.a - py, dza = Z.a - pz;
-                const double dxb = X.b - px, dyb = Y.b - py, dzb = Z.b - pz;
-                const bool hit0 = in0 && ((dxa * dxa + dya * dya) + dza * dza) <= r2;
-                const bool hit1 = in1 && ((dxb * dxb + dyb * dyb) + dzb * dzb) <= r2;
+                const bool in0 = j >= s && j < e, in1 = j + 1 < e;
+                const int jj = j < e ? j : j0; // unconditional loads (the arrays carry two padding elements)
+                const double2 X = *reinterpret_cast<const double2 *>(xs + jj);
+                const double2 Y = *reinterpret_cast<const double2 *>(ys + jj);
+                const double2 Z = *reinterpret_cast<const double2 *>(zs + jj);
+                const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
+                const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
+                // both distances are evaluated unconditionally (bitwise &): a short-circuit would let the compiler
+                // sink half of each 16-byte load into a branch and split it into two 8-byte loads
+                const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
+                const bool hit0 = in0 & (d2a <= r2);
+                const bool hit1 = in1 & (d2b <= r2);
                 const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
                 if (MODE != 0) {
                     const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
