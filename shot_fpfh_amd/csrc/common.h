@@ -129,7 +129,10 @@ struct sf_cloud {
     int32_t *inv_perm = nullptr;    // original index -> sorted position
     // cell-sorted SoA
     double *xs = nullptr, *ys = nullptr, *zs = nullptr;
-    double *nxs = nullptr, *nys = nullptr, *nzs = nullptr;
+    // cell-sorted AoS records {x, y, z, nx, ny, nz} (48 B, 16-byte aligned): what the list-driven kernels
+    // gather -- three 16-byte loads bring in a neighbour's position AND normal (the vector-memory pipe
+    // costs 16 cycles per wave instruction whatever the width, so 3 wide loads beat 6 narrow ones)
+    double *rec = nullptr;
     bool normals_sorted = false;
 };
 

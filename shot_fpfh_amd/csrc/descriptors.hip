@@ -27,8 +27,7 @@ __device__ inline double lane_bcast(double v, int src) { return __shfl(v, src); 
 
 // K3: normals.  cov = centered^T centered / k about the barycentre (pca_based_descriptors.py:21-23),
 // eigh, eigenvector of the smallest eigenvalue (:51), optional re-orientation (:53-57).
-__global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, const double *__restrict__ ys,
-                                                 const double *__restrict__ zs, const double *__restrict__ qx,
+__global__ __launch_bounds__(256) void k_normals(const double *__restrict__ rec, const double *__restrict__ qx,
                                                  const double *__restrict__ qy, const double *__restrict__ qz,
                                                  const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
@@ -48,18 +47,20 @@ __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ xs, 
         // pass 1: barycentre, accumulated relative to the query to keep the sums small
         double sx = 0.0, sy = 0.0, sz = 0.0;
         for (int u = lane; u < k; u += 64) {
-            const int j = idx[s + u];
-            sx += xs[j] - px;
-            sy += ys[j] - py;
-            sz += zs[j] - pz;
+            double x, y, z;
+            sf_load_xyz(rec, idx[s + u], x, y, z);
+            sx += x - px;
+            sy += y - py;
+            sz += z - pz;
         }
         const double kk = (double)k;
         const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
         // pass 2: lower triangle of the centred second moments
         double a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
         for (int u = lane; u < k; u += 64) {
-            const int j = idx[s + u];
-            const double ax = (xs[j] - px) - mx, ay = (ys[j] - py) - my, az = (zs[j] - pz) - mz;
+            double x, y, z;
+            sf_load_xyz(rec, idx[s + u], x, y, z);
+            const double ax = (x - px) - mx, ay = (y - py) - my, az = (z - pz) - mz;
             a11 += ax * ax;
             a21 += ay * ax;
             a31 += az * ax;
@@ -101,8 +102,7 @@ struct lrf_fetch {
     int k;
 };
 
-__device__ inline lrf_fetch lrf_prefetch(const double *__restrict__ xs, const double *__restrict__ ys,
-                                         const double *__restrict__ zs, const double *__restrict__ qx,
+__device__ inline lrf_fetch lrf_prefetch(const double *__restrict__ rec, const double *__restrict__ qx,
                                          const double *__restrict__ qy, const double *__restrict__ qz,
                                          const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
                                          const int32_t *__restrict__ idx, int64_t q, int lane)
@@ -118,12 +118,11 @@ __device__ inline lrf_fetch lrf_prefetch(const double *__restrict__ xs, const do
         j[c] = t < f.k ? idx[f.s + t] : 0;
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { f.x[c] = xs[j[c]]; f.y[c] = ys[j[c]]; f.z[c] = zs[j[c]]; }
+    for (int c = 0; c < 2; ++c) sf_load_xyz(rec, j[c], f.x[c], f.y[c], f.z[c]);
     return f;
 }
 
-__global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs, const double *__restrict__ ys,
-                                                  const double *__restrict__ zs, const double *__restrict__ qx,
+__global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec, const double *__restrict__ qx,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
                                                   const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
                                                   const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
@@ -135,9 +134,9 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
     const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
     // phase A: weighted covariance, w = r - ||c|| (shot.py:27-35)
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
-    lrf_fetch cur = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0, lane);
+    lrf_fetch cur = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0, lane);
     for (int t = 0; t < nq; ++t) {
-        const lrf_fetch nxt = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
+        const lrf_fetch nxt = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
         double ws = 0, a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
         auto add = [&](double x, double y, double z) {
             const double cx = x - cur.px, cy = y - cur.py, cz = z - cur.pz;
@@ -151,8 +150,9 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
         for (int c = 0; c < 2; ++c)
             if (c * 64 + lane < cur.k) add(cur.x[c], cur.y[c], cur.z[c]);
         for (int u = 128 + lane; u < cur.k; u += 64) { // neighbourhoods beyond 128 points: streamed
-            const int j = idx[cur.s + u];
-            add(xs[j], ys[j], zs[j]);
+            double x, y, z;
+            sf_load_xyz(rec, idx[cur.s + u], x, y, z);
+            add(x, y, z);
         }
         ws = sf_wave_sum(ws);
         a11 = sf_wave_sum(a11) / ws;
@@ -174,9 +174,9 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
     // phase C: sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
     bool flipx = false, flipz = false;
     int kmine = 0;
-    cur = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0, lane);
+    cur = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0, lane);
     for (int t = 0; t < nq; ++t) {
-        const lrf_fetch nxt = lrf_prefetch(xs, ys, zs, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
+        const lrf_fetch nxt = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
         const double bx0 = lane_bcast(x0, t), bx1 = lane_bcast(x1, t), bx2 = lane_bcast(x2, t);
         const double bz0 = lane_bcast(z0, t), bz1 = lane_bcast(z1, t), bz2 = lane_bcast(z2, t);
         int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ xs,
             if (c * 64 < cur.k) vote(c * 64 + lane < cur.k, cur.x[c], cur.y[c], cur.z[c]);
         for (int u0 = 128; u0 < cur.k; u0 += 64) {
             const int u = u0 + lane;
-            const int j = u < cur.k ? idx[cur.s + u] : 0;
-            vote(u < cur.k, xs[j], ys[j], zs[j]);
+            double x, y, z;
+            sf_load_xyz(rec, u < cur.k ? idx[cur.s + u] : 0, x, y, z);
+            vote(u < cur.k, x, y, z);
         }
         if (lane == t) { flipx = xneg > xpos; flipz = zneg > zpos; kmine = cur.k; }
         cur = nxt;
@@ -320,9 +321,7 @@ __device__ inline double untag_value(unsigned long long s)
     return fmax(-__longlong_as_double((long long)s), 0.0);
 }
 
-__global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, const double *__restrict__ ys,
-                                             const double *__restrict__ zs, const double *__restrict__ nxs,
-                                             const double *__restrict__ nys, const double *__restrict__ nzs,
+__global__ __launch_bounds__(64) void k_shot(const double *__restrict__ rec,
                                              const double *__restrict__ qx, const double *__restrict__ qy,
                                              const double *__restrict__ qz, const int64_t *__restrict__ offset,
                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
@@ -347,8 +346,9 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, cons
         const int t = t0 + lane;
         bool pos = false;
         if (t < k) {
-            const int j = idx[s + t];
-            const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+            double x, y, z;
+            sf_load_xyz(rec, idx[s + t], x, y, z);
+            const double cx = x - px, cy = y - py, cz = z - pz;
             pos = ((cx * cx + cy * cy) + cz * cz) > 0.0;
         }
         npos += __popcll(__ballot(pos));
@@ -367,12 +367,13 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, cons
 
     // sweep 1: elect the max-rho writer of every (key, bin)
     for (int t = lane; t < k; t += 64) {
-        const int j = idx[s + t];
-        const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+        double x, y, z, nx_, ny_, nz_;
+        sf_load_pn(rec, idx[s + t], x, y, z, nx_, ny_, nz_);
+        const double cx = x - px, cy = y - py, cz = z - pz;
         const double d2 = (cx * cx + cy * cy) + cz * cz;
         if (d2 > 0.0) {
             shot_sample sm;
-            shot_eval<false>(cx, cy, cz, d2, nxs[j], nys[j], nzs[j], E, radius, sm);
+            shot_eval<false>(cx, cy, cz, d2, nx_, ny_, nz_, E, radius, sm);
             const unsigned long long key = (unsigned long long)__double_as_longlong(sm.rho);
             atomicMax(&sA[sm.base], key);
             atomicMax(&sB[sm.bcos], key);
@@ -384,12 +385,13 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ xs, cons
     __syncthreads();
     // sweep 2: winners replace their key by their (tagged) value
     for (int t = lane; t < k; t += 64) {
-        const int j = idx[s + t];
-        const double cx = xs[j] - px, cy = ys[j] - py, cz = zs[j] - pz;
+        double x, y, z, nx_, ny_, nz_;
+        sf_load_pn(rec, idx[s + t], x, y, z, nx_, ny_, nz_);
+        const double cx = x - px, cy = y - py, cz = z - pz;
         const double d2 = (cx * cx + cy * cy) + cz * cz;
         if (d2 > 0.0) {
             shot_sample sm;
-            shot_eval<true>(cx, cy, cz, d2, nxs[j], nys[j], nzs[j], E, radius, sm);
+            shot_eval<true>(cx, cy, cz, d2, nx_, ny_, nz_, E, radius, sm);
             const unsigned long long key = (unsigned long long)__double_as_longlong(sm.rho);
             if (sA[sm.base] == key) sA[sm.base] = tag_value(sm.vA);
             if (sB[sm.bcos] == key) sB[sm.bcos] = tag_value(sm.vB);
@@ -525,9 +527,7 @@ __device__ inline void shot_interp(const shot_kept &g, double radius, shot_value
 }
 
 template <int NCH>
-__global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ xs, const double *__restrict__ ys,
-                                                    const double *__restrict__ zs, const double *__restrict__ nxs,
-                                                    const double *__restrict__ nys, const double *__restrict__ nzs,
+__global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ rec,
                                                     const double *__restrict__ qx, const double *__restrict__ qy,
                                                     const double *__restrict__ qz, const int64_t *__restrict__ offset,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
@@ -558,12 +558,11 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ x
         const int t = c * 64 + lane;
         const int j = t < k ? idx[s + t] : -1;
         const int jj = j < 0 ? 0 : j;
-        cx[c] = j < 0 ? 0.0 : xs[jj] - px;
-        cy[c] = j < 0 ? 0.0 : ys[jj] - py;
-        cz[c] = j < 0 ? 0.0 : zs[jj] - pz;
-        nx[c] = nxs[jj];
-        ny[c] = nys[jj];
-        nz[c] = nzs[jj];
+        double x, y, z;
+        sf_load_pn(rec, jj, x, y, z, nx[c], ny[c], nz[c]);
+        cx[c] = j < 0 ? 0.0 : x - px;
+        cy[c] = j < 0 ? 0.0 : y - py;
+        cz[c] = j < 0 ? 0.0 : z - pz;
     }
     double E[9];
 #pragma unroll
@@ -702,7 +701,7 @@ extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *p
     SF_CHECK(stage_in(ctx, pre, (size_t)m * 3, flags, &dpre, &opre));
     SF_CHECK(stage_out(ctx, out, (size_t)m * 3, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->xs, c->ys, c->zs, nb->qx,
+        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx,
                   nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, dpre, dout);
     }
     SF_CHECK(finish_out(ctx, out, (size_t)m * 3, dout, oout));
@@ -718,7 +717,7 @@ extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, i
     double *dout, *oout;
     SF_CHECK(stage_out(ctx, lrf, (size_t)m * 9, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->xs, c->ys, c->zs,
+        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec,
                   nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, dout);
     }
     return finish_out(ctx, lrf, (size_t)m * 9, dout, oout);
@@ -737,7 +736,7 @@ extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf,
     SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
     if (m) {
         const dim3 grid(sf_xcd_grid(m)), block(64);
-#define SF_SHOT_ARGS c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, \
+#define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, \
                      nb->radius, dlrf, normalize, min_nb, dout
         const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
         if (chunks <= 1) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<1>, grid, block, SF_SHOT_ARGS); }

@@ -69,6 +69,21 @@ __device__ inline long long sf_xcd_block()
     return (long long)(b & 7u) * chunk + (b >> 3);
 }
 
+// gathers from the AoS records {x, y, z, nx, ny, nz}
+__device__ inline void sf_load_xyz(const double *__restrict__ rec, int j, double &x, double &y, double &z)
+{
+    const double2 *p = reinterpret_cast<const double2 *>(rec + 6 * (size_t)j);
+    const double2 a = p[0], b = p[1];
+    x = a.x; y = a.y; z = b.x;
+}
+__device__ inline void sf_load_pn(const double *__restrict__ rec, int j, double &x, double &y, double &z, double &nx,
+                                  double &ny, double &nz)
+{
+    const double2 *p = reinterpret_cast<const double2 *>(rec + 6 * (size_t)j);
+    const double2 a = p[0], b = p[1], c = p[2];
+    x = a.x; y = a.y; z = b.x; nx = b.y; ny = c.x; nz = c.y;
+}
+
 __device__ inline int sf_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ inline long long sf_uniform64(long long v)

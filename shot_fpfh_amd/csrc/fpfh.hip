@@ -68,9 +68,7 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
 // coordinates / normals, are requested before any is used, so a wave pays ONE index round trip and ONE
 // gather round trip instead of one per chunk.  NCH == 0: streaming loop for any size.
 template <typename CT, int NCH>
-__global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, const double *__restrict__ ys,
-                                              const double *__restrict__ zs, const double *__restrict__ nxs,
-                                              const double *__restrict__ nys, const double *__restrict__ nzs,
+__global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb, int nb3, int stride,
@@ -85,8 +83,8 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
     const int64_t i = self_begin + q; // cell-sorted position of this point
     const int64_t s = offset[q];
     const int k = cnt[q];
-    const double px = xs[i], py = ys[i], pz = zs[i];
-    const double ux = nxs[i], uy = nys[i], uz = nzs[i];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const double ux = rec[6 * i + 3], uy = rec[6 * i + 4], uz = rec[6 * i + 5];
     __builtin_amdgcn_wave_barrier();
     auto pair = [&](double cx, double cy, double cz, double njx, double njy, double njz) {
         const double d2 = (cx * cx + cy * cy) + cz * cz;
@@ -113,16 +111,16 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = jj[c] < 0 ? 0 : jj[c];
-            cx[c] = xs[j]; cy[c] = ys[j]; cz[c] = zs[j];
-            ax[c] = nxs[j]; ay[c] = nys[j]; az[c] = nzs[j];
+            sf_load_pn(rec, j, cx[c], cy[c], cz[c], ax[c], ay[c], az[c]);
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c)
             if (jj[c] >= 0) pair(cx[c] - px, cy[c] - py, cz[c] - pz, ax[c], ay[c], az[c]);
     } else {
         for (int t = lane; t < k; t += 64) {
-            const int j = idx[s + t];
-            pair(xs[j] - px, ys[j] - py, zs[j] - pz, nxs[j], nys[j], nzs[j]);
+            double x, y, z, a, b, c;
+            sf_load_pn(rec, idx[s + t], x, y, z, a, b, c);
+            pair(x - px, y - py, z - pz, a, b, c);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -138,8 +136,7 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ xs, con
 // 16/sizeof(CT) bins of its 16-byte piece (NP pieces when a row is longer than 1 KiB) in float64 and the
 // lane groups are summed with shuffles at the end.  NCH as in K6 (0 = any list length).
 template <typename CT, int LPR, int NP, int NCH>
-__global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, const double *__restrict__ ys,
-                                              const double *__restrict__ zs, const int64_t *__restrict__ offset,
+__global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                               int64_t nbrs_begin,
                                               const int32_t *__restrict__ kp_pos, int64_t m, int nb3, int stride,
@@ -156,7 +153,7 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
     const int64_t slot = i - nbrs_begin;
     const int64_t s = offset[slot];
     const int k = cnt[slot];
-    const double px = xs[i], py = ys[i], pz = zs[i];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const int grp = lane / LPR, piece = lane % LPR;
     const unsigned row_bytes = (unsigned)stride * (unsigned)sizeof(CT);
     double acc[NP][BPP];
@@ -233,7 +230,7 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
         for (int c = 0; c < NC; ++c) {
             if (c * 64 < k) { // wave-uniform: chunks beyond the list cost nothing
                 const int j = jv[c] < 0 ? 0 : jv[c];
-                gx[c] = xs[j]; gy[c] = ys[j]; gz[c] = zs[j];
+                sf_load_xyz(rec, j, gx[c], gy[c], gz[c]);
                 gk[c] = kk[j];
             } else {
                 gx[c] = gy[c] = gz[c] = 0.0;
@@ -255,7 +252,9 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ xs, con
             double w = 0.0;
             if (t < k) {
                 j = idx[s + t];
-                w = weight_of(xs[j], ys[j], zs[j], kk[j]);
+                double x, y, z;
+                sf_load_xyz(rec, j, x, y, z);
+                w = weight_of(x, y, z, kk[j]);
             }
             stream_rows(j, w, min(64, k - t0));
         }
@@ -377,7 +376,7 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     int chunks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
-    SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH>), grid, block, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs, nb->offset,  \
+    SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH>), grid, block, c->rec, nb->offset,  \
               nb->count, nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k)
 #define SF_SPFH_DISPATCH(CT)                                     \
     switch (chunks) {                                            \
@@ -462,7 +461,7 @@ static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
         nch = chunks <= 2 ? 2 : (chunks <= 4 ? 4 : 0);
     }
 #define SF_FPFH_LAUNCH(LPR, NP, NCH)                                                                                 \
-    SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh<CT, LPR, NP, NCH>), grid, block, c->xs, c->ys, c->zs, nb->offset, nb->count, nb->idx,      \
+    SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh<CT, LPR, NP, NCH>), grid, block, c->rec, nb->offset, nb->count, nb->idx,      \
               nb->self_begin, kp_pos, m, sp->nb3, sp->stride, (const CT *)sp->counts, table_bytes, sp->k, dout)
 #define SF_FPFH_SHAPE(LPR, NP)                                                 \
     {                                                                          \

@@ -3,8 +3,8 @@
 // Replaces: KDTree(cloud_points) at fpfh.py:26, shot_parallelization.py:167/220/229/283,
 //           pca_based_descriptors.py:45-49.
 // Layout in HBM: the caller's AoS xyz / normals are kept as uploaded; the grid build writes
-// cell-sorted SoA copies (xs, ys, zs, nxs, nys, nzs) so that a wave scanning a run of cells reads
-// 64 consecutive doubles per load, plus perm / inv_perm (sorted position <-> original index) and
+// cell-sorted SoA positions (xs, ys, zs) so that a wave scanning a run of cells reads consecutive doubles,
+// cell-sorted AoS records {x,y,z,nx,ny,nz} for the list-driven gathers, plus perm / inv_perm (sorted position <-> original index) and
 // cell_start (first sorted position of every cell, x fastest).
 // Roofline: HBM; ~ n * (24 read + 4+4 id/idx + sort passes + 48 gather + 48 write) bytes, one-off.
 #include <rocprim/device/device_radix_sort.hpp>
@@ -64,17 +64,30 @@ __global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_de
     val[i] = (int32_t)i;
 }
 
+// positions: SoA (for the candidate sweeps of K2) + slots 0..2 of the AoS records (for gathers) + inv_perm
 __global__ void k_gather_sorted(const double *__restrict__ xyz, const int32_t *__restrict__ perm, int64_t n,
                                 double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ zs,
-                                int32_t *__restrict__ inv_perm)
+                                double *__restrict__ rec, int32_t *__restrict__ inv_perm)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t o = perm[i];
-    xs[i] = xyz[3 * o + 0];
-    ys[i] = xyz[3 * o + 1];
-    zs[i] = xyz[3 * o + 2];
-    if (inv_perm) inv_perm[o] = (int32_t)i;
+    const double x = xyz[3 * o + 0], y = xyz[3 * o + 1], z = xyz[3 * o + 2];
+    xs[i] = x; ys[i] = y; zs[i] = z;
+    rec[6 * i + 0] = x; rec[6 * i + 1] = y; rec[6 * i + 2] = z;
+    inv_perm[o] = (int32_t)i;
+}
+
+// normals: slots 3..5 of the AoS records
+__global__ void k_gather_normals(const double *__restrict__ nrm, const int32_t *__restrict__ perm, int64_t n,
+                                 double *__restrict__ rec)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t o = perm[i];
+    rec[6 * i + 3] = nrm[3 * o + 0];
+    rec[6 * i + 4] = nrm[3 * o + 1];
+    rec[6 * i + 5] = nrm[3 * o + 2];
 }
 
 __global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t n, int64_t ncell,
@@ -95,13 +108,13 @@ __global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t n, 
 
 static void cloud_release_grid(sf_ctx *ctx, sf_cloud *c)
 {
-    void *ptrs[] = {c->cell_start, c->perm, c->inv_perm, c->xs, c->ys, c->zs, c->nxs, c->nys, c->nzs};
+    void *ptrs[] = {c->cell_start, c->perm, c->inv_perm, c->xs, c->ys, c->zs, c->rec};
     for (void *p : ptrs)
         if (p) {
             if (ctx) sf_pool_release(ctx, p); else (void)hipFree(p);
         }
     c->cell_start = c->perm = c->inv_perm = nullptr;
-    c->xs = c->ys = c->zs = c->nxs = c->nys = c->nzs = nullptr;
+    c->xs = c->ys = c->zs = c->rec = nullptr;
     c->normals_sorted = false;
     c->cell = 0.0;
 }
@@ -156,15 +169,9 @@ int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
     if (c->normals_sorted) return SF_OK;
     if (!c->nrm_orig) { sf_set_error("this operation needs normals, but the cloud has none"); return SF_ERR_STATE; }
     if (!c->perm) { sf_set_error("grid not built"); return SF_ERR_STATE; }
-    size_t bytes = (size_t)(c->n ? c->n : 1) * sizeof(double);
-    if (!c->nxs) {
-        SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nxs));
-        SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nys));
-        SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nzs));
-    }
     if (c->n) {
-        SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(c->n, 256)), dim3(256),
-                  c->nrm_orig, c->perm, c->n, c->nxs, c->nys, c->nzs, (int32_t *)nullptr);
+        SF_LAUNCH(ctx, "k1_gather_normals", k_gather_normals, dim3((unsigned)sf_div_up(c->n, 256)), dim3(256),
+                  c->nrm_orig, c->perm, c->n, c->rec);
     }
     c->normals_sorted = true;
     return SF_OK;
@@ -229,6 +236,7 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
     SF_CHECK(sf_palloc(ctx, &c->xs, nn + 2)); // +2: K2 reads candidates in pairs (one element past the end)
     SF_CHECK(sf_palloc(ctx, &c->ys, nn + 2));
     SF_CHECK(sf_palloc(ctx, &c->zs, nn + 2));
+    SF_CHECK(sf_palloc(ctx, &c->rec, nn * 6 + 2));
     if (!n) {
         SF_HIP(hipMemsetAsync(c->cell_start, 0, (size_t)(ncell + 1) * sizeof(int32_t), ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
@@ -255,7 +263,7 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
                                          ctx->stream));
     }
     SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig,
-              c->perm, n, c->xs, c->ys, c->zs, c->inv_perm);
+              c->perm, n, c->xs, c->ys, c->zs, c->rec, c->inv_perm);
     SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, n,
               ncell, c->cell_start);
     sf_pool_release(ctx, tmp);
