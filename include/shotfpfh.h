@@ -147,6 +147,13 @@ int sf_fpfh(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, con
 int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, int64_t m2, int64_t d,
                     int64_t *idx, double *dist, int64_t *col_idx, int flags);
 
+/* Multi-scale ("minimum over scales") form of match_descriptors (matching.py:77-136).  a: n_scales x m1 x d,
+ * b: n_scales x m2 x d; a_ok / b_ok: n_scales x m bytes, 1 where the row has a non-zero entry at that scale.
+ * dist(i,j) = min over scales of (a_ok && b_ok ? euclidean distance : max_val); idx = first arg-min over j. */
+int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1, int64_t m2,
+                               int64_t d, const unsigned char *a_ok, const unsigned char *b_ok, double max_val,
+                               int64_t *idx, double *dist, int flags);
+
 /* ---- RANSAC scoring: inlier count of ransac.py:60-67, K9 ----------------------------------
  * a, b: m x 3 matched points; Rt: n_draws x 12 (row-major R, then t); counts ||a R^T + t - b|| <= thr. */
 int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, int64_t m, const double *Rt, int64_t n_draws,

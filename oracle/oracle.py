@@ -228,3 +228,25 @@ def ransac_score(a, b, rt, thr):
     out = np.zeros(rt.shape[0], dtype=np.int64)
     lib().orc_ransac_score(a, b, a.shape[0], rt, rt.shape[0], thr, out)
     return out
+
+
+def match_descriptors_multiscale(scan, ref, filter_callback=None, max_val=1000, **kwargs):
+    """3-D ("minimum over scales") branch of matching.py:77-136, restated with NumPy (small inputs only):
+    per scale a distance matrix that is max_val wherever either descriptor is all-zero, element-wise minimum
+    over scales, first arg-min per row, matches at max_val dropped."""
+    scan, ref = _f64(scan), _f64(ref)
+    n_scales, n_points, _ = scan.shape
+    inf = np.full((n_points, ref.shape[1]), float(max_val))
+    for s in range(n_scales):
+        ne_s, ne_r = np.any(scan[s], axis=1), np.any(ref[s], axis=1)
+        dm = np.full_like(inf, float(max_val))
+        diff = scan[s][ne_s][:, None, :] - ref[s][ne_r][None, :, :]
+        acc = np.zeros(diff.shape[:2])
+        for t in range(diff.shape[2]):  # left-to-right sum, as scipy's cdist accumulates
+            acc += diff[:, :, t] * diff[:, :, t]
+        dm[np.ix_(ne_s, ne_r)] = np.sqrt(acc)
+        inf = np.minimum(dm, inf)
+    idx = inf.argmin(axis=1)
+    dist = inf[np.arange(n_points), idx]
+    keep = (filter_callback(dist, **kwargs) if filter_callback is not None else np.ones(n_points, dtype=bool)) & (dist < max_val)
+    return np.arange(n_points)[keep], np.arange(ref.shape[1])[idx[keep]]

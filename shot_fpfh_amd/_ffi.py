@@ -61,6 +61,7 @@ SIGNATURES = {
     "sf_spfh_free": (None, [_vp, _vp]),
     "sf_fpfh": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _int]),
     "sf_match_argmin": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int]),
+    "sf_match_argmin_multiscale": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _f64, _vp, _vp, _int]),
     "sf_ransac_score": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _int]),
     "sf_comm_unique_id": (_int, [_vp]),
     "sf_comm_init": (_int, [_vp, _vp, _int, _int]),

@@ -16,8 +16,13 @@ namespace {
 
 constexpr int TM = 64, TN = 64, TK = 16;
 
+// n_scales == 1, masks null: plain cdist + argmin.  Otherwise the "minimum over scales" distance of
+// matching.py:77-136: dist(i,j) = min over scales s of (a_ok[s][i] && b_ok[s][j] ? ||a_s[i] - b_s[j]|| : max_val),
+// a, b being (n_scales, m, d) stacks; a row that is empty at every scale keeps max_val everywhere.
 __global__ __launch_bounds__(256) void k_match_tile(const double *__restrict__ a, int64_t m1,
                                                     const double *__restrict__ b, int64_t m2, int64_t d,
+                                                    int n_scales, const unsigned char *__restrict__ a_ok,
+                                                    const unsigned char *__restrict__ b_ok, double max_val,
                                                     int64_t tiles_per_split, double *__restrict__ pdist,
                                                     int64_t *__restrict__ pidx)
 {
@@ -36,36 +41,56 @@ __global__ __launch_bounds__(256) void k_match_tile(const double *__restrict__ a
 
     for (int64_t jt = jt0; jt < jt1; ++jt) {
         const int64_t j0 = jt * TN;
-        double acc[4][4];
+        double dmin[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-        for (int64_t t0 = 0; t0 < d; t0 += TK) {
-            // stage TM x TK of a and TN x TK of b (zero padded); 1024 elements each, 4 per thread
+            for (int v = 0; v < 4; ++v) dmin[u][v] = a_ok ? max_val : INFINITY;
+        for (int sc = 0; sc < n_scales; ++sc) {
+            const double *as = a + (int64_t)sc * m1 * d, *bs = b + (int64_t)sc * m2 * d;
+            double acc[4][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int lin = tid + 256 * e; // 0..1023
-                const int r = lin >> 4, cc = lin & 15;
-                const int64_t t = t0 + cc;
-                As[cc][r] = (i0 + r < m1 && t < d) ? a[(i0 + r) * d + t] : 0.0;
-                Bs[cc][r] = (j0 + r < m2 && t < d) ? b[(j0 + r) * d + t] : 0.0;
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+            for (int64_t t0 = 0; t0 < d; t0 += TK) {
+                // stage TM x TK of a and TN x TK of b (zero padded); 1024 elements each, 4 per thread
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int lin = tid + 256 * e; // 0..1023
+                    const int r = lin >> 4, cc = lin & 15;
+                    const int64_t t = t0 + cc;
+                    As[cc][r] = (i0 + r < m1 && t < d) ? as[(i0 + r) * d + t] : 0.0;
+                    Bs[cc][r] = (j0 + r < m2 && t < d) ? bs[(j0 + r) * d + t] : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < TK; ++t) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { av[u] = As[t][ty * 4 + u]; bv[u] = Bs[t][tx * 4 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double df = av[u] - bv[v];
+                            acc[u][v] += df * df;
+                        }
+                }
+                __syncthreads();
             }
-            __syncthreads();
 #pragma unroll
-            for (int t = 0; t < TK; ++t) {
-                double av[4], bv[4];
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { av[u] = As[t][ty * 4 + u]; bv[u] = Bs[t][tx * 4 + u]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const double df = av[u] - bv[v];
-                        acc[u][v] += df * df;
+                for (int v = 0; v < 4; ++v) {
+                    double dist = sqrt(acc[u][v]);
+                    if (a_ok) {
+                        const int64_t i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+                        const bool ok = i < m1 && j < m2 && a_ok[(int64_t)sc * m1 + i] && b_ok[(int64_t)sc * m2 + j];
+                        dist = ok ? dist : max_val;
                     }
-            }
-            __syncthreads();
+                    dmin[u][v] = fmin(dmin[u][v], dist);
+                }
         }
         // per-row minimum over this tile's 64 columns: 4 local columns, then the 16 tx lanes of the row group
 #pragma unroll
@@ -75,7 +100,7 @@ __global__ __launch_bounds__(256) void k_match_tile(const double *__restrict__ a
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int64_t j = j0 + tx * 4 + v;
-                const double dist = j < m2 ? sqrt(acc[u][v]) : INFINITY;
+                const double dist = j < m2 ? dmin[u][v] : INFINITY;
                 if (dist < bd) { bd = dist; bj = j; } // ascending j: first minimum kept
             }
 #pragma unroll
@@ -139,7 +164,8 @@ __global__ __launch_bounds__(256) void k_ransac_score(const double *__restrict__
 } // namespace
 
 static int match_one_way(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d,
-                         int64_t *didx, double *ddist, const char *name)
+                         int64_t *didx, double *ddist, const char *name, int n_scales = 1,
+                         const unsigned char *a_ok = nullptr, const unsigned char *b_ok = nullptr, double max_val = 0.0)
 {
     const int64_t row_tiles = sf_div_up(m1, TM), col_tiles = sf_div_up(m2, TN);
     int64_t nsplit = 1;
@@ -152,7 +178,7 @@ static int match_one_way(sf_ctx *ctx, const double *da, int64_t m1, const double
     SF_HIP(hipMalloc(&pdist, (size_t)(nsplit * m1) * sizeof(double)));
     SF_HIP(hipMalloc(&pidx, (size_t)(nsplit * m1) * sizeof(int64_t)));
     SF_LAUNCH(ctx, name, k_match_tile, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(256), da, m1, db, m2, d,
-              tiles_per_split, pdist, pidx);
+              n_scales, a_ok, b_ok, max_val, tiles_per_split, pdist, pidx);
     SF_LAUNCH(ctx, "k8_match_merge", k_match_merge, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), pdist, pidx, m1,
               (int)nsplit, didx, ddist);
     SF_HIP(hipStreamSynchronize(ctx->stream));
@@ -198,6 +224,41 @@ extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const d
         SF_HIP(hipFree(da));
         SF_HIP(hipFree(db));
     }
+    return SF_OK;
+}
+
+extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1,
+                                          int64_t m2, int64_t d, const unsigned char *a_ok, const unsigned char *b_ok,
+                                          double max_val, int64_t *idx, double *dist, int flags)
+{
+    if (!ctx || !a || !b || !a_ok || !b_ok || !idx || n_scales < 1 || m1 < 0 || m2 <= 0 || d <= 0) {
+        sf_set_error("sf_match_argmin_multiscale: bad argument");
+        return SF_ERR_ARG;
+    }
+    if (flags != SF_HOST) { sf_set_error("sf_match_argmin_multiscale: host pointers only"); return SF_ERR_UNSUPPORTED; }
+    SF_HIP(hipSetDevice(ctx->device));
+    const size_t na = (size_t)n_scales * m1 * d, nbv = (size_t)n_scales * m2 * d;
+    double *da = nullptr, *db = nullptr, *ddist = nullptr;
+    unsigned char *dao = nullptr, *dbo = nullptr;
+    int64_t *didx = nullptr;
+    SF_CHECK(sf_palloc(ctx, &da, na));
+    SF_CHECK(sf_palloc(ctx, &db, nbv));
+    SF_CHECK(sf_palloc(ctx, &dao, (size_t)n_scales * m1));
+    SF_CHECK(sf_palloc(ctx, &dbo, (size_t)n_scales * m2));
+    SF_CHECK(sf_palloc(ctx, &didx, (size_t)m1));
+    SF_CHECK(sf_palloc(ctx, &ddist, (size_t)m1));
+    if (na) SF_HIP(hipMemcpyAsync(da, a, na * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SF_HIP(hipMemcpyAsync(db, b, nbv * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (m1) SF_HIP(hipMemcpyAsync(dao, a_ok, (size_t)n_scales * m1, hipMemcpyHostToDevice, ctx->stream));
+    SF_HIP(hipMemcpyAsync(dbo, b_ok, (size_t)n_scales * m2, hipMemcpyHostToDevice, ctx->stream));
+    if (m1) {
+        SF_CHECK(match_one_way(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_tile_multiscale", n_scales, dao, dbo, max_val));
+        SF_HIP(hipMemcpyAsync(idx, didx, (size_t)m1 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (dist) SF_HIP(hipMemcpyAsync(dist, ddist, (size_t)m1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    sf_pool_release(ctx, da); sf_pool_release(ctx, db); sf_pool_release(ctx, dao); sf_pool_release(ctx, dbo);
+    sf_pool_release(ctx, didx); sf_pool_release(ctx, ddist);
     return SF_OK;
 }
 

@@ -155,6 +155,26 @@ class Engine:
             "sf_match_argmin",
         )
 
+    def match_argmin_multiscale(self, a, b, max_val: float = 1000.0):
+        """a: (S, M1, D), b: (S, M2, D).  Arg-min over j of min over scales of the per-scale distance, with
+        max_val wherever either descriptor is all-zero at that scale (matching.py:77-136)."""
+        a, b = _f64(a), _f64(b)
+        if a.ndim != 3 or b.ndim != 3 or a.shape[0] != b.shape[0] or a.shape[2] != b.shape[2]:
+            raise ValueError("multi-scale descriptor stacks must be (n_scales, n_points, length) with equal scales/length")
+        a_ok = np.ascontiguousarray(np.any(a, axis=2), dtype=np.uint8)
+        b_ok = np.ascontiguousarray(np.any(b, axis=2), dtype=np.uint8)
+        m1, m2 = a.shape[1], b.shape[1]
+        idx, dist = np.zeros(m1, dtype=np.int64), np.zeros(m1, dtype=np.float64)
+        if m1 and not m2:
+            raise ValueError("attempt to get argmin of an empty sequence")
+        if m1:
+            _ffi.check(
+                self.lib.sf_match_argmin_multiscale(self.h, _ptr(a), _ptr(b), a.shape[0], m1, m2, a.shape[2], _ptr(a_ok),
+                                                    _ptr(b_ok), float(max_val), _ptr(idx), _ptr(dist), SF_HOST),
+                "sf_match_argmin_multiscale",
+            )
+        return idx, dist
+
     def ransac_score(self, a, b, rt, thr: float) -> np.ndarray:
         a, b = _f64(a, 3), _f64(b, 3)
         rt = _f64(rt).reshape(-1, 12)

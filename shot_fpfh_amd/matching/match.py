@@ -53,11 +53,16 @@ def match_descriptors(
     `filter_callback(distances, **kwargs)` receives the winners' distances and returns a keep-mask.
     With `filter_nonreciprocal`, a match i -> j is also required to satisfy argmin_i' d(i', j) == i,
     but only if at least `n_min_matches` matches survive; otherwise the reciprocity test is dropped.
-    The 3-D "minimum over scales" input form (matching.py:77-136) is not on the device path yet.
+    A 3-D input (n_scales, n_points, length) selects the "minimum over scales" distance of
+    matching.py:77-136: per pair the smallest per-scale Euclidean distance, 1000 where either descriptor is
+    empty at a scale; matches whose distance stays at 1000 are dropped.  (The reference's reciprocity masking
+    in that branch writes into a temporary copy and has no effect, matching.py:106-108; its only observable
+    consequence -- the fallback call when fewer than n_min_matches survive -- is reproduced.)
     """
-    if np.ndim(scan_descriptors) != 2:
-        raise NotImplementedError("multi-scale (3-D) descriptor stacks are not supported on the device path yet")
     eng = engine or default_engine()
+    if np.ndim(scan_descriptors) == 3:
+        return _match_multiscale(eng, scan_descriptors, ref_descriptors, filter_callback, filter_nonreciprocal, verbose,
+                                 n_min_matches, **kwargs)
     if verbose:
         logging.info("")
         logging.info("-- Matching descriptors based on Euclidian-norm proximity --")
@@ -75,6 +80,23 @@ def match_descriptors(
     if verbose:
         logging.info(f"Kept {keep.sum()} matches out of {scan_descriptors.shape[-2]} descriptors.")
     return scan_rows[keep], ref_rows[idx[keep]]
+
+
+def _match_multiscale(eng, scan, ref, filter_callback, filter_nonreciprocal, verbose, n_min_matches, **kwargs):
+    max_val = 1000
+    if verbose:
+        logging.info("")
+        logging.info("-- Matching descriptors based on infinite-norm proximity --")
+    idx, dist = eng.match_argmin_multiscale(scan, ref, max_val)
+    keep = filter_callback(dist, **kwargs) if filter_callback is not None else np.ones(dist.shape[0], dtype=bool)
+    keep = keep & (dist < max_val)
+    if keep.sum() < n_min_matches and filter_nonreciprocal:
+        logging.warning("Too few reciprocal matches, keeping non-reciprocal matches.")
+        # as the reference does: same call without the reciprocity flag (and with the default n_min_matches)
+        return match_descriptors(scan, ref, filter_callback, filter_nonreciprocal=False, verbose=verbose, engine=eng, **kwargs)
+    if verbose:
+        logging.info(f"Kept {keep.sum()} matches out of {scan.shape[-2]} descriptors.")
+    return np.arange(scan.shape[1])[keep], np.arange(ref.shape[1])[idx[keep]]
 
 
 def double_matching_with_rejects(scan_descriptors, ref_descriptors, threshold, verbose=True):

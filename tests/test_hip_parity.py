@@ -309,3 +309,15 @@ def test_config_c4_registration_chain(O):
                                     disable_progress_bar=True)
     assert ratio >= correct - 1e-9
     assert np.abs(tf.rotation - rot).max() < 1e-6 and np.abs(tf.translation - t).max() < 1e-6
+
+
+def test_matching_multiscale_golden():
+    from shot_fpfh_amd.matching import match_descriptors, threshold_filter
+
+    g = load_golden("match3d_200.npz")
+    s_, r_ = match_descriptors(g["scan"], g["ref"], verbose=False)
+    assert np.array_equal(s_, g["md_s"]) and np.array_equal(r_, g["md_r"])
+    s_, r_ = match_descriptors(g["scan"], g["ref"], threshold_filter, verbose=False, threshold_multiplier=3)
+    assert np.array_equal(s_, g["thr_s"]) and np.array_equal(r_, g["thr_r"])
+    s_, r_ = match_descriptors(g["scan"], g["ref"], filter_nonreciprocal=True, verbose=False, n_min_matches=10**6)
+    assert np.array_equal(s_, g["rec_s"]) and np.array_equal(r_, g["rec_r"])

@@ -144,3 +144,14 @@ def test_ransac_scoring():
     inl = O.ransac_score(a, b, g["draw_rt"], float(g["thr"]))
     assert np.array_equal(inl, g["draw_inliers"])
     assert inl.max() / a.shape[0] == float(g["ratio"])
+
+
+def test_matching_multiscale():
+    from shot_fpfh_amd.matching.filters import threshold_filter
+
+    g = load_golden("match3d_200.npz")
+    s, r = O.match_descriptors_multiscale(g["scan"], g["ref"])
+    assert np.array_equal(s, g["md_s"]) and np.array_equal(r, g["md_r"])
+    assert 77 not in s  # empty at every scale -> stays at max_val -> dropped
+    s, r = O.match_descriptors_multiscale(g["scan"], g["ref"], threshold_filter, threshold_multiplier=3)
+    assert np.array_equal(s, g["thr_s"]) and np.array_equal(r, g["thr_r"])

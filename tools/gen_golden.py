@@ -190,6 +190,19 @@ def main():
                                                      n_min_matches=10**6)
     save("match_300.npz", scan=sa, ref=sb, **m)
 
+    # ---- 3-D (multi-scale, "minimum over scales") matching branch: matching.py:77-136 -------
+    rng = np.random.default_rng(19)
+    s3 = rng.random((2, 200, 352)) * (rng.random((2, 200, 352)) < 0.2)
+    r3 = s3[:, rng.permutation(200)][:, :180] + 0.01 * rng.standard_normal((2, 180, 352)) * (rng.random((2, 180, 352)) < 0.2)
+    s3[0, [3, 50]] = 0.0   # empty at one scale only
+    s3[:, 77] = 0.0        # empty at every scale -> distance stays at max_val and is dropped
+    r3[1, [5, 100]] = 0.0
+    m3 = {}
+    m3["md_s"], m3["md_r"] = match_descriptors(s3, r3, verbose=False)
+    m3["thr_s"], m3["thr_r"] = match_descriptors(s3, r3, threshold_filter, verbose=False, threshold_multiplier=3)
+    m3["rec_s"], m3["rec_r"] = match_descriptors(s3, r3, filter_nonreciprocal=True, verbose=False, n_min_matches=10**6)
+    save("match3d_200.npz", scan=s3, ref=r3, **m3)
+
     # ---- grid subsampling ------------------------------------------------------------------
     p, nr, rng = cloud(20000, 18)
     save("grid_sub_20k.npz", seed=18, n=20000, voxel=0.05, idx=grid_subsampling(p, 0.05))
