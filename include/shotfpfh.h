@@ -99,6 +99,9 @@ int sf_cloud_halo_range(sf_ctx *ctx, sf_cloud *cloud, int64_t begin, int64_t end
 sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, double radius,
                           int flags);
 sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *cloud, double radius, int64_t begin, int64_t end);
+/* k nearest neighbours: replaces KDTree.query(Q, k=k, return_distance=False) (pca_based_descriptors.py:46).
+ * Every list has exactly k entries, nearest first (ties: lower cell-sorted position).  1 <= k <= min(n, 448). */
+sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, int k, int flags);
 /* non-owning view of queries [first, first+count) of `nbrs` (free it before the parent) */
 sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nbrs, int64_t first, int64_t count);
 int64_t sf_nbrs_num_queries(const sf_nbrs *nbrs);

@@ -177,6 +177,33 @@ int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
     return SF_OK;
 }
 
+// min / max of the cloud's coordinates (block partials on the device, 1024 x 6 values finished on the host)
+int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3])
+{
+    const int64_t n = c->n;
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = 0.0;
+    if (!n) return SF_OK;
+    const int nb = 1024;
+    void *scr = nullptr;
+    SF_CHECK(sf_ctx_scratch(ctx, (size_t)nb * 6 * sizeof(double), &scr));
+    SF_LAUNCH(ctx, "k1_bbox", k_bbox_partial, dim3(nb), dim3(256), c->xyz_orig, n, (double *)scr);
+    std::vector<double> part((size_t)nb * 6);
+    SF_HIP(hipMemcpyAsync(part.data(), scr, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int b = 0; b < nb; ++b)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
+            hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
+        }
+    for (int a = 0; a < 3; ++a)
+        if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) {
+            sf_set_error("cloud has non-finite coordinates");
+            return SF_ERR_ARG;
+        }
+    return SF_OK;
+}
+
 extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
 {
     if (!ctx || !c || !(cell > 0.0) || !std::isfinite(cell)) {
@@ -188,26 +215,7 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
     const int64_t n = c->n;
     // ---- bounding box -------------------------------------------------------------------------
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    if (n) {
-        const int nb = 1024;
-        void *scr = nullptr;
-        SF_CHECK(sf_ctx_scratch(ctx, (size_t)nb * 6 * sizeof(double), &scr));
-        SF_LAUNCH(ctx, "k1_bbox", k_bbox_partial, dim3(nb), dim3(256), c->xyz_orig, n, (double *)scr);
-        std::vector<double> part((size_t)nb * 6);
-        SF_HIP(hipMemcpyAsync(part.data(), scr, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
-        for (int b = 0; b < nb; ++b)
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
-                hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
-            }
-        for (int a = 0; a < 3; ++a)
-            if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) {
-                sf_set_error("sf_cloud_build_grid: cloud has non-finite coordinates");
-                return SF_ERR_ARG;
-            }
-    }
+    SF_CHECK(sf_cloud_bbox(ctx, c, lo, hi));
     // ---- grid geometry: edge slightly above `cell` so that |a-b| <= cell never spans 2 cells ----
     double edge = cell * (1.0 + 9.5367431640625e-07); // 1 + 2^-20
     int64_t ncell;

@@ -175,6 +175,120 @@ __global__ __launch_bounds__(256) void k_export_lists(const double *__restrict__
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// k nearest neighbours on the grid -- replaces KDTree.query(Q, k) (pca_based_descriptors.py:46, the k-NN
+// branch of compute_normals).  One wave per query sweeps the 27-cell stencil of a grid whose cell edge is
+// >= R, so every point within distance R of the query is seen.  The best k candidates so far live in LDS,
+// kept sorted by (d2, position): a chunk's candidates not worse than the current k-th best are appended and
+// the buffer is pruned back to k by rank counting whenever it could overflow.  If fewer than k points lie
+// within R the query is flagged and the host retries it with a doubled R (coarser grid).
+// EPL = buffer entries per lane (capacity 64*EPL >= k + 64).
+// --------------------------------------------------------------------------------------------------
+template <int EPL>
+__global__ __launch_bounds__(64) void k_knn(sf_grid_desc g, const int32_t *__restrict__ cell_start,
+                                            const double *__restrict__ xs, const double *__restrict__ ys,
+                                            const double *__restrict__ zs, const double *__restrict__ qx,
+                                            const double *__restrict__ qy, const double *__restrict__ qz,
+                                            const int32_t *__restrict__ qsel, int64_t msel, int k, double R2,
+                                            const int32_t *__restrict__ perm, int32_t *__restrict__ idx_out,
+                                            int32_t *__restrict__ status)
+{
+    // idx_out receives ORIGINAL point indices (perm[position]): retries rebuild the grid, which renumbers the
+    // cell-sorted positions, so positions of different rounds would not be comparable
+    constexpr int CAP = 64 * EPL;
+    __shared__ double bd[CAP];
+    __shared__ int bj[CAP];
+    const int lane = threadIdx.x;
+    const int64_t slot = sf_xcd_block();
+    if (slot >= msel) return;
+    const int64_t q = qsel ? qsel[slot] : slot;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    int x0, x1, y0, y1, z0, z1;
+    stencil_bounds(px, g.lo[0], g.inv_cell, g.dim[0], x0, x1);
+    stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
+    stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
+    x0 = sf_uniform(x0); x1 = sf_uniform(x1);
+    y0 = sf_uniform(y0); y1 = sf_uniform(y1);
+    z0 = sf_uniform(z0); z1 = sf_uniform(z1);
+    int cnt = 0, within = 0;
+    double tau = INFINITY; // current k-th best d2 once the buffer holds k entries
+
+    // keep the k best of the first `cnt` entries, sorted by (d2, position)
+    auto prune = [&]() {
+        double d[EPL];
+        int j[EPL], rank[EPL];
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int i = lane + 64 * u;
+            d[u] = i < cnt ? bd[i] : INFINITY;
+            j[u] = i < cnt ? bj[i] : 0x7fffffff;
+            rank[u] = 0;
+        }
+        for (int l = 0; l < cnt; ++l) {
+            const double dl = bd[l];
+            const int jl = bj[l];
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) rank[u] += (dl < d[u]) || (dl == d[u] && jl < j[u]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < EPL; ++u)
+            if (lane + 64 * u < cnt && rank[u] < k) { bd[rank[u]] = d[u]; bj[rank[u]] = j[u]; }
+        __syncthreads();
+        if (cnt >= k) { cnt = k; tau = bd[k - 1]; }
+    };
+
+    for (int cz = z0; cz <= z1; ++cz)
+        for (int cy = y0; cy <= y1; ++cy) {
+            const int64_t row = ((int64_t)cz * g.dim[1] + cy) * g.dim[0];
+            const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+            for (int j0 = s; j0 < e; j0 += 64) {
+                const int j = j0 + lane;
+                bool cand = false, keep = false;
+                double d2 = 0.0;
+                if (j < e) {
+                    const double dx = xs[j] - px, dy = ys[j] - py, dz = zs[j] - pz;
+                    d2 = (dx * dx + dy * dy) + dz * dz;
+                    cand = d2 <= R2;
+                    keep = cand && d2 <= tau;
+                }
+                within += __popcll(__ballot(cand));
+                const unsigned long long mask = __ballot(keep);
+                if (keep) {
+                    const int pos = cnt + sf_prefix_count(mask);
+                    bd[pos] = d2;
+                    bj[pos] = j;
+                }
+                cnt += __popcll(mask);
+                __syncthreads();
+                if (cnt > CAP - 64) prune();
+            }
+        }
+    if (cnt > 0) prune(); // final order: the k best, nearest first
+    if (within >= k) {
+        for (int i = lane; i < k; i += 64) idx_out[q * (int64_t)k + i] = perm[bj[i]];
+        if (lane == 0) status[q] = 0;
+    } else if (lane == 0) {
+        status[q] = 1;
+    }
+}
+
+// original index -> cell-sorted position of the FINAL grid, for every stored neighbour
+__global__ void k_knn_to_positions(int64_t total, const int32_t *__restrict__ inv_perm, int32_t *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) idx[i] = inv_perm[idx[i]];
+}
+
+__global__ void k_knn_fill_csr(int64_t m, int k, int32_t *__restrict__ count, int64_t *__restrict__ offset)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > m) return;
+    if (i < m) count[i] = k;
+    offset[i] = i * (int64_t)k;
+}
+
 } // namespace
 
 struct to_i64_sum {
@@ -378,6 +492,100 @@ extern "C" sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *c, const double *que
     if (prepare_queries(ctx, c, nb, queries, flags) != SF_OK || run_search(ctx, c, nb) != SF_OK) {
         sf_nbrs_free(ctx, nb);
         return nullptr;
+    }
+    return nb;
+}
+
+
+int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3]); // grid.hip
+
+extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *queries, int64_t m, int k, int flags)
+{
+    if (!ctx || !c || (!queries && m > 0) || m < 0 || m > 2147483000LL) {
+        sf_set_error("sf_knn_search: bad arguments (m=%lld)", (long long)m);
+        return nullptr;
+    }
+    if (k < 1 || k > c->n) { // sklearn: "k must be less than or equal to the number of training points"
+        sf_set_error("sf_knn_search: k=%d must be in 1..%lld (the number of cloud points)", k, (long long)c->n);
+        return nullptr;
+    }
+    if (k > 448) { sf_set_error("sf_knn_search: k=%d > 448 unsupported on the device path", k); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
+    double lo[3], hi[3];
+    if (sf_cloud_bbox(ctx, c, lo, hi) != SF_OK) return nullptr;
+    double ext[3], emax = 0.0;
+    for (int a = 0; a < 3; ++a) { ext[a] = hi[a] - lo[a]; emax = std::max(emax, ext[a]); }
+    if (!(emax > 0.0)) emax = 1.0; // all points coincide: any radius works
+    double vol = 1.0;
+    for (int a = 0; a < 3; ++a) vol *= std::max(ext[a], 1e-3 * emax);
+    // radius expected to hold ~3.5 k points at the mean density of the bounding box
+    double R = std::cbrt(3.5 * (double)k * vol / ((double)c->n * 4.18879020478639));
+    const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]) + emax * 1e-6 + 1e-300;
+    sf_nbrs *nb = new sf_nbrs();
+    nb->m = m;
+    nb->radius = 0.0;
+    nb->self = false;
+    auto fail = [&]() { sf_nbrs_free(ctx, nb); return (sf_nbrs *)nullptr; };
+    if (sf_cloud_build_grid(ctx, c, R) != SF_OK) return fail();
+    if (prepare_queries(ctx, c, nb, queries, flags) != SF_OK) return fail();
+    if (sf_palloc(ctx, &nb->count, (size_t)(m + 1)) != SF_OK || sf_palloc(ctx, &nb->offset, (size_t)(m + 1)) != SF_OK ||
+        sf_palloc(ctx, &nb->idx, (size_t)(m * k) + 4) != SF_OK)
+        return fail();
+    nb->total = m * (int64_t)k;
+    nb->max_count = k;
+    {
+        sf_launch_timer t_(ctx, "k2_knn_fill_csr");
+        hipLaunchKernelGGL(k_knn_fill_csr, dim3((unsigned)sf_div_up(m + 1, 256)), dim3(256), 0, ctx->stream, m, k, nb->count,
+                           nb->offset);
+    }
+    if (!m) return nb;
+    int32_t *status = nullptr, *qsel = nullptr;
+    if (sf_palloc(ctx, &status, (size_t)m) != SF_OK || sf_palloc(ctx, &qsel, (size_t)m) != SF_OK) return fail();
+    std::vector<int32_t> hstatus((size_t)m), pending;
+    int64_t msel = m;
+    bool subset = false;
+    for (int round = 0; round < 64; ++round) {
+        sf_grid_desc g = sf_make_grid_desc(c);
+        const double R2 = R * R;
+        const dim3 grid(sf_xcd_grid(msel)), block(64);
+        const int32_t *sel = subset ? qsel : nullptr;
+        sf_launch_timer *tm = new sf_launch_timer(ctx, "k2_knn");
+        if (k <= 64) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status);
+        else if (k <= 192) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status);
+        else hipLaunchKernelGGL(k_knn<8>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status);
+        delete tm;
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            sf_set_error("sf_knn_search: launch failed");
+            sf_pool_release(ctx, status); sf_pool_release(ctx, qsel);
+            return fail();
+        }
+        pending.clear();
+        for (int64_t i = 0; i < m; ++i)
+            if (hstatus[(size_t)i] != 0) pending.push_back((int32_t)i);
+        if (pending.empty()) break;
+        if (R > 2.0 * diag) { // cannot happen for k <= n: a single cell already holds every point
+            sf_set_error("sf_knn_search: internal error, %zu queries unresolved", pending.size());
+            sf_pool_release(ctx, status); sf_pool_release(ctx, qsel);
+            return fail();
+        }
+        R *= 2.0; // sparse regions: retry only the unresolved queries on a coarser grid
+        if (sf_cloud_build_grid(ctx, c, R) != SF_OK ||
+            hipMemcpyAsync(qsel, pending.data(), pending.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            sf_pool_release(ctx, status); sf_pool_release(ctx, qsel);
+            return fail();
+        }
+        msel = (int64_t)pending.size();
+        subset = true;
+    }
+    sf_pool_release(ctx, status);
+    sf_pool_release(ctx, qsel);
+    {
+        sf_launch_timer t_(ctx, "k2_knn_to_positions");
+        hipLaunchKernelGGL(k_knn_to_positions, dim3((unsigned)sf_div_up(nb->total, 256)), dim3(256), 0, ctx->stream, nb->total,
+                           c->inv_perm, nb->idx);
     }
     return nb;
 }

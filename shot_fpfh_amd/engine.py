@@ -270,6 +270,16 @@ class Cloud:
         )
         return Neighbors(self, h)
 
+    def knn_search(self, queries, k: int) -> "Neighbors":
+        """Lists of the k nearest cloud points of each query (KDTree.query semantics)."""
+        q = _f64(queries, 3)
+        if not 1 <= int(k) <= self.n:
+            raise ValueError(f"k={k} must be between 1 and the number of cloud points ({self.n})")
+        h = _ffi.check_handle(
+            self.engine.lib.sf_knn_search(self.engine.h, self.h, _ptr(q), q.shape[0], int(k), SF_HOST), "sf_knn_search"
+        )
+        return Neighbors(self, h)
+
     def radius_search_self(self, radius: float, begin: int = 0, end: Optional[int] = None) -> "Neighbors":
         end = self.n if end is None else end
         h = _ffi.check_handle(

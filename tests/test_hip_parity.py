@@ -80,8 +80,32 @@ def test_normals_golden(eng):
     assert np.abs(n1 - g["n_radius"]).max() < 1e-9  # sign as LAPACK returns it
     n2 = s.compute_normals(g["queries"], g["cloud"], radius=float(g["radius"]), pre_computed_normals=g["pre"])
     assert np.abs(n2 - g["n_radius_pre"]).max() < 1e-9
-    with pytest.raises(NotImplementedError):
-        s.compute_normals(g["queries"], g["cloud"], k=30)
+    n3 = s.compute_normals(g["queries"], g["cloud"], k=int(g["k"]))
+    assert np.abs(n3 - g["n_knn"]).max() < 1e-9
+    n4 = s.compute_normals(g["queries"], g["cloud"], k=int(g["k"]), pre_computed_normals=g["pre"])
+    assert np.abs(n4 - g["n_knn_pre"]).max() < 1e-9
+    with pytest.raises(ValueError):
+        s.compute_normals(g["queries"], g["cloud"][:10], k=30)  # k > number of points, as sklearn
+
+
+@pytest.mark.parametrize("n,m,k,seed", [(20000, 1500, 30, 71), (5000, 400, 100, 72), (3000, 300, 300, 73), (50, 20, 50, 74)])
+def test_knn_search_vs_brute_force(eng, O, n, m, k, seed):
+    """k-NN lists (KDTree.query) incl. queries far outside the cloud, which need several radius doublings."""
+    p, _, rng = synth_cloud(n, seed)
+    if seed == 72:  # strongly non-uniform density: a dense blob inside a sparse cloud
+        p[: n // 2] = 0.5 + 0.02 * (p[: n // 2] - 0.5)
+    q = np.vstack([p[rng.choice(n, m // 2, replace=False)], rng.random((m - m // 2, 3)) * 3.0 - 1.0])
+    off, idx = eng.cloud(p).knn_search(q, k).export()
+    assert np.array_equal(np.diff(off), np.full(m, k))
+    off_o, idx_o = O.knn_lists(p, q, k)
+    got = idx.reshape(m, k)
+    want = np.sort(idx_o.reshape(m, k), axis=1)
+    same = (got == want).all(axis=1)
+    # rows may differ only where the k-th and (k+1)-th neighbours are exactly equidistant
+    for i in np.flatnonzero(~same):
+        d = np.sort(((p - q[i]) ** 2).sum(axis=1))
+        assert d[k - 1] == d[k], f"query {i}: different neighbour set without a distance tie"
+    assert same.mean() > 0.99
 
 
 # ---- K4 + K5 ---------------------------------------------------------------------------------------------
