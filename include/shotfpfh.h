@@ -66,6 +66,7 @@ void *sf_dev_alloc(sf_ctx *ctx, size_t bytes);
 int sf_dev_free(sf_ctx *ctx, void *dev_ptr);
 int sf_h2d(sf_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int sf_d2h(sf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int sf_d2d(sf_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* stream-ordered, asynchronous */
 
 /* ---- cloud + grid: replaces sklearn KDTree(X) -------------------------------------------
  * call sites: fpfh.py:26, shot_parallelization.py:167,220,229,283, pca_based_descriptors.py:45-49
@@ -153,6 +154,10 @@ int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, i
 /* Multi-scale ("minimum over scales") form of match_descriptors (matching.py:77-136).  a: n_scales x m1 x d,
  * b: n_scales x m2 x d; a_ok / b_ok: n_scales x m bytes, 1 where the row has a non-zero entry at that scale.
  * dist(i,j) = min over scales of (a_ok && b_ok ? euclidean distance : max_val); idx = first arg-min over j. */
+/* mask_dev[i] = 1 when row i of the device matrix rows_dev (m x d) has a non-zero entry (np.any(desc, axis=1)). */
+int sf_rows_nonzero(sf_ctx *ctx, const double *rows_dev, int64_t m, int64_t d, unsigned char *mask_dev);
+/* flags: SF_HOST, or SF_IN_DEVICE | SF_OUT_DEVICE with every pointer (masks included) on the device -- the form
+ * the sharded matching uses with n_scales = 1 and max_val = +inf to skip all-zero descriptors in place. */
 int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1, int64_t m2,
                                int64_t d, const unsigned char *a_ok, const unsigned char *b_ok, double max_val,
                                int64_t *idx, double *dist, int flags);

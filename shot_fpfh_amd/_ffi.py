@@ -36,6 +36,7 @@ SIGNATURES = {
     "sf_dev_free": (_int, [_vp, _vp]),
     "sf_h2d": (_int, [_vp, _vp, _vp, _sz]),
     "sf_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "sf_d2d": (_int, [_vp, _vp, _vp, _sz]),
     "sf_cloud_upload": (_vp, [_vp, _vp, _vp, _i64, _int]),
     "sf_cloud_set_normals": (_int, [_vp, _vp, _vp, _int]),
     "sf_cloud_build_grid": (_int, [_vp, _vp, _f64]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "sf_spfh_free": (None, [_vp, _vp]),
     "sf_fpfh": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _int]),
     "sf_match_argmin": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int]),
+    "sf_rows_nonzero": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "sf_match_argmin_multiscale": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _f64, _vp, _vp, _int]),
     "sf_ransac_score": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _int]),
     "sf_comm_unique_id": (_int, [_vp]),

@@ -110,6 +110,14 @@ extern "C" int sf_d2h(sf_ctx *ctx, void *dst, const void *src, size_t bytes)
     return SF_OK;
 }
 
+extern "C" int sf_d2d(sf_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    if (!bytes) return SF_OK;
+    SF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream)); // stream-ordered, no sync
+    return SF_OK;
+}
+
 int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out)
 {
     if (bytes > ctx->scratch_bytes) {

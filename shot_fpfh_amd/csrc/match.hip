@@ -124,6 +124,19 @@ __global__ __launch_bounds__(256) void k_match_tile(const double *__restrict__ a
     }
 }
 
+// mask[i] = 1 when row i of a (m x d) has a non-zero entry: np.any(desc, axis=1) of matching.py:43-44/162-163
+__global__ __launch_bounds__(256) void k_rows_nonzero(const double *__restrict__ a, int64_t m, int64_t d,
+                                                      unsigned char *__restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    bool nz = false;
+    for (int64_t t = lane; t < d; t += 64) nz |= a[i * d + t] != 0.0;
+    const unsigned long long any = __ballot(nz);
+    if (lane == 0) mask[i] = any != 0ull;
+}
+
 __global__ void k_match_merge(const double *__restrict__ pdist, const int64_t *__restrict__ pidx, int64_t m1, int nsplit,
                               int64_t *__restrict__ idx, double *__restrict__ dist)
 {
@@ -175,15 +188,14 @@ static int match_one_way(sf_ctx *ctx, const double *da, int64_t m1, const double
     nsplit = sf_div_up(col_tiles, tiles_per_split);
     double *pdist = nullptr;
     int64_t *pidx = nullptr;
-    SF_HIP(hipMalloc(&pdist, (size_t)(nsplit * m1) * sizeof(double)));
-    SF_HIP(hipMalloc(&pidx, (size_t)(nsplit * m1) * sizeof(int64_t)));
+    SF_CHECK(sf_palloc(ctx, &pdist, (size_t)(nsplit * m1)));
+    SF_CHECK(sf_palloc(ctx, &pidx, (size_t)(nsplit * m1)));
     SF_LAUNCH(ctx, name, k_match_tile, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(256), da, m1, db, m2, d,
               n_scales, a_ok, b_ok, max_val, tiles_per_split, pdist, pidx);
     SF_LAUNCH(ctx, "k8_match_merge", k_match_merge, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), pdist, pidx, m1,
               (int)nsplit, didx, ddist);
-    SF_HIP(hipStreamSynchronize(ctx->stream));
-    SF_HIP(hipFree(pdist));
-    SF_HIP(hipFree(pidx));
+    sf_pool_release(ctx, pdist); // stream-ordered: safe to reuse by later launches on this stream
+    sf_pool_release(ctx, pidx);
     return SF_OK;
 }
 
@@ -227,6 +239,17 @@ extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const d
     return SF_OK;
 }
 
+extern "C" int sf_rows_nonzero(sf_ctx *ctx, const double *rows_dev, int64_t m, int64_t d, unsigned char *mask_dev)
+{
+    if (!ctx || !rows_dev || !mask_dev || m < 0 || d <= 0) { sf_set_error("sf_rows_nonzero: bad argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    if (m) {
+        SF_LAUNCH(ctx, "k8_rows_nonzero", k_rows_nonzero, dim3((unsigned)sf_div_up(m, 4)), dim3(256), rows_dev, m, d,
+                  mask_dev);
+    }
+    return SF_OK;
+}
+
 extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1,
                                           int64_t m2, int64_t d, const unsigned char *a_ok, const unsigned char *b_ok,
                                           double max_val, int64_t *idx, double *dist, int flags)
@@ -235,8 +258,13 @@ extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const do
         sf_set_error("sf_match_argmin_multiscale: bad argument");
         return SF_ERR_ARG;
     }
-    if (flags != SF_HOST) { sf_set_error("sf_match_argmin_multiscale: host pointers only"); return SF_ERR_UNSUPPORTED; }
     SF_HIP(hipSetDevice(ctx->device));
+    if (flags == (SF_IN_DEVICE | SF_OUT_DEVICE)) { // everything resident: no copies, no synchronisation
+        if (m1)
+            SF_CHECK(match_one_way(ctx, a, m1, b, m2, d, idx, dist, "k8_match_tile_masked", n_scales, a_ok, b_ok, max_val));
+        return SF_OK;
+    }
+    if (flags != SF_HOST) { sf_set_error("sf_match_argmin_multiscale: flags must be SF_HOST or SF_IN_DEVICE|SF_OUT_DEVICE"); return SF_ERR_UNSUPPORTED; }
     const size_t na = (size_t)n_scales * m1 * d, nbv = (size_t)n_scales * m2 * d;
     double *da = nullptr, *db = nullptr, *ddist = nullptr;
     unsigned char *dao = nullptr, *dbo = nullptr;

@@ -68,6 +68,14 @@ class DeviceArray:
         _ffi.check(self.engine.lib.sf_h2d(self.engine.h, self.ptr, _ptr(a), self.nbytes), "sf_h2d")
         return self
 
+    def copy_from_device(self, src: "DeviceArray", dst_byte_offset: int = 0, nbytes: Optional[int] = None) -> "DeviceArray":
+        """Stream-ordered device-to-device copy of `src` into this array at a byte offset."""
+        nbytes = src.nbytes if nbytes is None else nbytes
+        if dst_byte_offset + nbytes > self.nbytes:
+            raise ValueError("copy exceeds the destination")
+        _ffi.check(self.engine.lib.sf_d2d(self.engine.h, self.offset_ptr(dst_byte_offset), src.ptr, nbytes), "sf_d2d")
+        return self
+
     def offset_ptr(self, byte_offset: int):
         return C.c_void_p(self.ptr + byte_offset)
 
@@ -174,6 +182,25 @@ class Engine:
                 "sf_match_argmin_multiscale",
             )
         return idx, dist
+
+    def rows_nonzero_device(self, rows: DeviceArray, out: Optional[DeviceArray] = None, n_rows: Optional[int] = None) -> DeviceArray:
+        """uint8 mask on the device: 1 where a descriptor row has a non-zero entry."""
+        m = rows.shape[0] if n_rows is None else n_rows
+        out = out if out is not None else self.empty((rows.shape[0],), np.uint8)
+        _ffi.check(self.lib.sf_rows_nonzero(self.h, rows.ptr, m, rows.shape[1], out.ptr), "sf_rows_nonzero")
+        return out
+
+    def match_masked_device(self, a: DeviceArray, a_ok: DeviceArray, b: DeviceArray, b_ok: DeviceArray, idx: DeviceArray,
+                            dist: Optional[DeviceArray] = None, a_rows: Optional[int] = None, b_rows: Optional[int] = None) -> None:
+        """Resident arg-min of a's rows over b's rows, skipping rows whose mask is 0 (they get distance +inf)."""
+        m1 = a.shape[0] if a_rows is None else a_rows
+        m2 = b.shape[0] if b_rows is None else b_rows
+        _ffi.check(
+            self.lib.sf_match_argmin_multiscale(self.h, a.ptr, b.ptr, 1, m1, m2, a.shape[1], a_ok.ptr, b_ok.ptr,
+                                                float("inf"), idx.ptr, None if dist is None else dist.ptr,
+                                                SF_IN_DEVICE | SF_OUT_DEVICE),
+            "sf_match_argmin_multiscale",
+        )
 
     def ransac_score(self, a, b, rt, thr: float) -> np.ndarray:
         a, b = _f64(a, 3), _f64(b, 3)

@@ -26,7 +26,7 @@ import numpy as np
 
 from .engine import Cloud, DeviceArray, Engine, Neighbors, Spfh
 
-__all__ = ["ShardPlan", "DescriptorJob"]
+__all__ = ["ShardPlan", "DescriptorJob", "MatchJob"]
 
 
 @dataclass(frozen=True)
@@ -130,3 +130,55 @@ class DescriptorJob:
             if obj is not None:
                 obj.free()
         self.spfh = self.fpfh_out = self.lrf_out = self.shot_out = None
+
+
+class MatchJob:
+    """basic_matching (matching.py:149-169) of two descriptor sets that live SHARDED in HBM: rank g holds its block
+    of the scan descriptors and its block of the reference descriptors (rows in the cell-sorted order of their
+    clouds, as DescriptorJob leaves them).
+
+    Exchange step: ONE all-gather of the reference rows over RCCL/xGMI (every scan row must see every reference
+    row).  Then each rank runs K8 on its own scan block against the gathered reference set; all-zero
+    descriptors (SHOT rows of too sparse neighbourhoods) are masked on the device instead of being compacted on
+    the host.  The row arg-min is local to the rank -- no second collective on the data path; the small
+    (index, flag) vectors are what a caller gathers afterwards.
+    """
+
+    def __init__(self, engine: Engine, length: int, n_scan: int, n_ref: int, world: int = 1, rank: int = 0):
+        self.engine, self.d = engine, int(length)
+        self.scan_plan, self.ref_plan = ShardPlan(n_scan, world, rank), ShardPlan(n_ref, world, rank)
+        rpr = max(self.ref_plan.rows_per_rank, 1)
+        self.ref_all: DeviceArray = engine.empty((rpr * world, self.d))
+        self.ref_ok: DeviceArray = engine.empty((rpr * world,), np.uint8)
+        m = self.scan_plan.end - self.scan_plan.begin
+        self.scan_ok: DeviceArray = engine.empty((max(m, 1),), np.uint8)
+        self.idx: DeviceArray = engine.empty((max(m, 1),), np.int64)
+        self.dist: DeviceArray = engine.empty((max(m, 1),), np.float64)
+        self.m = m
+
+    def run(self, scan_block: DeviceArray, ref_block: DeviceArray) -> None:
+        """scan_block: (m, d) rows of this rank's scan block; ref_block: this rank's reference block."""
+        eng, plan = self.engine, self.ref_plan
+        row_bytes = self.d * 8
+        b, e = plan.block()
+        self.ref_all.copy_from_device(ref_block, dst_byte_offset=b * row_bytes, nbytes=(e - b) * row_bytes)
+        if plan.world > 1:
+            eng.allgather(self.ref_all, plan.rows_per_rank * row_bytes)
+        eng.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=plan.n)
+        if self.m:
+            eng.rows_nonzero_device(scan_block, self.scan_ok, n_rows=self.m)
+            eng.match_masked_device(scan_block, self.scan_ok, self.ref_all, self.ref_ok, self.idx, self.dist,
+                                    a_rows=self.m, b_rows=plan.n)
+
+    def matches(self) -> tuple[np.ndarray, np.ndarray]:
+        """(local scan rows that are non-empty, their matched reference rows) -- both in cell-sorted numbering."""
+        if not self.m:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64)
+        ok = self.scan_ok.to_host()[: self.m].astype(bool)
+        idx = self.idx.to_host()[: self.m]
+        rows = np.flatnonzero(ok)
+        return rows + self.scan_plan.begin, idx[rows]
+
+    def close(self) -> None:
+        for a in (self.ref_all, self.ref_ok, self.scan_ok, self.idx, self.dist):
+            a.free()

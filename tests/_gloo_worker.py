@@ -15,10 +15,34 @@ from fake_engine import FakeEngine  # noqa: E402
 from shot_fpfh_amd.sharding import DescriptorJob  # noqa: E402
 
 
+def match_main(out_path, rank, world):
+    """Sharded basic_matching: each rank holds a block of scan and of ref rows; ref rows are all-gathered."""
+    from shot_fpfh_amd.sharding import MatchJob, ShardPlan
+
+    rng = np.random.default_rng(91)
+    a = rng.random((301, 40)) * (rng.random((301, 40)) < 0.4)
+    b = a[rng.permutation(301)][:277] + 0.01 * rng.standard_normal((277, 40))
+    a[[0, 150, 300]] = 0.0
+    b[[5, 276]] = 0.0
+    eng = FakeEngine()
+    job = MatchJob(eng, 40, 301, 277, world, rank)
+    sb, se = ShardPlan(301, world, rank).block()
+    rb, re = ShardPlan(277, world, rank).block()
+    job.run(eng.empty((se - sb, 40)).from_host(a[sb:se]), eng.empty((max(re - rb, 1), 40)).from_host(b[rb:re] if re > rb else 0.0))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, job.matches())
+    if rank == 0:
+        np.savez(out_path, s=np.concatenate([g[0] for g in gathered]), r=np.concatenate([g[1] for g in gathered]), a=a, b=b)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out_path, mode = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "match":
+        return match_main(out_path, rank, world)
     p, nr, _ = synth_cloud(1500, 41)
     job = DescriptorJob(FakeEngine(), p, nr, 0.15, n_bins=5, normalize=True, min_neighborhood_size=5, world=world,
                         rank=rank, spfh_exchange=mode)

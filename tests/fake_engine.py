@@ -11,11 +11,23 @@ from oracle import oracle as O
 
 
 class FakeArray:
-    def __init__(self, shape):
-        self.a = np.full(shape, np.nan)
+    def __init__(self, shape, dtype=np.float64):
+        self.a = np.full(shape, np.nan) if np.dtype(dtype) == np.float64 else np.zeros(shape, dtype)
+        self.shape = self.a.shape
+        self.nbytes = self.a.nbytes
 
     def to_host(self):
         return self.a.copy()
+
+    def from_host(self, x):
+        self.a[...] = x
+        return self
+
+    def copy_from_device(self, src, dst_byte_offset=0, nbytes=None):
+        flat, sflat = self.a.reshape(-1).view(np.uint8), src.a.reshape(-1).view(np.uint8)
+        nbytes = src.nbytes if nbytes is None else nbytes
+        flat[dst_byte_offset:dst_byte_offset + nbytes] = sflat[:nbytes]
+        return self
 
     def free(self):
         pass
@@ -133,7 +145,32 @@ class FakeEngine:
         return FakeCloud(points, normals)
 
     def empty(self, shape, dtype=np.float64):
-        return FakeArray(shape)
+        return FakeArray(shape, dtype)
+
+    def allgather(self, buf, bytes_per_rank):
+        import torch
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(), dist.get_rank()
+        flat = buf.a.reshape(-1).view(np.uint8)
+        mine = torch.from_numpy(flat[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy())
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
+
+    def rows_nonzero_device(self, rows, out=None, n_rows=None):
+        m = rows.shape[0] if n_rows is None else n_rows
+        out.a[:m] = np.any(np.nan_to_num(rows.a[:m], nan=1.0), axis=1)
+        return out
+
+    def match_masked_device(self, a, a_ok, b, b_ok, idx, dist=None, a_rows=None, b_rows=None):
+        m1 = a.shape[0] if a_rows is None else a_rows
+        m2 = b.shape[0] if b_rows is None else b_rows
+        ok_b = np.flatnonzero(b_ok.a[:m2])
+        i, d = O.match_argmin(a.a[:m1], b.a[:m2][ok_b])
+        idx.a[:m1] = ok_b[i]
+        if dist is not None:
+            dist.a[:m1] = d
 
     def spfh(self, cloud, n_bins, max_count):
         return FakeSpfh(cloud, n_bins)

@@ -345,3 +345,21 @@ def test_matching_multiscale_golden():
     assert np.array_equal(s_, g["thr_s"]) and np.array_equal(r_, g["thr_r"])
     s_, r_ = match_descriptors(g["scan"], g["ref"], filter_nonreciprocal=True, verbose=False, n_min_matches=10**6)
     assert np.array_equal(s_, g["rec_s"]) and np.array_equal(r_, g["rec_r"])
+
+
+def test_match_job_resident_equals_basic_matching(eng):
+    """The sharded matching step (device-resident, zero rows masked in place) on one rank == basic_matching."""
+    from shot_fpfh_amd.matching import basic_matching
+    from shot_fpfh_amd.sharding import MatchJob
+
+    rng = np.random.default_rng(81)
+    a = rng.random((700, 352)) * (rng.random((700, 352)) < 0.3)
+    b = a[rng.permutation(700)][:650] + 0.01 * rng.standard_normal((650, 352))
+    a[[3, 99, 500]] = 0.0
+    b[[7, 640]] = 0.0
+    job = MatchJob(eng, 352, 700, 650)
+    job.run(eng.empty((700, 352)).from_host(a), eng.empty((650, 352)).from_host(b))
+    s1, r1 = job.matches()
+    s2, r2 = basic_matching(a, b)
+    assert np.array_equal(s1, s2) and np.array_equal(r1, r2)
+    job.close()

@@ -51,3 +51,22 @@ def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode):
     fo = O.compute_fpfh_descriptor(np.arange(1500), p, nr, 0.15, 5)
     so = O.shot_single_scale(p, nr, p, 0.15, True, 5)
     assert np.abs(got["fpfh"] - fo).max() < 1e-9 and np.abs(got["shot"] - so).max() < 1e-12
+
+
+def test_two_rank_gloo_sharded_matching_equals_basic_matching(tmp_path):
+    """MatchJob over two gloo ranks: reference rows all-gathered, each rank matches its scan block; the union of
+    the per-rank results must equal basic_matching on the whole sets (oracle restatement)."""
+    from oracle import oracle as O
+
+    out = str(tmp_path / "match.npz")
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, "match"], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    s, r = O.basic_matching(got["a"], got["b"])
+    assert np.array_equal(got["s"], s) and np.array_equal(got["r"], r)
