@@ -9,6 +9,8 @@
 //   over several workgroups along M2 and merged by k_match_merge.
 //   Roofline: FP64 vector ALU (3 flop per pair-dimension), bytes are negligible.
 // K9 replaces the inlier count of ransac.py:60-67 (RigidTransform.__getitem__, rigid_transform.py:81-88).
+#include <cstdlib>
+
 #include "common.h"
 #include "device_util.h"
 
@@ -199,6 +201,27 @@ static int match_one_way(sf_ctx *ctx, const double *da, int64_t m1, const double
     return SF_OK;
 }
 
+// exact kernel, callable from the GEMM fast path (match_gemm.hip) for its undecided rows
+int sf_match_exact(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
+                   double *ddist, const char *name)
+{
+    return match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name);
+}
+
+int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
+                  double *ddist, const char *name, int64_t *n_slow); // match_gemm.hip
+
+// Large problems go through the FP64 matrix cores (same result, see match_gemm.hip); small ones, where the
+// fixed costs of the fast path dominate, straight through the exact kernel.  SF_MATCH_EXACT=1 forces the latter.
+static int match_dispatch(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d,
+                          int64_t *didx, double *ddist, const char *name_exact, const char *name_gemm)
+{
+    static const bool force_exact = getenv("SF_MATCH_EXACT") && getenv("SF_MATCH_EXACT")[0] == '1';
+    const double work = (double)m1 * (double)m2 * (double)d;
+    if (force_exact || work < 5e8 || m2 < 256) return match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name_exact);
+    return sf_match_gemm(ctx, da, m1, db, m2, d, didx, ddist, name_gemm, nullptr);
+}
+
 extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, int64_t m2, int64_t d,
                                int64_t *idx, double *dist, int64_t *col_idx, int flags)
 {
@@ -220,8 +243,9 @@ extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const d
         if (dist) SF_HIP(hipMalloc(&ddist, (size_t)std::max<int64_t>(m1, 1) * sizeof(double)));
         if (col_idx) SF_HIP(hipMalloc(&dcol, (size_t)std::max<int64_t>(m2, 1) * sizeof(int64_t)));
     }
-    if (m1) SF_CHECK(match_one_way(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_tile"));
-    if (col_idx && m2 && m1) SF_CHECK(match_one_way(ctx, db, m2, da, m1, d, dcol, nullptr, "k8_match_tile_cols"));
+    if (m1) SF_CHECK(match_dispatch(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_tile", "k8_match_gemm"));
+    if (col_idx && m2 && m1)
+        SF_CHECK(match_dispatch(ctx, db, m2, da, m1, d, dcol, nullptr, "k8_match_tile_cols", "k8_match_gemm_cols"));
     if (!out_dev) {
         if (m1) SF_HIP(hipMemcpyAsync(idx, didx, (size_t)m1 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         if (dist && m1) SF_HIP(hipMemcpyAsync(dist, ddist, (size_t)m1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

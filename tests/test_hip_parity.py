@@ -363,3 +363,23 @@ def test_match_job_resident_equals_basic_matching(eng):
     s2, r2 = basic_matching(a, b)
     assert np.array_equal(s1, s2) and np.array_equal(r1, r2)
     job.close()
+
+
+def test_match_gemm_fast_path_equals_exact(eng, O):
+    """Large problems take the FP64 matrix-core path (match_gemm.hip); the result must equal the exact
+    kernel's / scipy's bit for bit, including duplicated rows (exact ties -> first index) and near ties."""
+    rng = np.random.default_rng(83)
+    m1, m2, d = 2100, 2300, 352
+    b = rng.random((m2, d)) * (rng.random((m2, d)) < 0.3)
+    b /= np.maximum(np.linalg.norm(b, axis=1)[:, None], 1e-300)
+    a = b[rng.integers(0, m2, m1)] + 1e-3 * rng.standard_normal((m1, d))
+    b[1200] = b[17]  # exact duplicate reference rows: every scan row near them has a two-way exact tie
+    b[1201] = b[17]
+    a[5] = b[17]
+    a[6] = 0.5 * (b[40] + b[41])  # equidistant (up to rounding) from two reference rows
+    idx, dist, col = eng.match_argmin(a, b, want_col=True)
+    io, do, co = O.match_argmin(a, b, want_col=True)
+    assert np.array_equal(idx, io) and np.array_equal(dist, do) and np.array_equal(col, co)
+    assert idx[5] == 17
+    rep = eng.profile_report()
+    assert rep.get("k8_match_gemm", (0, 0))[0] >= 1, "the GEMM path was expected to run for this size"
