@@ -9,6 +9,7 @@
 //   over several workgroups along M2 and merged by k_match_merge.
 //   Roofline: FP64 vector ALU (3 flop per pair-dimension), bytes are negligible.
 // K9 replaces the inlier count of ransac.py:60-67 (RigidTransform.__getitem__, rigid_transform.py:81-88).
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -203,13 +204,23 @@ static int match_one_way(sf_ctx *ctx, const double *da, int64_t m1, const double
 
 // exact kernel, callable from the GEMM fast path (match_gemm.hip) for its undecided rows
 int sf_match_exact(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
-                   double *ddist, const char *name)
+                   double *ddist, const char *name, const unsigned char *a_ok, const unsigned char *b_ok)
 {
-    return match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name);
+    if (!a_ok && !b_ok) return match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name);
+    // masked form: a row whose mask is 0 is at distance +inf from everything (the scan side only if given)
+    unsigned char *ones = nullptr;
+    if (!a_ok) {
+        SF_CHECK(sf_palloc(ctx, &ones, (size_t)m1));
+        SF_HIP(hipMemsetAsync(ones, 1, (size_t)(m1 ? m1 : 1), ctx->stream));
+    }
+    int rc = match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name, 1, a_ok ? a_ok : ones, b_ok, INFINITY);
+    if (ones) sf_pool_release(ctx, ones);
+    return rc;
 }
 
 int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
-                  double *ddist, const char *name, int64_t *n_slow); // match_gemm.hip
+                  double *ddist, const char *name, int64_t *n_slow, const unsigned char *a_ok,
+                  const unsigned char *b_ok); // match_gemm.hip
 
 // Large problems go through the FP64 matrix cores (same result, see match_gemm.hip); small ones, where the
 // fixed costs of the fast path dominate, straight through the exact kernel.  SF_MATCH_EXACT=1 forces the latter.
@@ -219,7 +230,7 @@ static int match_dispatch(sf_ctx *ctx, const double *da, int64_t m1, const doubl
     static const bool force_exact = getenv("SF_MATCH_EXACT") && getenv("SF_MATCH_EXACT")[0] == '1';
     const double work = (double)m1 * (double)m2 * (double)d;
     if (force_exact || work < 5e8 || m2 < 256) return match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name_exact);
-    return sf_match_gemm(ctx, da, m1, db, m2, d, didx, ddist, name_gemm, nullptr);
+    return sf_match_gemm(ctx, da, m1, db, m2, d, didx, ddist, name_gemm, nullptr, nullptr, nullptr);
 }
 
 extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, int64_t m2, int64_t d,
@@ -283,9 +294,14 @@ extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const do
         return SF_ERR_ARG;
     }
     SF_HIP(hipSetDevice(ctx->device));
-    if (flags == (SF_IN_DEVICE | SF_OUT_DEVICE)) { // everything resident: no copies, no synchronisation
-        if (m1)
-            SF_CHECK(match_one_way(ctx, a, m1, b, m2, d, idx, dist, "k8_match_tile_masked", n_scales, a_ok, b_ok, max_val));
+    if (flags == (SF_IN_DEVICE | SF_OUT_DEVICE)) { // everything resident: no copies
+        if (!m1) return SF_OK;
+        static const bool force_exact = getenv("SF_MATCH_EXACT") && getenv("SF_MATCH_EXACT")[0] == '1';
+        const double work = (double)m1 * (double)m2 * (double)d;
+        if (n_scales == 1 && std::isinf(max_val) && max_val > 0 && !force_exact && work >= 5e8 && m2 >= 256)
+            // single scale, masked rows at +inf: the matrix-core path with ||b_j||^2 = +inf for masked reference rows
+            return sf_match_gemm(ctx, a, m1, b, m2, d, idx, dist, "k8_match_gemm", nullptr, a_ok, b_ok);
+        SF_CHECK(match_one_way(ctx, a, m1, b, m2, d, idx, dist, "k8_match_tile_masked", n_scales, a_ok, b_ok, max_val));
         return SF_OK;
     }
     if (flags != SF_HOST) { sf_set_error("sf_match_argmin_multiscale: flags must be SF_HOST or SF_IN_DEVICE|SF_OUT_DEVICE"); return SF_ERR_UNSUPPORTED; }

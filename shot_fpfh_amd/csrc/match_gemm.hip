@@ -26,7 +26,7 @@
 #include "device_util.h"
 
 int sf_match_exact(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
-                   double *ddist, const char *name); // match.hip
+                   double *ddist, const char *name, const unsigned char *a_ok, const unsigned char *b_ok); // match.hip
 
 namespace {
 
@@ -37,8 +37,10 @@ constexpr int GM = 128, GN = 128, GK = 16;
 // staging write of one row's 16 k (eight 16-byte pieces) is contiguous.
 constexpr int LDS_P = 18;
 
+// ||row||^2; rows whose mask is 0 (all-zero descriptors that must never be matched) get +inf, which keeps them
+// out of every arg-min without touching the GEMM
 __global__ __launch_bounds__(256) void k_row_sqnorm(const double *__restrict__ a, int64_t m, int64_t d,
-                                                    double *__restrict__ out)
+                                                    const unsigned char *__restrict__ ok, double *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,14 +48,14 @@ __global__ __launch_bounds__(256) void k_row_sqnorm(const double *__restrict__ a
     double s = 0.0;
     for (int64_t t = lane; t < d; t += 64) s += a[i * d + t] * a[i * d + t];
     s = sf_wave_sum(s);
-    if (lane == 0) out[i] = s;
+    if (lane == 0) out[i] = (ok && !ok[i]) ? INFINITY : s;
 }
 
 __global__ void k_max_partial(const double *__restrict__ v, int64_t n, double *__restrict__ partial)
 {
     double mx = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        mx = fmax(mx, v[i]);
+        mx = fmax(mx, isinf(v[i]) ? 0.0 : v[i]); // masked rows do not enter the error bound
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
     __shared__ double s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = mx;
@@ -289,14 +291,14 @@ __global__ void k_scatter_results(const int64_t *__restrict__ rows, int64_t nr, 
 
 // Row arg-min of cdist(a, b) with the exact kernel's result; returns the number of rows that needed the slow path.
 int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
-                  double *ddist, const char *name, int64_t *n_slow)
+                  double *ddist, const char *name, int64_t *n_slow, const unsigned char *a_ok, const unsigned char *b_ok)
 {
     if (n_slow) *n_slow = 0;
     if (!m1) return SF_OK;
     double *nb = nullptr, *part = nullptr;
     SF_CHECK(sf_palloc(ctx, &nb, (size_t)m2));
     SF_CHECK(sf_palloc(ctx, &part, (size_t)256));
-    SF_LAUNCH(ctx, "k8_row_sqnorm", k_row_sqnorm, dim3((unsigned)sf_div_up(m2, 4)), dim3(256), db, m2, d, nb);
+    SF_LAUNCH(ctx, "k8_row_sqnorm", k_row_sqnorm, dim3((unsigned)sf_div_up(m2, 4)), dim3(256), db, m2, d, b_ok, nb);
     SF_LAUNCH(ctx, "k8_max_partial", k_max_partial, dim3(256), dim3(256), (const double *)nb, m2, part);
     const int64_t row_tiles = sf_div_up(m1, GM), col_tiles = sf_div_up(m2, GN);
     int64_t nsplit = 1;
@@ -352,7 +354,7 @@ int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
         SF_HIP(hipMemcpyAsync(drows, rows.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
         SF_LAUNCH(ctx, "k8_gather_rows", k_gather_rows, dim3((unsigned)sf_div_up(nr * d, 256)), dim3(256), da, d,
                   (const int64_t *)drows, nr, sub);
-        rc = sf_match_exact(ctx, sub, nr, db, m2, d, sidx, sdist, "k8_match_tile_slowpath");
+        rc = sf_match_exact(ctx, sub, nr, db, m2, d, sidx, sdist, "k8_match_tile_slowpath", nullptr, b_ok);
         if (rc == SF_OK) {
             SF_LAUNCH(ctx, "k8_scatter_results", k_scatter_results, dim3((unsigned)sf_div_up(nr, 256)), dim3(256),
                       (const int64_t *)drows, nr, (const int64_t *)sidx, (const double *)sdist, didx, ddist);
