@@ -327,7 +327,8 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     sp->elem_bytes = max_count > 65535 ? 4 : 2;
     // rows padded to a multiple of 128 elements: lane l of a wave owns elements 2l, 2l+1 of each 128-element
     // slice, so no lane of the K7 row loads ever falls outside its row (256 B rows for 125 uint16 bins)
-    sp->stride = (int)sf_div_up(sp->nb3, 128) * 128;
+    sp->stride = 128; // ... and to a power of two, so that a row is 256 B, 512 B, 1 KiB or 2 KiB (the K7 row shapes)
+    while (sp->stride < sp->nb3) sp->stride *= 2;
     // room for ceil(n / nranks) rows per rank so the table can be all-gathered in place
     const int64_t nr = ctx->nranks > 0 ? ctx->nranks : 1;
     sp->rows_alloc = std::max<int64_t>(sf_div_up(c->n, nr) * nr, 1);

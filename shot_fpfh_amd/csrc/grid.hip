@@ -27,6 +27,7 @@ __global__ void k_bbox_partial(const double *__restrict__ xyz, int64_t n, double
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         for (int a = 0; a < 3; ++a) {
             double v = xyz[3 * i + a];
+            if (!(fabs(v) < INFINITY)) v = INFINITY; // NaN / inf poison the maximum (fmin/fmax would drop a NaN)
             mn[a] = fmin(mn[a], v);
             mx[a] = fmax(mx[a], v);
         }

@@ -383,3 +383,58 @@ def test_match_gemm_fast_path_equals_exact(eng, O):
     assert idx[5] == 17
     rep = eng.profile_report()
     assert rep.get("k8_match_gemm", (0, 0))[0] >= 1, "the GEMM path was expected to run for this size"
+
+
+# ---- less travelled paths ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nb", [1, 2, 7, 8])
+def test_fpfh_other_bin_counts_vs_oracle(O, nb):
+    import shot_fpfh_amd as s
+
+    p, nr, rng = synth_cloud(3000, 95)
+    kp = np.sort(rng.choice(3000, 150, replace=False))
+    f = s.compute_fpfh_descriptor(kp, p, nr, 0.13, nb, verbose=False)
+    fo = O.compute_fpfh_descriptor(kp, p, nr, 0.13, nb)
+    assert f.shape == (150, nb**3) and close(f, fo).all()
+    with pytest.raises(ValueError):
+        s.compute_fpfh_descriptor(kp, p, nr, 0.13, 9, verbose=False)  # more than 8 bins per axis: not on the device
+
+
+def test_fpfh_wide_count_table(eng, O):
+    """Neighbourhoods above 65 535 points switch the SPFH table to 32-bit counts; force that layout on a small cloud."""
+    from shot_fpfh_amd.engine import Spfh
+
+    p, nr, rng = synth_cloud(2500, 96)
+    cloud = eng.cloud(p, nr)
+    nb = cloud.radius_search_self(0.14)
+    sp = Spfh(cloud, 5, max_count=70000).compute(nb)
+    kp = np.sort(rng.choice(2500, 200, replace=False))
+    f = sp.fpfh(nb, kp)
+    fo, spo = O.compute_fpfh_descriptor(kp, p, nr, 0.14, 5, return_spfh=True)
+    assert close(f, fo).all() and np.array_equal(sp.export(), spo)
+
+
+def test_degenerate_inputs(eng):
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    p, nr, _ = synth_cloud(500, 97)
+    # empty keypoint sets
+    assert s.compute_fpfh_descriptor(np.zeros(0, dtype=np.int64), p, nr, 0.2, 5, verbose=False).shape == (0, 125)
+    with ShotMultiprocessor(min_neighborhood_size=5, verbose=False) as sm:
+        assert sm.compute_descriptor_single_scale(p, nr, np.zeros((0, 3)), 0.2).shape == (0, 352)
+        # all points identical: every rho is 0 -> all-zero descriptors, identity-less but finite frames
+        same = np.tile(p[:1], (50, 1))
+        d = sm.compute_descriptor_single_scale(same, nr[:50], same[:5], 0.1)
+        assert d.shape == (5, 352) and not d.any()
+    f = s.compute_fpfh_descriptor(np.arange(5), same, nr[:50], 0.1, 5, verbose=False)
+    assert f.shape == (5, 125) and not f.any()  # no pair at non-zero distance -> empty histograms
+    # non-finite coordinates are rejected loudly
+    bad = p.copy()
+    bad[7, 1] = np.nan
+    with pytest.raises(s.ShotFpfhError, match="non-finite"):
+        s.compute_fpfh_descriptor(np.arange(5), bad, nr, 0.2, 5, verbose=False)
+    with pytest.raises(s.ShotFpfhError):
+        eng.cloud(p).radius_search(p[:3], -1.0)
+    # one wave spans several tiny clouds' worth of points: n smaller than a wave
+    tiny = eng.cloud(p[:3]).radius_search(p[:3], 10.0).export()
+    assert tiny[0].tolist() == [0, 3, 6, 9]
