@@ -126,6 +126,10 @@ int sf_normals(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *pre, d
 int sf_shot_lrf(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, double *lrf /* m x 9 */, int flags);
 int sf_shot(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *lrf /* m x 9 */, int normalize,
             int64_t min_neighborhood_size, double *out /* m x 352 */, int flags);
+/* compute_descriptor_single_scale in one call (shot_parallelization.py:135-183): frames and descriptors from the
+ * same lists; the frame's sign votes are fused into K5.  lrf (m x 9, nullable) receives the frames. */
+int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int normalize, int64_t min_neighborhood_size,
+                         double *lrf /* m x 9, nullable */, double *out /* m x 352 */, int flags);
 
 /* ---- FPFH: compute_fpfh_descriptor (fpfh.py:16-117, decorrelated=False) -------------------
  * sf_spfh_create allocates the table for all n cloud points; sf_spfh_compute (K6) fills the rows of

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sf_normals": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
     "sf_shot_lrf": (_int, [_vp, _vp, _vp, _vp, _int]),
     "sf_shot": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _int]),
+    "sf_shot_single_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),
     "sf_spfh_create": (_vp, [_vp, _vp, _int, _i64]),
     "sf_spfh_compute": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "sf_spfh_allgather": (_int, [_vp, _vp, _i64]),

@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
                                                   const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
                                                   const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
-                                                  int64_t m, double radius, double *__restrict__ lrf)
+                                                  int64_t m, double radius, int raw, double *__restrict__ lrf)
 {
+    // raw != 0: stop after the eigen-decomposition and store the largest / smallest eigenvectors (x in slots
+    // 0..2, z in slots 3..5) as returned; the fused SHOT kernel does the sign votes from the neighbours it has
+    // in registers anyway and completes the frame in place.
     const int lane = threadIdx.x & 63;
     const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
     if (q0 >= m) return;
@@ -170,6 +173,16 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
         const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33);
         x0 = e.v13; x1 = e.v23; x2 = e.v33; // eigenvectors[:, 2]
         z0 = e.v11; z1 = e.v21; z2 = e.v31; // eigenvectors[:, 0]
+    }
+    if (raw) {
+        if (lane < nq) {
+            const int64_t q = q0 + lane;
+            double *o = lrf + 9 * (qrow ? qrow[q] : q);
+            o[0] = x0; o[1] = x1; o[2] = x2;
+            o[3] = z0; o[4] = z1; o[5] = z2;
+            o[6] = 0.0; o[7] = 0.0; o[8] = 0.0;
+        }
+        return;
     }
     // phase C: sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
     bool flipx = false, flipz = false;
@@ -526,15 +539,17 @@ __device__ inline void shot_interp(const shot_kept &g, double radius, shot_value
     o.vG = adth;
 }
 
-template <int NCH>
+template <int NCH, bool FUSED>
 __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ rec,
                                                     const double *__restrict__ qx, const double *__restrict__ qy,
                                                     const double *__restrict__ qz, const int64_t *__restrict__ offset,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                     const int32_t *__restrict__ qrow,
-                                                    int64_t m, double radius, const double *__restrict__ lrf,
+                                                    int64_t m, double radius, double *__restrict__ lrf,
                                                     int normalize, int64_t min_nb, double *__restrict__ out)
 {
+    // FUSED: `lrf` holds the raw axes written by k_shot_lrf(raw = 1); the sign votes (shot.py:40-45) are taken
+    // here from the gathered neighbours and the finished frame is written back before it is used.
     // 11 KB of LDS per wave (14 waves per CU).  sCD / sEF carry ONE value per slot plus a flag in bit 62
     // (unused by doubles below 2.0): the S3/S4 pair of a winner has a single non-zero member, selected by
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
@@ -565,8 +580,38 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
         cz[c] = j < 0 ? 0.0 : z - pz;
     }
     double E[9];
+    if (FUSED) {
+        double *lr = lrf + 9 * row;
+        double x0 = lr[0], x1 = lr[1], x2 = lr[2], z0 = lr[3], z1 = lr[4], z2 = lr[5];
+        int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+        for (int c = 0; c < NCH; ++c) {
+            const bool on = c * 64 + lane < k; // the query itself (c = 0) votes ">= 0", as in the reference
+            const double xo = (cx[c] * x0 + cy[c] * x1) + cz[c] * x2;
+            const double zo = (cx[c] * z0 + cy[c] * z1) + cz[c] * z2;
+            xneg += __popcll(__ballot(on && xo < 0.0)); xpos += __popcll(__ballot(on && xo >= 0.0));
+            zneg += __popcll(__ballot(on && zo < 0.0)); zpos += __popcll(__ballot(on && zo >= 0.0));
+        }
+        if (xneg > xpos) { x0 = -x0; x1 = -x1; x2 = -x2; }
+        if (zneg > zpos) { z0 = -z0; z1 = -z1; z2 = -z2; }
+        const double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0; // cross(z, x)
+        if (k == 0) { // shot.py:24-25
+            E[0] = 1.0; E[1] = 0.0; E[2] = 0.0; E[3] = 0.0; E[4] = 1.0; E[5] = 0.0; E[6] = 0.0; E[7] = 0.0; E[8] = 1.0;
+        } else {
+            E[0] = x0; E[1] = y0; E[2] = z0;
+            E[3] = x1; E[4] = y1; E[5] = z1;
+            E[6] = x2; E[7] = y2; E[8] = z2;
+        }
+        if (lane < 9) {
+            double v = E[0];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) v = lane == i ? E[i] : v;
+            lr[lane] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+    }
 
     // gate (shot.py:212): neighbours at non-zero distance; padding lanes have c = 0 -> d2 = 0
     double d2[NCH];
@@ -718,9 +763,34 @@ extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, i
     SF_CHECK(stage_out(ctx, lrf, (size_t)m * 9, flags, &dout, &oout));
     if (m) {
         SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec,
-                  nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, dout);
+                  nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, 0, dout);
     }
     return finish_out(ctx, lrf, (size_t)m * 9, dout, oout);
+}
+
+// launch K5 on resident buffers; fused != 0: dlrf holds raw axes (k_shot_lrf raw mode) and receives the frames
+static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int normalize, int64_t min_nb, double *dout,
+                       bool fused)
+{
+    const int64_t m = nb->m;
+    if (!m) return SF_OK;
+    const dim3 grid(sf_xcd_grid(m)), block(64);
+#define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius
+    const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+#define SF_SHOT_CASE(N)                                                                                              \
+    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, dlrf, normalize, min_nb, dout); } \
+    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, dlrf, normalize, min_nb, dout); }
+    if (chunks <= 1) { SF_SHOT_CASE(1) }
+    else if (chunks == 2) { SF_SHOT_CASE(2) }
+    else if (chunks == 3) { SF_SHOT_CASE(3) }
+    else if (chunks == 4) { SF_SHOT_CASE(4) }
+    else {
+        if (fused) { sf_set_error("internal: fused SHOT needs neighbourhoods of at most 256 points"); return SF_ERR_STATE; }
+        SF_LAUNCH(ctx, "k5_shot", k_shot, grid, block, SF_SHOT_ARGS, (const double *)dlrf, normalize, min_nb, dout); // streaming
+    }
+#undef SF_SHOT_CASE
+#undef SF_SHOT_ARGS
+    return SF_OK;
 }
 
 extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf, int normalize, int64_t min_nb,
@@ -734,19 +804,39 @@ extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf,
     double *olrf, *dout, *oout;
     SF_CHECK(stage_in(ctx, lrf, (size_t)m * 9, flags, &dlrf, &olrf));
     SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
-    if (m) {
-        const dim3 grid(sf_xcd_grid(m)), block(64);
-#define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, \
-                     nb->radius, dlrf, normalize, min_nb, dout
-        const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
-        if (chunks <= 1) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<1>, grid, block, SF_SHOT_ARGS); }
-        else if (chunks == 2) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<2>, grid, block, SF_SHOT_ARGS); }
-        else if (chunks == 3) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<3>, grid, block, SF_SHOT_ARGS); }
-        else if (chunks == 4) { SF_LAUNCH(ctx, "k5_shot", k_shot_cached<4>, grid, block, SF_SHOT_ARGS); }
-        else { SF_LAUNCH(ctx, "k5_shot", k_shot, grid, block, SF_SHOT_ARGS); } // streaming fallback, any size
-#undef SF_SHOT_ARGS
-    }
+    SF_CHECK(launch_shot(ctx, c, nb, const_cast<double *>(dlrf), normalize, min_nb, dout, false));
     SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
     if (olrf) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(olrf)); }
+    return SF_OK;
+}
+
+// Single-scale SHOT in one go (shot_parallelization.py:135-183: frames and descriptor from the SAME search):
+// K4 without its vote sweep, then the fused K5, which votes on the neighbours it gathers anyway.
+extern "C" int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int normalize, int64_t min_nb, double *lrf,
+                                    double *out, int flags)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_single_scale"));
+    if (!out) { sf_set_error("sf_shot_single_scale: null out"); return SF_ERR_ARG; }
+    SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
+    const int64_t m = nb->m;
+    const bool out_dev = flags & SF_OUT_DEVICE;
+    double *dlrf = lrf, *own_lrf = nullptr, *dout, *oout;
+    if (!out_dev || !lrf) { // frames wanted on the host, or not wanted at all: scratch on the device
+        SF_CHECK(sf_palloc(ctx, &own_lrf, (size_t)m * 9));
+        dlrf = own_lrf;
+    }
+    SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
+    const bool fused = nb->max_count <= 256;
+    if (m) {
+        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx, nb->qy,
+                  nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, fused ? 1 : 0, dlrf);
+    }
+    SF_CHECK(launch_shot(ctx, c, nb, dlrf, normalize, min_nb, dout, fused));
+    if (own_lrf && lrf && m) SF_HIP(hipMemcpyAsync(lrf, own_lrf, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
+    if (own_lrf) {
+        if (lrf) SF_HIP(hipStreamSynchronize(ctx->stream));
+        sf_pool_release(ctx, own_lrf);
+    }
     return SF_OK;
 }

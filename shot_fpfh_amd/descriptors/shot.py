@@ -103,8 +103,7 @@ class ShotMultiprocessor:
         try:
             nb = cloud.radius_search(keypoints, radius)
             try:
-                lrf = nb.shot_lrf()
-                return nb.shot(lrf, self.normalize, self.min_neighborhood_size)
+                return nb.shot_single_scale(self.normalize, self.min_neighborhood_size)
             finally:
                 nb.free()
         finally:

@@ -395,6 +395,25 @@ class Neighbors:
         )
         return res
 
+    def shot_single_scale(self, normalize: bool = True, min_neighborhood_size: int = 100, out: Optional[DeviceArray] = None,
+                          lrf_out: Optional[DeviceArray] = None):
+        """Frames + descriptors from these lists in one call (the frame's sign votes fused into the SHOT kernel)."""
+        if out is not None:
+            _ffi.check(
+                self.engine.lib.sf_shot_single_scale(self.engine.h, self.cloud.h, self.h, int(bool(normalize)),
+                                                     int(min_neighborhood_size), None if lrf_out is None else lrf_out.ptr,
+                                                     out.ptr, SF_OUT_DEVICE),
+                "sf_shot_single_scale",
+            )
+            return out
+        res = np.zeros((self.m, _ffi.SHOT_LEN))
+        _ffi.check(
+            self.engine.lib.sf_shot_single_scale(self.engine.h, self.cloud.h, self.h, int(bool(normalize)),
+                                                 int(min_neighborhood_size), None, _ptr(res), SF_HOST),
+            "sf_shot_single_scale",
+        )
+        return res
+
     def free(self) -> None:
         if getattr(self, "h", None) and self.engine.h:
             self.engine.lib.sf_nbrs_free(self.engine.h, self.h)

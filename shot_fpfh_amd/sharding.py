@@ -113,8 +113,7 @@ class DescriptorJob:
                         spfh.allgather(self.plan.rows_per_rank)
                     spfh.fpfh(blk, None, out=self.fpfh_out)
                 if self.do_shot:
-                    blk.shot_lrf(out=self.lrf_out)
-                    blk.shot(self.lrf_out, self.normalize, self.min_nb, out=self.shot_out)
+                    blk.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
             finally:
                 if blk is not nb:
                     blk.free()

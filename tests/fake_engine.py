@@ -55,6 +55,10 @@ class FakeNbrs:
         out.a[:] = O.shot(self.cloud.ps, self.cloud.ns, self._queries(), self.radius, lrf.a, normalize, min_nb)
         return out
 
+    def shot_single_scale(self, normalize=True, min_neighborhood_size=100, out=None, lrf_out=None):
+        self.shot_lrf(out=lrf_out)
+        return self.shot(lrf_out, normalize, min_neighborhood_size, out=out)
+
     def free(self):
         pass
 
