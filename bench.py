@@ -50,11 +50,11 @@ def make_cloud(n: int, seed: int):
 
 def cpu_baseline(points_per_gpu: int, radius: float) -> dict:
     """The CPU oracle (scalar C port of the reference algorithm, one thread) on a bounded sample:
-    a 50k-point cloud at the SAME point density per radius-ball (radius scaled by (n/50k)^(1/3)), all
-    points keypoints, FPFH + SHOT.  ~10-20 s of CPU work."""
+    a 150k-point cloud at the SAME point density per radius-ball (radius scaled by (n/150k)^(1/3)), all
+    points keypoints, FPFH + SHOT.  ~10 s of CPU work."""
     from oracle import oracle as O
 
-    ns = min(50000, points_per_gpu)
+    ns = min(150000, points_per_gpu)
     r = radius * (points_per_gpu / ns) ** (1.0 / 3.0)
     p, nr = make_cloud(ns, 33)
     O.lib()
@@ -84,6 +84,8 @@ def main() -> None:
     ap.add_argument("--spfh-exchange", choices=["halo", "allgather"], default="halo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", choices=["both", "fpfh", "shot"], default="both")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the FPFH and SHOT chains on two HIP streams (faster; per-kernel times then overlap)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,7 +119,7 @@ def main() -> None:
     points, normals = make_cloud(n_total, 3)
     job = DescriptorJob(eng, points, normals, radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world,
                         rank=rank, spfh_exchange=args.spfh_exchange, do_fpfh=args.only in ("both", "fpfh"),
-                        do_shot=args.only in ("both", "shot"))
+                        do_shot=args.only in ("both", "shot"), overlap_chains=args.overlap)
     del points, normals
 
     def barrier():

@@ -60,6 +60,13 @@ sf_ctx *sf_create(int device);
 void sf_destroy(sf_ctx *ctx);
 int sf_sync(sf_ctx *ctx);
 void *sf_stream(sf_ctx *ctx); /* hipStream_t the kernels are launched on */
+/* A context owns two HIP streams.  sf_fork: following calls go to the side stream, ordered after the work issued so
+ * far; sf_switch(0|1) picks the stream of the following calls while forked; sf_join: back on the main stream, ordered
+ * after the side stream.  While forked only calls that neither allocate nor free device memory may be issued
+ * (resident K4-K7 calls).  Used to run the FPFH chain and the SHOT chain of one pass side by side. */
+int sf_fork(sf_ctx *ctx);
+int sf_switch(sf_ctx *ctx, int side);
+int sf_join(sf_ctx *ctx);
 
 /* ---- raw device memory (for callers that keep results resident) ------------------------- */
 void *sf_dev_alloc(sf_ctx *ctx, size_t bytes);

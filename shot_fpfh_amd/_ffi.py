@@ -32,6 +32,9 @@ SIGNATURES = {
     "sf_destroy": (None, [_vp]),
     "sf_sync": (_int, [_vp]),
     "sf_stream": (_vp, [_vp]),
+    "sf_fork": (_int, [_vp]),
+    "sf_switch": (_int, [_vp, _int]),
+    "sf_join": (_int, [_vp]),
     "sf_dev_alloc": (_vp, [_vp, _sz]),
     "sf_dev_free": (_int, [_vp, _vp]),
     "sf_h2d": (_int, [_vp, _vp, _vp, _sz]),

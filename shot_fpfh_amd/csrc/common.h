@@ -48,7 +48,9 @@ struct sf_prof_entry {
 
 struct sf_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the stream calls are issued on (one of streams[])
+    hipStream_t streams[2] = {nullptr, nullptr};
+    hipEvent_t join_event = nullptr;
     bool profiling = false;
     std::map<std::string, sf_prof_entry> prof;
     std::vector<hipEvent_t> event_pool;

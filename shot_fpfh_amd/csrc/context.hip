@@ -37,12 +37,15 @@ extern "C" sf_ctx *sf_create(int device)
     SF_HIP_NULL(hipSetDevice(device));
     sf_ctx *ctx = new sf_ctx();
     ctx->device = device;
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->streams[1], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming);
     if (e != hipSuccess) {
         sf_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         delete ctx;
         return nullptr;
     }
+    ctx->stream = ctx->streams[0];
     return ctx;
 }
 
@@ -50,7 +53,9 @@ extern "C" void sf_destroy(sf_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->streams[0]);
+    (void)hipStreamSynchronize(ctx->streams[1]);
+    ctx->stream = ctx->streams[0];
     sf_comm_destroy(ctx);
     for (auto &kv : ctx->prof)
         for (auto &p : kv.second.pending) {
@@ -61,14 +66,48 @@ extern "C" void sf_destroy(sf_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     sf_pool_trim(ctx);
     for (auto &kv : ctx->pool_size) (void)hipFree(kv.first); // blocks still held by live handles
-    (void)hipStreamDestroy(ctx->stream);
+    (void)hipEventDestroy(ctx->join_event);
+    (void)hipStreamDestroy(ctx->streams[0]);
+    (void)hipStreamDestroy(ctx->streams[1]);
     delete ctx;
 }
 
 extern "C" int sf_sync(sf_ctx *ctx)
 {
     if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
-    SF_HIP(hipStreamSynchronize(ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->streams[0]));
+    SF_HIP(hipStreamSynchronize(ctx->streams[1]));
+    return SF_OK;
+}
+
+// Two streams per context let independent stages of the path (the FPFH chain K6 -> K7 and the SHOT chain
+// K4 -> K5, both consumers of the same neighbour lists) run side by side.  sf_fork: subsequent calls go to the
+// side stream, ordered after everything issued so far on the main one.  sf_join: back to the main stream,
+// ordered after the side stream.  Only calls that neither allocate nor free device memory may be issued while
+// forked (the caching allocator is ordered on the main stream).
+extern "C" int sf_fork(sf_ctx *ctx)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    if (ctx->stream != ctx->streams[0]) { sf_set_error("sf_fork: already forked"); return SF_ERR_STATE; }
+    SF_HIP(hipEventRecord(ctx->join_event, ctx->streams[0]));
+    SF_HIP(hipStreamWaitEvent(ctx->streams[1], ctx->join_event, 0));
+    ctx->stream = ctx->streams[1];
+    return SF_OK;
+}
+
+extern "C" int sf_switch(sf_ctx *ctx, int side)
+{
+    if (!ctx || side < 0 || side > 1) { sf_set_error("sf_switch: bad argument"); return SF_ERR_ARG; }
+    ctx->stream = ctx->streams[side];
+    return SF_OK;
+}
+
+extern "C" int sf_join(sf_ctx *ctx)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    SF_HIP(hipEventRecord(ctx->join_event, ctx->streams[1]));
+    SF_HIP(hipStreamWaitEvent(ctx->streams[0], ctx->join_event, 0));
+    ctx->stream = ctx->streams[0];
     return SF_OK;
 }
 
@@ -196,7 +235,8 @@ hipEvent_t sf_ctx_event(sf_ctx *ctx)
 
 static void prof_collect(sf_ctx *ctx)
 {
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->streams[0]);
+    (void)hipStreamSynchronize(ctx->streams[1]);
     for (auto &kv : ctx->prof) {
         for (auto &p : kv.second.pending) {
             float ms = 0.f;

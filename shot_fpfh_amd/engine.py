@@ -122,6 +122,17 @@ class Engine:
     def sync(self) -> None:
         _ffi.check(self.lib.sf_sync(self.h), "sf_sync")
 
+    def fork(self) -> None:
+        """Following calls go to the side stream (ordered after the work issued so far)."""
+        _ffi.check(self.lib.sf_fork(self.h), "sf_fork")
+
+    def switch(self, side: int) -> None:
+        _ffi.check(self.lib.sf_switch(self.h, int(side)), "sf_switch")
+
+    def join(self) -> None:
+        """Back on the main stream, ordered after the side stream."""
+        _ffi.check(self.lib.sf_join(self.h), "sf_join")
+
     def empty(self, shape, dtype=np.float64) -> DeviceArray:
         return DeviceArray(self, shape, dtype)
 

@@ -438,3 +438,19 @@ def test_degenerate_inputs(eng):
     # one wave spans several tiny clouds' worth of points: n smaller than a wave
     tiny = eng.cloud(p[:3]).radius_search(p[:3], 10.0).export()
     assert tiny[0].tolist() == [0, 3, 6, 9]
+
+
+def test_two_stream_overlap_gives_identical_results(eng):
+    """FPFH and SHOT chains on the context's two HIP streams (fork / switch / join) == single-stream results."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    p, nr, _ = synth_cloud(30000, 99)
+    outs = []
+    for overlap in (False, True):
+        job = DescriptorJob(eng, p, nr, 0.07, overlap_chains=overlap)
+        job.step()
+        job.step()
+        outs.append((job.fpfh_out.to_host(), job.shot_out.to_host(), job.lrf_out.to_host()))
+        job.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
