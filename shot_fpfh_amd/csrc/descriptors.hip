@@ -452,9 +452,89 @@ __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ rec,
 // reference's own expression, so the decision equals shot.py:283-288 in every case.
 // --------------------------------------------------------------------------------------------------
 struct shot_kept {
-    double rho, dc, lx, ly, lz;
-    unsigned bins0, bins1; // base | bcos << 9 | bth << 18 ; cd | ef << 8 ; bins1 bit 31 = valid
+    double rho, dc, tcross, tdot, lz; // tcross / tdot: (lx, ly) against the octant's centre ray (cross, dot)
+    unsigned bins0, bins1;            // base | bcos << 9 | bth << 18 ; cd | ef << 8 ; bins1 bit 31 = valid
 };
+
+// ---- short double-precision helpers for sweep 2 (coefficients: tools/fit_poly.py) ------------------------
+// The interpolation weights are continuous in theta / phi, so these only have to be accurate, not
+// correctly rounded: each is within ~2e-16 (absolute) of the libm value the reference uses, far inside the
+// 1e-5 parity tolerance, at a quarter of the instruction count of ocml's atan2 / acos / sqrt / division.
+__device__ inline double sf_rcp(double d) // 1/d for normal d, ~1 ulp (v_rcp_f64 + 2 Newton steps)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+__device__ inline double sf_sqrt_small(double x) // sqrt(x), 0 <= x <= 1/4, no denormal / huge handling
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
+// Polynomial coefficients are pinned to SGPR pairs (empty asm): as plain immediates the compiler copies every
+// one of them into a VGPR pair first (2 v_mov per FMA); as SGPRs they are the FMA's scalar operand (s_mov only).
+__device__ inline double sf_sgpr(double c)
+{
+    asm("" : "+s"(c));
+    return c;
+}
+#define SF_HORNER(p, s, c) p = __builtin_fma(p, s, sf_sgpr(c))
+
+__device__ inline double sf_atan_small(double t) // atan(t), 0 <= t <= tan(pi/8) (1 + 1e-3)
+{
+    const double s = t * t;
+    double p = sf_sgpr(0.021102961440831885);
+    SF_HORNER(p, s, -0.04345403041920663);
+    SF_HORNER(p, s, 0.05687431322104835);
+    SF_HORNER(p, s, -0.06640058350060206);
+    SF_HORNER(p, s, 0.07689933264608774);
+    SF_HORNER(p, s, -0.09090771637100807);
+    SF_HORNER(p, s, 0.11111106118508882);
+    SF_HORNER(p, s, -0.14285714179450393);
+    SF_HORNER(p, s, 0.19999999998836118);
+    SF_HORNER(p, s, -0.33333333333328347);
+    return __builtin_fma(t * s, p, t);
+}
+
+__device__ inline double sf_acos(double z) // acos(z), -1 <= z <= 1
+{
+    const double az = fabs(z);
+    const bool big = az > 0.5;
+    // straight-line on purpose (both forms are evaluated, then selected): the two Horner chains of sweep 2
+    // interleave only if no branch separates them
+    const double xb = __builtin_fma(-0.5, az, 0.5), xs = az * az; // (1 - |z|) / 2 is exact
+    const double rb = sf_sqrt_small(fmin(xb, 0.25));
+    const double x = big ? xb : xs;
+    const double r = big ? rb : az;
+    double p = sf_sgpr(0.028169218060881414); // asin(r) = r + r s R(s), s = r^2 <= 1/4
+    SF_HORNER(p, x, -0.010749050339697808);
+    SF_HORNER(p, x, 0.01603551434914882);
+    SF_HORNER(p, x, 0.0078029494773533175);
+    SF_HORNER(p, x, 0.011875494382636922);
+    SF_HORNER(p, x, 0.013929652902326633);
+    SF_HORNER(p, x, 0.017355259955786323);
+    SF_HORNER(p, x, 0.02237204763174451);
+    SF_HORNER(p, x, 0.03038194736709848);
+    SF_HORNER(p, x, 0.044642857103423646);
+    SF_HORNER(p, x, 0.07500000000020764);
+    SF_HORNER(p, x, 0.1666666666666665);
+    const double as = __builtin_fma(r * x, p, r);
+    // |z| <= 1/2: pi/2 -+ asin|z| ;  z > 1/2: 2 asin(sqrt((1-z)/2)) ;  z < -1/2: pi - 2 asin(sqrt((1+z)/2))
+    const bool neg = z < 0.0;
+    const double a = big ? (neg ? SHOT_PI : 0.0) : SHOT_PI / 2;
+    const double b = big ? (neg ? -2.0 : 2.0) : (neg ? 1.0 : -1.0);
+    return __builtin_fma(b, as, a);
+}
 
 __device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
                                      const double *E, double radius, shot_kept &o)
@@ -481,6 +561,7 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     const double ac = cos_is_c ? C8 : S8, as = cos_is_c ? S8 : C8;
     const double ctr_x = ((ti + 2) & 4) ? ac : -ac, ctr_y = ti >= 4 ? as : -as;
     const double cross = ctr_x * ly - ctr_y * lx;
+    const double dot = ctr_x * lx + ctr_y * ly;
     int sth;
     if (fabs(cross) > 1e-9 * (fabs(lx) + fabs(ly))) {
         sth = cross > 0.0 ? 1 : -1;
@@ -495,7 +576,7 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     const unsigned base = cd * 2 + ri;
     const unsigned bcos = (unsigned)(((cin * 8 + ti) * 2 + pi_) * 2 + ri);
     const unsigned bth = (unsigned)(((ci * 8 + tin) * 2 + pi_) * 2 + ri);
-    o.rho = rho; o.dc = dc; o.lx = lx; o.ly = ly; o.lz = lz;
+    o.rho = rho; o.dc = dc; o.tcross = cross; o.tdot = dot; o.lz = lz;
     o.bins0 = base | (bcos << 9) | (bth << 18);
     o.bins1 = cd | (ef << 8) | 0x80000000u;
 }
@@ -504,32 +585,43 @@ struct shot_values { double vA, vB, vG, vC, vD, vE, vF; };
 
 __device__ inline void shot_interp(const shot_kept &g, double radius, shot_values &o)
 {
-    // Same interpolation weights as shot_eval<true> (shot.py:73-171, 282-298); the divisions by the two
-    // constant bin sizes (r/2 and pi/2) are multiplications by their reciprocals here (<= 1 ulp apart).
+    // Same interpolation weights as shot_eval<true> (shot.py:73-171, 282-298); the divisions by the constant
+    // bin sizes (r/2, pi/2, pi/4) are multiplications by their reciprocals and theta / phi come from the short
+    // helpers above (all within ~1e-15 of the reference's libm expressions).  Written as straight-line code
+    // (values first, selects after) so that no branch separates the independent dependency chains.
     const unsigned base = g.bins0 & 511u;
-    const int ri = base & 1, pi_ = (base >> 1) & 1, ti = (base >> 2) & 7;
+    const int ri = base & 1, pi_ = (base >> 1) & 1;
     const double rho = g.rho;
     const double adc = fabs(g.dc);
-    const double theta = atan2(g.ly, g.lx);
-    const double tsz = 2 * SHOT_PI / 8;
-    double dth = (theta - (-SHOT_PI + ti * tsz)) / tsz - 0.5;
-    dth = fmin(fmax(dth, -0.5), 0.5);
-    const double adth = fabs(dth);
+    // |dth| of shot.py:283-288 = (angle between (lx, ly) and the octant's centre ray) / (pi/4), clipped to 1/2.
+    // lx = ly = 0 has dot = 0: the reference's atan2(0, 0) = 0 sits 3.5 octants from octant 0's start -> 1/2.
+    const double inv_tsz = 1.2732395447351628; // 1 / (pi/4)
+    const bool fwd = g.tdot > 0.0;
+    const double tq = fmin(fabs(g.tcross) * sf_rcp(fwd ? g.tdot : 1.0), 0.4146);
+    const double at = fmin(sf_atan_small(tq) * inv_tsz, 0.5);
+    const double adth = fwd ? at : 0.5;
     const double half_r = radius / 2, q1 = radius / 4, q3 = radius * 3 / 4;
     const double inv_hr = 1.0 / half_r; // wave-uniform
-    const double inner = ((rho > half_r) && (rho < q3)) ? (q3 - rho) * inv_hr : 0.0;
-    const double outer = ((rho < half_r) && (rho > q1)) ? (rho - q1) * inv_hr : 0.0;
-    const double cur = rho < half_r ? 1 - fabs(rho - q1) * inv_hr : (rho > half_r ? 1 - fabs(rho - q3) * inv_hr : 0.0);
-    double lzr = g.lz / rho;
+    const double in_v = (q3 - rho) * inv_hr, out_v = (rho - q1) * inv_hr;
+    const double cur_lo = 1 - fabs(rho - q1) * inv_hr, cur_hi = 1 - fabs(rho - q3) * inv_hr;
+    const bool lo = rho < half_r, hi = rho > half_r;
+    const double inner = (hi & (rho < q3)) ? in_v : 0.0;
+    const double outer = (lo & (rho > q1)) ? out_v : 0.0;
+    const double cur_h = hi ? cur_hi : 0.0;
+    const double cur = lo ? cur_lo : cur_h;
+    double lzr = g.lz * sf_rcp(rho);
     lzr = fmin(fmax(lzr, -1.0), 1.0);
-    const double phi = acos(lzr);
+    const double phi = sf_acos(lzr);
     const double hpi = SHOT_PI / 2, pi34 = SHOT_PI * 3 / 4, pi4 = SHOT_PI / 4;
     const double inv_hpi = 0.6366197723675814; // 1 / (pi/2)
-    const double upper =
-        (((phi > hpi) || ((fabs(phi - hpi) < 1e-10) && (g.lz <= 0.0))) && (phi <= pi34)) ? (pi34 - phi) * inv_hpi : 0.0;
-    const double lower =
-        (((phi < hpi) && ((fabs(phi - hpi) >= 1e-10) || (g.lz > 0.0))) && (phi >= pi4)) ? (phi - pi4) * inv_hpi : 0.0;
-    const double curv = phi < hpi ? 1 - fabs(phi - pi4) * inv_hpi : 1 - fabs(phi - pi34) * inv_hpi;
+    const bool near_eq = fabs(phi - hpi) < 1e-10;
+    const bool up_on = ((phi > hpi) | (near_eq & (g.lz <= 0.0))) & (phi <= pi34);
+    const bool lw_on = ((phi < hpi) & (!near_eq | (g.lz > 0.0))) & (phi >= pi4);
+    const double up_v = (pi34 - phi) * inv_hpi, lw_v = (phi - pi4) * inv_hpi;
+    const double upper = up_on ? up_v : 0.0;
+    const double lower = lw_on ? lw_v : 0.0;
+    const double cv_lo = 1 - fabs(phi - pi4) * inv_hpi, cv_hi = 1 - fabs(phi - pi34) * inv_hpi;
+    const double curv = phi < hpi ? cv_lo : cv_hi;
     o.vB = adc; // the reference's mask (cf > -0.5) & (cf < 10.5) is always true for cf in 0..10
     o.vA = (((1 - adc) + cur) + curv) + (1 - adth);
     o.vC = ri == 0 ? outer : 0.0;
@@ -575,9 +667,9 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
         const int jj = j < 0 ? 0 : j;
         double x, y, z;
         sf_load_pn(rec, jj, x, y, z, nx[c], ny[c], nz[c]);
-        cx[c] = j < 0 ? 0.0 : x - px;
-        cy[c] = j < 0 ? 0.0 : y - py;
-        cz[c] = j < 0 ? 0.0 : z - pz;
+        cx[c] = x - px; // padding lanes (j < 0) carry point 0's offset; they are masked by `on` / d2 = 0 below
+        cy[c] = y - py;
+        cz[c] = z - pz;
     }
     double E[9];
     if (FUSED) {
@@ -589,9 +681,11 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
             const bool on = c * 64 + lane < k; // the query itself (c = 0) votes ">= 0", as in the reference
             const double xo = (cx[c] * x0 + cy[c] * x1) + cz[c] * x2;
             const double zo = (cx[c] * z0 + cy[c] * z1) + cz[c] * z2;
-            xneg += __popcll(__ballot(on && xo < 0.0)); xpos += __popcll(__ballot(on && xo >= 0.0));
-            zneg += __popcll(__ballot(on && zo < 0.0)); zpos += __popcll(__ballot(on && zo >= 0.0));
+            xneg += __popcll(__ballot(on & (xo < 0.0)));
+            zneg += __popcll(__ballot(on & (zo < 0.0)));
         }
+        xpos = k - xneg; // coordinates are finite (checked at upload), so "not < 0" is ">= 0"
+        zpos = k - zneg;
         if (xneg > xpos) { x0 = -x0; x1 = -x1; x2 = -x2; }
         if (zneg > zpos) { z0 = -z0; z1 = -z1; z2 = -z2; }
         const double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0; // cross(z, x)
@@ -613,12 +707,13 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
         for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
     }
 
-    // gate (shot.py:212): neighbours at non-zero distance; padding lanes have c = 0 -> d2 = 0
+    // gate (shot.py:212): neighbours at non-zero distance; padding lanes get d2 = 0
     double d2[NCH];
     int npos = 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        d2[c] = (cx[c] * cx[c] + cy[c] * cy[c]) + cz[c] * cz[c];
+        const double dd = (cx[c] * cx[c] + cy[c] * cy[c]) + cz[c] * cz[c];
+        d2[c] = c * 64 + lane < k ? dd : 0.0;
         npos += __popcll(__ballot(d2[c] > 0.0));
     }
     if (!((int64_t)npos > min_nb)) {
@@ -664,24 +759,28 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
         }
     }
     __syncthreads();
+    // Every claimed slot has been resolved by its winner, so a slot is now either +0 (empty) or a tagged
+    // (negated) value: S1 / S2.. / S9 are subtracted as they are; a CD / EF slot feeds the bin whose radial /
+    // elevation bit differs from the winner's flag (bit 62), selected with an all-ones / all-zeros mask.
     double vals[6];
     double ss = 0.0;
+    const unsigned rb30 = (unsigned)(lane & 1) << 30, pb30 = (unsigned)((lane >> 1) & 1) << 30; // 64 u keeps both bits
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int b = lane + 64 * u;
         double v = 0.0;
         if (b < 352) {
             const int cdi = b >> 1, efi = ((b >> 2) << 1) | (b & 1);
-            const int rb = b & 1, pb = (b >> 1) & 1;
-            // S3 lands in radial bin 1 and comes from a winner in radial bin 0 (flag 0); S4 the other way round
             const unsigned long long cd = sCD[cdi], ef = sEF[efi];
-            const bool cd_on = (cd >> 63) && (((cd >> 62) & 1ull) != (unsigned long long)rb);
-            const bool ef_on = (ef >> 63) && (((ef >> 62) & 1ull) != (unsigned long long)pb);
-            v = untag_value(sB[b]);
-            v += untag_value(sA[b]);
-            v += cd_on ? __longlong_as_double((long long)(cd & 0x3fffffffffffffffull)) : 0.0;
-            v += ef_on ? __longlong_as_double((long long)(ef & 0x3fffffffffffffffull)) : 0.0;
-            v += untag_value(sG[b]);
+            const unsigned hcd = (unsigned)(cd >> 32), hef = (unsigned)(ef >> 32);
+            const unsigned mcd = (unsigned)((int)((hcd ^ rb30) << 1) >> 31), mef = (unsigned)((int)((hef ^ pb30) << 1) >> 31);
+            const double vcd = __hiloint2double((int)(hcd & 0x3fffffffu & mcd), (int)((unsigned)cd & mcd));
+            const double vef = __hiloint2double((int)(hef & 0x3fffffffu & mef), (int)((unsigned)ef & mef));
+            v = 0.0 - __longlong_as_double((long long)sB[b]);
+            v -= __longlong_as_double((long long)sA[b]);
+            v += vcd;
+            v += vef;
+            v -= __longlong_as_double((long long)sG[b]);
         }
         vals[u] = v;
         ss += v * v;
