@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
     const int k = cnt[slot];
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const int grp = lane / LPR, piece = lane % LPR;
-    const unsigned row_bytes = (unsigned)stride * (unsigned)sizeof(CT);
     double acc[NP][BPP];
 #pragma unroll
     for (int u = 0; u < NP; ++u)
@@ -175,14 +174,19 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
     };
     auto accumulate = [&](const uint4 &v, double ww, int u) {
         if (sizeof(CT) == 2) {
+            // A 32-bit word holds two counts, x = c1 * 65536 + c0.  The even accumulator takes w * c0; the odd
+            // one takes w * x WITHOUT extracting c1 (one VALU instruction less per pair) and is turned into
+            // sum(w * c1) = (odd - even) / 65536 once, after the loop.  Every product is exact inside the FMA and
+            // the final scaling is a power of two, so the odd bins lose nothing beyond eps * (their own sum +
+            // 2^-16 of the even neighbour's).
             acc[u][0] = __builtin_fma(u2d(v.x & 0xffffu), ww, acc[u][0]);
-            acc[u][1] = __builtin_fma(u2d(v.x >> 16), ww, acc[u][1]);
+            acc[u][1] = __builtin_fma(u2d(v.x), ww, acc[u][1]);
             acc[u][2] = __builtin_fma(u2d(v.y & 0xffffu), ww, acc[u][2]);
-            acc[u][3] = __builtin_fma(u2d(v.y >> 16), ww, acc[u][3]);
+            acc[u][3] = __builtin_fma(u2d(v.y), ww, acc[u][3]);
             acc[u][4 % BPP] = __builtin_fma(u2d(v.z & 0xffffu), ww, acc[u][4 % BPP]);
-            acc[u][5 % BPP] = __builtin_fma(u2d(v.z >> 16), ww, acc[u][5 % BPP]);
+            acc[u][5 % BPP] = __builtin_fma(u2d(v.z), ww, acc[u][5 % BPP]);
             acc[u][6 % BPP] = __builtin_fma(u2d(v.w & 0xffffu), ww, acc[u][6 % BPP]);
-            acc[u][7 % BPP] = __builtin_fma(u2d(v.w >> 16), ww, acc[u][7 % BPP]);
+            acc[u][7 % BPP] = __builtin_fma(u2d(v.w), ww, acc[u][7 % BPP]);
         } else {
             acc[u][0] = __builtin_fma(u2d(v.x), ww, acc[u][0]);
             acc[u][1] = __builtin_fma(u2d(v.y), ww, acc[u][1]);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
                 const int src = tt + e * RPI + grp; // < 64 whenever tt + e*RPI < 64; beyond cnt the weight is 0
                 const int jj = __shfl(j, src & 63);
                 ww[e] = (tt + e * RPI < cnt) ? __shfl(w, src & 63) : 0.0;
-                const unsigned voff = (unsigned)jj * row_bytes + (unsigned)piece * 16u;
+                const unsigned voff = (unsigned)jj * (unsigned)(LPR * 16 * NP) + (unsigned)piece * 16u; // row bytes: a shift
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)u * 1024u, 0, 0);
@@ -266,6 +270,12 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
         for (int u = 0; u < NP; ++u)
 #pragma unroll
             for (int e = 0; e < BPP; ++e) acc[u][e] += __shfl_xor(acc[u][e], off);
+    if (sizeof(CT) == 2) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+#pragma unroll
+            for (int e = 1; e < BPP; e += 2) acc[u][e] = (acc[u][e] - acc[u][e - 1]) * (1.0 / 65536.0);
+    }
     // every lane group now holds the complete sums; group g writes bins e = g, g + RPI, ... of each piece so the
     // divisions are shared out instead of being executed (predicated) by the whole wave for group 0 alone
     {
@@ -459,7 +469,7 @@ static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
     int nch = 0;
     if (sizeof(CT) == 2) {
         const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
-        nch = chunks <= 2 ? 2 : (chunks <= 4 ? 4 : 0);
+        nch = chunks <= 2 ? 2 : (chunks <= 4 ? (int)chunks : 0);
     }
 #define SF_FPFH_LAUNCH(LPR, NP, NCH)                                                                                 \
     SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh<CT, LPR, NP, NCH>), grid, block, c->rec, nb->offset, nb->count, nb->idx,      \
@@ -467,6 +477,7 @@ static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
 #define SF_FPFH_SHAPE(LPR, NP)                                                 \
     {                                                                          \
         if (sizeof(CT) == 2 && nch == 2) { SF_FPFH_LAUNCH(LPR, NP, 2); }       \
+        else if (sizeof(CT) == 2 && nch == 3) { SF_FPFH_LAUNCH(LPR, NP, 3); }  \
         else if (sizeof(CT) == 2 && nch == 4) { SF_FPFH_LAUNCH(LPR, NP, 4); }  \
         else { SF_FPFH_LAUNCH(LPR, NP, 0); }                                   \
     }

@@ -18,7 +18,7 @@ nrm /= np.linalg.norm(nrm, axis=1)[:, None]
 kp = np.sort(rng.choice(n, m, replace=False))
 with s.ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False, disable_progress_bar=True) as sm:
     shot = sm.compute_descriptor_single_scale(point_cloud=p, keypoints=p[kp], normals=nrm, radius=r)
-shot_o = O.shot_single_scale(p, p[kp], nrm, r, normalize=True, min_neighborhood_size=10)
+shot_o = O.shot_single_scale(p, nrm, p[kp], r, normalize=True, min_neighborhood_size=10)
 d = np.abs(shot - shot_o)
 print(f"SHOT  {m} x 352: max |gpu - oracle| = {d.max():.3e}, rows with any |d| > 1e-9: {(d.max(axis=1) > 1e-9).sum()}")
 fpfh = s.compute_fpfh_descriptor(kp, p, nrm, radius=r, n_bins=5, verbose=False)
