@@ -642,10 +642,15 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
 {
     // FUSED: `lrf` holds the raw axes written by k_shot_lrf(raw = 1); the sign votes (shot.py:40-45) are taken
     // here from the gathered neighbours and the finished frame is written back before it is used.
-    // 11 KB of LDS per wave (14 waves per CU).  sCD / sEF carry ONE value per slot plus a flag in bit 62
+    // LDS: 704 election slots (5.5 KB per wave), used twice.  Phase 1 elects and resolves the writers of
+    // S2+S5+S8+S10 (A, 352 slots), S3/S4 (CD, 176) and S6/S7 (EF, 176); phase 2 those of S1 (B, 352) and S9
+    // (G, 352).  Halving the footprint (it was 11 KB with all five tables live at once) is what lets the
+    // register file, not LDS, set the occupancy.  A CD / EF slot carries ONE value plus a flag in bit 62
     // (unused by doubles below 2.0): the S3/S4 pair of a winner has a single non-zero member, selected by
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
-    __shared__ unsigned long long sA[352], sB[352], sG[352], sCD[176], sEF[176];
+    __shared__ unsigned long long slot[704];
+    unsigned long long *const sA = slot, *const sCD = slot + 352, *const sEF = slot + 528; // phase 1
+    unsigned long long *const sB = slot, *const sG = slot + 352;                            // phase 2
     const int lane = threadIdx.x;
     const int64_t q = sf_xcd_block();
     if (q >= m) return;
@@ -655,8 +660,7 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
     double *o = out + (int64_t)SF_SHOT_LEN * row;
     const double px = qx[q], py = qy[q], pz = qz[q];
 
-    for (int b = lane; b < 352; b += 64) { sA[b] = 0; sB[b] = 0; sG[b] = 0; }
-    for (int b = lane; b < 176; b += 64) { sCD[b] = 0; sEF[b] = 0; }
+    for (int b = lane; b < 704; b += 64) slot[b] = 0;
 
     // one gather for all chunks
     double cx[NCH], cy[NCH], cz[NCH], nx[NCH], ny[NCH], nz[NCH];
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
         return;
     }
     __syncthreads();
-    // sweep 1: geometry + election of the max-rho writer of every (key, bin)
+    // phase 1, sweep 1: geometry + election of the max-rho writer of every (key, bin) of A / CD / EF
     shot_kept g[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -730,40 +734,32 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
             shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, radius, g[c]);
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             atomicMax(&sA[g[c].bins0 & 511u], key);
-            atomicMax(&sB[(g[c].bins0 >> 9) & 511u], key);
-            atomicMax(&sG[(g[c].bins0 >> 18) & 511u], key);
             atomicMax(&sCD[g[c].bins1 & 255u], key);
             atomicMax(&sEF[(g[c].bins1 >> 8) & 255u], key);
         }
     }
     __syncthreads();
-    // sweep 2: winners replace their key by their (tagged) value
+    // phase 1, sweep 2: winners replace their key by their (tagged) value; |dth| is kept for phase 2
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (g[c].bins1 >> 31) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
-            const unsigned iA = g[c].bins0 & 511u, iB = (g[c].bins0 >> 9) & 511u, iG = (g[c].bins0 >> 18) & 511u;
-            const unsigned iCD = g[c].bins1 & 255u, iEF = (g[c].bins1 >> 8) & 255u;
-            const bool wA = sA[iA] == key, wB = sB[iB] == key, wG = sG[iG] == key, wCD = sCD[iCD] == key,
-                       wEF = sEF[iEF] == key;
-            if (wA | wB | wG | wCD | wEF) { // a neighbour that won nothing needs no values
-                shot_values v;
-                shot_interp(g[c], radius, v);
-                if (wA) sA[iA] = tag_value(v.vA);
-                if (wB) sB[iB] = tag_value(v.vB);
-                if (wG) sG[iG] = tag_value(v.vG);
-                const unsigned long long ri_w = iA & 1u, pi_w = (iA >> 1) & 1u; // the winner's own radial / elevation bin
-                if (wCD) sCD[iCD] = tag_value(ri_w ? v.vD : v.vC) | (ri_w << 62);
-                if (wEF) sEF[iEF] = tag_value(pi_w ? v.vF : v.vE) | (pi_w << 62);
-            }
+            const unsigned iA = g[c].bins0 & 511u, iCD = g[c].bins1 & 255u, iEF = (g[c].bins1 >> 8) & 255u;
+            const bool wA = sA[iA] == key, wCD = sCD[iCD] == key, wEF = sEF[iEF] == key;
+            shot_values v;
+            shot_interp(g[c], radius, v);
+            g[c].tdot = v.vG;
+            if (wA) sA[iA] = tag_value(v.vA);
+            const unsigned long long ri_w = iA & 1u, pi_w = (iA >> 1) & 1u; // the winner's own radial / elevation bin
+            if (wCD) sCD[iCD] = tag_value(ri_w ? v.vD : v.vC) | (ri_w << 62);
+            if (wEF) sEF[iEF] = tag_value(pi_w ? v.vF : v.vE) | (pi_w << 62);
         }
     }
     __syncthreads();
     // Every claimed slot has been resolved by its winner, so a slot is now either +0 (empty) or a tagged
-    // (negated) value: S1 / S2.. / S9 are subtracted as they are; a CD / EF slot feeds the bin whose radial /
-    // elevation bit differs from the winner's flag (bit 62), selected with an all-ones / all-zeros mask.
+    // (negated) value: A is subtracted as it is; a CD / EF slot feeds the bin whose radial / elevation bit
+    // differs from the winner's flag (bit 62), selected with an all-ones / all-zeros mask.
     double vals[6];
-    double ss = 0.0;
     const unsigned rb30 = (unsigned)(lane & 1) << 30, pb30 = (unsigned)((lane >> 1) & 1) << 30; // 64 u keeps both bits
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
@@ -776,10 +772,43 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
             const unsigned mcd = (unsigned)((int)((hcd ^ rb30) << 1) >> 31), mef = (unsigned)((int)((hef ^ pb30) << 1) >> 31);
             const double vcd = __hiloint2double((int)(hcd & 0x3fffffffu & mcd), (int)((unsigned)cd & mcd));
             const double vef = __hiloint2double((int)(hef & 0x3fffffffu & mef), (int)((unsigned)ef & mef));
-            v = 0.0 - __longlong_as_double((long long)sB[b]);
-            v -= __longlong_as_double((long long)sA[b]);
+            v = 0.0 - __longlong_as_double((long long)sA[b]);
             v += vcd;
             v += vef;
+        }
+        vals[u] = v;
+    }
+    __syncthreads();
+    for (int b = lane; b < 704; b += 64) slot[b] = 0;
+    __syncthreads();
+    // phase 2: S1 (B, value |dc|) and S9 (G, value |dth|) through the same slots
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (g[c].bins1 >> 31) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            atomicMax(&sB[(g[c].bins0 >> 9) & 511u], key);
+            atomicMax(&sG[(g[c].bins0 >> 18) & 511u], key);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (g[c].bins1 >> 31) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            const unsigned iB = (g[c].bins0 >> 9) & 511u, iG = (g[c].bins0 >> 18) & 511u;
+            const bool wB = sB[iB] == key, wG = sG[iG] == key;
+            if (wB) sB[iB] = tag_value(fabs(g[c].dc)); // S1: |dc|; the reference's range mask is always true
+            if (wG) sG[iG] = tag_value(g[c].tdot);
+        }
+    }
+    __syncthreads();
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int b = lane + 64 * u;
+        double v = vals[u];
+        if (b < 352) {
+            v -= __longlong_as_double((long long)sB[b]);
             v -= __longlong_as_double((long long)sG[b]);
         }
         vals[u] = v;
