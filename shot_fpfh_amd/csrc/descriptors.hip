@@ -92,34 +92,41 @@ __global__ __launch_bounds__(256) void k_normals(const double *__restrict__ rec,
 }
 
 // K4: SHOT local reference frame (shot.py:16-48), query included in its own support.
-// The wave walks its queries one after the other; the first two chunks (128 neighbours) of the NEXT query
-// are requested before the current one is reduced, so the index -> coordinate round trips overlap the
-// arithmetic instead of serialising with it.
-struct lrf_fetch {
-    double x[2], y[2], z[2]; // raw neighbour coordinates of chunks 0 and 1 (garbage where t >= k)
-    double px, py, pz;
-    int64_t s;
-    int k;
-};
-
-__device__ inline lrf_fetch lrf_prefetch(const double *__restrict__ rec, const double *__restrict__ qx,
-                                         const double *__restrict__ qy, const double *__restrict__ qz,
-                                         const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
-                                         const int32_t *__restrict__ idx, int64_t q, int lane)
+// A wave owns 64 consecutive queries and works on FOUR of them at a time, one per 16-lane DPP row: in round
+// r, row w sweeps the list of query 16 w + r, 16 neighbours per step.  The seven moment sums are then reduced
+// inside the row with four register-to-register DPP steps (a full-wave reduction costs six steps plus a
+// readlane, per query instead of per four queries), and lane 16 w + r -- which sits in that same row -- keeps
+// them, so that phase B runs one eigen-solve per lane.  Lists of ~110 points fill 16-lane steps as well as
+// they fill 64-lane ones (7/8 against 113/128).
+// sqrt here only feeds the continuous weight r - |c| (no bin or sign decision hangs on its last bit), so it
+// is the 8-instruction v_rsq_f64 + Newton form instead of the correctly rounded 22-instruction one.
+__device__ inline double sf_sqrt_fast(double x) // x >= 0, normal range
 {
-    lrf_fetch f;
-    f.s = offset[q];
-    f.k = cnt[q];
-    f.px = qx[q]; f.py = qy[q]; f.pz = qz[q];
-    int j[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int t = c * 64 + lane;
-        j[c] = t < f.k ? idx[f.s + t] : 0;
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) sf_load_xyz(rec, j[c], f.x[c], f.y[c], f.z[c]);
-    return f;
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
+__device__ inline double sf_rcp_fast(double d) // 1/d for normal d, ~1 ulp
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// longest of the four rows' lists (wave-uniform loop bound)
+__device__ inline int sf_rows_max(int k)
+{
+    const int a = __builtin_amdgcn_readlane(k, 0), b = __builtin_amdgcn_readlane(k, 16);
+    const int c = __builtin_amdgcn_readlane(k, 32), d = __builtin_amdgcn_readlane(k, 48);
+    return max(max(a, b), max(c, d));
 }
 
 __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec, const double *__restrict__ qx,
@@ -131,41 +138,53 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
     // raw != 0: stop after the eigen-decomposition and store the largest / smallest eigenvectors (x in slots
     // 0..2, z in slots 3..5) as returned; the fused SHOT kernel does the sign votes from the neighbours it has
     // in registers anyway and completes the frame in place.
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
     const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
     if (q0 >= m) return;
     const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
     // phase A: weighted covariance, w = r - ||c|| (shot.py:27-35)
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
-    lrf_fetch cur = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0, lane);
-    for (int t = 0; t < nq; ++t) {
-        const lrf_fetch nxt = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
+    int kmine = 0;
+    for (int r = 0; r < 16; ++r) {
+        const int t = 16 * rw + r;
+        const bool have = t < nq;
+        const int64_t q = q0 + (have ? t : 0);
+        const int64_t s = offset[q];
+        const int k = have ? cnt[q] : 0;
+        const double px = qx[q], py = qy[q], pz = qz[q];
+        const int kmax = sf_rows_max(k);
         double ws = 0, a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
-        auto add = [&](double x, double y, double z) {
-            const double cx = x - cur.px, cy = y - cur.py, cz = z - cur.pz;
-            const double w = radius - sqrt((cx * cx + cy * cy) + cz * cz);
-            ws += w;
-            const double wx = cx * w, wy = cy * w, wz = cz * w;
-            a11 += cx * wx; a21 += cy * wx; a31 += cz * wx;
-            a22 += cy * wy; a32 += cz * wy; a33 += cz * wz;
-        };
+        for (int base = 0; base < kmax; base += 64) { // four 16-neighbour steps per trip, loads issued together
+            int j[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            if (c * 64 + lane < cur.k) add(cur.x[c], cur.y[c], cur.z[c]);
-        for (int u = 128 + lane; u < cur.k; u += 64) { // neighbourhoods beyond 128 points: streamed
-            double x, y, z;
-            sf_load_xyz(rec, idx[cur.s + u], x, y, z);
-            add(x, y, z);
+            for (int c = 0; c < 4; ++c) {
+                const int u = base + 16 * c + sl;
+                j[c] = u < k ? idx[s + u] : -1;
+            }
+            double x[4], y[4], z[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sf_load_xyz(rec, j[c] < 0 ? 0 : j[c], x[c], y[c], z[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (base + 16 * c < kmax) { // wave-uniform
+                    const double cx = x[c] - px, cy = y[c] - py, cz = z[c] - pz;
+                    const double wv = radius - sf_sqrt_fast((cx * cx + cy * cy) + cz * cz);
+                    const double w = j[c] < 0 ? 0.0 : wv;
+                    ws += w;
+                    const double wx = cx * w, wy = cy * w, wz = cz * w;
+                    a11 += cx * wx; a21 += cy * wx; a31 += cz * wx;
+                    a22 += cy * wy; a32 += cz * wy; a33 += cz * wz;
+                }
+            }
         }
-        ws = sf_wave_sum(ws);
-        a11 = sf_wave_sum(a11) / ws;
-        a21 = sf_wave_sum(a21) / ws;
-        a31 = sf_wave_sum(a31) / ws;
-        a22 = sf_wave_sum(a22) / ws;
-        a32 = sf_wave_sum(a32) / ws;
-        a33 = sf_wave_sum(a33) / ws;
-        if (lane == t) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; }
-        cur = nxt;
+        const double iw = sf_rcp_fast(sf_row16_sum(ws)); // empty list: 1/0 = inf, 0 * inf = NaN as in the reference
+        a11 = sf_row16_sum(a11) * iw;
+        a21 = sf_row16_sum(a21) * iw;
+        a31 = sf_row16_sum(a31) * iw;
+        a22 = sf_row16_sum(a22) * iw;
+        a32 = sf_row16_sum(a32) * iw;
+        a33 = sf_row16_sum(a33) * iw;
+        if (sl == r) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; kmine = k; }
     }
     // phase B: one eigen-decomposition per lane (shot.py:36)
     double x0 = 0, x1 = 0, x2 = 0, z0 = 0, z1 = 0, z2 = 0;
@@ -186,31 +205,41 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
     }
     // phase C: sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
     bool flipx = false, flipz = false;
-    int kmine = 0;
-    cur = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0, lane);
-    for (int t = 0; t < nq; ++t) {
-        const lrf_fetch nxt = lrf_prefetch(rec, qx, qy, qz, offset, cnt, idx, q0 + (t + 1 < nq ? t + 1 : t), lane);
-        const double bx0 = lane_bcast(x0, t), bx1 = lane_bcast(x1, t), bx2 = lane_bcast(x2, t);
-        const double bz0 = lane_bcast(z0, t), bz1 = lane_bcast(z1, t), bz2 = lane_bcast(z2, t);
-        int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
-        auto vote = [&](bool on, double x, double y, double z) {
-            const double cx = x - cur.px, cy = y - cur.py, cz = z - cur.pz;
-            const double xo = (cx * bx0 + cy * bx1) + cz * bx2;
-            const double zo = (cx * bz0 + cy * bz1) + cz * bz2;
-            xneg += __popcll(__ballot(on && xo < 0.0)); xpos += __popcll(__ballot(on && xo >= 0.0));
-            zneg += __popcll(__ballot(on && zo < 0.0)); zpos += __popcll(__ballot(on && zo >= 0.0));
-        };
+    for (int r = 0; r < 16; ++r) {
+        const int t = 16 * rw + r;
+        const bool have = t < nq;
+        const int64_t q = q0 + (have ? t : 0);
+        const int64_t s = offset[q];
+        const int k = have ? cnt[q] : 0;
+        const double px = qx[q], py = qy[q], pz = qz[q];
+        const int kmax = sf_rows_max(k);
+        const int src = 16 * rw + r; // lane holding this row's axes
+        const double bx0 = lane_bcast(x0, src), bx1 = lane_bcast(x1, src), bx2 = lane_bcast(x2, src);
+        const double bz0 = lane_bcast(z0, src), bz1 = lane_bcast(z1, src), bz2 = lane_bcast(z2, src);
+        int xneg = 0, zneg = 0;
+        for (int base = 0; base < kmax; base += 64) {
+            int j[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            if (c * 64 < cur.k) vote(c * 64 + lane < cur.k, cur.x[c], cur.y[c], cur.z[c]);
-        for (int u0 = 128; u0 < cur.k; u0 += 64) {
-            const int u = u0 + lane;
-            double x, y, z;
-            sf_load_xyz(rec, u < cur.k ? idx[cur.s + u] : 0, x, y, z);
-            vote(u < cur.k, x, y, z);
+            for (int c = 0; c < 4; ++c) {
+                const int u = base + 16 * c + sl;
+                j[c] = u < k ? idx[s + u] : -1;
+            }
+            double x[4], y[4], z[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sf_load_xyz(rec, j[c] < 0 ? 0 : j[c], x[c], y[c], z[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double cx = x[c] - px, cy = y[c] - py, cz = z[c] - pz;
+                const double xo = (cx * bx0 + cy * bx1) + cz * bx2;
+                const double zo = (cx * bz0 + cy * bz1) + cz * bz2;
+                xneg += ((j[c] >= 0) & (xo < 0.0)) ? 1 : 0;
+                zneg += ((j[c] >= 0) & (zo < 0.0)) ? 1 : 0;
+            }
         }
-        if (lane == t) { flipx = xneg > xpos; flipz = zneg > zpos; kmine = cur.k; }
-        cur = nxt;
+        xneg = sf_row16_sum(xneg);
+        zneg = sf_row16_sum(zneg);
+        // coordinates are finite (checked at upload), so the ">= 0" voters are the remaining k - neg
+        if (sl == r) { flipx = xneg > k - xneg; flipz = zneg > k - zneg; }
     }
     if (lane < nq) {
         const int64_t q = q0 + lane;
@@ -460,14 +489,7 @@ struct shot_kept {
 // The interpolation weights are continuous in theta / phi, so these only have to be accurate, not
 // correctly rounded: each is within ~2e-16 (absolute) of the libm value the reference uses, far inside the
 // 1e-5 parity tolerance, at a quarter of the instruction count of ocml's atan2 / acos / sqrt / division.
-__device__ inline double sf_rcp(double d) // 1/d for normal d, ~1 ulp (v_rcp_f64 + 2 Newton steps)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
+__device__ inline double sf_rcp(double d) { return sf_rcp_fast(d); } // v_rcp_f64 + 2 Newton steps, ~1 ulp
 
 __device__ inline double sf_sqrt_small(double x) // sqrt(x), 0 <= x <= 1/4, no denormal / huge handling
 {

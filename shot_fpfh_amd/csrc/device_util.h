@@ -57,6 +57,32 @@ __device__ inline double sf_wave_sum(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// Sum over each 16-lane DPP row, result in every lane of the row (the first four steps of sf_wave_sum).
+__device__ inline double sf_row16_sum(double v)
+{
+#define SF_DPP_ADD(ctrl)                                                                                  \
+    {                                                                                                     \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);          \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);          \
+        v += __hiloint2double(hi, lo);                                                                    \
+    }
+    SF_DPP_ADD(0xB1)  // quad_perm [1,0,3,2]
+    SF_DPP_ADD(0x4E)  // quad_perm [2,3,0,1]
+    SF_DPP_ADD(0x141) // row_half_mirror
+    SF_DPP_ADD(0x140) // row_mirror
+#undef SF_DPP_ADD
+    return v;
+}
+
+__device__ inline int sf_row16_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return v;
+}
+
 // XCD-aware block remap.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks
 // share an XCD / an L2).  Consecutive queries are spatial neighbours (cell-sorted order), so giving each
 // XCD ONE contiguous eighth of the queries makes the cells a query needs hot in that XCD's own 4 MB L2
