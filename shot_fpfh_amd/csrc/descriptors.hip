@@ -142,31 +142,36 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
     const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
     if (q0 >= m) return;
     const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
+    // Every lane fetches the header of ITS query once (coalesced); in round r the row reads the header of
+    // query 16 w + r from lane 16 w + r with shuffles, so a round starts without a memory round trip.
+    const bool mine = lane < nq;
+    const int64_t qm = q0 + (mine ? lane : 0);
+    const int64_t smine = offset[qm];
+    const int kmine = mine ? cnt[qm] : 0;
+    const double pxm = qx[qm], pym = qy[qm], pzm = qz[qm];
     // phase A: weighted covariance, w = r - ||c|| (shot.py:27-35)
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
-    int kmine = 0;
     for (int r = 0; r < 16; ++r) {
-        const int t = 16 * rw + r;
-        const bool have = t < nq;
-        const int64_t q = q0 + (have ? t : 0);
-        const int64_t s = offset[q];
-        const int k = have ? cnt[q] : 0;
-        const double px = qx[q], py = qy[q], pz = qz[q];
+        const int src = 16 * rw + r;
+        const int64_t s = __shfl(smine, src);
+        const int k = __shfl(kmine, src);
+        const double px = __shfl(pxm, src), py = __shfl(pym, src), pz = __shfl(pzm, src);
         const int kmax = sf_rows_max(k);
         double ws = 0, a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
-        for (int base = 0; base < kmax; base += 64) { // four 16-neighbour steps per trip, loads issued together
-            int j[4];
+        for (int base = 0; base < kmax; base += 128) { // eight 16-neighbour steps per trip, loads issued together
+            int j[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 const int u = base + 16 * c + sl;
                 j[c] = u < k ? idx[s + u] : -1;
             }
-            double x[4], y[4], z[4];
+            double x[8], y[8], z[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) sf_load_xyz(rec, j[c] < 0 ? 0 : j[c], x[c], y[c], z[c]);
+            for (int c = 0; c < 8; ++c)
+                if (base + 16 * c < kmax) sf_load_xyz(rec, j[c] < 0 ? 0 : j[c], x[c], y[c], z[c]); // wave-uniform test
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (base + 16 * c < kmax) { // wave-uniform
+            for (int c = 0; c < 8; ++c) {
+                if (base + 16 * c < kmax) {
                     const double cx = x[c] - px, cy = y[c] - py, cz = z[c] - pz;
                     const double wv = radius - sf_sqrt_fast((cx * cx + cy * cy) + cz * cz);
                     const double w = j[c] < 0 ? 0.0 : wv;
@@ -177,14 +182,14 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
                 }
             }
         }
-        const double iw = sf_rcp_fast(sf_row16_sum(ws)); // empty list: 1/0 = inf, 0 * inf = NaN as in the reference
+        const double iw = sf_rcp_fast(sf_row16_sum(ws)); // empty list: 0 * inf = NaN, overridden by the k == 0 rule
         a11 = sf_row16_sum(a11) * iw;
         a21 = sf_row16_sum(a21) * iw;
         a31 = sf_row16_sum(a31) * iw;
         a22 = sf_row16_sum(a22) * iw;
         a32 = sf_row16_sum(a32) * iw;
         a33 = sf_row16_sum(a33) * iw;
-        if (sl == r) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; kmine = k; }
+        if (sl == r) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; }
     }
     // phase B: one eigen-decomposition per lane (shot.py:36)
     double x0 = 0, x1 = 0, x2 = 0, z0 = 0, z1 = 0, z2 = 0;
@@ -206,14 +211,11 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
     // phase C: sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
     bool flipx = false, flipz = false;
     for (int r = 0; r < 16; ++r) {
-        const int t = 16 * rw + r;
-        const bool have = t < nq;
-        const int64_t q = q0 + (have ? t : 0);
-        const int64_t s = offset[q];
-        const int k = have ? cnt[q] : 0;
-        const double px = qx[q], py = qy[q], pz = qz[q];
+        const int src = 16 * rw + r; // lane holding this row's header and axes
+        const int64_t s = __shfl(smine, src);
+        const int k = __shfl(kmine, src);
+        const double px = __shfl(pxm, src), py = __shfl(pym, src), pz = __shfl(pzm, src);
         const int kmax = sf_rows_max(k);
-        const int src = 16 * rw + r; // lane holding this row's axes
         const double bx0 = lane_bcast(x0, src), bx1 = lane_bcast(x1, src), bx2 = lane_bcast(x2, src);
         const double bz0 = lane_bcast(z0, src), bz1 = lane_bcast(z1, src), bz2 = lane_bcast(z2, src);
         int xneg = 0, zneg = 0;
