@@ -124,6 +124,14 @@ void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nbrs);
  * sign is the one LAPACK dsyevd returns for the lower-triangle covariance (emulated on device). */
 int sf_normals(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *pre, double *out /* m x 3 */,
                int flags);
+/* Local PCA of every query's neighbourhood, same kernel (K3) with the full decomposition as output: replaces
+ * the per-point loops of compute_sphericity / compute_pca_based_basic_features (pca_based_descriptors.py:60-73,
+ * 150-187, via pca() :15-26) and compute_local_pca_with_moments (:75-146).  eigenvalues: ascending, m x 3.
+ * eigenvectors: m x 3 x 3 row-major exactly as numpy.linalg.eigh returns them (column k = eigenvector k, LAPACK
+ * dsyevd signs).  moments (nullable, m x 8): |mean(c V^T)| (3), mean((c V^T)^2) (3), mean(c_z), mean(c_z^2) with c
+ * the neighbours centred on their barycentre (:121-144).  The feature formulas on top stay on the host. */
+int sf_pca(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, double *eigenvalues /* m x 3 */,
+           double *eigenvectors /* m x 9 */, double *moments /* nullable, m x 8 */, int flags);
 
 /* ---- SHOT --------------------------------------------------------------------------------
  * sf_shot_lrf (K4): get_local_rf (shot.py:16-48) for every query of `nbrs`; radius = the search

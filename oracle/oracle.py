@@ -49,6 +49,8 @@ def lib() -> C.CDLL:
         L.orc_normals_radius.argtypes = [_f64p, C.c_int64, _f64p, C.c_int64, C.c_double, C.c_void_p, _f64p]
         L.orc_normals_from_lists.restype = None
         L.orc_normals_from_lists.argtypes = [_f64p, _i64p, _i32p, C.c_int64, C.c_void_p, _f64p]
+        L.orc_pca_from_lists.restype = None
+        L.orc_pca_from_lists.argtypes = [_f64p, _i64p, _i32p, C.c_int64, _f64p, _f64p, C.c_void_p]
         L.orc_shot_lrf.restype = C.c_int
         L.orc_shot_lrf.argtypes = [_f64p, C.c_int64, _f64p, C.c_int64, C.c_double, _f64p]
         L.orc_shot.restype = C.c_int
@@ -116,6 +118,51 @@ def compute_normals(query_points, cloud_points, *, k=None, radius=None, pre_comp
     else:
         lib().orc_normals_radius(p, p.shape[0], q, q.shape[0], radius, _ptr(pre), out)
     return out
+
+
+def local_pca(query_points, cloud_points, *, radius=None, k=None, moments=False):
+    """pca() / compute_local_pca_with_moments (pca_based_descriptors.py:15-26, 75-146): eigenvalues (m,3),
+    eigenvectors (m,3,3) as np.linalg.eigh returns them, [moments (m,8)], neighbourhood sizes (m,)."""
+    q, p = _f64(query_points), _f64(cloud_points)
+    if k is not None:
+        off, idx = knn_lists(p, q, k)
+    else:
+        off, idx = radius_search(p, q, radius)
+    m = q.shape[0]
+    w, v = np.zeros((m, 3)), np.zeros((m, 9))
+    mo = np.zeros((m, 8)) if moments else None
+    lib().orc_pca_from_lists(p, np.ascontiguousarray(off, np.int64), np.ascontiguousarray(idx, np.int32), m, w, v, _ptr(mo))
+    sizes = np.diff(off)
+    return (w, v.reshape(m, 3, 3), mo, sizes) if moments else (w, v.reshape(m, 3, 3), sizes)
+
+
+def compute_pca_based_features(query_points, cloud_points, radius):
+    """The (N, 21) feature matrix of pca_based_descriptors.py:190-244 on top of local_pca."""
+    ev, vec, moments, sizes = local_pca(query_points, cloud_points, radius=radius, moments=True)
+    lbd3, lbd2, lbd1 = ev[:, 0], ev[:, 1], ev[:, 2]
+    lbd1 += 1e-6  # in place, before the sums below (as in the reference)
+    normals, principal_axis = vec[:, :, 0], vec[:, :, 2]
+    eigensum = ev.sum(axis=-1)
+    cols = [
+        eigensum, (ev**2).sum(axis=-1), np.cbrt(ev.prod(axis=-1)), (-ev * np.log(ev + 1e-6)).sum(axis=-1),
+        1 - lbd2 / lbd1, (lbd2 - lbd3) / lbd1, lbd3 / lbd1, lbd3 / eigensum,
+        2 * np.arcsin(np.abs(normals[:, 2])) / np.pi, 2 * np.arcsin(np.abs(principal_axis[:, 2])) / np.pi,
+        2 * np.arcsin(np.abs(normals[:, 0])) / np.pi, 2 * np.arcsin(np.abs(normals[:, 1])) / np.pi,
+    ]
+    return np.hstack([c[:, None] for c in cols] + [moments, sizes[:, None].astype(np.float64)])
+
+
+def compute_pca_based_basic_features(query_points, cloud_points, radius):
+    """(verticality, linearity, planarity, sphericity), pca_based_descriptors.py:150-187."""
+    ev, vec, _ = local_pca(query_points, cloud_points, radius=radius)
+    lbd3, lbd2, lbd1 = ev[:, 0], ev[:, 1], ev[:, 2] + 1e-6
+    return 2 * np.arcsin(np.abs(vec[:, 2, 0])) / np.pi, 1 - lbd2 / lbd1, (lbd2 - lbd3) / lbd1, lbd3 / lbd1
+
+
+def compute_sphericity(query_points, cloud_points, radius):
+    """pca_based_descriptors.py:60-73."""
+    ev = local_pca(query_points, cloud_points, radius=radius)[0]
+    return ev[:, 0] / (ev[:, 2] + 1e-6)
 
 
 def knn_lists(cloud, queries, k):

@@ -578,6 +578,49 @@ void orc_normals_from_lists(const double *xyz, const int64_t *offsets, const int
     }
 }
 
+/* pca() for every list with the whole decomposition kept, plus the moments of
+ * compute_local_pca_with_moments (pca_based_descriptors.py:15-26, 115-144).  evals m x 3 ascending,
+ * evecs m x 9 row-major as numpy.linalg.eigh returns them, moments (nullable) m x 8. */
+void orc_pca_from_lists(const double *xyz, const int64_t *offsets, const int32_t *idx, int64_t m,
+                        double *evals, double *evecs, double *moments)
+{
+    for (int64_t i = 0; i < m; ++i) {
+        int64_t s = offsets[i], k = offsets[i + 1] - s;
+        double mean[3] = {0, 0, 0}, cov[9] = {0};
+        for (int64_t t = 0; t < k; ++t)
+            for (int a = 0; a < 3; ++a) mean[a] += xyz[3 * (int64_t)idx[s + t] + a];
+        for (int a = 0; a < 3; ++a) mean[a] /= (double)k;
+        for (int64_t t = 0; t < k; ++t) {
+            double c[3];
+            for (int a = 0; a < 3; ++a) c[a] = xyz[3 * (int64_t)idx[s + t] + a] - mean[a];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b <= a; ++b) cov[3 * a + b] += c[a] * c[b];
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b <= a; ++b) cov[3 * a + b] /= (double)k;
+        double *w = evals + 3 * i, *v = evecs + 9 * i;
+        orc_eigh3(cov, w, v);
+        if (!moments) continue;
+        /* moment = centered @ eigenvectors.T (124): component a uses ROW a of v; vert_moment = centered[:, 2] */
+        double sm[3] = {0, 0, 0}, sq[3] = {0, 0, 0}, vz = 0, vz2 = 0;
+        for (int64_t t = 0; t < k; ++t) {
+            double c[3];
+            for (int a = 0; a < 3; ++a) c[a] = xyz[3 * (int64_t)idx[s + t] + a] - mean[a];
+            for (int a = 0; a < 3; ++a) {
+                double u = (c[0] * v[3 * a] + c[1] * v[3 * a + 1]) + c[2] * v[3 * a + 2];
+                sm[a] += u;
+                sq[a] += u * u;
+            }
+            vz += c[2];
+            vz2 += c[2] * c[2];
+        }
+        double *o = moments + 8 * i;
+        for (int a = 0; a < 3; ++a) { o[a] = fabs(sm[a] / (double)k); o[3 + a] = sq[a] / (double)k; }
+        o[6] = vz / (double)k;
+        o[7] = vz2 / (double)k;
+    }
+}
+
 int orc_normals_radius(const double *xyz, int64_t n, const double *q, int64_t m, double radius,
                        const double *pre, double *out)
 {

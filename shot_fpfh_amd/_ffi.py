@@ -57,6 +57,7 @@ SIGNATURES = {
     "sf_nbrs_export": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sf_nbrs_free": (None, [_vp, _vp]),
     "sf_normals": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
+    "sf_pca": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "sf_shot_lrf": (_int, [_vp, _vp, _vp, _vp, _int]),
     "sf_shot": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _int]),
     "sf_shot_single_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),

@@ -11,7 +11,7 @@ import numpy as np
 import numpy.typing as npt
 from scipy.spatial.transform import Rotation
 
-__all__ = ["RigidTransform", "solver_point_to_point", "grid_subsampling"]
+__all__ = ["RigidTransform", "solver_point_to_point", "solver_point_to_plane", "grid_subsampling", "voxel_closest_to_barycentre"]
 
 
 class RigidTransform:
@@ -69,9 +69,20 @@ def solver_point_to_point(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.flo
     return RigidTransform(rot, ref_center - rot.dot(scan_center))
 
 
-def grid_subsampling(points: npt.NDArray[np.float64], voxel_size: float) -> npt.NDArray[np.int64]:
-    """Voxel subsampling: per occupied voxel keep the point closest to the voxel's barycentre; voxels
-    come out in np.unique's lexicographic key order (shot_fpfh/core/subsampling.py:5-39).
+def solver_point_to_plane(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.float64],
+                          normals_ref: npt.NDArray[np.float64]) -> RigidTransform:
+    """Linearised point-to-plane fit (small-angle Euler xyz + translation), shot_fpfh/core/solvers.py:33-48:
+    rows g_i = [scan_i x n_i, n_i], h_i = (ref_i - scan_i) . n_i, solve (G^T G) s = G^T h."""
+    g = np.hstack((np.cross(scan, normals_ref), normals_ref))
+    h = np.einsum("ij, ij->i", ref - scan, normals_ref)
+    solution = np.linalg.solve(g.T @ g, g.T @ h)
+    return RigidTransform(Rotation.from_euler("xyz", solution[:3]).as_matrix(), solution[3:6])
+
+
+def voxel_closest_to_barycentre(points: npt.NDArray[np.float64], voxel_size: float):
+    """Per occupied voxel (np.unique's lexicographic key order): the index of the point closest to the voxel's
+    barycentre, and the number of points in the voxel (shot_fpfh/core/subsampling.py:12-37 and the identical
+    loop of keypoint_selection.py:80-101).
 
     Segment-vectorised (no per-voxel Python loop).  The within-voxel visiting order is the one
     np.argsort(inverse) yields, as in the reference, because the first minimum wins on distance ties
@@ -90,4 +101,10 @@ def grid_subsampling(points: npt.NDArray[np.float64], voxel_size: float) -> npt.
     seg_min = np.minimum.reduceat(dist, starts)
     hit = np.flatnonzero(dist == seg_min[seg])
     first = hit[np.unique(seg[hit], return_index=True)[1]]
-    return order[first]
+    return order[first], counts
+
+
+def grid_subsampling(points: npt.NDArray[np.float64], voxel_size: float) -> npt.NDArray[np.int64]:
+    """Voxel subsampling: per occupied voxel keep the point closest to the voxel's barycentre; voxels
+    come out in np.unique's lexicographic key order (shot_fpfh/core/subsampling.py:5-39)."""
+    return voxel_closest_to_barycentre(points, voxel_size)[0]

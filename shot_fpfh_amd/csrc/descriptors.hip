@@ -15,79 +15,167 @@
 namespace {
 
 // --------------------------------------------------------------------------------------------------
-// K3 / K4 share one structure: a wave owns 64 consecutive queries.
-//   phase A  for each of its queries in turn, all 64 lanes sweep that query's neighbour list and
-//            wave-reduce the moment sums; lane t keeps the sums of query t (no LDS, no scratch);
-//   phase B  every lane runs the LAPACK-compatible 3x3 eigensolver on ITS query (one solve per lane
-//            instead of one redundant solve per wave);
-//   phase C  (K4 only) the sign votes: lane t's axes are broadcast with v_readlane, the wave sweeps
-//            query t's list again and ballots the projections.
+// K3 / K4 share one structure: a wave owns 64 consecutive queries and works on FOUR of them at a time, one
+// per 16-lane DPP row.  In round r, row w sweeps the list of query 16 w + r, 16 neighbours per step; the
+// moment sums are reduced inside the row with four register-to-register DPP steps and lane 16 w + r --
+// which sits in that same row -- keeps them (no LDS, no scratch).  Then every lane runs the
+// LAPACK-compatible 3x3 eigensolver on ITS query: one solve per lane instead of one redundant solve per wave.
+// Lists of ~110 points fill 16-lane steps as well as they fill 64-lane ones (7/8 against 113/128).
 // --------------------------------------------------------------------------------------------------
 __device__ inline double lane_bcast(double v, int src) { return __shfl(v, src); }
 
-// K3: normals.  cov = centered^T centered / k about the barycentre (pca_based_descriptors.py:21-23),
-// eigh, eigenvector of the smallest eigenvalue (:51), optional re-orientation (:53-57).
-__global__ __launch_bounds__(256) void k_normals(const double *__restrict__ rec, const double *__restrict__ qx,
-                                                 const double *__restrict__ qy, const double *__restrict__ qz,
-                                                 const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
-    const int32_t *__restrict__ idx,
-                                                 const int32_t *__restrict__ qrow, int64_t m,
-                                                 const double *__restrict__ pre, double *__restrict__ out)
+// longest of the four rows' lists (wave-uniform loop bound)
+__device__ inline int sf_rows_max(int k)
 {
-    const int lane = threadIdx.x & 63;
+    const int a = __builtin_amdgcn_readlane(k, 0), b = __builtin_amdgcn_readlane(k, 16);
+    const int c = __builtin_amdgcn_readlane(k, 32), d = __builtin_amdgcn_readlane(k, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// One row-sweep over a list: f(x, y, z, on) for every neighbour, 4 x 16 neighbours per trip with the four index
+// loads, then the four coordinate gathers, issued together.  `on` is false on padding lanes (point 0 is loaded).
+template <typename F>
+__device__ inline void sf_row_sweep(const double *__restrict__ rec, const int32_t *__restrict__ idx, int64_t s, int k,
+                                    int kmax, int sl, F f)
+{
+    for (int base = 0; base < kmax; base += 64) {
+        int j[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int u = base + 16 * c + sl;
+            j[c] = u < k ? idx[s + u] : -1;
+        }
+        double x[4], y[4], z[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sf_load_xyz(rec, j[c] < 0 ? 0 : j[c], x[c], y[c], z[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (base + 16 * c < kmax) f(x[c], y[c], z[c], j[c] >= 0); // wave-uniform test
+    }
+}
+
+// K3: local PCA of every query's neighbourhood.  cov = centered^T centered / k about the barycentre
+// (pca_based_descriptors.py:15-26), numpy.linalg.eigh.
+//   MODE 0  normals: eigenvector of the smallest eigenvalue (:51), optional re-orientation (:53-57)
+//   MODE 1  eigenvalues (ascending) + the eigenvector matrix as eigh returns it (column k = eigenvector k)
+//   MODE 2  MODE 1 + the eight moments of compute_local_pca_with_moments (:121-144):
+//           |mean(c V^T)| (3), mean((c V^T)^2) (3), mean(c_z), mean(c_z^2) with c the centred neighbours
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pca(const double *__restrict__ rec, const double *__restrict__ qx,
+                                             const double *__restrict__ qy, const double *__restrict__ qz,
+                                             const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+                                             const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
+                                             int64_t m, const double *__restrict__ pre, double *__restrict__ out_n,
+                                             double *__restrict__ out_w, double *__restrict__ out_v,
+                                             double *__restrict__ out_m)
+{
+    const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
     const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
     if (q0 >= m) return;
     const int nq = (int)(m - q0 < 64 ? m - q0 : 64);
+    // every lane fetches the header of ITS query once; rows read it from lane 16 w + r with shuffles
+    const bool mine = lane < nq;
+    const int64_t qm = q0 + (mine ? lane : 0);
+    const int64_t smine = offset[qm];
+    const int kmine = mine ? cnt[qm] : 0;
+    const double pxm = qx[qm], pym = qy[qm], pzm = qz[qm];
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
-    for (int t = 0; t < nq; ++t) {
-        const int64_t q = q0 + t;
-        const int64_t s = offset[q];
-        const int k = cnt[q];
-        const double px = qx[q], py = qy[q], pz = qz[q];
+    double bx = 0, by = 0, bz = 0; // barycentre relative to the query (kept for the moments)
+    for (int r = 0; r < 16; ++r) {
+        const int src = 16 * rw + r;
+        const int64_t s = __shfl(smine, src);
+        const int k = __shfl(kmine, src);
+        const double px = __shfl(pxm, src), py = __shfl(pym, src), pz = __shfl(pzm, src);
+        const int kmax = sf_rows_max(k);
         // pass 1: barycentre, accumulated relative to the query to keep the sums small
         double sx = 0.0, sy = 0.0, sz = 0.0;
-        for (int u = lane; u < k; u += 64) {
-            double x, y, z;
-            sf_load_xyz(rec, idx[s + u], x, y, z);
-            sx += x - px;
-            sy += y - py;
-            sz += z - pz;
-        }
+        sf_row_sweep(rec, idx, s, k, kmax, sl, [&](double x, double y, double z, bool on) {
+            sx += on ? x - px : 0.0;
+            sy += on ? y - py : 0.0;
+            sz += on ? z - pz : 0.0;
+        });
         const double kk = (double)k;
-        const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
+        const double mx = sf_row16_sum(sx) / kk, my = sf_row16_sum(sy) / kk, mz = sf_row16_sum(sz) / kk;
         // pass 2: lower triangle of the centred second moments
         double a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
-        for (int u = lane; u < k; u += 64) {
-            double x, y, z;
-            sf_load_xyz(rec, idx[s + u], x, y, z);
-            const double ax = (x - px) - mx, ay = (y - py) - my, az = (z - pz) - mz;
+        sf_row_sweep(rec, idx, s, k, kmax, sl, [&](double x, double y, double z, bool on) {
+            const double ax = on ? (x - px) - mx : 0.0, ay = on ? (y - py) - my : 0.0, az = on ? (z - pz) - mz : 0.0;
             a11 += ax * ax;
             a21 += ay * ax;
             a31 += az * ax;
             a22 += ay * ay;
             a32 += az * ay;
             a33 += az * az;
+        });
+        a11 = sf_row16_sum(a11) / kk;
+        a21 = sf_row16_sum(a21) / kk;
+        a31 = sf_row16_sum(a31) / kk;
+        a22 = sf_row16_sum(a22) / kk;
+        a32 = sf_row16_sum(a32) / kk;
+        a33 = sf_row16_sum(a33) / kk;
+        if (sl == r) {
+            c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33;
+            bx = mx; by = my; bz = mz;
         }
-        a11 = sf_wave_sum(a11) / kk;
-        a21 = sf_wave_sum(a21) / kk;
-        a31 = sf_wave_sum(a31) / kk;
-        a22 = sf_wave_sum(a22) / kk;
-        a32 = sf_wave_sum(a32) / kk;
-        a33 = sf_wave_sum(a33) / kk;
-        if (lane == t) { c11 = a11; c21 = a21; c31 = a31; c22 = a22; c32 = a32; c33 = a33; }
     }
-    if (lane < nq) {
-        const int64_t q = q0 + lane;
-        const int64_t row = qrow ? qrow[q] : q;
-        const sf_eig::eig3 e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33);
-        double nx = e.v11, ny = e.v21, nz = e.v31;
-        if (pre) {
-            const double dot = (nx * pre[3 * row] + ny * pre[3 * row + 1]) + nz * pre[3 * row + 2];
-            if (dot < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+    sf_eig::eig3 e;
+    e.w1 = e.w2 = e.w3 = 0.0;
+    e.v11 = e.v21 = e.v31 = e.v12 = e.v22 = e.v32 = e.v13 = e.v23 = e.v33 = 0.0;
+    if (mine) e = sf_eig::eigh3_lower(c11, c21, c31, c22, c32, c33);
+    const int64_t row = mine ? (qrow ? (int64_t)qrow[qm] : qm) : 0;
+    if (MODE == 0) {
+        if (mine) {
+            double nx = e.v11, ny = e.v21, nz = e.v31;
+            if (pre) {
+                const double dot = (nx * pre[3 * row] + ny * pre[3 * row + 1]) + nz * pre[3 * row + 2];
+                if (dot < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+            }
+            out_n[3 * row + 0] = nx;
+            out_n[3 * row + 1] = ny;
+            out_n[3 * row + 2] = nz;
         }
-        out[3 * row + 0] = nx;
-        out[3 * row + 1] = ny;
-        out[3 * row + 2] = nz;
+        return;
+    }
+    if (mine) {
+        out_w[3 * row + 0] = e.w1; out_w[3 * row + 1] = e.w2; out_w[3 * row + 2] = e.w3;
+        double *v = out_v + 9 * row; // row-major: v[3 i + k] = component i of eigenvector k
+        v[0] = e.v11; v[1] = e.v12; v[2] = e.v13;
+        v[3] = e.v21; v[4] = e.v22; v[5] = e.v23;
+        v[6] = e.v31; v[7] = e.v32; v[8] = e.v33;
+    }
+    if (MODE == 2) {
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int src = 16 * rw + r;
+            const int64_t s = __shfl(smine, src);
+            const int k = __shfl(kmine, src);
+            const double px = __shfl(pxm, src), py = __shfl(pym, src), pz = __shfl(pzm, src);
+            const double mx = lane_bcast(bx, src), my = lane_bcast(by, src), mz = lane_bcast(bz, src);
+            // moment = centred @ eigenvectors.T : component i uses ROW i of the eigenvector matrix (:124)
+            const double r11 = lane_bcast(e.v11, src), r12 = lane_bcast(e.v12, src), r13 = lane_bcast(e.v13, src);
+            const double r21 = lane_bcast(e.v21, src), r22 = lane_bcast(e.v22, src), r23 = lane_bcast(e.v23, src);
+            const double r31 = lane_bcast(e.v31, src), r32 = lane_bcast(e.v32, src), r33 = lane_bcast(e.v33, src);
+            const int kmax = sf_rows_max(k);
+            double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0;
+            sf_row_sweep(rec, idx, s, k, kmax, sl, [&](double x, double y, double z, bool on) {
+                const double ax = on ? (x - px) - mx : 0.0, ay = on ? (y - py) - my : 0.0, az = on ? (z - pz) - mz : 0.0;
+                const double u0 = (ax * r11 + ay * r12) + az * r13;
+                const double u1 = (ax * r21 + ay * r22) + az * r23;
+                const double u2 = (ax * r31 + ay * r32) + az * r33;
+                t0 += u0; t1 += u1; t2 += u2;
+                t3 += u0 * u0; t4 += u1 * u1; t5 += u2 * u2;
+                t6 += az; t7 += az * az;
+            });
+            const double kk = (double)k;
+            t0 = fabs(sf_row16_sum(t0) / kk); t1 = fabs(sf_row16_sum(t1) / kk); t2 = fabs(sf_row16_sum(t2) / kk);
+            t3 = sf_row16_sum(t3) / kk; t4 = sf_row16_sum(t4) / kk; t5 = sf_row16_sum(t5) / kk;
+            t6 = sf_row16_sum(t6) / kk; t7 = sf_row16_sum(t7) / kk;
+            if (sl == r) { m0 = t0; m1 = t1; m2 = t2; m3 = t3; m4 = t4; m5 = t5; m6 = t6; m7 = t7; }
+        }
+        if (mine) {
+            double *o = out_m + 8 * row;
+            o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3; o[4] = m4; o[5] = m5; o[6] = m6; o[7] = m7;
+        }
     }
 }
 
@@ -119,14 +207,6 @@ __device__ inline double sf_rcp_fast(double d) // 1/d for normal d, ~1 ulp
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-d, r, 1.0);
     return __builtin_fma(r, e, r);
-}
-
-// longest of the four rows' lists (wave-uniform loop bound)
-__device__ inline int sf_rows_max(int k)
-{
-    const int a = __builtin_amdgcn_readlane(k, 0), b = __builtin_amdgcn_readlane(k, 16);
-    const int c = __builtin_amdgcn_readlane(k, 32), d = __builtin_amdgcn_readlane(k, 48);
-    return max(max(a, b), max(c, d));
 }
 
 __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec, const double *__restrict__ qx,
@@ -898,11 +978,38 @@ extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *p
     SF_CHECK(stage_in(ctx, pre, (size_t)m * 3, flags, &dpre, &opre));
     SF_CHECK(stage_out(ctx, out, (size_t)m * 3, flags, &dout, &oout));
     if (m) {
-        SF_LAUNCH(ctx, "k3_normals", k_normals, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx,
-                  nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, dpre, dout);
+        SF_LAUNCH(ctx, "k3_normals", k_pca<0>, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx,
+                  nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, dpre, dout, (double *)nullptr,
+                  (double *)nullptr, (double *)nullptr);
     }
     SF_CHECK(finish_out(ctx, out, (size_t)m * 3, dout, oout));
     if (opre) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(opre)); }
+    return SF_OK;
+}
+
+extern "C" int sf_pca(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *eigenvalues, double *eigenvectors, double *moments,
+                      int flags)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_pca"));
+    if (!eigenvalues || !eigenvectors) { sf_set_error("sf_pca: null output"); return SF_ERR_ARG; }
+    const int64_t m = nb->m;
+    double *dw, *ow, *dv, *ov, *dm = nullptr, *om = nullptr;
+    SF_CHECK(stage_out(ctx, eigenvalues, (size_t)m * 3, flags, &dw, &ow));
+    SF_CHECK(stage_out(ctx, eigenvectors, (size_t)m * 9, flags, &dv, &ov));
+    if (moments) SF_CHECK(stage_out(ctx, moments, (size_t)m * 8, flags, &dm, &om));
+    if (m) {
+        const dim3 grid(sf_xcd_grid(sf_div_up(m, 256))), block(256);
+        if (moments) {
+            SF_LAUNCH(ctx, "k3_pca_moments", k_pca<2>, grid, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count,
+                      nb->idx, nb->qrow, m, (const double *)nullptr, (double *)nullptr, dw, dv, dm);
+        } else {
+            SF_LAUNCH(ctx, "k3_pca", k_pca<1>, grid, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count,
+                      nb->idx, nb->qrow, m, (const double *)nullptr, (double *)nullptr, dw, dv, (double *)nullptr);
+        }
+    }
+    SF_CHECK(finish_out(ctx, eigenvalues, (size_t)m * 3, dw, ow));
+    SF_CHECK(finish_out(ctx, eigenvectors, (size_t)m * 9, dv, ov));
+    if (moments) SF_CHECK(finish_out(ctx, moments, (size_t)m * 8, dm, om));
     return SF_OK;
 }
 

@@ -368,6 +368,12 @@ class Neighbors:
             return off, idx[: self.total], dist[: self.total]
         return off, idx[: self.total]
 
+    def counts(self) -> np.ndarray:
+        """Neighbourhood size of every query (len of each KDTree.query_radius list), without the lists."""
+        off = np.zeros(self.m + 1, dtype=np.int64)
+        _ffi.check(self.engine.lib.sf_nbrs_export(self.engine.h, self.cloud.h, self.h, _ptr(off), None, None), "sf_nbrs_export")
+        return np.diff(off)
+
     # ---- descriptors on these lists ---------------------------------------------------------------
     def normals(self, pre_computed_normals=None) -> np.ndarray:
         pre = None if pre_computed_normals is None else _f64(pre_computed_normals, 3)
@@ -376,6 +382,14 @@ class Neighbors:
         out = np.zeros((self.m, 3))
         _ffi.check(self.engine.lib.sf_normals(self.engine.h, self.cloud.h, self.h, _ptr(pre), _ptr(out), SF_HOST), "sf_normals")
         return out
+
+    def pca(self, moments: bool = False):
+        """Local PCA of every neighbourhood: (eigenvalues (m,3) ascending, eigenvectors (m,3,3) as np.linalg.eigh
+        returns them[, moments (m,8)]) -- pca() / compute_local_pca_with_moments of the reference."""
+        w, v = np.zeros((self.m, 3)), np.zeros((self.m, 3, 3))
+        mo = np.zeros((self.m, 8)) if moments else None
+        _ffi.check(self.engine.lib.sf_pca(self.engine.h, self.cloud.h, self.h, _ptr(w), _ptr(v), _ptr(mo), SF_HOST), "sf_pca")
+        return (w, v, mo) if moments else (w, v)
 
     def shot_lrf(self, out: Optional[DeviceArray] = None):
         if out is not None:

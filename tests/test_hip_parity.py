@@ -454,3 +454,56 @@ def test_two_stream_overlap_gives_identical_results(eng):
         job.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+# ---- keypoint selection, PCA features (kernels K2 + K3) ---------------------------
+def test_keypoint_selection_search_branches_match_reference_golden(eng):
+    import shot_fpfh_amd.keypoint_selection as ks
+
+    g = load_golden("keypoints_6k.npz")
+    p = g["cloud"]
+    assert np.array_equal(ks.select_keypoints_iteratively(p, float(g["radius"])), g["iterative"])
+    got = ks.select_keypoints_with_density_threshold(p, float(g["voxel"]), 25, float(g["density_radius"]))
+    assert np.array_equal(got, g["density_radius_sel"])
+    assert ks.select_keypoints_iteratively(np.zeros((0, 3)), 0.1).size == 0
+
+
+def test_local_pca_and_features_match_reference_golden(eng):
+    from shot_fpfh_amd.descriptors import (
+        compute_local_pca_with_moments,
+        compute_pca_based_basic_features,
+        compute_pca_based_features,
+        compute_sphericity,
+    )
+
+    g = load_golden("pca_features_300.npz")
+    q, p, r = g["queries"], g["cloud"], float(g["radius"])
+    w, v, mo, sizes = compute_local_pca_with_moments(q, p, radius=r)
+    assert sizes == list(g["sizes"])
+    assert np.abs(w - g["eigenvalues"]).max() < 1e-12 and np.abs(mo - g["moments"]).max() < 1e-12
+    assert np.abs(v - g["eigenvectors"]).max() < 1e-9  # eigenvector signs as LAPACK returns them
+    wk, vk, mok, sk = compute_local_pca_with_moments(q, p, nghbrd_search="knn", k=int(g["k"]))
+    assert sk == list(g["sizes_knn"])
+    assert np.abs(wk - g["eigenvalues_knn"]).max() < 1e-12 and np.abs(mok - g["moments_knn"]).max() < 1e-12
+    assert np.abs(vk - g["eigenvectors_knn"]).max() < 1e-9
+    assert close(compute_pca_based_features(q, p, r), g["features"], 1e-9).all()
+    for got, key in zip(compute_pca_based_basic_features(q, p, r), ("verticality", "linearity", "planarity", "basic_sphericity")):
+        assert close(got, g[key], 1e-9).all()
+    assert close(compute_sphericity(q, p, r), g["sphericity"], 1e-9).all()
+
+
+def test_local_pca_vs_oracle_on_a_seeded_cloud(eng, O):
+    p, _, rng = synth_cloud(40000, 41)
+    q = np.vstack([p[rng.choice(40000, 1500, replace=False)], rng.random((37, 3))])  # 1537 queries: ragged last wave
+    cloud = eng.cloud(p)
+    nb = cloud.radius_search(q, 0.07)
+    w, v, mo = nb.pca(moments=True)
+    wo, vo, moo, sizes = O.local_pca(q, p, radius=0.07, moments=True)
+    ok = sizes >= 4  # rank-deficient neighbourhoods have LAPACK-arbitrary eigenvectors
+    assert np.array_equal(nb.counts(), sizes)
+    assert np.abs(w - wo)[ok].max() < 1e-12 and np.abs(mo - moo)[ok].max() < 1e-12
+    gap = np.minimum(wo[:, 1] - wo[:, 0], wo[:, 2] - wo[:, 1]) / wo[:, 2]
+    good = ok & (gap > 1e-3)
+    assert good.sum() > 1400 and np.abs(v - vo)[good].max() < 1e-9
+    w2, v2 = nb.pca()
+    assert np.array_equal(w2, w) and np.array_equal(v2, v)

@@ -96,3 +96,36 @@ def test_api_surface_matches_reference_signatures():
     p = inspect.signature(ransac_on_matches).parameters
     assert (p["n_draws"].default, p["draw_size"].default, p["distance_threshold"].default) == (10000, 4, 1)
     assert list(inspect.signature(basic_matching).parameters)[:2] == ["scan_descriptors", "ref_descriptors"]
+
+
+def test_keypoint_selection_host_branches_match_reference_golden():
+    """The branches of keypoint_selection.py that need no neighbour search (voxel subsampling, voxel-count
+    density threshold, the seeded random draw); the radius-search branches are GPU tests."""
+    import importlib
+
+    import shot_fpfh_amd.keypoint_selection as ks
+
+    g = load_golden("keypoints_6k.npz")
+    p = g["cloud"]
+    assert np.array_equal(ks.select_keypoints_subsampling(p, float(g["voxel"])), g["subsampling"])
+    assert np.array_equal(ks.select_keypoints_with_density_threshold(p, float(g["voxel"]), int(g["density_value"])), g["density_voxel"])
+    importlib.reload(ks)  # fresh module-level default_rng(1), as in a fresh process of the reference
+    assert np.array_equal(ks.select_keypoints_randomly(p, 50), g["random_points"])
+    idx = ks.select_query_indices_randomly(100, 10)
+    assert idx.shape == (10,) and np.unique(idx).size == 10 and idx.max() < 100
+
+
+def test_point_to_plane_solver_recovers_a_small_motion():
+    from scipy.spatial.transform import Rotation
+
+    from shot_fpfh_amd.core import solver_point_to_plane
+
+    rng = np.random.default_rng(3)
+    ref = rng.random((400, 3))
+    nrm = rng.standard_normal((400, 3))
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    rot = Rotation.from_euler("xyz", [2e-3, -1e-3, 1.5e-3]).as_matrix()
+    t = np.array([1e-3, -2e-3, 5e-4])
+    scan = (ref - t) @ rot  # ref = scan @ rot.T + t
+    tf = solver_point_to_plane(scan, ref, nrm)
+    assert np.abs(tf.rotation - rot).max() < 1e-5 and np.abs(tf.translation - t).max() < 1e-5

@@ -155,3 +155,23 @@ def test_matching_multiscale():
     assert 77 not in s  # empty at every scale -> stays at max_val -> dropped
     s, r = O.match_descriptors_multiscale(g["scan"], g["ref"], threshold_filter, threshold_multiplier=3)
     assert np.array_equal(s, g["thr_s"]) and np.array_equal(r, g["thr_r"])
+
+
+def test_local_pca_and_features_match_reference_golden():
+    """pca() / compute_local_pca_with_moments and the feature functions on top."""
+    g = load_golden("pca_features_300.npz")
+    r = float(g["radius"])
+    w, v, mo, sizes = O.local_pca(g["queries"], g["cloud"], radius=r, moments=True)
+    assert np.array_equal(sizes, g["sizes"])
+    assert np.abs(w - g["eigenvalues"]).max() < TOL
+    assert np.abs(v - g["eigenvectors"]).max() < 1e-9  # signs as LAPACK returns them
+    assert np.abs(mo - g["moments"]).max() < TOL
+    wk, vk, mok, sk = O.local_pca(g["queries"], g["cloud"], k=int(g["k"]), moments=True)
+    assert np.array_equal(sk, g["sizes_knn"])
+    assert np.abs(wk - g["eigenvalues_knn"]).max() < TOL and np.abs(mok - g["moments_knn"]).max() < TOL
+    assert np.abs(vk - g["eigenvectors_knn"]).max() < 1e-9
+    assert np.abs(O.compute_pca_based_features(g["queries"], g["cloud"], r) - g["features"]).max() < 1e-9
+    basic = O.compute_pca_based_basic_features(g["queries"], g["cloud"], r)
+    for got, key in zip(basic, ("verticality", "linearity", "planarity", "basic_sphericity")):
+        assert np.abs(got - g[key]).max() < 1e-9
+    assert np.abs(O.compute_sphericity(g["queries"], g["cloud"], r) - g["sphericity"]).max() < 1e-9
