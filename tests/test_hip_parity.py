@@ -507,3 +507,26 @@ def test_local_pca_vs_oracle_on_a_seeded_cloud(eng, O):
     assert good.sum() > 1400 and np.abs(v - vo)[good].max() < 1e-9
     w2, v2 = nb.pca()
     assert np.array_equal(w2, w) and np.array_equal(v2, v)
+
+
+def test_icp_matches_reference_golden(eng):
+    """ICP with the nearest-neighbour query on the device (k-NN kernel, k = 1)."""
+    import shot_fpfh_amd.icp as icp
+    from shot_fpfh_amd.core import RigidTransform
+
+    g = load_golden("icp_3500.npz")
+    tf, rms, ok = icp.icp_point_to_plane(g["scan"], g["ref"], g["ref_normals"], RigidTransform(), d_max=float(g["d_max"]),
+                                         voxel_size=float(g["voxel"]), max_iter=int(g["plane_max_iter"]),
+                                         rms_threshold=float(g["plane_rms_threshold"]), disable_progress_bar=True)
+    assert np.abs(tf.rotation - g["plane_rotation"]).max() < 1e-9 and np.abs(tf.translation - g["plane_translation"]).max() < 1e-9
+    assert abs(rms - float(g["plane_rms"])) < 1e-9 and bool(ok) == bool(g["plane_converged"])
+    err, moved = icp.compute_point_to_point_error(g["scan"], g["ref"], tf)
+    assert abs(err - float(g["p2p_error"])) < 1e-9 and np.abs(moved[:50] - g["moved_head"]).max() < 1e-9
+    np.random.seed(int(g["sampling_seed"]))
+    aligned, rms_s, ok_s = icp.icp_point_to_point_with_sampling(
+        g["scan"], g["ref"], d_max=float(g["d_max"]), max_iter=int(g["sampling_max_iter"]),
+        rms_threshold=float(g["sampling_rms_threshold"]), sampling_limit=int(g["sampling_limit"]), disable_progress_bar=True)
+    assert np.abs(aligned[:200] - g["sampling_aligned_head"]).max() < 1e-9 and abs(rms_s - float(g["sampling_rms"])) < 1e-9
+    tf2, rms2, ok2 = icp.icp_point_to_point(g["scan"], g["ref"], RigidTransform(), d_max=float(g["d_max"]),
+                                            voxel_size=float(g["voxel"]), max_iter=30, rms_threshold=1e-9)
+    assert np.abs(tf2.rotation - g["true_rotation"]).max() < 5e-3

@@ -129,3 +129,42 @@ def test_point_to_plane_solver_recovers_a_small_motion():
     scan = (ref - t) @ rot  # ref = scan @ rot.T + t
     tf = solver_point_to_plane(scan, ref, nrm)
     assert np.abs(tf.rotation - rot).max() < 1e-5 and np.abs(tf.translation - t).max() < 1e-5
+
+
+def test_icp_host_logic_matches_reference_golden_with_a_cpu_nearest_neighbour(monkeypatch):
+    """The ICP loops (shot_fpfh_amd/icp.py) with the device 1-NN swapped for sklearn's KDTree: everything
+    around the search must reproduce the reference's iterates.  The GPU suite runs the same check on the device."""
+    from sklearn.neighbors import KDTree
+
+    import shot_fpfh_amd.icp as icp
+    from shot_fpfh_amd.core import RigidTransform
+
+    class TreeNN:
+        def __init__(self, ref, engine=None):
+            self.tree = KDTree(ref)
+
+        def query(self, points):
+            d, i = self.tree.query(points)
+            return d[:, 0], i[:, 0]
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(icp, "_NearestNeighbour", TreeNN)
+    g = load_golden("icp_3500.npz")
+    tf, rms, ok = icp.icp_point_to_plane(g["scan"], g["ref"], g["ref_normals"], RigidTransform(), d_max=float(g["d_max"]),
+                                         voxel_size=float(g["voxel"]), max_iter=int(g["plane_max_iter"]),
+                                         rms_threshold=float(g["plane_rms_threshold"]), disable_progress_bar=True)
+    assert np.abs(tf.rotation - g["plane_rotation"]).max() < 1e-12 and np.abs(tf.translation - g["plane_translation"]).max() < 1e-12
+    assert abs(rms - float(g["plane_rms"])) < 1e-12 and bool(ok) == bool(g["plane_converged"])
+    err, moved = icp.compute_point_to_point_error(g["scan"], g["ref"], tf)
+    assert abs(err - float(g["p2p_error"])) < 1e-12 and np.abs(moved[:50] - g["moved_head"]).max() < 1e-12
+    np.random.seed(int(g["sampling_seed"]))
+    aligned, rms_s, ok_s = icp.icp_point_to_point_with_sampling(
+        g["scan"], g["ref"], d_max=float(g["d_max"]), max_iter=int(g["sampling_max_iter"]),
+        rms_threshold=float(g["sampling_rms_threshold"]), sampling_limit=int(g["sampling_limit"]), disable_progress_bar=True)
+    assert np.abs(aligned[:200] - g["sampling_aligned_head"]).max() < 1e-12 and abs(rms_s - float(g["sampling_rms"])) < 1e-12
+    # the variant the reference cannot run (module docstring): converges on the same data
+    tf2, rms2, _ = icp.icp_point_to_point(g["scan"], g["ref"], RigidTransform(), d_max=float(g["d_max"]),
+                                          voxel_size=float(g["voxel"]), max_iter=30, rms_threshold=1e-9)
+    assert np.abs(tf2.rotation - g["true_rotation"]).max() < 5e-3 and np.isscalar(float(rms2))
