@@ -530,3 +530,33 @@ def test_icp_matches_reference_golden(eng):
     tf2, rms2, ok2 = icp.icp_point_to_point(g["scan"], g["ref"], RigidTransform(), d_max=float(g["d_max"]),
                                             voxel_size=float(g["voxel"]), max_iter=30, rms_threshold=1e-9)
     assert np.abs(tf2.rotation - g["true_rotation"]).max() < 5e-3
+
+
+def test_register_point_clouds_script_end_to_end(eng, tmp_path):
+    """PLY in -> normals -> keypoints -> SHOT -> matching -> RANSAC -> ICP -> metrics, through
+    scripts/register_point_clouds.py, recovers the motion that generated the scan."""
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+    from shot_fpfh_amd.helpers import read_ply, write_ply
+
+    g = load_golden("icp_3500.npz")
+    scan_file, ref_file = str(tmp_path / "scan.ply"), str(tmp_path / "ref.ply")
+    write_ply(scan_file, [g["scan"]], ["x", "y", "z"])
+    write_ply(ref_file, [g["ref"], g["ref_normals"]], ["x", "y", "z", "nx", "ny", "nz"])
+    spec = importlib.util.spec_from_file_location("register_point_clouds", os.path.join(ROOT, "scripts", "register_point_clouds.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "aligned")
+    rc = mod.main([scan_file, ref_file, "--radius", "0.2", "--keypoints", "subsampling", "--keypoint-size", "0.05",
+                   "--min-neighborhood-size", "10", "--ransac-draws", "2000", "--ransac-threshold", "0.02",
+                   "--icp", "point_to_plane", "--icp-dmax", "0.05", "--icp-voxel", "0.04", "--icp-rms", "1e-9",
+                   "--metric-threshold", "0.01", "--write", out])
+    assert rc == 0
+    merged = read_ply(out + "_icp.ply")
+    n_scan = g["scan"].shape[0]
+    assert merged.shape[0] == n_scan + g["ref"].shape[0] and merged["is_scan"][:n_scan].all() and not merged["is_scan"][n_scan:].any()
+    moved = np.vstack((merged["x"], merged["y"], merged["z"])).T[:n_scan]
+    truth = g["scan"] @ g["true_rotation"].T + g["true_translation"]
+    assert np.abs(moved - truth).max() < 2e-3  # the script found the generating motion
