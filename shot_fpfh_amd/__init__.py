@@ -9,7 +9,9 @@ from . import _ffi
 from ._ffi import ShotFpfhError
 from .descriptors import ShotMultiprocessor, compute_fpfh_descriptor, compute_normals
 from .engine import Cloud, DeviceArray, Engine, Neighbors, Spfh, default_engine
+from .helpers import get_data, read_ply, write_ply
 from .matching import basic_matching, match_descriptors, ransac_on_matches
+from .pipeline import RegistrationPipeline
 
 __all__ = [
     "ShotFpfhError",
@@ -25,4 +27,8 @@ __all__ = [
     "basic_matching",
     "match_descriptors",
     "ransac_on_matches",
+    "RegistrationPipeline",
+    "read_ply",
+    "write_ply",
+    "get_data",
 ]
