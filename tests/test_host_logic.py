@@ -207,3 +207,33 @@ def test_ply_reader_and_writer_against_a_file_the_reference_wrote(tmp_path):
         f.write("ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
     with pytest.raises(ValueError):
         read_ply(str(tmp_path / "ascii.ply"))
+
+
+def test_every_mirrored_function_keeps_the_reference_signature():
+    """tests/golden/api_signatures.json (tools/gen_api_signatures.py) lists the reference's parameters, kinds and
+    defaults; the drop-in may only ADD optional keyword-only parameters (e.g. `engine=`)."""
+    import importlib
+    import inspect
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    recorded = json.load(open(os.path.join(GOLDEN, "api_signatures.json")))
+    rename = {"shot_fpfh.descriptors.pca_based_descriptors": "shot_fpfh_amd.descriptors",
+              "shot_fpfh.helpers.io_ply": "shot_fpfh_amd.helpers", "shot_fpfh.core": "shot_fpfh_amd.core"}
+    relocated = {"shot_fpfh.core:compute_point_to_point_error": "shot_fpfh_amd.icp"}
+    assert len(recorded) >= 40
+    for key, params in recorded.items():
+        module, name = key.split(":")
+        mine = relocated.get(key) or rename.get(module) or module.replace("shot_fpfh", "shot_fpfh_amd", 1)
+        obj = importlib.import_module(mine)
+        for part in name.split("."):
+            obj = getattr(obj, part)
+        got = [[n, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+               for n, p in inspect.signature(inspect.unwrap(obj)).parameters.items()]
+        names = {n for n, _, _ in params}
+        assert [g for g in got if g[0] in names] == params, f"{key}: {got} != {params}"
+        for n, kind, default in got:
+            if n not in names:
+                assert default is not None and kind == "KEYWORD_ONLY", f"{key}: extra parameter {n} must be an optional keyword"
