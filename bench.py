@@ -77,8 +77,8 @@ def cpu_baseline(points_per_gpu: int, radius: float) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--radius", type=float, default=0.03)
     ap.add_argument("--spfh-exchange", choices=["halo", "allgather"], default="halo")
