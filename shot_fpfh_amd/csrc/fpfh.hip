@@ -67,13 +67,17 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
 // NCH > 0: neighbourhoods of at most 64*NCH points -- every chunk's indices, then every chunk's
 // coordinates / normals, are requested before any is used, so a wave pays ONE index round trip and ONE
 // gather round trip instead of one per chunk.  NCH == 0: streaming loop for any size.
-template <typename CT, int NCH>
+// NB > 0: the bin count is a compile-time constant (5, the reference's default): the edge comparisons unroll to
+// exactly NB - 1 per feature and only the edges in use occupy SGPRs.  With the run-time count every slot of the
+// 4 x 9 edge table stays live and the compiler spills SGPRs into VGPR lanes (v_readlane per comparison).
+template <typename CT, int NCH, int NB>
 __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
-                                              int64_t m, int64_t self_begin, fpfh_edges ed, int nb, int nb3, int stride,
+                                              int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
                                               CT *__restrict__ counts, int32_t *__restrict__ kout)
 {
+    const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[4][SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = sf_uniform64(sf_xcd_block() * 4 + wave);
@@ -387,8 +391,13 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     int chunks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
-    SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH>), grid, block, c->rec, nb->offset,  \
-              nb->count, nb->idx, m, nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k)
+    if (nbn == 5) {                                                                                                    \
+        SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, 5>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,         \
+                  nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k);                              \
+    } else {                                                                                                           \
+        SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, 0>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,         \
+                  nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k);                              \
+    }
 #define SF_SPFH_DISPATCH(CT)                                     \
     switch (chunks) {                                            \
     case 1: { SF_SPFH_LAUNCH(CT, 1); } break;                    \
