@@ -49,15 +49,16 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
     const double aa = fabs(a);
     if (b > band * aa) {
         int bin = 0;
-        bool near = false;
+        double gap = 1.0e300; // smallest |a - tan(e_i) b| over the interior edges
 #pragma unroll
         for (int i = 1; i < SF_MAX_FPFH_BINS; ++i)
             if (i < nb) {
                 const double tb = ed.tan_t[i] * b;
                 bin += a >= tb ? 1 : 0;
-                near |= fabs(a - tb) <= band * (aa + fabs(tb));
+                gap = fmin(gap, fabs(a - tb));
             }
-        if (!near) return bin;
+        // one (conservative) test for all edges: |tan(e_i) b| <= |tan(e_1)| b, the outermost interior edge
+        if (gap > band * (aa + fabs(ed.tan_t[1]) * b)) return bin;
     } else if (b < -band * aa) {
         return -1; // |theta| > pi/2: outside the histogram range, dropped (fpfh.py:86)
     }
@@ -90,14 +91,22 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const double ux = rec[6 * i + 3], uy = rec[6 * i + 4], uz = rec[6 * i + 5];
     __builtin_amdgcn_wave_barrier();
+    const double p_inv_width = (double)nb / (ed.p[nb] - ed.p[0]); // np.linspace edges: equal widths up to rounding
     auto pair = [&](double cx, double cy, double cz, double njx, double njy, double njz) {
         const double d2 = (cx * cx + cy * cy) + cz * cz;
         if (d2 > 0.0) { // dist > 0 (fpfh.py:50-57)
-            const double dist = sqrt(d2);
             const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
             const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
             const double alpha = (vx * njx + vy * njy) + vz * njz;
-            const double phi = ((cx * ux + cy * uy) + cz * uz) / dist;
+            // phi = (c . u) / sqrt(d2) only picks a bin.  One Newton step on v_rsq_f64 gives it to ~1e-15; the
+            // reference's own expression (sqrt, then the division: 34 instructions) is evaluated only when that
+            // value lies within 1e-9 bin widths of an edge, so the bin is the reference's in every case.
+            const double num = (cx * ux + cy * uy) + cz * uz;
+            const double y0 = __builtin_amdgcn_rsq(d2);
+            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(d2 * y0), y0, 1.0), y0);
+            double phi = num * y1;
+            const double pos = (phi - ed.p[0]) * p_inv_width;
+            if (fabs(pos - rint(pos)) <= 1e-9) phi = num / sqrt(d2);
             const int bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, (njx * ux + njy * uy) + njz * uz);
             const int ba = hist_bin(ed.a, nb, alpha), bp = hist_bin(ed.p, nb, phi);
             if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt], 1u);
