@@ -86,15 +86,21 @@ def main() -> None:
     ap.add_argument("--only", choices=["both", "fpfh", "shot"], default="both")
     ap.add_argument("--overlap", action="store_true",
                     help="run the FPFH and SHOT chains on two HIP streams (faster; per-kernel times then overlap)")
+    ap.add_argument("--emulate-rank", type=int, default=None, metavar="R",
+                    help="single process, no rendezvous: run rank R's share of a --gpus N job on this GPU (what one "
+                         "GPU of an N-GPU node does per step; for sizing the sharded path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    emulated = args.emulate_rank is not None
+    if emulated:
+        world, rank, local_rank = args.gpus, args.emulate_rank, 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 and not emulated:
         import torch.distributed as dist  # control plane only: rendezvous, barrier, max-reduce of the timing
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -109,7 +115,7 @@ def main() -> None:
     if local_rank >= n_dev and rank == 0:
         print(f"# warning: {world} ranks share {n_dev} GPU(s) (functional test only, timings are not a scaling result)", file=sys.stderr)
     eng = s.Engine(local_rank % n_dev)
-    if world > 1 and args.spfh_exchange == "allgather":
+    if world > 1 and args.spfh_exchange == "allgather" and not emulated:
         ids = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.comm_init(ids[0], world, rank)
@@ -150,7 +156,7 @@ def main() -> None:
     ms_per_step = 1000.0 * elapsed / args.steps
     value = n_desc / (elapsed / args.steps)
 
-    if rank == 0:
+    if rank == 0 or emulated:
         rep = eng.profile_report()
         kern = {k: (v[0], v[1] / max(v[0], 1)) for k, v in rep.items() if v[0] > 0 and v[1] > 0}
         per_step_ms = {k: rep[k][1] / args.steps for k in kern}

@@ -84,6 +84,14 @@ int sf_d2d(sf_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* st
 sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const double *normals, int64_t n, int flags);
 int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *cloud, const double *normals, int flags);
 int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *cloud, double cell);
+/* Multi-GPU variant of K1: build only what the queries at cell-sorted positions [begin, end) -- a rank's block --
+ * can reach within `reach` grid cells (1 for SHOT / normals / SPFH of the block, 2 when the SPFH rows of the
+ * block's one-cell halo are recomputed locally for FPFH).  Whole z-layers of cells are kept; positions, perm and
+ * the cell table keep their GLOBAL numbering, so block / halo ranges and every result are exactly those of a
+ * whole-cloud build, but only ~1/N of the cloud is sorted and gathered.  [*pop_begin, *pop_end) (nullable) returns
+ * the populated position range; self-searches must stay inside it (anything else rebuilds the whole grid). */
+int sf_cloud_build_grid_block(sf_ctx *ctx, sf_cloud *cloud, double cell, int64_t begin, int64_t end, int reach,
+                              int64_t *pop_begin, int64_t *pop_end);
 int64_t sf_cloud_size(const sf_cloud *cloud);
 void sf_cloud_free(sf_ctx *ctx, sf_cloud *cloud);
 /* cell-sorted position -> original index (n entries, host) */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sf_cloud_upload": (_vp, [_vp, _vp, _vp, _i64, _int]),
     "sf_cloud_set_normals": (_int, [_vp, _vp, _vp, _int]),
     "sf_cloud_build_grid": (_int, [_vp, _vp, _f64]),
+    "sf_cloud_build_grid_block": (_int, [_vp, _vp, _f64, _i64, _i64, _int, _vp, _vp]),
     "sf_cloud_size": (_i64, [_vp]),
     "sf_cloud_free": (None, [_vp, _vp]),
     "sf_cloud_perm": (_int, [_vp, _vp, _vp]),

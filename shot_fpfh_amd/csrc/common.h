@@ -136,6 +136,9 @@ struct sf_cloud {
     // costs 16 cycles per wave instruction whatever the width, so 3 wide loads beat 6 narrow ones)
     double *rec = nullptr;
     bool normals_sorted = false;
+    // cell-sorted positions that are actually populated: [0, n) after sf_cloud_build_grid, the slab a block needs
+    // after sf_cloud_build_grid_block (positions keep their GLOBAL numbering either way)
+    int64_t pop_begin = 0, pop_end = 0;
 };
 
 struct sf_nbrs {

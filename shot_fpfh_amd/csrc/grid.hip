@@ -10,6 +10,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
@@ -66,12 +67,14 @@ __global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_de
 }
 
 // positions: SoA (for the candidate sweeps of K2) + slots 0..2 of the AoS records (for gathers) + inv_perm
-__global__ void k_gather_sorted(const double *__restrict__ xyz, const int32_t *__restrict__ perm, int64_t n,
+// (positions [base, base + n): the whole cloud, or the slab a block build populates)
+__global__ void k_gather_sorted(const double *__restrict__ xyz, const int32_t *__restrict__ perm, int64_t base, int64_t n,
                                 double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ zs,
                                 double *__restrict__ rec, int32_t *__restrict__ inv_perm)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    i += base;
     int64_t o = perm[i];
     const double x = xyz[3 * o + 0], y = xyz[3 * o + 1], z = xyz[3 * o + 2];
     xs[i] = x; ys[i] = y; zs[i] = z;
@@ -80,21 +83,23 @@ __global__ void k_gather_sorted(const double *__restrict__ xyz, const int32_t *_
 }
 
 // normals: slots 3..5 of the AoS records
-__global__ void k_gather_normals(const double *__restrict__ nrm, const int32_t *__restrict__ perm, int64_t n,
+__global__ void k_gather_normals(const double *__restrict__ nrm, const int32_t *__restrict__ perm, int64_t base, int64_t n,
                                  double *__restrict__ rec)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    i += base;
     int64_t o = perm[i];
     rec[6 * i + 3] = nrm[3 * o + 0];
     rec[6 * i + 4] = nrm[3 * o + 1];
     rec[6 * i + 5] = nrm[3 * o + 2];
 }
 
-__global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t n, int64_t ncell,
+__global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t base, int64_t n, int64_t ncell,
                              int32_t *__restrict__ cell_start)
 {
-    // cell_start[c] = first sorted position whose cell id >= c (lower bound); cell_start[ncell] = n
+    // cell_start[c] = first sorted position whose cell id >= c (lower bound over the n populated positions that
+    // start at `base`); cells before / after the populated slab come out empty
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c > ncell) return;
     int64_t lo = 0, hi = n;
@@ -102,8 +107,28 @@ __global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t n, 
         int64_t mid = (lo + hi) >> 1;
         if ((int64_t)sorted_cid[mid] < c) lo = mid + 1; else hi = mid;
     }
-    cell_start[c] = (int32_t)lo;
+    cell_start[c] = (int32_t)(base + lo);
 }
+
+#define SF_MAX_LAYERS 4096
+// points per z-layer of cells (block build: where do the cell-sorted positions of a layer start?)
+__global__ void k_layer_hist(const int32_t *__restrict__ cid, int64_t n, int layer_cells, int nlayers,
+                             unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int sh[SF_MAX_LAYERS];
+    for (int b = threadIdx.x; b < nlayers; b += blockDim.x) sh[b] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&sh[cid[i] / layer_cells], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nlayers; b += blockDim.x)
+        if (sh[b]) atomicAdd(&hist[b], sh[b]);
+}
+
+struct cid_in_range {
+    int32_t lo, hi;
+    __host__ __device__ bool operator()(int32_t c) const { return c >= lo && c < hi; }
+};
 
 } // namespace
 
@@ -118,6 +143,7 @@ static void cloud_release_grid(sf_ctx *ctx, sf_cloud *c)
     c->xs = c->ys = c->zs = c->rec = nullptr;
     c->normals_sorted = false;
     c->cell = 0.0;
+    c->pop_begin = c->pop_end = 0;
 }
 
 extern "C" sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const double *normals, int64_t n, int flags)
@@ -170,9 +196,10 @@ int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
     if (c->normals_sorted) return SF_OK;
     if (!c->nrm_orig) { sf_set_error("this operation needs normals, but the cloud has none"); return SF_ERR_STATE; }
     if (!c->perm) { sf_set_error("grid not built"); return SF_ERR_STATE; }
-    if (c->n) {
-        SF_LAUNCH(ctx, "k1_gather_normals", k_gather_normals, dim3((unsigned)sf_div_up(c->n, 256)), dim3(256),
-                  c->nrm_orig, c->perm, c->n, c->rec);
+    const int64_t np = c->pop_end - c->pop_begin;
+    if (np > 0) {
+        SF_LAUNCH(ctx, "k1_gather_normals", k_gather_normals, dim3((unsigned)sf_div_up(np, 256)), dim3(256),
+                  c->nrm_orig, c->perm, c->pop_begin, np, c->rec);
     }
     c->normals_sorted = true;
     return SF_OK;
@@ -205,12 +232,14 @@ int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3])
     return SF_OK;
 }
 
-extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
+// Common grid build.  block_end < 0: the whole cloud.  Otherwise only the z-layers of cells that the queries at
+// cell-sorted positions [block_begin, block_end) can reach within `reach` cells are sorted and gathered -- the
+// positions, perm and cell_start keep their GLOBAL numbering (a layer's first position is the number of points in
+// the layers below it, known from a per-layer histogram), so everything downstream is unchanged and the result of
+// any query is bit-identical to a whole-cloud build.  A rank of an N-GPU job pays for ~1/N of the sort and gather
+// instead of all of it; only the streaming passes (bounding box, cell ids, layer histogram, selection) see every point.
+static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin, int64_t block_end, int reach)
 {
-    if (!ctx || !c || !(cell > 0.0) || !std::isfinite(cell)) {
-        sf_set_error("sf_cloud_build_grid: bad arguments (cell=%g)", cell);
-        return SF_ERR_ARG;
-    }
     SF_HIP(hipSetDevice(ctx->device));
     cloud_release_grid(ctx, c);
     const int64_t n = c->n;
@@ -261,24 +290,106 @@ extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
               val);
     int bits = 1;
     while (((int64_t)1 << bits) < ncell) ++bits;
-    size_t tmp_bytes = 0;
-    SF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, cid, cid_sorted, val, c->perm, (size_t)n, 0, bits,
-                                     ctx->stream));
-    void *tmp = nullptr;
-    SF_CHECK(sf_pool_alloc(ctx, tmp_bytes ? tmp_bytes : 8, &tmp));
-    {
-        sf_launch_timer t_(ctx, "k1_radix_sort");
-        SF_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cid, cid_sorted, val, c->perm, (size_t)n, 0, bits,
-                                         ctx->stream));
+
+    int64_t base = 0, ns = n;                  // populated slice [base, base + ns) of the global order
+    int32_t *key_in = cid, *val_in = val;      // what gets sorted
+    int32_t *cid_sel = nullptr, *val_sel = nullptr;
+    const bool whole = block_end < 0 || c->dim[2] > SF_MAX_LAYERS; // (the layer histogram lives in LDS)
+    if (!whole) {
+        // ---- which z-layers does the block need? ------------------------------------------------
+        const int nl = c->dim[2];
+        const int layer_cells = c->dim[0] * c->dim[1];
+        unsigned int *dhist = nullptr;
+        SF_CHECK(sf_palloc(ctx, &dhist, (size_t)nl));
+        SF_HIP(hipMemsetAsync(dhist, 0, (size_t)nl * sizeof(unsigned int), ctx->stream));
+        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist, dim3(1024), dim3(256), cid, n, layer_cells, nl, dhist);
+        std::vector<unsigned int> hist((size_t)nl);
+        SF_HIP(hipMemcpyAsync(hist.data(), dhist, (size_t)nl * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        sf_pool_release(ctx, dhist);
+        std::vector<int64_t> first((size_t)nl + 1, 0); // global position of each layer's first point
+        for (int z = 0; z < nl; ++z) first[(size_t)z + 1] = first[(size_t)z] + hist[(size_t)z];
+        int zb = 0, ze = nl - 1;
+        if (block_begin < block_end) {
+            while (zb + 1 < nl && first[(size_t)zb + 1] <= block_begin) ++zb;          // layer holding position block_begin
+            ze = zb;
+            while (ze + 1 < nl && first[(size_t)ze + 1] <= block_end - 1) ++ze;        // layer holding position block_end - 1
+        } else {
+            zb = 0; ze = -1; // empty block: populate nothing
+        }
+        const int zlo = std::max(zb - reach, 0), zhi = block_begin < block_end ? std::min(ze + reach, nl - 1) : -1;
+        base = zhi >= zlo ? first[(size_t)zlo] : 0;
+        ns = zhi >= zlo ? first[(size_t)zhi + 1] - base : 0;
+        // ---- stable selection of the points of those layers ----------------------------------------
+        if (ns > 0 && ns < n) {
+            SF_CHECK(sf_palloc(ctx, &cid_sel, (size_t)ns + 1));
+            SF_CHECK(sf_palloc(ctx, &val_sel, (size_t)ns + 1));
+            size_t *dcount = nullptr;
+            SF_CHECK(sf_palloc(ctx, &dcount, 2));
+            const cid_in_range pred{(int32_t)((int64_t)zlo * layer_cells), (int32_t)std::min<int64_t>((int64_t)(zhi + 1) * layer_cells, 2147483647LL)};
+            auto flags = rocprim::make_transform_iterator(cid, pred);
+            size_t sel_bytes = 0;
+            SF_HIP(rocprim::select(nullptr, sel_bytes, cid, flags, cid_sel, dcount, (size_t)n, ctx->stream));
+            void *sel_tmp = nullptr;
+            SF_CHECK(sf_pool_alloc(ctx, sel_bytes ? sel_bytes : 8, &sel_tmp));
+            {
+                sf_launch_timer t_(ctx, "k1_select_slab");
+                SF_HIP(rocprim::select(sel_tmp, sel_bytes, cid, flags, cid_sel, dcount, (size_t)n, ctx->stream));
+                SF_HIP(rocprim::select(sel_tmp, sel_bytes, val, flags, val_sel, dcount + 1, (size_t)n, ctx->stream));
+            }
+            sf_pool_release(ctx, sel_tmp);
+            sf_pool_release(ctx, dcount);
+            key_in = cid_sel;
+            val_in = val_sel;
+        }
     }
-    SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig,
-              c->perm, n, c->xs, c->ys, c->zs, c->rec, c->inv_perm);
-    SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, n,
+    c->pop_begin = base;
+    c->pop_end = base + ns;
+    if (ns > 0) {
+        size_t tmp_bytes = 0;
+        SF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
+                                         ctx->stream));
+        void *tmp = nullptr;
+        SF_CHECK(sf_pool_alloc(ctx, tmp_bytes ? tmp_bytes : 8, &tmp));
+        {
+            sf_launch_timer t_(ctx, "k1_radix_sort");
+            SF_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
+                                             ctx->stream));
+        }
+        SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,
+                  c->perm, base, ns, c->xs, c->ys, c->zs, c->rec, c->inv_perm);
+        sf_pool_release(ctx, tmp);
+    }
+    SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, base, ns,
               ncell, c->cell_start);
-    sf_pool_release(ctx, tmp);
+    if (cid_sel) sf_pool_release(ctx, cid_sel);
+    if (val_sel) sf_pool_release(ctx, val_sel);
     sf_pool_release(ctx, cid);
     sf_pool_release(ctx, cid_sorted);
     sf_pool_release(ctx, val);
+    return SF_OK;
+}
+
+extern "C" int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *c, double cell)
+{
+    if (!ctx || !c || !(cell > 0.0) || !std::isfinite(cell)) {
+        sf_set_error("sf_cloud_build_grid: bad arguments (cell=%g)", cell);
+        return SF_ERR_ARG;
+    }
+    return build_grid(ctx, c, cell, 0, -1, 0);
+}
+
+extern "C" int sf_cloud_build_grid_block(sf_ctx *ctx, sf_cloud *c, double cell, int64_t begin, int64_t end, int reach,
+                                         int64_t *pop_begin, int64_t *pop_end)
+{
+    if (!ctx || !c || !(cell > 0.0) || !std::isfinite(cell) || begin < 0 || end > c->n || begin > end || reach < 0) {
+        sf_set_error("sf_cloud_build_grid_block: bad arguments (cell=%g, block [%lld, %lld), reach %d)", cell,
+                     (long long)begin, (long long)end, reach);
+        return SF_ERR_ARG;
+    }
+    SF_CHECK(build_grid(ctx, c, cell, begin, end, reach));
+    if (pop_begin) *pop_begin = c->pop_begin;
+    if (pop_end) *pop_end = c->pop_end;
     return SF_OK;
 }
 

@@ -391,14 +391,17 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     return SF_OK;
 }
 
-static int ensure_grid(sf_ctx *ctx, sf_cloud *c, double radius)
+static int ensure_grid(sf_ctx *ctx, sf_cloud *c, double radius, int64_t need_begin = 0, int64_t need_end = -1)
 {
     if (!(radius > 0.0) || !std::isfinite(radius)) {
         sf_set_error("radius must be positive and finite (got %g)", radius);
         return SF_ERR_ARG;
     }
-    // a grid built for a larger radius stays valid; a far too coarse one is rebuilt for speed
-    if (c->cell_start && c->cell >= radius && c->cell <= 2.0 * radius * (1.0 + 1e-6)) return SF_OK;
+    // a grid built for a larger radius stays valid; a far too coarse one is rebuilt for speed.  A grid that only
+    // populates a block's slab (sf_cloud_build_grid_block) serves self-searches inside [need_begin, need_end).
+    const bool covers = need_end < 0 ? (c->pop_begin == 0 && c->pop_end == c->n)
+                                     : (need_begin >= c->pop_begin && need_end <= c->pop_end);
+    if (c->cell_start && covers && c->cell >= radius && c->cell <= 2.0 * radius * (1.0 + 1e-6)) return SF_OK;
     return sf_cloud_build_grid(ctx, c, radius);
 }
 
@@ -411,7 +414,7 @@ extern "C" sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *c, double radiu
         return nullptr;
     }
     if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
-    if (ensure_grid(ctx, c, radius) != SF_OK) return nullptr;
+    if (ensure_grid(ctx, c, radius, begin, end) != SF_OK) return nullptr;
     sf_nbrs *nb = new sf_nbrs();
     nb->m = end - begin;
     nb->radius = radius;

@@ -282,8 +282,20 @@ class Cloud:
             raise ValueError("normals must have one row per point")
         _ffi.check(self.engine.lib.sf_cloud_set_normals(self.engine.h, self.h, _ptr(nrm), SF_HOST), "sf_cloud_set_normals")
 
-    def build_grid(self, cell: float) -> None:
-        _ffi.check(self.engine.lib.sf_cloud_build_grid(self.engine.h, self.h, float(cell)), "sf_cloud_build_grid")
+    def build_grid(self, cell: float, block: Optional[tuple[int, int]] = None, reach: int = 2) -> tuple[int, int]:
+        """K1.  With `block=(begin, end)` only the z-layers that block's queries can reach within `reach` cells are
+        sorted and gathered (global position numbering kept): what one rank of a sharded job needs.  Returns the
+        populated range of cell-sorted positions."""
+        if block is None:
+            _ffi.check(self.engine.lib.sf_cloud_build_grid(self.engine.h, self.h, float(cell)), "sf_cloud_build_grid")
+            return 0, self.n
+        pb, pe = C.c_int64(0), C.c_int64(0)
+        _ffi.check(
+            self.engine.lib.sf_cloud_build_grid_block(self.engine.h, self.h, float(cell), int(block[0]), int(block[1]),
+                                                      int(reach), C.byref(pb), C.byref(pe)),
+            "sf_cloud_build_grid_block",
+        )
+        return pb.value, pe.value
 
     def perm(self) -> np.ndarray:
         """cell-sorted position -> original point index (valid after a grid build / search)."""

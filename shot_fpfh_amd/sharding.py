@@ -100,7 +100,12 @@ class DescriptorJob:
 
     def step(self) -> None:
         cloud, (b, e) = self.cloud, self.plan.block()
-        cloud.build_grid(self.radius)
+        if self.plan.world > 1:
+            # only this rank's slab of the replicated cloud is sorted: the block's queries reach one cell, the SPFH
+            # rows of the block's halo (recomputed here) one more
+            cloud.build_grid(self.radius, block=(b, e), reach=2 if self.do_fpfh and self.exchange == "halo" else 1)
+        else:
+            cloud.build_grid(self.radius)
         if self.do_fpfh and self.exchange == "halo":
             hb, he = cloud.halo_range(b, e)
         else:

@@ -115,7 +115,8 @@ class FakeCloud:
         self.p, self.nr = np.asarray(points, dtype=np.float64), np.asarray(normals, dtype=np.float64)
         self.n = self.p.shape[0]
 
-    def build_grid(self, cell):
+    def build_grid(self, cell, block=None, reach=2):
+        # (the stand-in always sorts the whole cloud; `block` only restricts what the device build populates)
         edge = cell * (1.0 + 2.0**-20)
         self.lo = self.p.min(axis=0)
         c = np.floor((self.p - self.lo) / edge).astype(np.int64)

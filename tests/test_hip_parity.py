@@ -560,3 +560,29 @@ def test_register_point_clouds_script_end_to_end(eng, tmp_path):
     moved = np.vstack((merged["x"], merged["y"], merged["z"])).T[:n_scan]
     truth = g["scan"] @ g["true_rotation"].T + g["true_translation"]
     assert np.abs(moved - truth).max() < 2e-3  # the script found the generating motion
+
+
+def test_block_grid_build_keeps_global_numbering(eng):
+    """sf_cloud_build_grid_block: only the slab a block needs is sorted, yet positions / lists / results are those
+    of the whole-cloud build; a search outside the populated slab falls back to a whole build."""
+    p, nr, _ = synth_cloud(30000, 71)
+    r = 0.05
+    full = eng.cloud(p, nr)
+    full.build_grid(r)
+    perm_full = full.perm()
+    b, e = 11000, 17000
+    hb, he = full.halo_range(b, e)
+    off_f, idx_f = full.radius_search_self(r, hb, he).export()
+    part = eng.cloud(p, nr)
+    pb, pe = part.build_grid(r, block=(b, e), reach=2)
+    assert 0 < pb <= hb and he <= pe < 30000 and pe - pb < 20000  # a slab, not the whole cloud
+    assert np.array_equal(part.perm()[pb:pe], perm_full[pb:pe])
+    assert part.halo_range(b, e) == (hb, he)
+    off_p, idx_p = part.radius_search_self(r, hb, he).export()
+    assert np.array_equal(off_p, off_f) and np.array_equal(idx_p, idx_f)
+    # outside the slab: the grid is rebuilt for the whole cloud and the answer is still right
+    off_o, idx_o = part.radius_search_self(r, 0, 500).export()
+    off_g, idx_g = full.radius_search_self(r, 0, 500).export()
+    assert np.array_equal(off_o, off_g) and np.array_equal(idx_o, idx_g)
+    empty = eng.cloud(p, nr)
+    assert empty.build_grid(r, block=(100, 100)) == (0, 0)
