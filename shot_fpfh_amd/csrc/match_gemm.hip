@@ -32,10 +32,8 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int GM = 128, GN = 128, GK = 16;
-// LDS tiles are row-major [row][k] with a pitch of 18 doubles: the 16-row x 2-k footprint of one MFMA fragment
-// read (lanes 0-15: k, lanes 16-31: k+1) then falls on 32 distinct 8-byte bank slots ((18 r + k) mod 32), and a
-// staging write of one row's 16 k (eight 16-byte pieces) is contiguous.
-constexpr int LDS_P = 18;
+// LDS tiles are row-major [row][k], 16 doubles per row, columns swizzled by sw() (see there).
+constexpr int LDS_P = 16; // no padding: bank conflicts are avoided by the XOR swizzle sw() below
 
 // ||row||^2; rows whose mask is 0 (all-zero descriptors that must never be matched) get +inf, which keeps them
 // out of every arg-min without touching the GEMM
@@ -81,8 +79,15 @@ __device__ inline void top2_merge(top2 &t, double om1, double om2, int64_t oj1)
 
 // VEC: the descriptor length is even and both matrices are 16-byte aligned -> a stage is fetched with 16-byte
 // loads, eight lanes per 128-byte row segment (8 cache lines per wave instruction instead of 64).
+// LDS column swizzle: a tile row holds GK = 16 doubles = four 32-byte groups; row r stores group g at slot
+// g ^ (r & 3).  An MFMA fragment read (16 consecutive rows x the 4 k of one group, 8 bytes per lane) then touches
+// every bank exactly once per 16 lanes -- the minimum of four passes per wave read -- where the padded layout
+// (pitch 18) had rows r and r + 8 and neighbouring k colliding; and without padding the tile pair is 64 KB, so
+// two workgroups fit a CU's LDS.
+__device__ __forceinline__ int sw(int row, int c) { return (((c >> 2) ^ (row & 3)) << 2) | (c & 3); }
+
 template <bool VEC>
-__global__ __launch_bounds__(256) void k_match_gemm(const double *__restrict__ a, int64_t m1,
+__global__ __launch_bounds__(256, 2) void k_match_gemm(const double *__restrict__ a, int64_t m1,
                                                     const double *__restrict__ b, int64_t m2, int64_t d,
                                                     const double *__restrict__ nb, int64_t tiles_per_split,
                                                     double *__restrict__ pm1, int64_t *__restrict__ pj1,
@@ -140,14 +145,14 @@ __global__ __launch_bounds__(256) void k_match_gemm(const double *__restrict__ a
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int p = tid + 256 * u, row = p >> 3, kp = p & 7;
-                    *reinterpret_cast<double2 *>(&As[buf][row][2 * kp]) = make_double2(ra[2 * u], ra[2 * u + 1]);
-                    *reinterpret_cast<double2 *>(&Bs[buf][row][2 * kp]) = make_double2(rb[2 * u], rb[2 * u + 1]);
+                    *reinterpret_cast<double2 *>(&As[buf][row][sw(row, 2 * kp)]) = make_double2(ra[2 * u], ra[2 * u + 1]);
+                    *reinterpret_cast<double2 *>(&Bs[buf][row][sw(row, 2 * kp)]) = make_double2(rb[2 * u], rb[2 * u + 1]);
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    As[buf][srow][skh * 8 + u] = ra[u];
-                    Bs[buf][srow][skh * 8 + u] = rb[u];
+                    As[buf][srow][sw(srow, skh * 8 + u)] = ra[u];
+                    Bs[buf][srow][sw(srow, skh * 8 + u)] = rb[u];
                 }
             }
         };
@@ -162,8 +167,8 @@ __global__ __launch_bounds__(256) void k_match_gemm(const double *__restrict__ a
                 double af[4], bf[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    af[t] = As[buf][64 * wr + 16 * t + l15][kk * 4 + l4];
-                    bf[t] = Bs[buf][64 * wc + 16 * t + l15][kk * 4 + l4];
+                    af[t] = As[buf][64 * wr + 16 * t + l15][sw(l15, kk * 4 + l4)]; // (row & 3) == (l15 & 3)
+                    bf[t] = Bs[buf][64 * wc + 16 * t + l15][sw(l15, kk * 4 + l4)];
                 }
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti)
