@@ -61,6 +61,13 @@ __global__ void k_max_partial(const double *__restrict__ v, int64_t n, double *_
     if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
+
 // best / second-best bookkeeping for one row; ties count as "second best equal to best" (-> slow path)
 struct top2 {
     double m1, m2;
@@ -196,21 +203,29 @@ __global__ __launch_bounds__(256, 2) void k_match_gemm(const double *__restrict_
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj)
                     top2_insert(t, jcol[tj] < m2 ? nbv[tj] - 2.0 * acc[ti][tj][r] : INFINITY, jcol[tj]);
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    const double om1 = __shfl_xor(t.m1, off, 16), om2 = __shfl_xor(t.m2, off, 16);
-                    const int64_t oj1 = __shfl_xor(t.j1, off, 16);
-                    // symmetric merge so that both partners end with the same triple
-                    if (om1 < t.m1 || (om1 == t.m1 && oj1 < t.j1)) {
-                        const double keep = t.m1;
-                        t.m2 = fmin(om2, keep);
-                        t.m1 = om1;
-                        t.j1 = oj1;
-                    } else {
-                        t.m2 = fmin(t.m2, om1);
-                    }
-                }
-                if (l15 == 4 * ti + r) top2_merge(run, t.m1, t.m2, t.j1);
+                // butterfly over the 16 lanes of the DPP row (register-to-register: the LDS pipe is busy feeding the
+                // MFMA fragments); the merge is symmetric, so mirror patterns serve as well as xor ones and every lane
+                // of the row ends with the same triple
+#define SF_TOP2_STEP(CTRL)                                                                                          \
+    {                                                                                                               \
+        const double om1 = dpp_f64<CTRL>(t.m1), om2 = dpp_f64<CTRL>(t.m2);                                          \
+        const int oj = __builtin_amdgcn_update_dpp(0, jloc, CTRL, 0xf, 0xf, false);                                 \
+        if (om1 < t.m1 || (om1 == t.m1 && oj < jloc)) {                                                             \
+            const double keep = t.m1;                                                                               \
+            t.m2 = fmin(om2, keep);                                                                                 \
+            t.m1 = om1;                                                                                             \
+            jloc = oj;                                                                                              \
+        } else {                                                                                                    \
+            t.m2 = fmin(t.m2, om1);                                                                                 \
+        }                                                                                                           \
+    }
+                int jloc = (int)(t.j1 - j0); // column inside the tile (0..127): one register through the butterfly
+                SF_TOP2_STEP(0xB1)  // quad_perm [1,0,3,2]
+                SF_TOP2_STEP(0x4E)  // quad_perm [2,3,0,1]
+                SF_TOP2_STEP(0x141) // row_half_mirror
+                SF_TOP2_STEP(0x140) // row_mirror
+#undef SF_TOP2_STEP
+                if (l15 == 4 * ti + r) top2_merge(run, t.m1, t.m2, j0 + jloc);
             }
     }
     // merge the two column halves (waves wc = 0, 1 of the same row half) through LDS and write the partials
