@@ -194,18 +194,10 @@ __global__ __launch_bounds__(256, 2) void k_match_gemm(const double *__restrict_
             jcol[tj] = j0 + 64 * wc + 16 * tj + l15;
             nbv[tj] = jcol[tj] < m2 ? nb[jcol[tj]] : INFINITY;
         }
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                top2 t;
-                t.m1 = INFINITY; t.m2 = INFINITY; t.j1 = 0;
-#pragma unroll
-                for (int tj = 0; tj < 4; ++tj)
-                    top2_insert(t, jcol[tj] < m2 ? nbv[tj] - 2.0 * acc[ti][tj][r] : INFINITY, jcol[tj]);
-                // butterfly over the 16 lanes of the DPP row (register-to-register: the LDS pipe is busy feeding the
-                // MFMA fragments); the merge is symmetric, so mirror patterns serve as well as xor ones and every lane
-                // of the row ends with the same triple
+        // Per row (TI, R) of the wave's 64 x 64 block: the four keys each lane holds are first tested against the
+        // row's running SECOND-best (owned by lane 4 TI + R of the DPP row, broadcast with row_newbcast).  Only a
+        // key below it can change the top-2, and after t column tiles that happens with probability ~2/t, so the
+        // insert + butterfly + merge below is skipped (wave-uniformly) for almost every row of almost every tile.
 #define SF_TOP2_STEP(CTRL)                                                                                          \
     {                                                                                                               \
         const double om1 = dpp_f64<CTRL>(t.m1), om2 = dpp_f64<CTRL>(t.m2);                                          \
@@ -219,14 +211,32 @@ __global__ __launch_bounds__(256, 2) void k_match_gemm(const double *__restrict_
             t.m2 = fmin(t.m2, om1);                                                                                 \
         }                                                                                                           \
     }
-                int jloc = (int)(t.j1 - j0); // column inside the tile (0..127): one register through the butterfly
-                SF_TOP2_STEP(0xB1)  // quad_perm [1,0,3,2]
-                SF_TOP2_STEP(0x4E)  // quad_perm [2,3,0,1]
-                SF_TOP2_STEP(0x141) // row_half_mirror
-                SF_TOP2_STEP(0x140) // row_mirror
+#define SF_EPI_ROW(TI, R)                                                                                           \
+    {                                                                                                               \
+        const double thr = dpp_f64<0x150 + 4 * (TI) + (R)>(run.m2);                                                 \
+        double key[4];                                                                                              \
+        bool below = false;                                                                                         \
+        _Pragma("unroll") for (int tj = 0; tj < 4; ++tj) {                                                          \
+            key[tj] = jcol[tj] < m2 ? nbv[tj] - 2.0 * acc[TI][tj][R] : INFINITY;                                    \
+            below |= key[tj] < thr;                                                                                 \
+        }                                                                                                           \
+        if (__ballot(below)) {                                                                                      \
+            top2 t;                                                                                                 \
+            t.m1 = INFINITY; t.m2 = INFINITY; t.j1 = 0;                                                             \
+            _Pragma("unroll") for (int tj = 0; tj < 4; ++tj) top2_insert(t, key[tj], jcol[tj]);                     \
+            int jloc = (int)(t.j1 - j0); /* column inside the tile: one register through the butterfly */           \
+            SF_TOP2_STEP(0xB1)  /* quad_perm [1,0,3,2] */                                                           \
+            SF_TOP2_STEP(0x4E)  /* quad_perm [2,3,0,1] */                                                           \
+            SF_TOP2_STEP(0x141) /* row_half_mirror */                                                               \
+            SF_TOP2_STEP(0x140) /* row_mirror: the merge is symmetric, every lane of the row ends with the same triple */ \
+            if (l15 == 4 * (TI) + (R)) top2_merge(run, t.m1, t.m2, j0 + jloc);                                      \
+        }                                                                                                           \
+    }
+#define SF_EPI_TI(TI) SF_EPI_ROW(TI, 0) SF_EPI_ROW(TI, 1) SF_EPI_ROW(TI, 2) SF_EPI_ROW(TI, 3)
+        SF_EPI_TI(0) SF_EPI_TI(1) SF_EPI_TI(2) SF_EPI_TI(3)
+#undef SF_EPI_TI
+#undef SF_EPI_ROW
 #undef SF_TOP2_STEP
-                if (l15 == 4 * ti + r) top2_merge(run, t.m1, t.m2, j0 + jloc);
-            }
     }
     // merge the two column halves (waves wc = 0, 1 of the same row half) through LDS and write the partials
     __syncthreads();
