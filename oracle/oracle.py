@@ -107,13 +107,13 @@ def eigh3(a):
 # --------------------------------------------------------------------------------------------
 # (a2) compute_normals, radius branch (pca_based_descriptors.py:29-59)
 # --------------------------------------------------------------------------------------------
-def compute_normals(query_points, cloud_points, *, k=None, radius=None, pre_computed_normals=None):
+def compute_normals(query_points, cloud_points, *, k=None, radius=None, pre_computed_normals=None, knn_radius_hint=None):
     assert k is not None or radius is not None, "No parameter provided for the neighborhood search."
     q, p = _f64(query_points), _f64(cloud_points)
     out = np.zeros((q.shape[0], 3))
     pre = None if pre_computed_normals is None else _f64(pre_computed_normals)
     if k is not None:
-        off, idx = knn_lists(p, q, k)
+        off, idx = knn_lists(p, q, k, knn_radius_hint)
         lib().orc_normals_from_lists(p, off, idx, q.shape[0], _ptr(pre), out)
     else:
         lib().orc_normals_radius(p, p.shape[0], q, q.shape[0], radius, _ptr(pre), out)
@@ -165,13 +165,27 @@ def compute_sphericity(query_points, cloud_points, radius):
     return ev[:, 0] / (ev[:, 2] + 1e-6)
 
 
-def knn_lists(cloud, queries, k):
-    """Brute-force k nearest neighbours as CSR (KDTree.query(k=k, return_distance=False),
-    pca_based_descriptors.py:46).  Ties in distance are broken by lower index."""
+def knn_lists(cloud, queries, k, radius_hint=None):
+    """k nearest neighbours as CSR (KDTree.query(k=k, return_distance=False), pca_based_descriptors.py:46).
+    Ties in distance are broken by lower index.  Brute force by default; with `radius_hint` the candidates come
+    from the C radius search (any query with fewer than k points inside the hint falls back to brute force)."""
     cloud, queries = _f64(cloud), _f64(queries)
     m = queries.shape[0]
     idx = np.zeros((m, k), dtype=np.int32)
-    for i in range(m):
+    todo = np.arange(m)
+    if radius_hint is not None:
+        off, cand = radius_search(cloud, queries, radius_hint)
+        short = []
+        for i in range(m):
+            c = cand[off[i] : off[i + 1]]  # ascending index
+            if c.shape[0] < k:
+                short.append(i)
+                continue
+            d = cloud[c] - queries[i]
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            idx[i] = c[np.argsort(d2, kind="stable")[:k]]
+        todo = np.array(short, dtype=np.int64)
+    for i in todo:
         d = cloud - queries[i]
         d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         idx[i] = np.argsort(d2, kind="stable")[:k]

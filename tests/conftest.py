@@ -31,3 +31,13 @@ def synth_cloud(n, seed, scale=1.0):
     nr = rng.standard_normal((n, 3))
     nr /= np.linalg.norm(nr, axis=1)[:, None]
     return p, nr, rng
+
+
+def config1_cloud(n, seed):
+    """BASELINE config 1 stand-in (tools/gen_golden_next.py): noisy sphere of the Stanford bunny's size, float32-grid
+    coordinates, outward unit directions as stored normals."""
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    p = (0.5 + 0.5 * d * (1.0 + 0.01 * rng.standard_normal((n, 1)))).astype(np.float32).astype(np.float64)
+    return p, d

@@ -586,3 +586,20 @@ def test_block_grid_build_keeps_global_numbering(eng):
     assert np.array_equal(off_o, off_g) and np.array_equal(idx_o, idx_g)
     empty = eng.cloud(p, nr)
     assert empty.build_grid(r, block=(100, 100)) == (0, 0)
+
+
+def test_config1_plumbing_case_through_a_ply_file(eng, tmp_path):
+    """BASELINE config 1 end to end on the device: write the stand-in cloud as binary PLY, get_data (k = 30 normals
+    re-oriented by the stored ones), 500 random keypoints, FPFH -- against the reference's outputs."""
+    from conftest import config1_cloud
+    from shot_fpfh_amd import compute_fpfh_descriptor, compute_normals
+    from shot_fpfh_amd.helpers import get_data, write_ply
+
+    g = load_golden("config1_fpfh_500.npz")
+    p, d = config1_cloud(int(g["n"]), int(g["seed"]))
+    path = str(tmp_path / "config1.ply")
+    write_ply(path, [p, d], ["x", "y", "z", "nx", "ny", "nz"])
+    points, normals = get_data(path, k=30, normals_computation_callback=compute_normals)
+    assert np.array_equal(points, p) and np.abs(normals[:200] - g["normals_head"]).max() < 1e-9
+    f = compute_fpfh_descriptor(g["kp_idx"], points, normals, radius=float(g["radius"]), n_bins=5, verbose=False)
+    assert close(f, g["fpfh"]).all() and np.abs(f - g["fpfh"]).max() < 1e-9

@@ -175,3 +175,16 @@ def test_local_pca_and_features_match_reference_golden():
     for got, key in zip(basic, ("verticality", "linearity", "planarity", "basic_sphericity")):
         assert np.abs(got - g[key]).max() < 1e-9
     assert np.abs(O.compute_sphericity(g["queries"], g["cloud"], r) - g["sphericity"]).max() < 1e-9
+
+
+def test_config1_plumbing_case_fpfh_matches_reference_golden():
+    """BASELINE config 1: ~35k-point surface cloud, k = 30 PCA normals oriented by the stored ones, 500 random
+    keypoints, FPFH 5 bins at radius 0.05 x the bounding-box extent (reference outputs: config1_fpfh_500.npz)."""
+    from conftest import config1_cloud
+
+    g = load_golden("config1_fpfh_500.npz")
+    p, d = config1_cloud(int(g["n"]), int(g["seed"]))
+    normals = O.compute_normals(p, p, k=30, pre_computed_normals=d, knn_radius_hint=0.05)
+    assert np.abs(normals[:200] - g["normals_head"]).max() < 1e-9
+    f = O.compute_fpfh_descriptor(g["kp_idx"], p, normals, float(g["radius"]), 5)
+    assert np.abs(f - g["fpfh"]).max() <= 1e-10 * max(1.0, np.abs(g["fpfh"]).max())
