@@ -183,7 +183,13 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
     auto weight_of = [&](double x, double y, double z, int kj) -> double {
         const double cx = x - px, cy = y - py, cz = z - pz;
         const double d2 = (cx * cx + cy * cy) + cz * cz;
-        return d2 > 0.0 ? 1.0 / ((double)kj * sqrt(d2)) : 0.0; // = (1/k_j)/d_j up to one rounding
+        // 1 / (k_j d_j) = rsqrt(d2 k_j^2): v_rsq_f64 and two Newton steps (~1 ulp; the weight is a continuous
+        // factor, no decision depends on its last bit) instead of sqrt + division (~35 instructions)
+        const double kd = (double)kj, xx = d2 * (kd * kd);
+        const double y0 = __builtin_amdgcn_rsq(xx);
+        const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+        const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+        return d2 > 0.0 ? y2 : 0.0;
     };
     auto accumulate = [&](const uint4 &v, double ww, int u) {
         if (sizeof(CT) == 2) {
@@ -293,6 +299,9 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
     // divisions are shared out instead of being executed (predicated) by the whole wave for group 0 alone
     {
         const double kd = (double)k;
+        double inv_k = __builtin_amdgcn_rcp(kd); // 1 / k to ~1 ulp for the neighbour term (the SPFH term keeps its division)
+        inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+        inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
         const CT *own = counts + i * (int64_t)stride;
         double *o = out + q * (int64_t)nb3;
 #pragma unroll
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
                     if (e0 + g < BPP) a = grp == g ? acc[u][e0 + g] : a;
                 const int e = e0 + grp;
                 const int b = (u * 64 + piece) * BPP + e; // == byte offset (u*1024 + piece*16) / sizeof(CT) + e
-                if (e < BPP && b < nb3) o[b] = (double)own[b] / kd + a / kd;
+                if (e < BPP && b < nb3) o[b] = (double)own[b] / kd + a * inv_k;
             }
     }
 }
