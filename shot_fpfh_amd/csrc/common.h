@@ -59,6 +59,9 @@ struct sf_ctx {
     // small reusable device scratch (bbox partials etc.)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // page-locked host words for the few scalars a step reads back (bounding box, list statistics): a copy into
+    // pageable memory is staged and costs tens of microseconds of idle GPU each time
+    void *pinned = nullptr; // SF_PINNED_BYTES
     // stream-ordered caching allocator: freed blocks are reused by later launches on the SAME stream,
     // so neither hipMalloc nor the implicit device sync of hipFree sits inside a step of the path
     std::multimap<size_t, void *> pool_free;
@@ -79,6 +82,8 @@ static inline int sf_palloc(sf_ctx *ctx, T **out, size_t count)
 }
 
 int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out);
+#define SF_PINNED_BYTES 4096
+int sf_ctx_pinned(sf_ctx *ctx, void **out);
 hipEvent_t sf_ctx_event(sf_ctx *ctx);
 
 // RAII-ish timing scope around one kernel launch (active only when profiling is on).

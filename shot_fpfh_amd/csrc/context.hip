@@ -64,6 +64,7 @@ extern "C" void sf_destroy(sf_ctx *ctx)
         }
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     sf_pool_trim(ctx);
     for (auto &kv : ctx->pool_size) (void)hipFree(kv.first); // blocks still held by live handles
     (void)hipEventDestroy(ctx->join_event);
@@ -171,6 +172,13 @@ int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out)
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;
+    return SF_OK;
+}
+
+int sf_ctx_pinned(sf_ctx *ctx, void **out)
+{
+    if (!ctx->pinned) SF_HIP(hipHostMalloc(&ctx->pinned, SF_PINNED_BYTES, hipHostMallocDefault));
+    *out = ctx->pinned;
     return SF_OK;
 }
 

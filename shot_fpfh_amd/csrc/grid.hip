@@ -54,6 +54,19 @@ __global__ void k_bbox_partial(const double *__restrict__ xyz, int64_t n, double
     }
 }
 
+// second stage of the bounding box: one block, wave a folds component a of the per-block partials
+__global__ __launch_bounds__(384) void k_bbox_final(const double *__restrict__ partial, int nb, double *__restrict__ out6)
+{
+    const int a = threadIdx.x >> 6, lane = threadIdx.x & 63; // a = 0..5
+    double v = a < 3 ? INFINITY : -INFINITY;
+    for (int b = lane; b < nb; b += 64) v = a < 3 ? fmin(v, partial[b * 6 + a]) : fmax(v, partial[b * 6 + a]);
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off);
+        v = a < 3 ? fmin(v, o) : fmax(v, o);
+    }
+    if (lane == 0) out6[a] = v;
+}
+
 __global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_desc g, int32_t *__restrict__ cid,
                            int32_t *__restrict__ val)
 {
@@ -213,17 +226,16 @@ int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3])
     if (!n) return SF_OK;
     const int nb = 1024;
     void *scr = nullptr;
-    SF_CHECK(sf_ctx_scratch(ctx, (size_t)nb * 6 * sizeof(double), &scr));
+    SF_CHECK(sf_ctx_scratch(ctx, ((size_t)nb * 6 + 8) * sizeof(double), &scr));
     SF_LAUNCH(ctx, "k1_bbox", k_bbox_partial, dim3(nb), dim3(256), c->xyz_orig, n, (double *)scr);
-    std::vector<double> part((size_t)nb * 6);
-    SF_HIP(hipMemcpyAsync(part.data(), scr, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double *fin = (double *)scr + (size_t)nb * 6;
+    SF_LAUNCH(ctx, "k1_bbox", k_bbox_final, dim3(1), dim3(384), (const double *)scr, nb, fin);
+    void *pin = nullptr;
+    SF_CHECK(sf_ctx_pinned(ctx, &pin));
+    double *part = (double *)pin;
+    SF_HIP(hipMemcpyAsync(part, fin, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
-    for (int b = 0; b < nb; ++b)
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
-            hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
-        }
+    for (int a = 0; a < 3; ++a) { lo[a] = part[a]; hi[a] = part[3 + a]; }
     for (int a = 0; a < 3; ++a)
         if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) {
             sf_set_error("cloud has non-finite coordinates");

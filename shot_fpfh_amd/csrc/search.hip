@@ -296,33 +296,53 @@ struct to_i64_sum {
 };
 
 // max and sum of the per-query counts (two small rocPRIM reductions), read back with one sync
+// sum and maximum of the per-query counts: per-block partials in one pass, folded on the host after ONE small
+// read-back into page-locked memory (two library reductions + two pageable copies cost several idle gaps per step)
+#define SF_STATS_BLOCKS 128
+__global__ __launch_bounds__(256) void k_count_stats(const int32_t *__restrict__ count, int64_t m,
+                                                     long long *__restrict__ psum, int *__restrict__ pmax)
+{
+    long long sacc = 0;
+    int macc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = count[i];
+        sacc += v;
+        macc = max(macc, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sacc += __shfl_xor(sacc, off);
+        macc = max(macc, __shfl_xor(macc, off));
+    }
+    __shared__ long long ss[4];
+    __shared__ int sm[4];
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = sacc; sm[threadIdx.x >> 6] = macc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        psum[blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
+        pmax[blockIdx.x] = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    }
+}
+
 static int count_stats(sf_ctx *ctx, sf_nbrs *nb, int64_t *total, int32_t *mx)
 {
     const int64_t m = nb->m;
-    auto in64 = rocprim::make_transform_iterator(nb->count, to_i64());
-    size_t tb1 = 0, tb2 = 0;
-    int32_t *d_max = nullptr;
-    int64_t *d_sum = nullptr;
-    SF_HIP(rocprim::reduce(nullptr, tb1, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
-                           ctx->stream));
-    SF_HIP(rocprim::reduce(nullptr, tb2, in64, d_sum, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
-                           ctx->stream));
-    size_t tb = ((std::max(tb1, tb2) + 15) / 16) * 16;
-    void *tmp = nullptr;
-    SF_CHECK(sf_pool_alloc(ctx, tb + 32, &tmp));
-    d_sum = (int64_t *)((char *)tmp + tb);
-    d_max = (int32_t *)((char *)tmp + tb + 16);
-    {
-        sf_launch_timer t_(ctx, "k2_reduce");
-        SF_HIP(rocprim::reduce(tmp, tb1, nb->count, d_max, (int32_t)0, (size_t)(m + 1), rocprim::maximum<int32_t>(),
-                               ctx->stream));
-        SF_HIP(rocprim::reduce(tmp, tb2, in64, d_sum, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
-                               ctx->stream));
-    }
-    SF_HIP(hipMemcpyAsync(total, d_sum, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipMemcpyAsync(mx, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    void *tmp = nullptr, *pin = nullptr;
+    const size_t bytes = SF_STATS_BLOCKS * (sizeof(long long) + sizeof(int));
+    SF_CHECK(sf_pool_alloc(ctx, bytes, &tmp));
+    SF_CHECK(sf_ctx_pinned(ctx, &pin));
+    long long *psum = (long long *)tmp;
+    int *pmax = (int *)(psum + SF_STATS_BLOCKS);
+    SF_LAUNCH(ctx, "k2_reduce", k_count_stats, dim3(SF_STATS_BLOCKS), dim3(256), (const int32_t *)nb->count, m, psum, pmax);
+    SF_HIP(hipMemcpyAsync(pin, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
     sf_pool_release(ctx, tmp);
+    const long long *hs = (const long long *)pin;
+    const int *hm = (const int *)(hs + SF_STATS_BLOCKS);
+    int64_t t = 0;
+    int32_t mm = 0;
+    for (int b = 0; b < SF_STATS_BLOCKS; ++b) { t += hs[b]; mm = std::max<int32_t>(mm, hm[b]); }
+    *total = t;
+    *mx = mm;
     return SF_OK;
 }
 

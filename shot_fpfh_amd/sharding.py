@@ -106,7 +106,7 @@ class DescriptorJob:
             cloud.build_grid(self.radius, block=(b, e), reach=2 if self.do_fpfh and self.exchange == "halo" else 1)
         else:
             cloud.build_grid(self.radius)
-        if self.do_fpfh and self.exchange == "halo":
+        if self.do_fpfh and self.exchange == "halo" and self.plan.world > 1:
             hb, he = cloud.halo_range(b, e)
         else:
             hb, he = b, e
