@@ -11,6 +11,7 @@
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
@@ -136,6 +137,13 @@ __global__ void k_layer_hist(const int32_t *__restrict__ cid, int64_t n, int lay
     __syncthreads();
     for (int b = threadIdx.x; b < nlayers; b += blockDim.x)
         if (sh[b]) atomicAdd(&hist[b], sh[b]);
+}
+
+__global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__restrict__ sel, int64_t n,
+                             int32_t *__restrict__ dst)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[sel[i]];
 }
 
 struct cid_in_range {
@@ -316,8 +324,12 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         SF_HIP(hipMemsetAsync(dhist, 0, (size_t)nl * sizeof(unsigned int), ctx->stream));
         SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist, dim3(1024), dim3(256), cid, n, layer_cells, nl, dhist);
         std::vector<unsigned int> hist((size_t)nl);
-        SF_HIP(hipMemcpyAsync(hist.data(), dhist, (size_t)nl * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        void *pin = nullptr;
+        SF_CHECK(sf_ctx_pinned(ctx, &pin));
+        unsigned int *dst = (size_t)nl * sizeof(unsigned int) <= SF_PINNED_BYTES ? (unsigned int *)pin : hist.data();
+        SF_HIP(hipMemcpyAsync(dst, dhist, (size_t)nl * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
+        if (dst != hist.data()) std::copy(dst, dst + nl, hist.begin());
         sf_pool_release(ctx, dhist);
         std::vector<int64_t> first((size_t)nl + 1, 0); // global position of each layer's first point
         for (int z = 0; z < nl; ++z) first[(size_t)z + 1] = first[(size_t)z] + hist[(size_t)z];
@@ -341,14 +353,18 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
             const cid_in_range pred{(int32_t)((int64_t)zlo * layer_cells), (int32_t)std::min<int64_t>((int64_t)(zhi + 1) * layer_cells, 2147483647LL)};
             auto flags = rocprim::make_transform_iterator(cid, pred);
             size_t sel_bytes = 0;
-            SF_HIP(rocprim::select(nullptr, sel_bytes, cid, flags, cid_sel, dcount, (size_t)n, ctx->stream));
+            // ONE pass over the n cell ids: the (ascending) indices of the points kept; their cell ids are then a
+            // gather over the ~n/N kept points
+            auto ids = rocprim::make_counting_iterator<int32_t>(0);
+            SF_HIP(rocprim::select(nullptr, sel_bytes, ids, flags, val_sel, dcount, (size_t)n, ctx->stream));
             void *sel_tmp = nullptr;
             SF_CHECK(sf_pool_alloc(ctx, sel_bytes ? sel_bytes : 8, &sel_tmp));
             {
                 sf_launch_timer t_(ctx, "k1_select_slab");
-                SF_HIP(rocprim::select(sel_tmp, sel_bytes, cid, flags, cid_sel, dcount, (size_t)n, ctx->stream));
-                SF_HIP(rocprim::select(sel_tmp, sel_bytes, val, flags, val_sel, dcount + 1, (size_t)n, ctx->stream));
+                SF_HIP(rocprim::select(sel_tmp, sel_bytes, ids, flags, val_sel, dcount, (size_t)n, ctx->stream));
             }
+            SF_LAUNCH(ctx, "k1_select_slab", k_gather_i32, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), (const int32_t *)cid,
+                      (const int32_t *)val_sel, ns, cid_sel);
             sf_pool_release(ctx, sel_tmp);
             sf_pool_release(ctx, dcount);
             key_in = cid_sel;
