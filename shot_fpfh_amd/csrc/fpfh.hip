@@ -68,9 +68,9 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
 // NCH > 0: neighbourhoods of at most 64*NCH points -- every chunk's indices, then every chunk's
 // coordinates / normals, are requested before any is used, so a wave pays ONE index round trip and ONE
 // gather round trip instead of one per chunk.  NCH == 0: streaming loop for any size.
-// NB > 0: the bin count is a compile-time constant (5, the reference's default): the edge comparisons unroll to
-// exactly NB - 1 per feature and only the edges in use occupy SGPRs.  With the run-time count every slot of the
-// 4 x 9 edge table stays live and the compiler spills SGPRs into VGPR lanes (v_readlane per comparison).
+// NB: the bin count as a compile-time constant (1..8, one instantiation each): the edge comparisons unroll to exactly
+// NB - 1 per feature and only the edges in use occupy SGPRs.  With a run-time count every slot of the 4 x 9 edge
+// table stays live and the compiler spills SGPRs into VGPR lanes (a v_readlane per comparison: +40 % time).
 template <typename CT, int NCH, int NB>
 __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
@@ -408,13 +408,19 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
     int chunks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
     if (chunks > 4) chunks = 0; // streaming kernel
+#define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
+    SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
+              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
-    if (nbn == 5) {                                                                                                    \
-        SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, 5>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,         \
-                  nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k);                              \
-    } else {                                                                                                           \
-        SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, 0>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,         \
-                  nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k);                              \
+    switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
+    case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
+    case 2: { SF_SPFH_NB(CT, NCH, 2); } break;                                                                         \
+    case 3: { SF_SPFH_NB(CT, NCH, 3); } break;                                                                         \
+    case 4: { SF_SPFH_NB(CT, NCH, 4); } break;                                                                         \
+    case 5: { SF_SPFH_NB(CT, NCH, 5); } break;                                                                         \
+    case 6: { SF_SPFH_NB(CT, NCH, 6); } break;                                                                         \
+    case 7: { SF_SPFH_NB(CT, NCH, 7); } break;                                                                         \
+    default: { SF_SPFH_NB(CT, NCH, 8); } break;                                                                        \
     }
 #define SF_SPFH_DISPATCH(CT)                                     \
     switch (chunks) {                                            \
@@ -431,6 +437,7 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     }
 #undef SF_SPFH_DISPATCH
 #undef SF_SPFH_LAUNCH
+#undef SF_SPFH_NB
     return SF_OK;
 }
 
