@@ -603,3 +603,53 @@ def test_config1_plumbing_case_through_a_ply_file(eng, tmp_path):
     assert np.array_equal(points, p) and np.abs(normals[:200] - g["normals_head"]).max() < 1e-9
     f = compute_fpfh_descriptor(g["kp_idx"], points, normals, radius=float(g["radius"]), n_bins=5, verbose=False)
     assert close(f, g["fpfh"]).all() and np.abs(f - g["fpfh"]).max() < 1e-9
+
+
+def test_pipeline_stage_methods_other_choices(eng):
+    """RegistrationPipeline with the non-default choices: density keypoints, FPFH descriptors, threshold matching,
+    RANSAC, point-to-point ICP, metrics; stage caching and the error paths of the dispatchers."""
+    from shot_fpfh_amd import compute_normals
+    from shot_fpfh_amd.core import RigidTransform
+    from shot_fpfh_amd.pipeline import RegistrationPipeline
+
+    g = load_golden("icp_3500.npz")
+    scan, ref = g["scan"], g["ref"]
+    scan_normals = compute_normals(scan, scan, k=20)
+    pipe = RegistrationPipeline(scan=scan, scan_normals=scan_normals, ref=ref, ref_normals=g["ref_normals"])
+    with pytest.raises(ValueError):
+        pipe.select_keypoints("nope")
+    pipe.select_keypoints("subsampling_with_density", neighborhood_size=0.06, min_n_neighbors=3)
+    kept = pipe.scan_keypoints.copy()
+    pipe.select_keypoints("random", proportion_picked=0.1)  # cached: a second call changes nothing ...
+    assert np.array_equal(pipe.scan_keypoints, kept)
+    pipe.select_keypoints("iterative", neighborhood_size=0.05, force_recompute=True)  # ... unless forced
+    assert pipe.scan_keypoints.shape[0] > 50 and pipe.ref_keypoints.shape[0] > 50
+    with pytest.raises(ValueError):
+        pipe.compute_descriptors(0.2, descriptor_choice="nope")
+    pipe.compute_descriptors(0.2, descriptor_choice="fpfh", fpfh_n_bins=4, disable_progress_bars=True, verbose=False)
+    assert pipe.scan_descriptors.shape == (pipe.scan_keypoints.shape[0], 64)
+    with pytest.raises(ValueError):
+        pipe.find_descriptors_matches("nope", reject_threshold=0.8, threshold_multiplier=10)
+    pipe.find_descriptors_matches("threshold", reject_threshold=0.8, threshold_multiplier=10, debug_mode=True)
+    assert pipe.matches[0].shape == pipe.matches[1].shape and pipe.matches[0].shape[0] > 20
+    tf, ratio = pipe.run_ransac(n_draws=1500, draw_size=4, max_inliers_distance=0.03, disable_progress_bar=True,
+                                exact_transformation=RigidTransform(g["true_rotation"], g["true_translation"]))
+    assert 0.0 < ratio <= 1.0
+    with pytest.raises(ValueError):
+        pipe.run_icp("nope", tf, d_max=0.05)
+    tf_icp, rms, converged = pipe.run_icp("point_to_point", tf, d_max=0.05, voxel_size=0.04, max_iter=40, rms_threshold=1e-9)
+    # a smooth height field lets point-to-point ICP slide a little: it must land near the generating motion and
+    # must not be worse than the RANSAC start it was given
+    from shot_fpfh_amd.icp import compute_point_to_point_error
+
+    assert np.abs(tf_icp.rotation - g["true_rotation"]).max() < 5e-2 and np.abs(tf_icp.translation - g["true_translation"]).max() < 5e-2
+    assert compute_point_to_point_error(scan, ref, tf_icp)[0] <= compute_point_to_point_error(scan, ref, tf)[0] + 1e-12
+    overlap, kp_ratio = pipe.compute_metrics_post_icp(tf_icp, 0.02)
+    assert overlap > 0.9 and 0.0 <= kp_ratio <= 1.0
+    # SHOT variants through the dispatcher (bi-scale needs the subsampled support, as in the reference)
+    pipe.compute_descriptors(0.1, descriptor_choice="shot_bi_scale", phi=2.0, rho=10.0, min_neighborhood_size=10,
+                             disable_progress_bars=True, verbose=False, force_recompute=True)
+    assert pipe.scan_descriptors.shape[1] == 352
+    pipe.compute_descriptors(0.1, descriptor_choice="shot_multiscale", phi=2.0, n_scales=2, min_neighborhood_size=10,
+                             disable_progress_bars=True, verbose=False, force_recompute=True)
+    assert pipe.scan_descriptors.shape[1] == 704
