@@ -3,9 +3,10 @@
 // Replaces: compute_normals / pca        pca_based_descriptors.py:15-59   (K3)
 //           get_local_rf                 shot.py:16-48                     (K4)
 //           compute_single_shot_descriptor  shot.py:175-306                (K5)
-// Mapping: one wave per query point; the wave walks the query's CSR neighbour list (search.hip) 64
-// neighbours at a time, gathering cell-sorted SoA xyz / normals (L2-resident: consecutive queries
-// share cells).  All bin-deciding arithmetic is float64 with FMA contraction off.
+// Mapping: K5 one wave per keypoint (the wave holds the whole neighbourhood, 64 neighbours per register
+// chunk); K3 / K4 one 16-lane DPP row per query, four queries per wave.  Lists are the CSR of sorted
+// positions written by search.hip; neighbours are gathered from the cell-sorted AoS records (L2-resident:
+// consecutive queries share cells).  All bin-deciding arithmetic is float64 with FMA contraction off.
 // HBM roofline, algorithmic bytes: K3 24 B in + 24 B out per query; K4 24 + 72; K5 writes the
 // 352 x 8 = 2816 B descriptor row + 24 B keypoint + 72 B frame per keypoint.
 #include "common.h"
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
 // S7 -> elevation bin 0].  Sweep 1 elects winners with 64-bit LDS atomicMax on the bit pattern of rho
 // (positive doubles order like unsigned integers); sweep 2 lets each winner overwrite its slot with its
 // value, tagged by the sign bit (all values are >= 0) so that later lanes cannot mistake it for a key.
-// One wave per keypoint, 14 KB of LDS per wave.
+// One wave per keypoint; this streaming form keeps all five tables in LDS (14 KB per wave) and serves lists of
+// any length -- the register-cached form below (5.5 KB, two phases) takes every list of at most 256 points.
 // --------------------------------------------------------------------------------------------------
 #define SHOT_PI 3.141592653589793
 
