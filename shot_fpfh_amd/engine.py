@@ -61,6 +61,16 @@ class DeviceArray:
         _ffi.check(self.engine.lib.sf_d2h(self.engine.h, _ptr(out), self.ptr, self.nbytes), "sf_d2h")
         return out
 
+    def rows_to_host(self, first: int, count: int) -> np.ndarray:
+        """Rows [first, first + count) of a 2-D (or longer) array, without copying the rest."""
+        if not (0 <= first and count >= 0 and first + count <= self.shape[0]):
+            raise ValueError("row range outside the array")
+        row_bytes = self.nbytes // max(self.shape[0], 1)
+        out = np.empty((count,) + self.shape[1:], dtype=self.dtype)
+        if count:
+            _ffi.check(self.engine.lib.sf_d2h(self.engine.h, _ptr(out), self.offset_ptr(first * row_bytes), count * row_bytes), "sf_d2h")
+        return out
+
     def from_host(self, a: np.ndarray) -> "DeviceArray":
         a = np.ascontiguousarray(a, dtype=self.dtype)
         if a.nbytes != self.nbytes:

@@ -653,3 +653,45 @@ def test_pipeline_stage_methods_other_choices(eng):
     pipe.compute_descriptors(0.1, descriptor_choice="shot_multiscale", phi=2.0, n_scales=2, min_neighborhood_size=10,
                              disable_progress_bars=True, verbose=False, force_recompute=True)
     assert pipe.scan_descriptors.shape[1] == 704
+
+
+def test_config_c3_full_size_properties(eng, O):
+    """BASELINE config 3 at its full size (1M points, every point a keypoint, r = 0.03, FPFH + SHOT), checked
+    through properties that do not need a CPU run of the whole cloud:
+      * a 1/50 shard computed through the block grid build equals the same rows of the unsharded run, bit for bit;
+      * every SHOT row has unit norm (all neighbourhoods exceed min_neighborhood_size here);
+      * a sample of SHOT rows of that shard equals the oracle's (which searches the full 1M cloud for them);
+      * the neighbour relation is symmetric: sum_i sum_{j in N(i)} j == sum_i i |N(i)| over the shard's halo-free
+        interior is replaced by the stronger per-list check on a sample: j in N(i) => i in N(j)."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    n, r = 1_000_000, 0.03
+    p, nr, rng = synth_cloud(n, 3)
+    full = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10)
+    full.step()
+    world, rank = 50, 17
+    part = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=rank)
+    part.step()
+    b, e = part.plan.block()
+    assert e - b == n // world
+    shot_part, fpfh_part = part.shot_out.to_host(), part.fpfh_out.to_host()
+    assert np.array_equal(shot_part, full.shot_out.rows_to_host(b, e - b))
+    assert np.array_equal(fpfh_part, full.fpfh_out.rows_to_host(b, e - b))
+    assert np.abs(np.linalg.norm(shot_part, axis=1) - 1.0).max() < 1e-12
+    assert np.isfinite(fpfh_part).all() and (fpfh_part >= 0).all() and fpfh_part.sum(axis=1).min() > 0
+    rows = part.block_original_indices()
+    assert np.array_equal(rows, full.block_original_indices()[b:e])
+    pick = rng.choice(e - b, 300, replace=False)
+    shot_o = O.shot_single_scale(p, nr, p[rows[pick]], r, normalize=True, min_neighborhood_size=10)
+    assert close(shot_part[pick], shot_o).all() and np.abs(shot_part[pick] - shot_o).max() < 1e-9
+    # symmetry of the radius search at full size, on lists exported for a sample of the shard
+    cloud = eng.cloud(p)
+    q_idx = rows[pick[:60]]
+    off, idx = cloud.radius_search(p[q_idx], r).export()
+    nbr = np.unique(idx)
+    off2, idx2 = cloud.radius_search(p[nbr], r).export()
+    back = {int(j): set(idx2[off2[t]:off2[t + 1]].tolist()) for t, j in enumerate(nbr)}
+    for t, i in enumerate(q_idx):
+        assert all(int(i) in back[int(j)] for j in idx[off[t]:off[t + 1]])
+    part.close()
+    full.close()
