@@ -695,3 +695,34 @@ def test_config_c3_full_size_properties(eng, O):
         assert all(int(i) in back[int(j)] for j in idx[off[t]:off[t + 1]])
     part.close()
     full.close()
+
+
+def test_clustered_cloud_overflows_the_optimistic_slots(eng, O):
+    """A cloud whose density varies by two orders of magnitude: the mean-density slot capacity of the single-pass
+    search is exceeded inside the cluster, so the exact count -> scan -> fill scheme runs; lists, normals, SHOT
+    and FPFH must still be the oracle's (K5 / K6 / K7 take their streaming variants for the long lists)."""
+    from shot_fpfh_amd import ShotMultiprocessor, compute_fpfh_descriptor
+
+    rng = np.random.default_rng(81)
+    sparse = rng.random((6000, 3), dtype=np.float32).astype(np.float64)
+    dense = (0.5 + 0.02 * rng.standard_normal((3000, 3))).astype(np.float32).astype(np.float64)
+    p = np.vstack([sparse, dense])
+    nr = rng.standard_normal(p.shape)
+    nr /= np.linalg.norm(nr, axis=1)[:, None]
+    r = 0.06
+    cloud = eng.cloud(p)
+    q = np.vstack([p[rng.choice(9000, 300, replace=False)], p[6000:6050]])
+    nb = cloud.radius_search(q, r)
+    off, idx = nb.export()
+    off_o, idx_o = O.radius_search(p, q, r)
+    assert np.array_equal(off, off_o) and np.array_equal(idx, idx_o)
+    counts = np.diff(off)
+    assert counts.max() > 1500 and np.median(counts) < 50  # slots sized for the mean cannot hold the cluster's lists
+    kp = np.concatenate([rng.choice(6000, 80, replace=False), 6000 + rng.choice(3000, 40, replace=False)])
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=5, verbose=False, disable_progress_bar=True) as sm:
+        shot = sm.compute_descriptor_single_scale(point_cloud=p, keypoints=p[kp], normals=nr, radius=r)
+    shot_o = O.shot_single_scale(p, nr, p[kp], r, normalize=True, min_neighborhood_size=5)
+    assert close(shot, shot_o).all()
+    f = compute_fpfh_descriptor(kp, p, nr, radius=r, n_bins=5, verbose=False)
+    f_o = O.compute_fpfh_descriptor(kp, p, nr, r, 5)
+    assert close(f, f_o).all()
