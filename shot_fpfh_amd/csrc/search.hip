@@ -86,36 +86,72 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
     int total = 0;
     const int64_t out = MODE == 1 ? offset[q] : q * (int64_t)cap;
     const int room = MODE == 2 ? cap : 0x7fffffff;
-    for (int cz = z0; cz <= z1; ++cz)
-        for (int cy = y0; cy <= y1; ++cy) {
-            const int64_t row = ((int64_t)cz * g.dim[1] + cy) * g.dim[0];
-            const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
-            // pairs start at an EVEN position so that every 16-byte load is naturally aligned (the arrays
-            // are 256-byte aligned); the element before the run, if any, is masked out by `j >= s`
-            for (int j0 = s & ~1; j0 < e; j0 += 128) {
-                const int j = j0 + 2 * lane;
-                const bool in0 = j >= s && j < e, in1 = j + 1 < e;
-                const int jj = j < e ? j : j0; // unconditional loads (the arrays carry two padding elements)
-                const double2 X = *reinterpret_cast<const double2 *>(xs + jj);
-                const double2 Y = *reinterpret_cast<const double2 *>(ys + jj);
-                const double2 Z = *reinterpret_cast<const double2 *>(zs + jj);
-                const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
-                const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
-                // both distances are evaluated unconditionally (bitwise &): a short-circuit would let the compiler
-                // sink half of each 16-byte load into a branch and split it into two 8-byte loads
-                const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
-                const bool hit0 = in0 & (d2a <= r2);
-                const bool hit1 = in1 & (d2b <= r2);
-                const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-                if (MODE != 0) {
-                    const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
-                    if (hit0 && pos < room) idx[out + pos] = j;
-                    const int pos1 = pos + (hit0 ? 1 : 0);
-                    if (hit1 && pos1 < room) idx[out + pos1] = j + 1;
-                }
-                total += __popcll(m0) + __popcll(m1);
-            }
+    // The stencil is up to 9 runs of consecutive positions, one per (cz, cy) row of cells, ~80 candidates each at
+    // C3.  Swept run by run, 128 candidates per step, a step is barely half full; so the runs are laid end to end
+    // in units of candidate PAIRS (a pair = one even-aligned 16-byte load) and every step takes the next 64 pairs,
+    // whichever runs they fall in: ~6 full steps instead of ~10 partial ones.  Everything a lane needs to find its
+    // pair is vector work -- lanes 0..8 each describe one run, a DPP scan gives the runs' first pair slots, the
+    // eight interior boundaries go to SGPRs once per query -- because the scalar unit is shared by the whole CU
+    // and per-step scalar bookkeeping is what sank an earlier packed variant.
+    __shared__ int4 runs[4][12];
+    int4 *const tab = runs[threadIdx.x >> 6];
+    int first_slot = 0; // lane r < 9: first pair slot of run r; lane 8 + 1 ... : total
+    {
+        const int r = lane < 9 ? lane : 8;
+        const int cz = z0 + r / 3, cy = y0 + r % 3;
+        const bool ok = lane < 9 && cz <= z1 && cy <= y1;
+        const int64_t row = ((int64_t)(ok ? cz : z0) * g.dim[1] + (ok ? cy : y0)) * g.dim[0];
+        int s = 0, e = 0;
+        if (lane < 9) {
+            s = cell_start[row + x0];
+            e = cell_start[row + x1 + 1];
         }
+        if (!ok) { s = 0; e = 0; }
+        const int base = s & ~1; // pairs start at an EVEN position: every 16-byte load is naturally aligned
+        const int npairs = (e - base + 1) >> 1;
+        // inclusive scan of npairs over lanes 0..15 (row_shr DPP steps), then exclusive = inclusive - own
+        int inc = npairs;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false); // row_shr:1
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false); // row_shr:2
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false); // row_shr:4
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false); // row_shr:8
+        first_slot = inc - npairs;
+        if (lane < 9) tab[lane] = make_int4(base - 2 * first_slot, s, e, 0); // j = .x + 2 * slot
+        if (lane == 9) tab[9] = make_int4(0, 0, 0, 0);
+    }
+    // boundaries between runs (first slot of runs 1..8) and the number of pair slots, as scalars
+    const int b1 = __builtin_amdgcn_readlane(first_slot, 1), b2 = __builtin_amdgcn_readlane(first_slot, 2);
+    const int b3 = __builtin_amdgcn_readlane(first_slot, 3), b4 = __builtin_amdgcn_readlane(first_slot, 4);
+    const int b5 = __builtin_amdgcn_readlane(first_slot, 5), b6 = __builtin_amdgcn_readlane(first_slot, 6);
+    const int b7 = __builtin_amdgcn_readlane(first_slot, 7), b8 = __builtin_amdgcn_readlane(first_slot, 8);
+    const int nslots = __builtin_amdgcn_readlane(first_slot, 9); // lane 9 has npairs = 0: its exclusive sum is the total
+    __builtin_amdgcn_wave_barrier(); // the table is written and read by this wave only
+    for (int f0 = 0; f0 < nslots; f0 += 64) {
+        const int f = f0 + lane;
+        const int r = (f >= b1) + (f >= b2) + (f >= b3) + (f >= b4) + (f >= b5) + (f >= b6) + (f >= b7) + (f >= b8);
+        const int4 t = tab[r];
+        const bool live = f < nslots;
+        const int j = live ? t.x + 2 * f : 0; // idle lanes of the last step load pair 0 (always there)
+        const bool in0 = live & (j >= t.y), in1 = live & (j + 1 < t.z);
+        const double2 X = *reinterpret_cast<const double2 *>(xs + j);
+        const double2 Y = *reinterpret_cast<const double2 *>(ys + j);
+        const double2 Z = *reinterpret_cast<const double2 *>(zs + j);
+        const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
+        const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
+        // both distances are evaluated unconditionally (bitwise &): a short-circuit would let the compiler
+        // sink half of each 16-byte load into a branch and split it into two 8-byte loads
+        const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
+        const bool hit0 = in0 & (d2a <= r2);
+        const bool hit1 = in1 & (d2b <= r2);
+        const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+        if (MODE != 0) {
+            const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
+            if (hit0 && pos < room) idx[out + pos] = j;
+            const int pos1 = pos + (hit0 ? 1 : 0);
+            if (hit1 && pos1 < room) idx[out + pos1] = j + 1;
+        }
+        total += __popcll(m0) + __popcll(m1);
+    }
     if (lane == 0) {
         if (MODE != 1) count[q] = total;
         if (MODE == 2) {

@@ -726,3 +726,21 @@ def test_clustered_cloud_overflows_the_optimistic_slots(eng, O):
     f = compute_fpfh_descriptor(kp, p, nr, radius=r, n_bins=5, verbose=False)
     f_o = O.compute_fpfh_descriptor(kp, p, nr, r, 5)
     assert close(f, f_o).all()
+
+
+def test_rccl_communicator_single_rank(eng):
+    """The exchange layer on the one GPU a test box has: RCCL initialises a 1-rank communicator through the C ABI,
+    the in-place all-gather of a 1-rank job leaves the buffer as it is, and a second init on the same context is
+    refused.  (The N-rank data path is covered on CPU by tests/test_multi_gpu_gloo.py.)"""
+    import shot_fpfh_amd as s
+
+    e2 = s.Engine(0)
+    uid = e2.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    e2.comm_init(uid, 1, 0)
+    a = e2.empty((4, 8)).from_host(np.arange(32.0).reshape(4, 8))
+    e2.allgather(a, a.nbytes)
+    assert np.array_equal(a.to_host(), np.arange(32.0).reshape(4, 8))
+    with pytest.raises(s.ShotFpfhError):
+        e2.comm_init(uid, 1, 0)
+    a.free()
