@@ -116,19 +116,21 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false); // row_shr:4
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false); // row_shr:8
         first_slot = inc - npairs;
-        if (lane < 9) tab[lane] = make_int4(base - 2 * first_slot, s, e, 0); // j = .x + 2 * slot
-        if (lane == 9) tab[9] = make_int4(0, 0, 0, 0);
+        if (lane < 12) tab[lane] = make_int4(base - 2 * first_slot, s, e, first_slot); // j = .x + 2 * slot; .w: first slot
     }
-    // boundaries between runs (first slot of runs 1..8) and the number of pair slots, as scalars
-    const int b1 = __builtin_amdgcn_readlane(first_slot, 1), b2 = __builtin_amdgcn_readlane(first_slot, 2);
-    const int b3 = __builtin_amdgcn_readlane(first_slot, 3), b4 = __builtin_amdgcn_readlane(first_slot, 4);
-    const int b5 = __builtin_amdgcn_readlane(first_slot, 5), b6 = __builtin_amdgcn_readlane(first_slot, 6);
-    const int b7 = __builtin_amdgcn_readlane(first_slot, 7), b8 = __builtin_amdgcn_readlane(first_slot, 8);
+    // two of the boundaries between runs and the number of pair slots, as scalars
+    const int b4 = __builtin_amdgcn_readlane(first_slot, 4), b8 = __builtin_amdgcn_readlane(first_slot, 8);
     const int nslots = __builtin_amdgcn_readlane(first_slot, 9); // lane 9 has npairs = 0: its exclusive sum is the total
     __builtin_amdgcn_wave_barrier(); // the table is written and read by this wave only
     for (int f0 = 0; f0 < nslots; f0 += 64) {
         const int f = f0 + lane;
-        const int r = (f >= b1) + (f >= b2) + (f >= b3) + (f >= b4) + (f >= b5) + (f >= b6) + (f >= b7) + (f >= b8);
+        // run of slot f = last run whose first slot is <= f: a three-level binary search, the first level against a
+        // scalar, the other two against the first-slot column of the table in LDS (an LDS read costs the vector
+        // pipe one instruction; eight compare-and-add pairs cost it sixteen and more)
+        int r = f >= b4 ? 4 : 0;
+        r += f >= tab[r + 2].w ? 2 : 0;
+        r += f >= tab[r + 1].w ? 1 : 0;
+        r = f >= b8 ? 8 : r;
         const int4 t = tab[r];
         const bool live = f < nslots;
         const int j = live ? t.x + 2 * f : 0; // idle lanes of the last step load pair 0 (always there)
