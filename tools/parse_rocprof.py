@@ -20,7 +20,8 @@ SHORT = [
     ("k_spfh", "k6_spfh"), ("k_radius<2>", "k2_radius_slots"), ("k_radius<1>", "k2_radius_fill"), ("k_radius<0>", "k2_radius_count"),
     ("k_radius<true>", "k2_radius_fill"), ("k_radius<false>", "k2_radius_count"), ("k_export_lists", "k2_export_lists"),
     ("k_radius", "k2_radius"), ("k_normals", "k3_normals"), ("k_match_tile", "k8_match_tile"), ("k_ransac", "k9_ransac_score"),
-    ("k_gather_sorted", "k1_gather_sorted"), ("k_cell_ids", "k1_cell_ids"), ("k_cell_start", "k1_cell_start"),
+    ("k_gather_sorted", "k1_gather_sorted"), ("k_gather_normals", "k1_gather_normals"), ("k_count_stats", "k2_reduce"),
+    ("k_layer_hist", "k1_layer_hist"), ("k_gather_i32", "k1_select_slab"), ("k_lrf_eigen", "k4_lrf_eigen"), ("k_pca", "k3_pca"), ("k_cell_ids", "k1_cell_ids"), ("k_cell_start", "k1_cell_start"),
     ("k_bbox", "k1_bbox"), ("radix_sort", "rocprim_radix_sort"), ("merge_sort", "rocprim_radix_sort"),
     ("scan", "rocprim_scan"), ("reduce", "rocprim_reduce"), ("copyBuffer", "hip_copy"), ("fillBuffer", "hip_fill"),
 ]
