@@ -167,7 +167,8 @@ struct sf_spfh {
     int n_bins = 0;
     int nb3 = 0;
     int stride = 0;      // elements per row (padded)
-    int elem_bytes = 2;  // 2 = uint16 counts, 4 = uint32 counts
+    int elem_bytes = 2;  // 1 = biased uint8 counts (matrix-core K7), 2 = uint16 counts, 4 = uint32 counts
+    int bias = 0;        // stored value = count ^ bias (128 for the uint8 table: the byte read as int8 is count - 128)
     void *counts = nullptr; // n x stride, by sorted position
     int32_t *k = nullptr;   // n, neighbourhood size (self included), by sorted position
 };

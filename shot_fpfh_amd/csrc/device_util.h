@@ -57,6 +57,26 @@ __device__ inline double sf_wave_sum(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// Maximum of non-negative values over the 64 lanes (same DPP ladder; rows that receive nothing keep max(v, 0)).
+__device__ inline double sf_wave_max_nonneg(double v)
+{
+#define SF_DPP_MAX(ctrl, row_mask)                                                                              \
+    {                                                                                                           \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, row_mask, 0xf, false);           \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, row_mask, 0xf, false);           \
+        v = fmax(v, __hiloint2double(hi, lo));                                                                  \
+    }
+    SF_DPP_MAX(0xB1, 0xf)
+    SF_DPP_MAX(0x4E, 0xf)
+    SF_DPP_MAX(0x141, 0xf)
+    SF_DPP_MAX(0x140, 0xf)
+    SF_DPP_MAX(0x142, 0xa)
+    SF_DPP_MAX(0x143, 0xc)
+#undef SF_DPP_MAX
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 // Sum over each 16-lane DPP row, result in every lane of the row (the first four steps of sf_wave_sum).
 __device__ inline double sf_row16_sum(double v)
 {

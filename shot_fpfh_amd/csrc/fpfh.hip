@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
-                                              CT *__restrict__ counts, int32_t *__restrict__ kout)
+                                              CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[4][SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     CT *row = counts + i * (int64_t)stride;
-    for (int b = lane; b < stride; b += 64) row[b] = b < nb3 ? (CT)h[b] : (CT)0;
+    for (int b = lane; b < stride; b += 64) row[b] = (CT)((b < nb3 ? h[b] : 0u) ^ bias); // (padding bins: count 0)
     if (lane == 0) kout[i] = k;
 }
 
@@ -320,15 +320,198 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// K7 on the matrix cores (uint8 table: at most 128 bins, neighbourhoods of at most 255 points).
+//
+// fpfh[q][b] - spfh[q][b] = (1/k_q) sum_j w_j c_jb is, per keypoint, the product of a 1 x k row of weights with
+// the k x 128 matrix of its neighbours' integer bin counts.  Done on the vector ALU it costs three instructions
+// per count (extract, convert, FMA).  Here the weights are turned into 63-bit fixed point (scaled by the
+// keypoint's largest weight) and cut into nine 7-bit limbs, and  R[limb][bin] = sum_j limb_j * (c_jb - 128)  is
+// accumulated EXACTLY in int32 by v_mfma_i32_16x16x64_i8: A = limbs x 64 neighbours, B = 64 neighbours x 16 bins,
+// the counts going from the table to the matrix unit as the bytes they are (the table stores count ^ 128, which
+// read as int8 is count - 128; a padding bin holds -128, so its column is -128 * sum_j limb_j and cancels the bias).
+// The sums are recombined in float64 once per keypoint:  sum_j w_j c_jb = 2^-S sum_i 2^(7i) (R[i][b] - R[i][pad]).
+// The only rounding is in the fixed-point weights (2^-62 of the largest one) and in that final recombination.
+//
+// One wave per keypoint, 64 neighbours per step.  Layouts (tools/ubench: probed on the device): operand lane l
+// holds row / column l % 16 and the 16 consecutive k of block l / 16, one per byte; the result lane holds column
+// l % 16 and rows 4 (l / 16) .. + 3.  Per step the 64 rows (128 B each) are staged in LDS with 16-byte loads; lane
+// (a, kb) then reads, for its 16 neighbours, the dword holding bins 4a .. 4a+3 (of the lower, then the upper 64
+// bins), and four 4x4 byte transposes (v_perm_b32) turn them into the B operands of four MFMAs whose column a is
+// bin 4a + q.  The k order inside a block is rotated by 4 kb so that the four blocks hit different LDS banks.
+// --------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tr4x4(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned &t0, unsigned &t1,
+                                      unsigned &t2, unsigned &t3)
+{
+    // v_perm_b32(hi, lo, sel): selector byte 0..3 picks a byte of lo, 4..7 of hi
+    const unsigned a = __builtin_amdgcn_perm(d1, d0, 0x05010400u); // d0.0 d1.0 d0.1 d1.1
+    const unsigned b = __builtin_amdgcn_perm(d1, d0, 0x07030602u); // d0.2 d1.2 d0.3 d1.3
+    const unsigned c = __builtin_amdgcn_perm(d3, d2, 0x05010400u);
+    const unsigned e = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+    t0 = __builtin_amdgcn_perm(c, a, 0x05040100u); // d0.0 d1.0 d2.0 d3.0
+    t1 = __builtin_amdgcn_perm(c, a, 0x07060302u); // d0.1 d1.1 d2.1 d3.1
+    t2 = __builtin_amdgcn_perm(e, b, 0x05040100u);
+    t3 = __builtin_amdgcn_perm(e, b, 0x07060302u);
+}
+
+#define SF_MC_PITCH 36 // dwords per staged row (144 B: 16-byte aligned rows)
+
+template <int NKS>
+__global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                                 const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                 int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
+                                                 int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
+                                                 const int32_t *__restrict__ kk, double *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[4][64 * SF_MC_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char abuf_all[4][9 * 64];
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    unsigned *const rowbuf = rowbuf_all[wv_id];
+    unsigned char *const abuf = abuf_all[wv_id];
+    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + wv_id);
+    if (q >= m) return;
+    const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
+    const int64_t slot = i - nbrs_begin;
+    const int64_t s = offset[slot];
+    const int k = cnt[slot];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
+    const int a = lane & 15, kb = lane >> 4;
+
+    // ---- weights of all neighbours (lane t of step ks <-> neighbour 64 ks + t), as in the vector kernel ----
+    int jv[NKS];
+    double wv[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const int t = c * 64 + lane;
+        jv[c] = t < k ? idx[s + t] : -1;
+    }
+    double gx[NKS], gy[NKS], gz[NKS];
+    int gk[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const int j = jv[c] < 0 ? 0 : jv[c];
+        sf_load_xyz(rec, j, gx[c], gy[c], gz[c]);
+        gk[c] = kk[j];
+    }
+    double wmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
+        const double d2 = (cx * cx + cy * cy) + cz * cz;
+        const double kd = (double)gk[c], xx = d2 * (kd * kd);
+        const double y0 = __builtin_amdgcn_rsq(xx);
+        const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+        const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+        wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0; // 1 / (k_j d_j); d == 0 is masked out (fpfh.py:110-114)
+        jv[c] = jv[c] < 0 ? 0 : jv[c];
+        wmax = fmax(wmax, wv[c]);
+    }
+    wmax = sf_wave_max_nonneg(wmax);
+    // fixed point: W = floor(w 2^S) < 2^63 with S = 62 - floor(log2 wmax)
+    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
+    const int S = 62 - e2;
+
+    v4i acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[h][qq] = v4i{0, 0, 0, 0};
+
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks * 64 < k) { // wave-uniform
+            // ---- stage the 64 rows of this step in LDS (8 x 16 bytes per lane) ----
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = lane + 64 * u, r = p >> 3, c = p & 7;
+                const int jr = __shfl(jv[ks], r);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)jr * 128u + (unsigned)c * 16u, 0, 0);
+                *reinterpret_cast<uint4 *>(&rowbuf[r * SF_MC_PITCH + 4 * c]) = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+            // ---- this lane's weight as nine 7-bit limbs, written where the A operand's lanes will read them ----
+            {
+                const double x = ldexp(wv[ks], S - 32); // < 2^31
+                const unsigned hi = (unsigned)x;
+                const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
+                const int pos = 16 * kb + ((a - 4 * kb) & 15); // k slot of neighbour (kb, a) after the bank rotation
+                abuf[0 * 64 + pos] = (unsigned char)(lo & 127u);
+                abuf[1 * 64 + pos] = (unsigned char)((lo >> 7) & 127u);
+                abuf[2 * 64 + pos] = (unsigned char)((lo >> 14) & 127u);
+                abuf[3 * 64 + pos] = (unsigned char)((lo >> 21) & 127u);
+                abuf[4 * 64 + pos] = (unsigned char)(((lo >> 28) | (hi << 4)) & 127u);
+                abuf[5 * 64 + pos] = (unsigned char)((hi >> 3) & 127u);
+                abuf[6 * 64 + pos] = (unsigned char)((hi >> 10) & 127u);
+                abuf[7 * 64 + pos] = (unsigned char)((hi >> 17) & 127u);
+                abuf[8 * 64 + pos] = (unsigned char)((hi >> 24) & 127u);
+            }
+            __builtin_amdgcn_wave_barrier(); // both buffers are private to the wave; LDS operations of a wave stay in order
+            v4i A = v4i{0, 0, 0, 0};
+            if (a < 9) A = *reinterpret_cast<const v4i *>(&abuf[a * 64 + 16 * kb]); // row a = limb a
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned d[16];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) d[b] = rowbuf[(16 * kb + ((b + 4 * kb) & 15)) * SF_MC_PITCH + 16 * h + a];
+                unsigned t[4][4]; // t[g][qq]: bin 4a + qq of neighbours 4g .. 4g+3
+#pragma unroll
+                for (int g = 0; g < 4; ++g) tr4x4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3], t[g][0], t[g][1], t[g][2], t[g][3]);
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const v4i B = v4i{(int)t[0][qq], (int)t[1][qq], (int)t[2][qq], (int)t[3][qq]};
+                    acc[h][qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[h][qq], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- recombination: lane (a, g) holds rows (limbs) 4g .. 4g+3 of column a; bin = 64 h + 4 a + qq ----
+    int rpad[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[1][3][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of (h=1, qq=3) = bin 127
+    const double p0 = ldexp(1.0, 28 * kb - S); // 2^(7 (4 g) - S)
+    const double f0 = p0, f1 = p0 * 128.0, f2 = p0 * 16384.0, f3 = p0 * 2097152.0;
+    const double kd = (double)k;
+    double inv_k = __builtin_amdgcn_rcp(kd);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    double vsel0 = 0.0, vsel1 = 0.0; // the two bins this lane writes: h = kb >> 1, qq = 2 (kb & 1) + {0, 1}
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            double v = (double)(acc[h][qq][0] - rpad[0]) * f0;
+            v = __builtin_fma((double)(acc[h][qq][1] - rpad[1]), f1, v);
+            v = __builtin_fma((double)(acc[h][qq][2] - rpad[2]), f2, v);
+            v = __builtin_fma((double)(acc[h][qq][3] - rpad[3]), f3, v);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (h == (kb >> 1) && (qq >> 1) == (kb & 1)) {
+                if (qq & 1) vsel1 = v; else vsel0 = v;
+            }
+        }
+    {
+        const int h = kb >> 1, q0 = 2 * (kb & 1);
+        const int b0 = 64 * h + 4 * a + q0;
+        const uint8_t *own = counts + i * 128;
+        double *o = out + q * (int64_t)nb3;
+        if (b0 < nb3) o[b0] = (double)((unsigned)own[b0] ^ 128u) / kd + vsel0 * inv_k;
+        if (b0 + 1 < nb3) o[b0 + 1] = (double)((unsigned)own[b0 + 1] ^ 128u) / kd + vsel1 * inv_k;
+    }
+}
+
 template <typename CT>
 __global__ void k_spfh_export(const CT *__restrict__ counts, const int32_t *__restrict__ kk,
-                              const int32_t *__restrict__ perm, int64_t n, int nb3, int stride, double *__restrict__ out)
+                              const int32_t *__restrict__ perm, int64_t n, int nb3, int stride, unsigned bias,
+                              double *__restrict__ out)
 {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n * nb3) return;
     int64_t i = g / nb3;
     int b = (int)(g - i * nb3);
-    out[(int64_t)perm[i] * nb3 + b] = (double)counts[i * stride + b] / (double)kk[i];
+    out[(int64_t)perm[i] * nb3 + b] = (double)((unsigned)counts[i * stride + b] ^ bias) / (double)kk[i];
 }
 
 __global__ void k_map_positions(const int64_t *__restrict__ kp_idx, const int32_t *__restrict__ inv_perm, int64_t m,
@@ -356,7 +539,10 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     sp->n = c->n;
     sp->n_bins = n_bins;
     sp->nb3 = n_bins * n_bins * n_bins;
-    sp->elem_bytes = max_count > 65535 ? 4 : 2;
+    // neighbourhoods of at most 255 points and at most 128 bins: one BYTE per bin, biased by 128 (a 128-byte row the
+    // matrix-core K7 consumes as int8); else uint16, uint32 beyond 65535
+    sp->elem_bytes = (max_count <= 255 && sp->nb3 <= 128) ? 1 : (max_count > 65535 ? 4 : 2);
+    sp->bias = sp->elem_bytes == 1 ? 128 : 0;
     // rows padded to a multiple of 128 elements: lane l of a wave owns elements 2l, 2l+1 of each 128-element
     // slice, so no lane of the K7 row loads ever falls outside its row (256 B rows for 125 uint16 bins)
     sp->stride = 128; // ... and to a power of two, so that a row is 256 B, 512 B, 1 KiB or 2 KiB (the K7 row shapes)
@@ -388,6 +574,11 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     if (!ctx || !c || !nb || !sp || !edges) { sf_set_error("sf_spfh_compute: null argument"); return SF_ERR_ARG; }
     if (!nb->self) { sf_set_error("sf_spfh_compute: needs a sf_radius_search_self result"); return SF_ERR_ARG; }
     if (sp->n != c->n || nb->self_begin + nb->m > sp->n) { sf_set_error("sf_spfh_compute: table/cloud size mismatch"); return SF_ERR_ARG; }
+    if (sp->elem_bytes == 1 && nb->max_count > 255) {
+        sf_set_error("sf_spfh_compute: neighbourhood of %lld points needs a wider table (pass max_count to sf_spfh_create)",
+                     (long long)nb->max_count);
+        return SF_ERR_ARG;
+    }
     if (sp->elem_bytes == 2 && nb->max_count > 65535) {
         sf_set_error("sf_spfh_compute: neighbourhood of %lld points needs a 32-bit table (pass max_count to sf_spfh_create)",
                      (long long)nb->max_count);
@@ -410,7 +601,7 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
-              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k)
+              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
@@ -430,7 +621,9 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     case 4: { SF_SPFH_LAUNCH(CT, 4); } break;                    \
     default: { SF_SPFH_LAUNCH(CT, 0); } break;                   \
     }
-    if (sp->elem_bytes == 2) {
+    if (sp->elem_bytes == 1) {
+        SF_SPFH_DISPATCH(uint8_t)
+    } else if (sp->elem_bytes == 2) {
         SF_SPFH_DISPATCH(uint16_t)
     } else {
         SF_SPFH_DISPATCH(uint32_t)
@@ -472,12 +665,15 @@ extern "C" int sf_spfh_export(sf_ctx *ctx, sf_cloud *c, sf_spfh *sp, double *out
     }
     if (tot) {
         const dim3 grid((unsigned)sf_div_up(tot, 256)), block(256);
-        if (sp->elem_bytes == 2) {
+        if (sp->elem_bytes == 1) {
+            SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint8_t>, grid, block, (const uint8_t *)sp->counts, sp->k,
+                      c->perm, n, sp->nb3, sp->stride, (unsigned)sp->bias, dout);
+        } else if (sp->elem_bytes == 2) {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint16_t>, grid, block, (const uint16_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, dout);
+                      c->perm, n, sp->nb3, sp->stride, 0u, dout);
         } else {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint32_t>, grid, block, (const uint32_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, dout);
+                      c->perm, n, sp->nb3, sp->stride, 0u, dout);
         }
     }
     if (owned) {
@@ -528,6 +724,27 @@ static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
     return SF_OK;
 }
 
+static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const int32_t *kp_pos, int64_t m, double *dout)
+{
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
+    const size_t tb = (size_t)sp->rows_alloc * 128;
+    if (tb >= ((size_t)1 << 32) || sp->stride != 128 || nb->max_count > 255) {
+        sf_set_error("sf_fpfh: uint8 SPFH table of %zu bytes / lists of %lld points outside the matrix-core kernel's range", tb,
+                     (long long)nb->max_count);
+        return SF_ERR_UNSUPPORTED;
+    }
+    const int nks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+#define SF_MC_LAUNCH(NKS)                                                                                            \
+    SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc<NKS>, grid, block, c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, \
+              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, sp->k, dout)
+    if (nks <= 1) { SF_MC_LAUNCH(1); }
+    else if (nks == 2) { SF_MC_LAUNCH(2); }
+    else if (nks == 3) { SF_MC_LAUNCH(3); }
+    else { SF_MC_LAUNCH(4); }
+#undef SF_MC_LAUNCH
+    return SF_OK;
+}
+
 extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const int64_t *kp_idx, int64_t m, double *out,
                        int flags)
 {
@@ -572,8 +789,9 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
         dout = owned;
     }
     int rc = SF_OK;
-    if (m) rc = sp->elem_bytes == 2 ? launch_fpfh<uint16_t>(ctx, c, nb, sp, pos, m, dout)
-                                    : launch_fpfh<uint32_t>(ctx, c, nb, sp, pos, m, dout);
+    if (m) rc = sp->elem_bytes == 1   ? launch_fpfh_mc(ctx, c, nb, sp, pos, m, dout)
+                : sp->elem_bytes == 2 ? launch_fpfh<uint16_t>(ctx, c, nb, sp, pos, m, dout)
+                                      : launch_fpfh<uint32_t>(ctx, c, nb, sp, pos, m, dout);
     if (rc == SF_OK && owned) {
         if (tot) SF_HIP(hipMemcpyAsync(out, owned, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }

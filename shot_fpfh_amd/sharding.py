@@ -86,11 +86,11 @@ class DescriptorJob:
         self.lrf_out: Optional[DeviceArray] = engine.empty((m, 9)) if do_shot else None
         self.shot_out: Optional[DeviceArray] = engine.empty((m, 352)) if do_shot else None
         self.spfh: Optional[Spfh] = None
-        self._spfh_wide = False
+        self._spfh_wide = -1
         self.last_pairs = 0
 
     def _spfh_table(self, max_count: int) -> Spfh:
-        wide = max_count > 65535
+        wide = 0 if (max_count <= 255 and self.n_bins**3 <= 128) else (2 if max_count > 65535 else 1)  # table kind
         if self.spfh is None or wide != self._spfh_wide:
             if self.spfh is not None:
                 self.spfh.free()
