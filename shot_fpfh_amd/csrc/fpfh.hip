@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
 // l % 16 and rows 4 (l / 16) .. + 3.  Per step the 64 rows (128 B each) are staged in LDS with 16-byte loads; lane
 // (a, kb) then reads, for its 16 neighbours, the dword holding bins 4a .. 4a+3 (of the lower, then the upper 64
 // bins), and four 4x4 byte transposes (v_perm_b32) turn them into the B operands of four MFMAs whose column a is
-// bin 4a + q.  The k order inside a block is rotated by 4 kb so that the four blocks hit different LDS banks.
+// bin 4a + q.  Every block of 16 staged rows is skewed by 8 dwords so that the four k blocks of a read hit
+// different LDS banks (two lanes per bank: the minimum for 64 x 4 bytes).
 // --------------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -357,6 +358,7 @@ __device__ __forceinline__ void tr4x4(unsigned d0, unsigned d1, unsigned d2, uns
 }
 
 #define SF_MC_PITCH 36 // dwords per staged row (144 B: 16-byte aligned rows)
+#define SF_MC_SKEW 8   // extra dwords in front of every block of 16 rows: the four k blocks of a read hit different banks
 
 template <int NKS>
 __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const int32_t *__restrict__ kk, double *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[4][64 * SF_MC_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[4][64 * SF_MC_PITCH + 4 * SF_MC_SKEW];
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[4][9 * 64];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     unsigned *const rowbuf = rowbuf_all[wv_id];
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
     const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
     const int S = 62 - e2;
 
+    const int rd_base = 16 * kb * SF_MC_PITCH + kb * SF_MC_SKEW + a; // row 16 kb, dword a of this lane's reads
     v4i acc[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -429,14 +432,14 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
                 const int p = lane + 64 * u, r = p >> 3, c = p & 7;
                 const int jr = __shfl(jv[ks], r);
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)jr * 128u + (unsigned)c * 16u, 0, 0);
-                *reinterpret_cast<uint4 *>(&rowbuf[r * SF_MC_PITCH + 4 * c]) = make_uint4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint4 *>(&rowbuf[r * SF_MC_PITCH + (r >> 4) * SF_MC_SKEW + 4 * c]) = make_uint4(v[0], v[1], v[2], v[3]);
             }
             // ---- this lane's weight as nine 7-bit limbs, written where the A operand's lanes will read them ----
             {
                 const double x = ldexp(wv[ks], S - 32); // < 2^31
                 const unsigned hi = (unsigned)x;
                 const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
-                const int pos = 16 * kb + ((a - 4 * kb) & 15); // k slot of neighbour (kb, a) after the bank rotation
+                const int pos = lane; // k slot of this lane's neighbour: block kb, byte a
                 abuf[0 * 64 + pos] = (unsigned char)(lo & 127u);
                 abuf[1 * 64 + pos] = (unsigned char)((lo >> 7) & 127u);
                 abuf[2 * 64 + pos] = (unsigned char)((lo >> 14) & 127u);
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
             for (int h = 0; h < 2; ++h) {
                 unsigned d[16];
 #pragma unroll
-                for (int b = 0; b < 16; ++b) d[b] = rowbuf[(16 * kb + ((b + 4 * kb) & 15)) * SF_MC_PITCH + 16 * h + a];
+                for (int b = 0; b < 16; ++b) d[b] = rowbuf[rd_base + b * SF_MC_PITCH + 16 * h]; // constant offsets off one register
                 unsigned t[4][4]; // t[g][qq]: bin 4a + qq of neighbours 4g .. 4g+3
 #pragma unroll
                 for (int g = 0; g < 4; ++g) tr4x4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3], t[g][0], t[g][1], t[g][2], t[g][3]);
@@ -477,7 +480,8 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
     double inv_k = __builtin_amdgcn_rcp(kd);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
-    double vsel0 = 0.0, vsel1 = 0.0; // the two bins this lane writes: h = kb >> 1, qq = 2 (kb & 1) + {0, 1}
+    // partial sums over this lane's four limbs, for its eight bins (h, qq)
+    double part[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -485,13 +489,19 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
             double v = (double)(acc[h][qq][0] - rpad[0]) * f0;
             v = __builtin_fma((double)(acc[h][qq][1] - rpad[1]), f1, v);
             v = __builtin_fma((double)(acc[h][qq][2] - rpad[2]), f2, v);
-            v = __builtin_fma((double)(acc[h][qq][3] - rpad[3]), f3, v);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (h == (kb >> 1) && (qq >> 1) == (kb & 1)) {
-                if (qq & 1) vsel1 = v; else vsel0 = v;
-            }
+            part[h][qq] = __builtin_fma((double)(acc[h][qq][3] - rpad[3]), f3, v);
         }
+    // sum over the four limb groups g = kb, transposing as we go: after the exchange with lane ^ 32 a lane keeps only
+    // the half h = kb >> 1, after the one with lane ^ 16 only the pair qq = 2 (kb & 1) + {0, 1} -- the two bins it writes
+    const bool up = (kb >> 1) != 0, odd = (kb & 1) != 0;
+    double keep[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const double mine = up ? part[1][qq] : part[0][qq], send = up ? part[0][qq] : part[1][qq];
+        keep[qq] = mine + __shfl_xor(send, 32);
+    }
+    const double vsel0 = (odd ? keep[2] : keep[0]) + __shfl_xor(odd ? keep[0] : keep[2], 16);
+    const double vsel1 = (odd ? keep[3] : keep[1]) + __shfl_xor(odd ? keep[1] : keep[3], 16);
     {
         const int h = kb >> 1, q0 = 2 * (kb & 1);
         const int b0 = 64 * h + 4 * a + q0;
