@@ -162,7 +162,9 @@ int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int normal
  * given either as original indices kp_idx (m; needs lists of the whole cloud) or, when kp_idx == NULL,
  * for every query of `self_nbrs` in cell-sorted order (m must equal its query count; with a
  * sf_nbrs_slice view this is how a shard reduces only its own block).
- * sf_spfh_export writes the float64 SPFH table (n x n_bins^3, original numbering). */
+ * sf_spfh_export writes the float64 SPFH table (n x n_bins^3, original numbering).
+ * max_count (the largest neighbourhood the table will see, sf_nbrs_max_count) picks the storage of the integer
+ * bin counts: bytes up to 255 points (and n_bins <= 5), 16 bits up to 65535, 32 bits beyond. */
 sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_count);
 int sf_spfh_compute(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const double *edges);
 int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *spfh, int64_t rows_per_rank); /* RCCL, in place */

@@ -6,12 +6,14 @@
 //       np.histogramdd over (-1,1) x (-1,1) x (-pi/2,pi/2) with np.linspace edges -- samples outside
 //       any range are DROPPED while the normaliser stays k = len(neighbourhood), self included.
 //   K7  fpfh.py:101-116 fpfh[kp] = spfh[kp] + (sum_{j in nbrs(kp), d_j > 0} spfh[j] / d_j) / k_kp.
-// Data layout in HBM: the SPFH table is kept as INTEGER bin counts (uint16, or uint32 when a
-// neighbourhood exceeds 65535) plus the per-point k, by cell-sorted position: spfh[j][b] is
-// reconstructed as (double)count/k exactly as the reference computed it, but a row costs 256 B instead
-// of 1000 B in the K7 gather, which is that kernel's dominant traffic (k x row per keypoint).
-// Mapping: one wave per point.  K6 bins with per-wave LDS atomics; K7 puts two bins on each lane and
-// streams the neighbour rows (one coalesced 256-B load per neighbour).
+// Data layout in HBM: the SPFH table is kept as INTEGER bin counts plus the per-point k, by cell-sorted
+// position -- uint8 (stored as count ^ 128) when no neighbourhood exceeds 255 points and there are at most
+// 128 bins, else uint16, or uint32 when a neighbourhood exceeds 65535.  spfh[j][b] is reconstructed as
+// (double)count/k exactly as the reference computed it, but a row costs 128 / 256 B instead of 1000 B in
+// the K7 gather (k x row per keypoint).
+// Mapping: one wave per point.  K6 bins with per-wave LDS atomics.  K7 on the uint8 table is an exact
+// int8 matrix-core contraction (k_fpfh_mc); on the wider tables it streams the neighbour rows through the
+// vector ALU, eight bins per lane (k_fpfh).
 // HBM roofline, algorithmic bytes (float64 API widths): 48 in + 1000 SPFH write + 1000 SPFH
 // read + 1000 FPFH write = 3048 B per descriptor when every point is a keypoint.
 #include <algorithm>
