@@ -744,3 +744,31 @@ def test_rccl_communicator_single_rank(eng):
     with pytest.raises(s.ShotFpfhError):
         e2.comm_init(uid, 1, 0)
     a.free()
+
+
+@pytest.mark.parametrize("n,r,kmin", [(6000, 0.105, 192), (4000, 0.12, 128), (3000, 0.1, 64)])
+def test_fpfh_matrix_core_path_with_peaked_histograms(eng, O, n, r, kmin):
+    """The uint8 SPFH table / int8 matrix-core K7 at its limits: neighbourhoods of 130-250 points (three and four
+    64-neighbour steps) on a nearly flat patch with nearly parallel normals, so that single bins collect more than
+    127 pairs -- the stored byte count ^ 128 is then positive as int8 and the padding-bin bias correction has to
+    hold.  FPFH and the exported SPFH against the oracle."""
+    from shot_fpfh_amd import compute_fpfh_descriptor
+
+    rng = np.random.default_rng(91)
+    xy = rng.random((n, 2), dtype=np.float32).astype(np.float64)
+    p = np.column_stack([xy, (0.002 * rng.standard_normal(n)).astype(np.float32).astype(np.float64)])
+    nr = np.column_stack([0.02 * rng.standard_normal((n, 2)), np.ones(n)])
+    nr /= np.linalg.norm(nr, axis=1)[:, None]
+    cloud = eng.cloud(p, nr)
+    nb = cloud.radius_search_self(r)
+    assert kmin < nb.max_count <= 255  # two, three and four 64-neighbour steps
+    sp = eng.spfh(cloud, 5, nb.max_count)
+    sp.compute(nb)
+    spfh = sp.export()
+    kp = np.sort(rng.choice(n, 400, replace=False))
+    f_o, spfh_o = O.compute_fpfh_descriptor(kp, p, nr, r, 5, return_spfh=True)
+    assert np.array_equal(spfh, spfh_o)  # integer counts / k: bit-exact
+    peak = (spfh * nb.counts()[np.argsort(cloud.perm())][:, None]).max()
+    assert peak > 127.5 or kmin < 128  # some bin really holds > 127 pairs
+    f = compute_fpfh_descriptor(kp, p, nr, radius=r, n_bins=5, verbose=False)
+    assert close(f, f_o).all() and np.abs(f - f_o).max() < 1e-9 * max(1.0, np.abs(f_o).max())
