@@ -271,11 +271,18 @@ __global__ __launch_bounds__(256, 2) void k_match_gemm(const double *__restrict_
 // sequential float64 sum (one lane per row, exactly scipy's loop).  Undecided rows are flagged.
 __global__ void k_match_decide(const double *__restrict__ a, int64_t m1, const double *__restrict__ b, int64_t d,
                                const double *__restrict__ pm1, const int64_t *__restrict__ pj1,
-                               const double *__restrict__ pm2, int nsplit, double nb_max, int64_t *__restrict__ idx,
+                               const double *__restrict__ pm2, int nsplit, double nb_max,
+                               const unsigned char *__restrict__ a_ok, int64_t *__restrict__ idx,
                                double *__restrict__ dist, int *__restrict__ flag, int *__restrict__ n_flagged)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m1) return;
+    if (a_ok && !a_ok[i]) { // masked scan row: +inf from everything, first column (the exact kernel's answer)
+        idx[i] = 0;
+        if (dist) dist[i] = INFINITY;
+        flag[i] = 0;
+        return;
+    }
     double bm1 = pm1[i], bm2 = pm2[i];
     int64_t bj = pj1[i];
     for (int s = 1; s < nsplit; ++s) {
@@ -320,7 +327,7 @@ __global__ void k_scatter_results(const int64_t *__restrict__ rows, int64_t nr, 
 } // namespace
 
 // Row arg-min of cdist(a, b) with the exact kernel's result; returns the number of rows that needed the slow path.
-int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
+int sf_match_gemm_f64(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
                   double *ddist, const char *name, int64_t *n_slow, const unsigned char *a_ok, const unsigned char *b_ok)
 {
     if (n_slow) *n_slow = 0;
@@ -359,8 +366,8 @@ int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     double nb_max = 0.0;
     for (double v : hpart) nb_max = std::max(nb_max, v);
     SF_LAUNCH(ctx, "k8_match_decide", k_match_decide, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), da, m1, db, d,
-              (const double *)pm1, (const int64_t *)pj1, (const double *)pm2, (int)nsplit, nb_max, didx, ddist, flag,
-              nflag);
+              (const double *)pm1, (const int64_t *)pj1, (const double *)pm2, (int)nsplit, nb_max, a_ok, didx, ddist,
+              flag, nflag);
     int nf = 0;
     SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
@@ -396,4 +403,24 @@ int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     sf_pool_release(ctx, nb); sf_pool_release(ctx, part); sf_pool_release(ctx, pm1); sf_pool_release(ctx, pm2);
     sf_pool_release(ctx, pj1); sf_pool_release(ctx, flag); sf_pool_release(ctx, nflag);
     return rc;
+}
+
+int sf_match_half_mode(); // match_half.hip
+int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
+                  double *ddist, const char *name, int64_t *n_slow, const unsigned char *a_ok, const unsigned char *b_ok,
+                  int *used);
+
+// The matrix-core paths: FP16 pre-filter + float64 decision (match_half.hip) when the problem is large enough to
+// pay for the conversion passes, the FP64 GEMM otherwise.  Same result either way.
+int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
+                  double *ddist, const char *name, int64_t *n_slow, const unsigned char *a_ok, const unsigned char *b_ok)
+{
+    const int mode = sf_match_half_mode();
+    const double work = (double)m1 * (double)m2 * (double)d;
+    if (mode == 1 || (mode < 0 && work >= 2e10 && m1 >= 2048)) {
+        int used = 0;
+        const int rc = sf_match_half(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_half", n_slow, a_ok, b_ok, &used);
+        if (rc != SF_OK || used) return rc;
+    }
+    return sf_match_gemm_f64(ctx, da, m1, db, m2, d, didx, ddist, name, n_slow, a_ok, b_ok);
 }

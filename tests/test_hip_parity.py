@@ -385,6 +385,86 @@ def test_match_gemm_fast_path_equals_exact(eng, O):
     assert rep.get("k8_match_gemm", (0, 0))[0] >= 1, "the GEMM path was expected to run for this size"
 
 
+def _half_cases():
+    rng = np.random.default_rng(831)
+    # (a) SHOT-like: sparse unit rows, scan = perturbed reference rows, exact duplicates, an equidistant pair, zero rows
+    m1, m2, d = 1500, 1700, 352
+    b = rng.random((m2, d)) * (rng.random((m2, d)) < 0.3)
+    b /= np.maximum(np.linalg.norm(b, axis=1)[:, None], 1e-300)
+    a = b[rng.integers(0, m2, m1)] + 1e-3 * rng.standard_normal((m1, d))
+    b[1200] = b[17]; b[1201] = b[17]; a[5] = b[17]
+    a[6] = 0.5 * (b[40] + b[41])
+    a[7] = 0.0
+    b[9] = 0.0
+    yield "shot_like", a, b
+    # (b) FPFH-like: 125 columns of percentages (short K: the 8-step instantiation), many near-equal rows
+    m1, m2, d = 2500, 2600, 125
+    b = rng.random((m2, d)) ** 4 * 100.0
+    b[100:400] = b[100] + 1e-4 * rng.standard_normal((300, d))  # 300 columns within the FP16 window of each other
+    a = b[rng.integers(0, m2, m1)] + 0.05 * rng.standard_normal((m1, d))
+    yield "fpfh_like", a, b
+    # (c) odd length, rows spanning twelve orders of magnitude in norm
+    m1, m2, d = 4200, 4100, 33
+    b = rng.standard_normal((m2, d)) * 10.0 ** rng.integers(-6, 6, (m2, 1))
+    a = rng.standard_normal((m1, d)) * 10.0 ** rng.integers(-6, 6, (m1, 1))
+    a[:500] = b[rng.integers(0, m2, 500)] * (1 + 1e-9)
+    yield "wide_range", a, b
+    # (d) adversarial order: every later column is nearer than all earlier ones for every scan row, so each
+    # column tile lowers every threshold and the candidate lists overflow -> float64 path for those rows
+    m1, m2, d = 1300, 1500, 352
+    u = rng.random(d); u /= np.linalg.norm(u)
+    b = np.linspace(0.2, 0.9, m2)[:, None] * u[None, :] + 1e-7 * rng.standard_normal((m2, d))
+    a = (1.0 + 0.1 * rng.random((m1, 1))) * u[None, :] + 1e-7 * rng.standard_normal((m1, d))
+    yield "descending", a, b
+
+
+@pytest.mark.parametrize("case", ["shot_like", "fpfh_like", "wide_range", "descending"])
+def test_match_half_prefilter_equals_exact(eng, O, monkeypatch, case):
+    """The FP16 matrix-core pre-filter (match_half.hip) only prunes: index AND distance must equal scipy's / the exact
+    kernel's bit for bit on ties, near ties, zero rows, short / odd descriptor lengths, extreme norms and an
+    order that overflows every candidate list."""
+    a, b = next((a, b) for name, a, b in _half_cases() if name == case)
+    monkeypatch.setenv("SF_MATCH_HALF", "1")
+    eng.profile_reset()
+    eng.profile(True)
+    idx, dist, col = eng.match_argmin(a, b, want_col=True)
+    eng.profile(False)
+    rep = eng.profile_report()
+    io, do, co = O.match_argmin(a, b, want_col=True)
+    assert np.array_equal(idx, io) and np.array_equal(dist, do) and np.array_equal(col, co)
+    assert rep.get("k8_match_half", (0, 0))[0] == 2, "the FP16 pre-filter was expected to run for both directions"
+    overflow = rep.get("k8_match_gemm_overflow", (0, 0))[0]
+    if case == "descending":
+        assert overflow >= 1, "the adversarial order should have overflowed candidate lists"
+    if case == "shot_like":
+        assert overflow == 0, "no candidate list should overflow on ordinary data"
+
+
+def test_match_half_prefilter_masked_rows(eng, monkeypatch):
+    """Resident, masked form (zero descriptors never match and are never matched) through the pre-filter."""
+    from shot_fpfh_amd.matching import basic_matching
+    from shot_fpfh_amd.sharding import MatchJob
+
+    rng = np.random.default_rng(832)
+    a = rng.random((1500, 352)) * (rng.random((1500, 352)) < 0.3)
+    b = a[rng.permutation(1500)][:1400] + 0.01 * rng.standard_normal((1400, 352))
+    a[[3, 99, 500]] = 0.0
+    b[[7, 640]] = 0.0
+    monkeypatch.setenv("SF_MATCH_HALF", "1")
+    job = MatchJob(eng, 352, 1500, 1400)
+    eng.profile_reset()
+    eng.profile(True)
+    job.run(eng.empty((1500, 352)).from_host(a), eng.empty((1400, 352)).from_host(b))
+    eng.profile(False)
+    s1, r1 = job.matches()
+    dist = job.dist.to_host()
+    s2, r2 = basic_matching(a, b)
+    assert np.array_equal(s1, s2) and np.array_equal(r1, r2)
+    assert np.isinf(dist[[3, 99, 500]]).all() and np.isfinite(np.delete(dist, [3, 99, 500])).all()
+    assert eng.profile_report().get("k8_match_half", (0, 0))[0] >= 1
+    job.close()
+
+
 # ---- less travelled paths ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nb", [1, 2, 7, 8])
 def test_fpfh_other_bin_counts_vs_oracle(O, nb):

@@ -28,3 +28,17 @@ t = time.perf_counter() - t0
 eng.profile(False)
 print(f"K8 {m1}x{m2}x{d}: {t*1e3:.2f} ms, {m1*m2/t/1e9:.2f} G pair-dists/s, {3*m1*m2*d/t/1e12:.2f} TFLOP/s (difference form)")
 print(eng.profile_report())
+if os.environ.get("SF_BENCH_COMPARE"):  # same problem through the other matrix-core path: results must be identical
+    i1, d1 = idx.to_host().copy(), dist.to_host().copy()
+    prev = os.environ.get("SF_MATCH_HALF")
+    os.environ["SF_MATCH_HALF"] = "0" if prev != "0" else "1"
+    eng.profile_reset()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    eng.match_argmin_device(da, db, idx, dist)
+    eng.sync()
+    t2 = time.perf_counter() - t0
+    eng.profile(False)
+    print(f"other path (SF_MATCH_HALF={os.environ['SF_MATCH_HALF']}): {t2*1e3:.2f} ms; identical idx {np.array_equal(i1, idx.to_host())}, "
+          f"identical dist {np.array_equal(d1, dist.to_host())}")
+    print(eng.profile_report())
