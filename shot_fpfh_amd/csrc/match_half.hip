@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_half_convert(const double *__restrict__
                                                       int dp, double scale, const unsigned char *__restrict__ ok,
                                                       _Float16 *__restrict__ out, double *__restrict__ err,
                                                       double *__restrict__ qn, double *__restrict__ n2,
-                                                      float *__restrict__ n2f)
+                                                      float *__restrict__ n2f, double n2f_scale)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_half_convert(const double *__restrict__
         qn[i] = real ? sqrt(sq) : 0.0;
         n2[i] = real ? sn : 0.0;
         if (n2f) { // +inf keeps masked / padding columns out of every candidate list; rounded to nearest otherwise
-            n2f[i] = masked ? INFINITY : (float)sn;
+            n2f[i] = masked ? INFINITY : (float)(sn * n2f_scale); // power-of-two scale: one rounding
         }
     }
 }
@@ -106,14 +106,16 @@ __global__ void k_half_max(const double *__restrict__ v, int64_t n, double *__re
 // W_i of the header, rounded up to float; rows beyond m get 0 (their thresholds start at -inf and never move)
 __global__ void k_half_window(const double *__restrict__ ea, const double *__restrict__ qa, const double *__restrict__ na2,
                               int64_t m, int64_t m_pad, double bmax, double ebmax, double qbmax, double nbmax,
-                              double gamma, float *__restrict__ win)
+                              double gamma, double unit, float *__restrict__ win)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m_pad) return;
     if (i >= m) { win[i] = 0.0f; return; }
-    const double eps = 2.0 * (ea[i] * bmax + qa[i] * ebmax + gamma * qa[i] * qbmax) * (1.0 + 1e-6) + 1e-12 * (na2[i] + nbmax);
+    // the accumulator starts at the threshold (|T| <= nbmax + 2 qa qbmax + W), hence the second gamma term
+    const double eps = (2.0 * (ea[i] * bmax + qa[i] * ebmax + gamma * qa[i] * qbmax) + gamma * (nbmax + 4.0 * qa[i] * qbmax)) *
+                           (1.0 + 1e-6) + 1e-12 * (na2[i] + nbmax);
     const double eta = 1.1920928955078125e-07 * (nbmax + 2.0 * qa[i] * qbmax); // 2^-23 (|key| terms)
-    const double w = (2.0 * eps + 8.0 * eta) * (1.0 + 1e-6);
+    const double w = (2.0 * eps + 12.0 * eta) * (1.0 + 1e-6) * unit; // in accumulator units (unit = 1 / 2s)
     float wf = (float)w;
     if ((double)wf < w) wf = nextafterf(wf, INFINITY);
     win[i] = wf;
@@ -126,23 +128,30 @@ __device__ __forceinline__ float dpp_f32(float v)
 }
 
 // The pass.  ah: m1_pad x DP (m1_pad a multiple of 256), bh: m2_pad x DP (m2_pad a multiple of 64), row-major FP16.
-// LDS: two column tiles of 64 x (DP + 8) halfs; the 16-byte pad makes the fragment read (32 lanes = 32 columns,
-// 16 bytes each, pitch = 4 (mod 64) banks... see PITCH below) conflict-free.
+// All keys, thresholds and windows are in "accumulator units": divided by 2s = 2 / (scale_a scale_b), a power of
+// two, so that  key(i, j) = nbs_j - dot  with dot the raw MFMA result and nbs_j = ||b_j||^2 / 2s.
+// Epilogue: a warm row's accumulator STARTS at its threshold T_i (the C operand of the first MFMA), so after the
+// K loop it holds T_i + dot and  key <= T_i  <=>  acc >= nbs_j : the test is a max over the lane's 16 rows and
+// one compare per column block.  Rows without any finite key yet (T = +inf: "cold", normally the first tile
+// only) start from 0 and always take the slow path.
+// LDS: two column tiles, filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  A
+// DMA instruction writes its 64 lanes' 16-byte chunks back to back, so the image is lane-linear: 64 columns x PC
+// chunk slots (PC = chunks per row rounded up to 16; 768-byte rows for d <= 352).  The bank spread comes from the
+// SOURCE side instead: slot p of column col holds chunk p ^ (col & 15), so the 16 lanes of a fragment read
+// (same chunk, 16 consecutive columns, pitch = 0 mod 64 banks) hit 16 different slots = all 64 banks once.
 template <int KS>
 __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restrict__ ah, int64_t m1,
                                                         const _Float16 *__restrict__ bh, int64_t m2_pad,
-                                                        const float *__restrict__ nbf, const float *__restrict__ win,
-                                                        float two_s, int *__restrict__ cnt,
-                                                        int32_t *__restrict__ cand_j, float *__restrict__ cand_k,
-                                                        float *__restrict__ thr_out)
+                                                        const float *__restrict__ nbs, const float *__restrict__ win,
+                                                        int *__restrict__ cnt, int32_t *__restrict__ cand_j,
+                                                        float *__restrict__ cand_k, float *__restrict__ thr_out)
 {
     constexpr int DP = 16 * KS;
-    // pitch in halfs: (DP + 8) * 2 bytes = 4 * (8 KS + 4) -> 8 KS + 4 dwords, = 52 (mod 64) for KS = 22 and = 4 for
-    // KS = 8: 16 consecutive columns x 4 dwords land on 64 distinct banks either way
-    constexpr int PITCH = DP + 8;
-    constexpr int NCHUNK = HN * DP / 8;               // 16-byte chunks of one tile
-    constexpr int NST = (NCHUNK + 511) / 512;         // staging rounds per thread
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][HN * PITCH];
+    constexpr int CPR = 2 * KS;                  // 16-byte chunks per row
+    constexpr int PC = (CPR + 15) / 16 * 16;     // chunk slots per row in LDS
+    constexpr int NI = PC / 8;                   // DMA instructions per wave per tile (64 PC slots / 64 lanes / 8 waves)
+    constexpr int TILE_BYTES = HN * PC * 16 + 256; // + the tile's 64 column norms (floats), DMA'd like the rest
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * HM + 32 * wave;
@@ -152,72 +161,124 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
         const _Float16 *ap = ah + (row0 + r31) * DP + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const h8 *>(ap + 16 * ks);
+        // have the fragments land here, once: otherwise every k-step of the main loop carries a vmcnt wait for
+        // "its" fragment, which would also drain the DMA of the next tile in the middle of the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(af[ks]));
     }
     // thresholds of the 16 rows this lane sees in an accumulator: row (r & 3) + 8 (r >> 2) + 4 h
-    float thr[16];
+    f16v T;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) thr[r] = (row0 + (r & 3) + 8 * (r >> 2) + 4 * h) < m1 ? INFINITY : -INFINITY;
+    for (int r = 0; r < 16; ++r) T[r] = (row0 + (r & 3) + 8 * (r >> 2) + 4 * h) < m1 ? INFINITY : -INFINITY;
+    bool cold = row0 < m1; // wave-uniform: some real row still has T = +inf
+    f16v zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+
+    // DMA source offsets (bytes inside a tile of bh) of this lane's NI slots; slots whose chunk index falls into
+    // the row padding (>= CPR) are never read: they fetch chunk 0 of their column
+    unsigned soff[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int P = 64 * (wave + 8 * u) + lane, col = P / PC, p = P - col * PC;
+        int c = p ^ (col & 15);
+        if (c >= CPR) c = 0;
+        soff[u] = (unsigned)(col * (CPR * 16) + c * 16);
+    }
+    // fragment read addresses: column r31 (+32 for the second block), chunk 2 ks + h -> slot (2 ks + h) ^ (r31 & 15);
+    // the low nibble of 2 ks + h takes 8 values per lane, the rest is an immediate offset
+    unsigned roff[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) roff[k] = (unsigned)(r31 * (PC * 16) + (((2 * k + h) ^ (r31 & 15)) * 16));
 
     const int64_t ntiles = m2_pad / HN;
-    // staging registers (plain variables and macros: a lambda-captured array is demoted to LDS by the compiler)
-    uint4 st0, st1, st2, st3, st4, st5;
-    st0 = st1 = st2 = st3 = st4 = st5 = make_uint4(0, 0, 0, 0);
-#define SF_H_FETCH1(U, V)                                                                  \
-    if ((U) < NST) {                                                                       \
-        const int q = tid + 512 * (U);                                                     \
-        if (NCHUNK % 512 == 0 || q < NCHUNK) V = src_[q];                                  \
+    const unsigned char *bbytes = reinterpret_cast<const unsigned char *>(bh);
+    // The DMA is issued from inline assembly: the compiler then does not know about it and puts no vmcnt(0) in
+    // front of the fragment reads of the OTHER buffer (it cannot tell the two halves of Bs apart); completion is
+    // waited for explicitly before the barrier that publishes the tile.  M0 = LDS destination (wave-uniform).
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)Bs;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+#define SF_H_DMA16(GPTR, LDS_DST)                                                                                   \
+    {                                                                                                               \
+        unsigned keep_;                                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"       \
+                     "s_mov_b32 m0, %0"                                                                             \
+                     : "=&s"(keep_)                                                                                 \
+                     : "v"(GPTR), "s"(LDS_DST)                                                                      \
+                     : "memory");                                                                                   \
     }
-#define SF_H_FETCH(JT)                                                                     \
-    {                                                                                      \
-        const uint4 *src_ = reinterpret_cast<const uint4 *>(bh + (JT) * HN * DP);          \
-        SF_H_FETCH1(0, st0) SF_H_FETCH1(1, st1) SF_H_FETCH1(2, st2) SF_H_FETCH1(3, st3)    \
-        SF_H_FETCH1(4, st4) SF_H_FETCH1(5, st5)                                            \
+#define SF_H_DMA4(GPTR, LDS_DST)                                                                                    \
+    {                                                                                                               \
+        unsigned keep_;                                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"         \
+                     "s_mov_b32 m0, %0"                                                                             \
+                     : "=&s"(keep_)                                                                                 \
+                     : "v"(GPTR), "s"(LDS_DST)                                                                      \
+                     : "memory");                                                                                   \
     }
-#define SF_H_STASH1(U, V, BUF)                                                             \
-    if ((U) < NST) {                                                                       \
-        const int q = tid + 512 * (U);                                                     \
-        if (NCHUNK % 512 == 0 || q < NCHUNK) {                                             \
-            const int col = q / (2 * KS), c16 = q - col * (2 * KS);                        \
-            *reinterpret_cast<uint4 *>(&Bs[BUF][col * PITCH + 8 * c16]) = V;               \
-        }                                                                                  \
+#define SF_H_DMA(JT, BUF)                                                                                           \
+    {                                                                                                               \
+        const unsigned char *tile_ = bbytes + (JT) * (int64_t)(HN * DP * 2);                                        \
+        const unsigned dst_ = lds_base + (unsigned)(BUF) * TILE_BYTES + 1024u * wave_u;                             \
+        _Pragma("unroll") for (int u = 0; u < NI; ++u) SF_H_DMA16(tile_ + soff[u], dst_ + 8192u * u)                \
+        if (wave_u == 0) SF_H_DMA4(nbs + (JT) * HN + lane, lds_base + (unsigned)(BUF) * TILE_BYTES + HN * PC * 16)  \
     }
-#define SF_H_STASH(BUF)                                                                    \
-    {                                                                                      \
-        SF_H_STASH1(0, st0, BUF) SF_H_STASH1(1, st1, BUF) SF_H_STASH1(2, st2, BUF)         \
-        SF_H_STASH1(3, st3, BUF) SF_H_STASH1(4, st4, BUF) SF_H_STASH1(5, st5, BUF)         \
-    }
-    static_assert(NST <= 6, "staging registers");
-    SF_H_FETCH((int64_t)0)
-    SF_H_STASH(0)
+    SF_H_DMA((int64_t)0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int64_t jt = 0; jt < ntiles; ++jt) {
         const int buf = (int)(jt & 1);
-        if (jt + 1 < ntiles) SF_H_FETCH(jt + 1)
-        f16v acc[2];
+        if (jt + 1 < ntiles) SF_H_DMA(jt + 1, buf ^ 1)
+        const unsigned char *bp = Bs + buf * TILE_BYTES;
+#define SF_H_FRAG(KSTEP, CB) \
+    (*reinterpret_cast<const h8 *>(bp + roff[(KSTEP) & 7] + ((KSTEP) >> 3) * 256 + (CB) * (32 * PC * 16)))
+        // One basic block: fragments are read PF k-steps ahead of the MFMAs that use them, and the scheduler is
+        // told to keep that interleave (2 MFMA : 2 LDS reads) instead of sinking every read next to its use.
+        constexpr int PF = 3;
+        h8 q0[PF], q1[PF];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
-        const _Float16 *bp = &Bs[buf][r31 * PITCH + 8 * h];
+        for (int i = 0; i < PF; ++i) {
+            q0[i] = SF_H_FRAG(i, 0);
+            q1[i] = SF_H_FRAG(i, 1);
+        }
+        f16v acc[2];
+        acc[0] = cold ? zero : T;
+        acc[1] = acc[0];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const h8 b0 = *reinterpret_cast<const h8 *>(bp + 16 * ks);
-            const h8 b1 = *reinterpret_cast<const h8 *>(bp + 32 * PITCH + 16 * ks);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], b1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], q0[ks % PF], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], q1[ks % PF], acc[1], 0, 0, 0);
+            if (ks + PF < KS) {
+                q0[ks % PF] = SF_H_FRAG(ks + PF, 0);
+                q1[ks % PF] = SF_H_FRAG(ks + PF, 1);
+            }
         }
-        if (jt + 1 < ntiles) SF_H_STASH(buf ^ 1)
-        // epilogue: key <= thr  <=>  2s acc + thr >= ||b_j||^2 ; the fast test takes the max over the lane's 16 rows
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0); // DS reads
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); // MFMA
+            if (ks + PF < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        const float *nbl = reinterpret_cast<const float *>(bp + HN * PC * 16);
+        const float nbv2[2] = {nbl[r31], nbl[32 + r31]};
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const int64_t j = jt * HN + 32 * cb + r31;
-            const float nbv = nbf[j];
-            float mx = -INFINITY;
+            const float nbv = nbv2[cb];
+            float mx = acc[cb][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaf(acc[cb][r], two_s, thr[r]));
-            if (__ballot(mx >= nbv)) {
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[cb][r]);
+            if (cold || __ballot(mx >= nbv)) {
+                const bool was_cold = cold;
+                // rare path: keep its address arithmetic out of the loop-invariant registers of the MFMA loop
+                int rowb = (int)(row0 - (int64_t)blockIdx.x * HM) + 4 * h;
+                asm volatile("" : "+v"(rowb));
+                const int64_t rowbase = (int64_t)blockIdx.x * HM + rowb;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float key = fmaf(-two_s, acc[cb][r], nbv);
-                    const bool hit = (key <= thr[r]) & (key < INFINITY);
+                    const float dot = was_cold ? acc[cb][r] : acc[cb][r] - T[r];
+                    const float key = nbv - dot;
+                    const bool hit = (key <= T[r]) & (key < INFINITY);
                     if (__ballot(hit)) {
                         float v = hit ? key : INFINITY;
                         v = fminf(v, dpp_f32<0xB1>(v));  // quad_perm [1,0,3,2]
@@ -225,9 +286,8 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
                         v = fminf(v, dpp_f32<0x141>(v)); // row_half_mirror
                         v = fminf(v, dpp_f32<0x140>(v)); // row_mirror: min of the 16-lane row in every lane
                         v = fminf(v, __shfl_xor(v, 16)); // the two DPP rows of this 32-lane half
-                        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const float tn = fminf(thr[r], v + win[row]);
-                        thr[r] = tn;
+                        const int64_t row = rowbase + (r & 3) + 8 * (r >> 2);
+                        const float tn = fminf(T[r], v + win[row]);
                         if (hit && key <= tn) {
                             const int s = atomicAdd(&cnt[row], 1);
                             if (s < HCAP) {
@@ -235,16 +295,31 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
                                 cand_k[row * HCAP + s] = key;
                             }
                         }
+                        // the second column block of this tile was accumulated from the OLD threshold: keep its
+                        // dots recoverable by moving the difference into its accumulator
+                        if (cb == 0 && !was_cold) acc[1][r] += tn - T[r];
+                        T[r] = tn;
                     }
+                }
+                if (was_cold && cb == 1) {
+                    bool c = false;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c |= T[r] == INFINITY;
+                    cold = __ballot(c) != 0;
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMA pieces of the next tile have landed
         __syncthreads();
     }
     if (r31 == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) thr_out[row0 + (r & 3) + 8 * (r >> 2) + 4 * h] = thr[r];
+        for (int r = 0; r < 16; ++r) thr_out[row0 + (r & 3) + 8 * (r >> 2) + 4 * h] = T[r];
     }
+#undef SF_H_DMA
+#undef SF_H_DMA16
+#undef SF_H_DMA4
+#undef SF_H_FRAG
 }
 
 // Step 3: the reference's arithmetic on the surviving candidates (one lane per row; scipy's loop order).
@@ -378,18 +453,21 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     {
         // ||row||^2 through the converter with scale 1 into the same buffers (overwritten below)
         SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m1p, 4)), dim3(256), da, m1, m1p, d, dp,
-                  1.0, (const unsigned char *)nullptr, ah, ea, qa, na2, (float *)nullptr);
+                  1.0, (const unsigned char *)nullptr, ah, ea, qa, na2, (float *)nullptr, 1.0);
         SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m2p, 4)), dim3(256), db, m2, m2p, d, dp,
-                  1.0, b_ok, bh, eb, qb, nb2, nbf);
+                  1.0, b_ok, bh, eb, qb, nb2, (float *)nullptr, 1.0);
         int rc = host_max(ctx, na2, m1, part, &namax);
         if (rc == SF_OK) rc = host_max(ctx, nb2, m2, part, &nbmax);
         if (rc != SF_OK) { release(); return rc; }
     }
-    if (!pick_scale(namax, &sa) || !pick_scale(nbmax, &sb) || !(nbmax < 1e37)) { release(); return SF_OK; }
+    if (!pick_scale(namax, &sa) || !pick_scale(nbmax, &sb)) { release(); return SF_OK; }
+    // accumulator units: 1 / 2s = sa sb / 2.  ||b||^2 / 2s ~ 2^27 ||b||max / ||a||max must stay a normal float
+    const double unit = 0.5 * sa * sb;
+    if (!(nbmax * unit < 1e30) || !(nbmax * unit > 1e-20)) { release(); return SF_OK; }
     SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m1p, 4)), dim3(256), da, m1, m1p, d, dp, sa,
-              (const unsigned char *)nullptr, ah, ea, qa, na2, (float *)nullptr);
+              (const unsigned char *)nullptr, ah, ea, qa, na2, (float *)nullptr, 1.0);
     SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m2p, 4)), dim3(256), db, m2, m2p, d, dp, sb,
-              b_ok, bh, eb, qb, nb2, nbf);
+              b_ok, bh, eb, qb, nb2, nbf, unit);
     double ebmax = 0.0, qbmax = 0.0;
     {
         int rc = host_max(ctx, eb, m2, part, &ebmax);
@@ -402,17 +480,15 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     SF_HALLOC(flag, m1); SF_HALLOC(nflag, 1);
     const double gamma = (double)(dp + 32) * 2.384185791015625e-07; // 2^-22
     SF_LAUNCH(ctx, "k8_half_window", k_half_window, dim3((unsigned)sf_div_up(m1p, 256)), dim3(256), (const double *)ea,
-              (const double *)qa, (const double *)na2, m1, m1p, std::sqrt(nbmax), ebmax, qbmax, nbmax, gamma, win);
+              (const double *)qa, (const double *)na2, m1, m1p, std::sqrt(nbmax), ebmax, qbmax, nbmax, gamma, unit, win);
     SF_HIP(hipMemsetAsync(cnt, 0, (size_t)m1p * sizeof(int), ctx->stream));
     SF_HIP(hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream));
-    const float two_s = (float)(2.0 / (sa * sb)); // a power of two
-    if (!(two_s > 0.0f) || !std::isfinite(two_s)) { release(); return SF_OK; }
     if (ks == 8) {
         SF_LAUNCH(ctx, name, k_match_half<8>, dim3((unsigned)(m1p / HM)), dim3(512), (const _Float16 *)ah, m1,
-                  (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, two_s, cnt, candj, candk, thr);
+                  (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, cnt, candj, candk, thr);
     } else {
         SF_LAUNCH(ctx, name, k_match_half<22>, dim3((unsigned)(m1p / HM)), dim3(512), (const _Float16 *)ah, m1,
-                  (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, two_s, cnt, candj, candk, thr);
+                  (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, cnt, candj, candk, thr);
     }
     SF_LAUNCH(ctx, "k8_half_final", k_half_final, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), da, m1, db, d, a_ok,
               (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, didx, ddist, flag, nflag);
