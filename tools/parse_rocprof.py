@@ -20,6 +20,9 @@ SHORT = [
     ("k_spfh", "k6_spfh"), ("k_radius<2>", "k2_radius_slots"), ("k_radius<1>", "k2_radius_fill"), ("k_radius<0>", "k2_radius_count"),
     ("k_radius<true>", "k2_radius_fill"), ("k_radius<false>", "k2_radius_count"), ("k_export_lists", "k2_export_lists"),
     ("k_radius", "k2_radius"), ("k_normals", "k3_normals"), ("k_match_tile", "k8_match_tile"), ("k_ransac", "k9_ransac_score"),
+    ("k_match_half", "k8_match_half"), ("k_half_convert", "k8_half_convert"), ("k_half_final", "k8_half_final"),
+    ("k_half_window", "k8_half_window"), ("k_half_max", "k8_half_max"), ("k_match_gemm", "k8_match_gemm"),
+    ("k_match_decide", "k8_match_decide"), ("k_row_sqnorm", "k8_row_sqnorm"),
     ("k_gather_sorted", "k1_gather_sorted"), ("k_gather_normals", "k1_gather_normals"), ("k_count_stats", "k2_reduce"),
     ("k_layer_hist", "k1_layer_hist"), ("k_gather_i32", "k1_select_slab"), ("k_lrf_eigen", "k4_lrf_eigen"), ("k_pca", "k3_pca"), ("k_cell_ids", "k1_cell_ids"), ("k_cell_start", "k1_cell_start"),
     ("k_bbox", "k1_bbox"), ("radix_sort", "rocprim_radix_sort"), ("merge_sort", "rocprim_radix_sort"),
@@ -46,6 +49,8 @@ def read_counter(path, counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    cmd = sys.argv[2] if len(sys.argv) > 2 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+    bench_run = len(sys.argv) <= 2  # only the bench profile feeds bench.py's roofline.traffic
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     stats = defaultdict(lambda: [0, 0.0])
     for row in csv.DictReader(open(os.path.join(base, "trace", "trace_kernel_stats.csv"))):
@@ -58,7 +63,7 @@ def main():
     hit = read_counter(os.path.join(base, "pmc_l2", "pmc_counter_collection.csv"), "TCC_HIT_sum")
     miss = read_counter(os.path.join(base, "pmc_l2", "pmc_counter_collection.csv"), "TCC_MISS_sum")
     lines = [f"# rocprofv3 summary `{tag}`", "",
-             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
+             f"Command: `rocprofv3 --kernel-trace --stats -- {cmd}` "
              "(+ separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc TCC_HIT_sum TCC_MISS_sum` passes).", "",
              "HBM traffic/launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md).", "",
              "| kernel | calls | avg us | % of GPU time | FETCH_SIZE KiB/launch (raw) | WRITE_SIZE KiB/launch | HBM MB/launch (corrected) | L2 hit rate |",
@@ -79,7 +84,8 @@ def main():
                      f"{'' if tb is None else f'{tb / 1e6:.1f}'} | {'' if hr is None else f'{hr:.3f}'} |")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    if bench_run:
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
