@@ -17,14 +17,16 @@
 //      ties) wins, exactly scipy's first-minimum rule.
 //
 // Exactness.  Let eps_i bound |k(i, j) - key(i, j)| over j, with key the exact ||b_j||^2 - 2 a_i . b_j:
-//     eps_i = 2 (ea_i Bmax + qa_i EBmax + gamma qa_i QBmax)        ea_i = ||a_i - a'_i||, qa_i = ||a'_i||,
-//     Bmax = max ||b_j||, EBmax = max ||b_j - b'_j||, QBmax = max ||b'_j||, gamma = (d + 32) 2^-22
-// (Cauchy-Schwarz on (a - a').b + a'.(b - b'); FP16 x FP16 products are exact in FP32, gamma covers the FP32
-// accumulation of the matrix core however it rounds).  The reference's arg-min j* has an exact key no larger
-// than that of the column j1 that set the final threshold, plus float64 rounding (1e-12 relative, folded into
-// eps).  Hence k(i, j*) <= k(i, j1) + 2 eps_i, and with W_i = 2 eps_i + 8 eta_i (eta_i: the FP32 rounding of the
-// key / threshold arithmetic in the epilogue) j* passes the threshold test at the moment it is scanned and the
-// final filter.  So the candidate set always contains the reference's arg-min and everything that ties with
+//     eps_i = 2 (ea_i Bmax + qa_i EBmax + gamma qa_i QBmax) + gamma (nbmax + 4 qa_i QBmax)
+//     ea_i = ||a_i - a'_i||, qa_i = ||a'_i||, Bmax = max ||b_j||, EBmax = max ||b_j - b'_j||, QBmax = max ||b'_j||,
+//     nbmax = Bmax^2, gamma = (d + 32) 2^-22
+// (Cauchy-Schwarz on (a - a').b + a'.(b - b'); FP16 x FP16 products are exact in FP32; gamma covers the FP32
+// accumulation of the matrix core however it rounds, the second gamma term because the accumulator starts at
+// the threshold rather than at zero).  The reference's arg-min j* has an exact key no larger than that of the
+// column j1 that set the final threshold, plus float64 rounding (1e-12 relative, folded into eps).  Hence
+// k(i, j*) <= k(i, j1) + 2 eps_i, and with W_i = 2 eps_i + 12 eta_i (eta_i: the FP32 rounding of the key /
+// threshold arithmetic in the epilogue) j* passes the threshold test at the moment it is scanned and the final
+// filter.  So the candidate set always contains the reference's arg-min and everything that ties with
 // it; step 3 then decides in the reference's arithmetic.  Rows whose list overflows (more than `cap` near-
 // minimal columns, e.g. many duplicated descriptors), or that hold non-finite values, go to the FP64 path
 // (match_gemm.hip, which has its own exact slow path).  The result equals the exact kernel's for every
@@ -143,6 +145,7 @@ template <int KS>
 __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restrict__ ah, int64_t m1,
                                                         const _Float16 *__restrict__ bh, int64_t m2_pad,
                                                         const float *__restrict__ nbs, const float *__restrict__ win,
+                                                        int64_t tiles_per_split, int64_t m1_pad,
                                                         int *__restrict__ cnt, int32_t *__restrict__ cand_j,
                                                         float *__restrict__ cand_k, float *__restrict__ thr_out)
 {
@@ -191,7 +194,14 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
 #pragma unroll
     for (int k = 0; k < 8; ++k) roff[k] = (unsigned)(r31 * (PC * 16) + (((2 * k + h) ^ (r31 & 15)) * 16));
 
-    const int64_t ntiles = m2_pad / HN;
+    // column split blockIdx.y scans its own range of tiles with its own thresholds and candidate lists (used when
+    // there are too few 256-row blocks to fill the chip); k_half_final merges the splits
+    const int64_t jt0 = (int64_t)blockIdx.y * tiles_per_split;
+    const int64_t ntiles = (m2_pad / HN < jt0 + tiles_per_split) ? m2_pad / HN : jt0 + tiles_per_split; // end tile
+    cnt += (int64_t)blockIdx.y * m1_pad;
+    cand_j += (int64_t)blockIdx.y * m1_pad * HCAP;
+    cand_k += (int64_t)blockIdx.y * m1_pad * HCAP;
+    thr_out += (int64_t)blockIdx.y * m1_pad;
     const unsigned char *bbytes = reinterpret_cast<const unsigned char *>(bh);
     // The DMA is issued from inline assembly: the compiler then does not know about it and puts no vmcnt(0) in
     // front of the fragment reads of the OTHER buffer (it cannot tell the two halves of Bs apart); completion is
@@ -223,11 +233,11 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
         _Pragma("unroll") for (int u = 0; u < NI; ++u) SF_H_DMA16(tile_ + soff[u], dst_ + 8192u * u)                \
         if (wave_u == 0) SF_H_DMA4(nbs + (JT) * HN + lane, lds_base + (unsigned)(BUF) * TILE_BYTES + HN * PC * 16)  \
     }
-    SF_H_DMA((int64_t)0, 0)
+    SF_H_DMA(jt0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int64_t jt = 0; jt < ntiles; ++jt) {
-        const int buf = (int)(jt & 1);
+    for (int64_t jt = jt0; jt < ntiles; ++jt) {
+        const int buf = (int)((jt - jt0) & 1);
         if (jt + 1 < ntiles) SF_H_DMA(jt + 1, buf ^ 1)
         const unsigned char *bp = Bs + buf * TILE_BYTES;
 #define SF_H_FRAG(KSTEP, CB) \
@@ -326,8 +336,9 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
 __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const double *__restrict__ b, int64_t d,
                              const unsigned char *__restrict__ a_ok, const int *__restrict__ cnt,
                              const int32_t *__restrict__ cand_j, const float *__restrict__ cand_k,
-                             const float *__restrict__ thr, int64_t *__restrict__ idx, double *__restrict__ dist,
-                             int *__restrict__ flag, int *__restrict__ n_flagged)
+                             const float *__restrict__ thr, const float *__restrict__ win, int nsplit,
+                             int64_t m1_pad, int64_t *__restrict__ idx,
+                             double *__restrict__ dist, int *__restrict__ flag, int *__restrict__ n_flagged)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m1) return;
@@ -337,26 +348,37 @@ __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const dou
         flag[i] = 0;
         return;
     }
-    const int n = cnt[i];
-    const float t = thr[i];
+    // final threshold: the smallest over the column splits (each = that split's smallest key + W_i)
+    float t = INFINITY;
+    for (int s = 0; s < nsplit; ++s) t = fminf(t, thr[(int64_t)s * m1_pad + i]);
+    // a split whose list overflowed lost columns with keys >= its own minimum = thr_s - W_i; they matter only if
+    // that minimum is within the final threshold
+    bool overflow = false;
+    const float w = win[i] * 1.001f;
+    for (int s = 0; s < nsplit; ++s)
+        overflow |= cnt[(int64_t)s * m1_pad + i] > HCAP && !(thr[(int64_t)s * m1_pad + i] - w > t);
     double best = INFINITY;
     int64_t bj = -1;
-    if (n <= HCAP) {
+    if (!overflow) {
         const double *ai = a + i * d;
-        for (int c = 0; c < n; ++c) {
-            if (!(cand_k[i * HCAP + c] <= t)) continue;
-            const int64_t j = cand_j[i * HCAP + c];
-            const double *bjp = b + j * d;
-            double acc = 0.0;
-            for (int64_t u = 0; u < d; ++u) {
-                const double df = ai[u] - bjp[u];
-                acc += df * df; // left to right, no FMA: scipy's euclidean loop
-            }
-            const double dj = sqrt(acc);
-            if (dj < best || (dj == best && j < bj) || bj < 0) {
-                if (!(dj == dj)) continue; // NaN: leave the row to the float64 path
-                best = dj;
-                bj = j;
+        for (int s = 0; s < nsplit; ++s) {
+            const int64_t base = ((int64_t)s * m1_pad + i) * HCAP;
+            const int n = min(cnt[(int64_t)s * m1_pad + i], HCAP);
+            for (int c = 0; c < n; ++c) {
+                if (!(cand_k[base + c] <= t)) continue;
+                const int64_t j = cand_j[base + c];
+                const double *bjp = b + j * d;
+                double acc = 0.0;
+                for (int64_t u = 0; u < d; ++u) {
+                    const double df = ai[u] - bjp[u];
+                    acc += df * df; // left to right, no FMA: scipy's euclidean loop
+                }
+                const double dj = sqrt(acc);
+                if (dj < best || (dj == best && j < bj) || bj < 0) {
+                    if (!(dj == dj)) continue; // NaN: leave the row to the float64 path
+                    best = dj;
+                    bj = j;
+                }
             }
         }
     }
@@ -475,23 +497,34 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
         if (rc != SF_OK) { release(); return rc; }
     }
     if (!std::isfinite(ebmax) || !std::isfinite(qbmax)) { release(); return SF_OK; }
-    SF_HALLOC(win, m1p); SF_HALLOC(thr, m1p); SF_HALLOC(cnt, m1p);
-    SF_HALLOC(candj, m1p * HCAP); SF_HALLOC(candk, m1p * HCAP);
+    // column splits: enough workgroups for two per CU's worth of the chip, each with at least 32 tiles to scan
+    const int64_t row_blocks = m1p / HM, col_tiles = m2p / HN;
+    int64_t nsplit = 1;
+    if (row_blocks < 512) nsplit = std::max<int64_t>(1, std::min<int64_t>(sf_div_up(512, row_blocks), col_tiles / 32));
+    if (const char *e = getenv("SF_MATCH_HALF_SPLITS")) nsplit = std::max<int64_t>(1, std::min<int64_t>(atoll(e), col_tiles));
+    const int64_t tiles_per_split = sf_div_up(col_tiles, nsplit);
+    nsplit = sf_div_up(col_tiles, tiles_per_split);
+    SF_HALLOC(win, m1p); SF_HALLOC(thr, nsplit * m1p); SF_HALLOC(cnt, nsplit * m1p);
+    SF_HALLOC(candj, nsplit * m1p * HCAP); SF_HALLOC(candk, nsplit * m1p * HCAP);
     SF_HALLOC(flag, m1); SF_HALLOC(nflag, 1);
     const double gamma = (double)(dp + 32) * 2.384185791015625e-07; // 2^-22
     SF_LAUNCH(ctx, "k8_half_window", k_half_window, dim3((unsigned)sf_div_up(m1p, 256)), dim3(256), (const double *)ea,
               (const double *)qa, (const double *)na2, m1, m1p, std::sqrt(nbmax), ebmax, qbmax, nbmax, gamma, unit, win);
-    SF_HIP(hipMemsetAsync(cnt, 0, (size_t)m1p * sizeof(int), ctx->stream));
+    SF_HIP(hipMemsetAsync(cnt, 0, (size_t)(nsplit * m1p) * sizeof(int), ctx->stream));
     SF_HIP(hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream));
     if (ks == 8) {
-        SF_LAUNCH(ctx, name, k_match_half<8>, dim3((unsigned)(m1p / HM)), dim3(512), (const _Float16 *)ah, m1,
-                  (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, cnt, candj, candk, thr);
+        SF_LAUNCH(ctx, name, k_match_half<8>, dim3((unsigned)row_blocks, (unsigned)nsplit), dim3(512), (const _Float16 *)ah,
+                  m1, (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, tiles_per_split, m1p, cnt, candj,
+                  candk, thr);
     } else {
-        SF_LAUNCH(ctx, name, k_match_half<22>, dim3((unsigned)(m1p / HM)), dim3(512), (const _Float16 *)ah, m1,
-                  (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, cnt, candj, candk, thr);
+        SF_LAUNCH(ctx, name, k_match_half<22>, dim3((unsigned)row_blocks, (unsigned)nsplit), dim3(512), (const _Float16 *)ah,
+                  m1, (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, tiles_per_split, m1p, cnt, candj,
+                  candk, thr);
     }
     SF_LAUNCH(ctx, "k8_half_final", k_half_final, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), da, m1, db, d, a_ok,
-              (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, didx, ddist, flag, nflag);
+              (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, (const float *)win, (int)nsplit,
+              m1p, didx, ddist,
+              flag, nflag);
     int nf = 0;
     SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));

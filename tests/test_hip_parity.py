@@ -418,13 +418,16 @@ def _half_cases():
     yield "descending", a, b
 
 
+@pytest.mark.parametrize("splits", [None, 5])
 @pytest.mark.parametrize("case", ["shot_like", "fpfh_like", "wide_range", "descending"])
-def test_match_half_prefilter_equals_exact(eng, O, monkeypatch, case):
+def test_match_half_prefilter_equals_exact(eng, O, monkeypatch, case, splits):
     """The FP16 matrix-core pre-filter (match_half.hip) only prunes: index AND distance must equal scipy's / the exact
     kernel's bit for bit on ties, near ties, zero rows, short / odd descriptor lengths, extreme norms and an
     order that overflows every candidate list."""
     a, b = next((a, b) for name, a, b in _half_cases() if name == case)
     monkeypatch.setenv("SF_MATCH_HALF", "1")
+    if splits:  # column splits (normally chosen for problems with few 256-row blocks): per-split thresholds, merged at the end
+        monkeypatch.setenv("SF_MATCH_HALF_SPLITS", str(splits))
     eng.profile_reset()
     eng.profile(True)
     idx, dist, col = eng.match_argmin(a, b, want_col=True)
@@ -436,7 +439,7 @@ def test_match_half_prefilter_equals_exact(eng, O, monkeypatch, case):
     overflow = rep.get("k8_match_gemm_overflow", (0, 0))[0]
     if case == "descending":
         assert overflow >= 1, "the adversarial order should have overflowed candidate lists"
-    if case == "shot_like":
+    if case == "shot_like":  # (with splits too: a split full of ties far above the final minimum is ignored)
         assert overflow == 0, "no candidate list should overflow on ordinary data"
 
 
