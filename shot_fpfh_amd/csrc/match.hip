@@ -155,26 +155,63 @@ __global__ void k_match_merge(const double *__restrict__ pdist, const int64_t *_
     if (dist) dist[i] = bd;
 }
 
+// K9: inlier counts of all candidate transforms (ransac.py:60-67).  A workgroup keeps a tile of 256 x 8 matched
+// pairs in registers and walks over its range of draws; the 12 coefficients of a draw are wave-uniform (scalar
+// loads), the votes of a wave are a ballot + popcount, one LDS add per wave and draw, one global add per workgroup
+// and draw at the end.  (A workgroup per draw re-reads all pairs from L2 for every draw: 48 B per pair-draw.)
+// The residual is formed exactly like the reference's (a @ R.T + t) - b, left to right, without FMA.  The
+// reference tests sqrt(s) <= thr; s <= lo and s >= hi (the squares of thr and of the next double, rounded
+// outwards) decide that without the square root for all but a 2^-51-wide band, where the square root is taken.
+constexpr int K9_MPT = 8;         // pairs per thread
+constexpr int K9_TILE = 256 * K9_MPT;
+constexpr int K9_MAX_DRAWS = 8192; // draws per workgroup (LDS counters)
+
 __global__ __launch_bounds__(256) void k_ransac_score(const double *__restrict__ a, const double *__restrict__ b,
-                                                      int64_t m, const double *__restrict__ Rt, double thr,
-                                                      int64_t *__restrict__ inliers)
+                                                      int64_t m, const double *__restrict__ Rt, int64_t n_draws,
+                                                      int64_t draws_per_split, double thr, double lo, double hi,
+                                                      unsigned long long *__restrict__ inliers)
 {
-    __shared__ int wsum[4];
-    const double *R = Rt + 12 * (int64_t)blockIdx.x;
-    const double r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4], r5 = R[5], r6 = R[6], r7 = R[7], r8 = R[8];
-    const double t0 = R[9], t1 = R[10], t2 = R[11];
-    int cnt = 0;
-    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
-        const double p0 = a[3 * i], p1 = a[3 * i + 1], p2 = a[3 * i + 2];
-        const double e0 = ((p0 * r0 + p1 * r1) + p2 * r2) + t0 - b[3 * i];
-        const double e1 = ((p0 * r3 + p1 * r4) + p2 * r5) + t1 - b[3 * i + 1];
-        const double e2 = ((p0 * r6 + p1 * r7) + p2 * r8) + t2 - b[3 * i + 2];
-        cnt += sqrt((e0 * e0 + e1 * e1) + e2 * e2) <= thr ? 1 : 0;
+    __shared__ int cnt[K9_MAX_DRAWS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t d0 = (int64_t)blockIdx.y * draws_per_split;
+    const int nd = (int)((n_draws - d0 < draws_per_split) ? n_draws - d0 : draws_per_split);
+    for (int d = tid; d < nd; d += 256) cnt[d] = 0;
+    double px[K9_MPT], py[K9_MPT], pz[K9_MPT], qx[K9_MPT], qy[K9_MPT], qz[K9_MPT];
+    unsigned valid = 0;
+#pragma unroll
+    for (int u = 0; u < K9_MPT; ++u) {
+        const int64_t i = (int64_t)blockIdx.x * K9_TILE + u * 256 + tid;
+        const bool ok = i < m;
+        const int64_t ii = ok ? i : 0;
+        px[u] = a[3 * ii]; py[u] = a[3 * ii + 1]; pz[u] = a[3 * ii + 2];
+        qx[u] = b[3 * ii]; qy[u] = b[3 * ii + 1]; qz[u] = b[3 * ii + 2];
+        valid |= (ok ? 1u : 0u) << u;
     }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) inliers[blockIdx.x] = (int64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int d = 0; d < nd; ++d) {
+        const double *R = Rt + 12 * (d0 + d); // uniform address: scalar loads
+        const double r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4], r5 = R[5], r6 = R[6], r7 = R[7], r8 = R[8];
+        const double t0 = R[9], t1 = R[10], t2 = R[11];
+        int votes = 0;
+#pragma unroll
+        for (int u = 0; u < K9_MPT; ++u) {
+            const double e0 = ((px[u] * r0 + py[u] * r1) + pz[u] * r2) + t0 - qx[u];
+            const double e1 = ((px[u] * r3 + py[u] * r4) + pz[u] * r5) + t1 - qy[u];
+            const double e2 = ((px[u] * r6 + py[u] * r7) + pz[u] * r8) + t2 - qz[u];
+            const double s = (e0 * e0 + e1 * e1) + e2 * e2;
+            bool in = s <= lo;
+            if (__ballot(!in & (s < hi))) { // the band between the two squares (NaN: neither); practically never
+                double sb = s;
+                asm volatile("" : "+v"(sb)); // keeps the square root inside the branch
+                in |= sqrt(sb) <= thr;
+            }
+            votes += __popcll(__ballot(in & ((valid >> u) & 1u)));
+        }
+        if (lane == 0 && votes) atomicAdd(&cnt[d], votes);
+    }
+    __syncthreads();
+    for (int d = tid; d < nd; d += 256)
+        if (cnt[d]) atomicAdd(&inliers[d0 + d], (unsigned long long)cnt[d]);
 }
 
 } // namespace
@@ -350,7 +387,27 @@ extern "C" int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, in
     int64_t *dinl = inliers;
     if (!out_dev) SF_HIP(hipMalloc(&dinl, (size_t)std::max<int64_t>(n_draws, 1) * sizeof(int64_t)));
     if (n_draws) {
-        SF_LAUNCH(ctx, "k9_ransac_score", k_ransac_score, dim3((unsigned)n_draws), dim3(256), da, db, m, dR, thr, dinl);
+        SF_HIP(hipMemsetAsync(dinl, 0, (size_t)n_draws * sizeof(int64_t), ctx->stream));
+        if (m) {
+            // sqrt(s) <= thr is certain for s <= lo = thr^2 rounded down, impossible for s >= hi = (next double)^2
+            // rounded up (sqrt is monotone and correctly rounded); a negative or NaN threshold admits nothing
+            double lo = -1.0, hi = -1.0;
+            if (thr >= 0.0) {
+                const double up = std::nextafter(thr, INFINITY);
+                lo = std::nextafter(thr * thr, -INFINITY);
+                hi = std::isinf(up) ? INFINITY : std::nextafter(up * up, INFINITY);
+                if (std::isinf(thr)) lo = hi = INFINITY; // everything finite is an inlier; s = inf: sqrt path
+            }
+            const int64_t tiles = sf_div_up(m, K9_TILE);
+            int64_t splits = sf_div_up(n_draws, K9_MAX_DRAWS);
+            if (tiles * splits < 1024) splits = std::min<int64_t>(n_draws, sf_div_up(1024, tiles));
+            if (splits > 65535) splits = 65535;
+            const int64_t dps = sf_div_up(n_draws, splits);
+            if (dps > K9_MAX_DRAWS) { sf_set_error("sf_ransac_score: more than 65535 x 8192 draws"); return SF_ERR_UNSUPPORTED; }
+            splits = sf_div_up(n_draws, dps);
+            SF_LAUNCH(ctx, "k9_ransac_score", k_ransac_score, dim3((unsigned)tiles, (unsigned)splits), dim3(256), da, db, m, dR,
+                      n_draws, dps, thr, lo, hi, reinterpret_cast<unsigned long long *>(dinl));
+        }
     }
     if (!out_dev) {
         if (n_draws) SF_HIP(hipMemcpyAsync(inliers, dinl, (size_t)n_draws * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));

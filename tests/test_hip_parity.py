@@ -261,6 +261,42 @@ def test_ransac_golden(eng):
     assert np.array_equal(tf.rotation, g["rotation"]) and np.array_equal(tf.translation, g["translation"])
 
 
+def test_ransac_score_threshold_band_and_tiling(eng):
+    """K9 decides `norm <= thr` on the squared residual and takes the square root only inside the one-ulp band around
+    thr^2: residuals sitting exactly on / next to the threshold, a ragged pair count (tile tail), more draws than one
+    workgroup's LDS counters, thresholds 0 / inf / NaN -- all against the NumPy expression of ransac.py:60-67."""
+    rng = np.random.default_rng(77)
+    thr = 0.0123
+    xs = [thr]
+    for _ in range(4):
+        xs.append(np.nextafter(xs[-1], np.inf))
+    x = thr
+    for _ in range(4):
+        x = np.nextafter(x, -np.inf)
+        xs.append(x)
+    xs = np.array(xs)
+    m = 2048 * 3 + 37
+    a = rng.random((m, 3))
+    b = a + 0.02 * rng.standard_normal((m, 3))
+    k = xs.shape[0]
+    a[:k] = 0.0
+    b[:k] = 0.0
+    b[:k, 0] = xs  # identity draw: residual norm is exactly xs
+    b[k:2 * k, 1] = a[k:2 * k, 1]  # keep the rest generic
+    n_draws = 8192 + 301
+    rt = np.tile(np.concatenate((np.eye(3).ravel(), np.zeros(3))), (n_draws, 1))
+    rt[1:, 9:] = 0.02 * rng.standard_normal((n_draws - 1, 3))
+    rt[5:, :9] += 1e-3 * rng.standard_normal((n_draws - 5, 9))
+
+    def ref(thr_):
+        with np.errstate(invalid="ignore"):
+            return np.array([(np.linalg.norm(a @ r[:9].reshape(3, 3).T + r[9:] - b, axis=1) <= thr_).sum() for r in rt])
+
+    for t in (thr, 0.0, np.inf, np.nan, -1.0):
+        assert np.array_equal(eng.ransac_score(a, b, rt, t), ref(t)), t
+    assert eng.ransac_score(a[:0], b[:0], rt[:7], thr).tolist() == [0] * 7
+
+
 # ---- sharding on one device: G shards run one after the other must reproduce the single-shard result -------------
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_blocks_bit_identical_to_single(eng, O, world):
