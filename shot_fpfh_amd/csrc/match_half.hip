@@ -336,8 +336,9 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
 __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const double *__restrict__ b, int64_t d,
                              const unsigned char *__restrict__ a_ok, const int *__restrict__ cnt,
                              const int32_t *__restrict__ cand_j, const float *__restrict__ cand_k,
-                             const float *__restrict__ thr, const float *__restrict__ win, int nsplit,
-                             int64_t m1_pad, int64_t *__restrict__ idx,
+                             const float *__restrict__ thr, const float *__restrict__ win,
+                             const double *__restrict__ na2, double unit, int nsplit, int64_t m1_pad,
+                             int64_t *__restrict__ idx,
                              double *__restrict__ dist, int *__restrict__ flag, int *__restrict__ n_flagged)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,8 +360,10 @@ __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const dou
         overflow |= cnt[(int64_t)s * m1_pad + i] > HCAP && !(thr[(int64_t)s * m1_pad + i] - w > t);
     double best = INFINITY;
     int64_t bj = -1;
+    bool model_ok = true;
     if (!overflow) {
         const double *ai = a + i * d;
+        const double half_w = 0.5 * (double)win[i], na = na2[i];
         for (int s = 0; s < nsplit; ++s) {
             const int64_t base = ((int64_t)s * m1_pad + i) * HCAP;
             const int n = min(cnt[(int64_t)s * m1_pad + i], HCAP);
@@ -373,6 +376,9 @@ __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const dou
                     const double df = ai[u] - bjp[u];
                     acc += df * df; // left to right, no FMA: scipy's euclidean loop
                 }
+                // safety net for the error model: the pre-filter's key of this pair must be within eps_i (< W_i / 2)
+                // of the float64 one, ||a - b||^2 - ||a||^2; a row where it is not is handed to the FP64 path
+                model_ok &= fabs((acc - na) * unit - (double)cand_k[base + c]) <= half_w;
                 const double dj = sqrt(acc);
                 if (dj < best || (dj == best && j < bj) || bj < 0) {
                     if (!(dj == dj)) continue; // NaN: leave the row to the float64 path
@@ -382,7 +388,7 @@ __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const dou
             }
         }
     }
-    const bool decided = bj >= 0;
+    const bool decided = bj >= 0 && model_ok;
     idx[i] = decided ? bj : 0;
     if (dist) dist[i] = best;
     flag[i] = decided ? 0 : 1;
@@ -522,7 +528,8 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
                   candk, thr);
     }
     SF_LAUNCH(ctx, "k8_half_final", k_half_final, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), da, m1, db, d, a_ok,
-              (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, (const float *)win, (int)nsplit,
+              (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, (const float *)win,
+              (const double *)na2, unit, (int)nsplit,
               m1p, didx, ddist,
               flag, nflag);
     int nf = 0;
