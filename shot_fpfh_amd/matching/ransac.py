@@ -2,9 +2,10 @@
 (ransac.py:17-82).
 
 Host: the draws (same module-level np.random.default_rng(seed=72) stream as ransac.py:14, so draw
-k of a process equals the reference's draw k) and one Kabsch fit per draw.  Device (K9): the
-O(n_draws x n_matches) inlier count of every candidate transform in ONE launch, instead of one NumPy
-pass over all matches per draw.
+k of a process equals the reference's draw k) and one Kabsch fit per draw -- solved as one stack through
+the same BLAS / LAPACK routines (bit-identical transforms, checked against the per-draw solver on the
+first draws of every call).  Device (K9): the O(n_draws x n_matches) inlier count of every candidate
+transform in ONE launch, instead of one NumPy pass over all matches per draw.
 """
 from __future__ import annotations
 
@@ -15,6 +16,7 @@ import numpy as np
 import numpy.typing as npt
 
 from ..core import RigidTransform, solver_point_to_point
+from ..core.geometry import solver_point_to_point_batched
 from ..engine import Engine, default_engine
 
 __all__ = ["ransac_on_matches", "rng"]
@@ -45,18 +47,25 @@ def ransac_on_matches(
     scan_pts = np.ascontiguousarray(scan_keypoints[scan_descriptors_indices], dtype=np.float64)
     ref_pts = np.ascontiguousarray(ref_keypoints[ref_descriptors_indices], dtype=np.float64)
 
-    candidates: list[RigidTransform] = []
+    draws = np.empty((n_draws, draw_size), dtype=np.int64)
+    for d in range(n_draws):  # one generator call per draw, as ransac.py:50-55 (keeps the stream aligned)
+        draws[d] = rng.choice(n_matches, draw_size, replace=False, shuffle=False)
     records = np.empty((n_draws, 12), dtype=np.float64)
-    for d in range(n_draws):
-        draw = rng.choice(n_matches, draw_size, replace=False, shuffle=False)  # ransac.py:50-55
-        tf = solver_point_to_point(scan_pts[draw], ref_pts[draw])
-        candidates.append(tf)
-        records[d] = tf.as_row12()
+    if n_draws:
+        rot, tr = solver_point_to_point_batched(scan_pts[draws], ref_pts[draws])
+        records[:, :9] = rot.reshape(n_draws, 9)
+        records[:, 9:] = tr
+        for d in range(min(n_draws, 8)):  # the stacked solve must reproduce the per-draw one bit for bit
+            if not np.array_equal(records[d], solver_point_to_point(scan_pts[draws[d]], ref_pts[draws[d]]).as_row12()):
+                logging.warning("stacked Kabsch differs from the per-draw solver on this NumPy build: using the per-draw loop")
+                for e in range(n_draws):
+                    records[e] = solver_point_to_point(scan_pts[draws[e]], ref_pts[draws[e]]).as_row12()
+                break
 
     inliers = eng.ransac_score(scan_pts, ref_pts, records, distance_threshold)
     best = int(np.argmax(inliers))  # first maximum == reference's strict-greater update rule
     if verbose:
         logging.info(f"Best draw {best}: {int(inliers[best])} inliers out of {n_matches}")
-    best_transform = candidates[best]
+    best_transform = RigidTransform(records[best, :9].reshape(3, 3).copy(), records[best, 9:].copy())
     best_transform.normalize_rotation()
     return inliers[best] / n_matches, best_transform

@@ -237,3 +237,27 @@ def test_every_mirrored_function_keeps_the_reference_signature():
         for n, kind, default in got:
             if n not in names:
                 assert default is not None and kind == "KEYWORD_ONLY", f"{key}: extra parameter {n} must be an optional keyword"
+
+
+def test_stacked_kabsch_is_bit_identical_to_the_per_draw_solver():
+    """ransac_on_matches solves all draws as one stack; every transform must equal solver_point_to_point's bit for
+    bit (plain, mirrored = every draw a reflection, noisy, planar = rank-deficient covariances)."""
+    from shot_fpfh_amd.core import solver_point_to_point
+    from shot_fpfh_amd.core.geometry import solver_point_to_point_batched
+
+    rng = np.random.default_rng(7)
+    for mirror, noise, planar in ((False, 0.01, False), (True, 0.01, False), (False, 0.3, False), (False, 0.0, True)):
+        a = rng.random((5000, 3))
+        if planar:
+            a[:, 2] = 0.5
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        q *= np.sign(np.linalg.det(q))
+        if mirror:
+            q[:, 0] *= -1
+        b = a @ q.T + 0.3 + noise * rng.standard_normal((5000, 3))
+        for k in (3, 4, 7):
+            draws = np.array([rng.choice(5000, k, replace=False, shuffle=False) for _ in range(1500)])
+            rot, tr = solver_point_to_point_batched(a[draws], b[draws])
+            ref = [solver_point_to_point(a[d], b[d]) for d in draws]
+            assert np.array_equal(rot, np.array([t.rotation for t in ref]))
+            assert np.array_equal(tr, np.array([t.translation for t in ref]))
