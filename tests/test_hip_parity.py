@@ -891,3 +891,39 @@ def test_fpfh_matrix_core_path_with_peaked_histograms(eng, O, n, r, kmin):
     assert peak > 127.5 or kmin < 128  # some bin really holds > 127 pairs
     f = compute_fpfh_descriptor(kp, p, nr, radius=r, n_bins=5, verbose=False)
     assert close(f, f_o).all() and np.abs(f - f_o).max() < 1e-9 * max(1.0, np.abs(f_o).max())
+
+
+def test_match_large_permutation_property(eng, O):
+    """BASELINE config 4's matching step at a size the CPU cannot check pair by pair (400k x 400k x 352, the FP16
+    pre-filter by default), through properties: the reference set is a row permutation of the scan set plus noise far
+    below the spacing of the descriptors, so the arg-min must invert the permutation exactly; the distances must be the
+    sequential float64 ones of those pairs; and a sample of rows must equal the exact kernel / oracle bit for bit."""
+    rng = np.random.default_rng(404)
+    m, d = 400_000, 352
+    a = rng.random((m, d), dtype=np.float32).astype(np.float64)
+    a *= rng.random((m, d), dtype=np.float32) < 0.3  # SHOT-like sparsity
+    a /= np.maximum(np.linalg.norm(a, axis=1)[:, None], 1e-300)
+    perm = rng.permutation(m)
+    b = a[perm] + 1e-6 * rng.standard_normal((m, d)).astype(np.float32)
+    inv = np.empty(m, dtype=np.int64)
+    inv[perm] = np.arange(m)
+    da, db = eng.empty((m, d)).from_host(a), eng.empty((m, d)).from_host(b)
+    idx, dist = eng.empty((m,), np.int64), eng.empty((m,), np.float64)
+    eng.profile_reset()
+    eng.profile(True)
+    eng.match_argmin_device(da, db, idx, dist)
+    eng.sync()
+    eng.profile(False)
+    assert eng.profile_report().get("k8_match_half", (0, 0))[0] == 1, "this size was expected to take the FP16 pre-filter"
+    i_h, d_h = idx.to_host(), dist.to_host()
+    assert np.array_equal(i_h, inv)
+    pick = rng.choice(m, 2000, replace=False)
+    diff = a[pick] - b[inv[pick]]
+    seq = np.zeros(pick.shape[0])
+    for t in range(d):  # scipy's left-to-right sum
+        seq += diff[:, t] * diff[:, t]
+    assert np.array_equal(d_h[pick], np.sqrt(seq))
+    io, do = O.match_argmin(a[pick[:40]], b)
+    assert np.array_equal(io, i_h[pick[:40]]) and np.array_equal(do, d_h[pick[:40]])
+    for x in (da, db, idx, dist):
+        x.free()
