@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_half_convert(const double *__restrict__
     for (int t = lane; t < dp; t += 64) {
         const double v = (real && t < d) ? a[i * d + t] : 0.0;
         const _Float16 hv = (_Float16)(v * scale);
-        out[i * dp + t] = hv;
+        if (out) out[i * dp + t] = hv;
         const double back = (double)hv * inv, e = v - back;
         se += e * e;
         sq += back * back;
@@ -475,15 +475,13 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     SF_HALLOC(nb2, m2p); SF_HALLOC(eb, m2p); SF_HALLOC(qb, m2p); SF_HALLOC(nbf, m2p);
     SF_HALLOC(na2, m1p); SF_HALLOC(ea, m1p); SF_HALLOC(qa, m1p);
     SF_HALLOC(ah, m1p * dp); SF_HALLOC(bh, m2p * dp);
-    // scales from the largest row norms (first conversion pass with scale 1 only for the norms would cost another
-    // read of both matrices; the norms are cheap on their own)
+    // the scales come from the largest row norms: a first pass of the converter that only produces ||row||^2
     double namax = 0.0, nbmax = 0.0, sa = 1.0, sb = 1.0;
     {
-        // ||row||^2 through the converter with scale 1 into the same buffers (overwritten below)
         SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m1p, 4)), dim3(256), da, m1, m1p, d, dp,
-                  1.0, (const unsigned char *)nullptr, ah, ea, qa, na2, (float *)nullptr, 1.0);
+                  1.0, (const unsigned char *)nullptr, (_Float16 *)nullptr, ea, qa, na2, (float *)nullptr, 1.0);
         SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m2p, 4)), dim3(256), db, m2, m2p, d, dp,
-                  1.0, b_ok, bh, eb, qb, nb2, (float *)nullptr, 1.0);
+                  1.0, b_ok, (_Float16 *)nullptr, eb, qb, nb2, (float *)nullptr, 1.0);
         int rc = host_max(ctx, na2, m1, part, &namax);
         if (rc == SF_OK) rc = host_max(ctx, nb2, m2, part, &nbmax);
         if (rc != SF_OK) { release(); return rc; }
