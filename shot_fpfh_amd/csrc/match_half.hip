@@ -11,7 +11,8 @@
 //      Every wave owns 32 rows of `a` (fragments resident in registers for the whole pass) and keeps, per row, a
 //      threshold thr_i = (smallest key seen so far) + W_i.  A key above the threshold is dropped; one below it
 //      is appended to the row's candidate list and may lower the threshold.  After t column tiles that happens
-//      with probability ~ 1/t, so the pass is MFMA + two vector instructions per pair.
+//      with probability ~ 1/t, so the pass is MFMA + one v_max3 per 32 pairs (the threshold is the start value of
+//      the accumulator, see k_match_half).
 //   3. k_half_final: per row, the candidates still within W_i of the final minimum (typically 1-3) get the
 //      reference's distance -- sequential float64 sum, square root -- and the smallest (lowest column on
 //      ties) wins, exactly scipy's first-minimum rule.
