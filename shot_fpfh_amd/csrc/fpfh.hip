@@ -337,30 +337,20 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
 //
 // One wave per keypoint, 64 neighbours per step.  Layouts (tools/ubench: probed on the device): operand lane l
 // holds row / column l % 16 and the 16 consecutive k of block l / 16, one per byte; the result lane holds column
-// l % 16 and rows 4 (l / 16) .. + 3.  Per step the 64 rows (128 B each) are staged in LDS with 16-byte loads; lane
-// (a, kb) then reads, for its 16 neighbours, the dword holding bins 4a .. 4a+3 (of the lower, then the upper 64
-// bins), and four 4x4 byte transposes (v_perm_b32) turn them into the B operands of four MFMAs whose column a is
-// bin 4a + q.  Every block of 16 staged rows is skewed by 8 dwords so that the four k blocks of a read hit
-// different LDS banks (two lanes per bank: the minimum for 64 x 4 bytes).
+// l % 16 and rows 4 (l / 16) .. + 3.  Per step the 64 rows (128 B each) are staged in LDS with 16-byte loads; the B
+// operand of the MFMA for bins 16 bb .. 16 bb + 15 -- lane (a, kb): bin 16 bb + a of neighbours 16 kb .. 16 kb + 15,
+// one per byte -- is exactly what two transposing reads (ds_read_b64_tr_b8: 8 rows x 16 bytes per 16-lane group,
+// delivered column-major) return, so no byte shuffling is left to the vector pipe.
 // --------------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void tr4x4(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned &t0, unsigned &t1,
-                                      unsigned &t2, unsigned &t3)
-{
-    // v_perm_b32(hi, lo, sel): selector byte 0..3 picks a byte of lo, 4..7 of hi
-    const unsigned a = __builtin_amdgcn_perm(d1, d0, 0x05010400u); // d0.0 d1.0 d0.1 d1.1
-    const unsigned b = __builtin_amdgcn_perm(d1, d0, 0x07030602u); // d0.2 d1.2 d0.3 d1.3
-    const unsigned c = __builtin_amdgcn_perm(d3, d2, 0x05010400u);
-    const unsigned e = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
-    t0 = __builtin_amdgcn_perm(c, a, 0x05040100u); // d0.0 d1.0 d2.0 d3.0
-    t1 = __builtin_amdgcn_perm(c, a, 0x07060302u); // d0.1 d1.1 d2.1 d3.1
-    t2 = __builtin_amdgcn_perm(e, b, 0x05040100u);
-    t3 = __builtin_amdgcn_perm(e, b, 0x07060302u);
-}
-
 #define SF_MC_PITCH 36 // dwords per staged row (144 B: 16-byte aligned rows)
-#define SF_MC_SKEW 8   // extra dwords in front of every block of 16 rows: the four k blocks of a read hit different banks
+// Extra dwords in front of the four blocks of 16 staged rows.  A transposing read (ds_read_b64_tr_b8) of one 32-lane
+// half touches 8 rows x 16 bytes of block g and of block g + 1; with a 36-dword pitch the eight rows of a block land
+// on half of the 64 banks, and 32 dwords between the two blocks of a half put the other block on the other half.
+__device__ __forceinline__ int sf_mc_skew(int g) { return g == 0 ? 0 : (g == 3 ? 64 : 32); }
+#define SF_MC_SKEW_TOTAL 64
+typedef int v2i_t __attribute__((ext_vector_type(2)));
 
 template <int NKS>
 __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
@@ -369,7 +359,7 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const int32_t *__restrict__ kk, double *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[4][64 * SF_MC_PITCH + 4 * SF_MC_SKEW];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[4][64 * SF_MC_PITCH + SF_MC_SKEW_TOTAL];
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[4][9 * 64];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     unsigned *const rowbuf = rowbuf_all[wv_id];
@@ -418,12 +408,12 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
     const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
     const int S = 62 - e2;
 
-    const int rd_base = 16 * kb * SF_MC_PITCH + kb * SF_MC_SKEW + a; // row 16 kb, dword a of this lane's reads
-    v4i acc[2][4];
+    // transposing reads: in its 16-lane group (k block kb) lane 2 q + p supplies the address of row 16 kb + 8 t + q,
+    // bytes 16 bb + 8 p .. + 7, and receives bin 16 bb + a of those eight rows -- the B operand's bytes 8 t .. 8 t + 7
+    const int rd_base = 4 * ((16 * kb + (a >> 1)) * SF_MC_PITCH + sf_mc_skew(kb)) + 8 * (a & 1); // bytes, t = 0, bb = 0
+    v4i acc[8]; // acc[bb]: column a = bin 16 bb + a, rows = limbs 4 kb .. 4 kb + 3
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) acc[h][qq] = v4i{0, 0, 0, 0};
+    for (int bb = 0; bb < 8; ++bb) acc[bb] = v4i{0, 0, 0, 0};
 
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -434,7 +424,7 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
                 const int p = lane + 64 * u, r = p >> 3, c = p & 7;
                 const int jr = __shfl(jv[ks], r);
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)jr * 128u + (unsigned)c * 16u, 0, 0);
-                *reinterpret_cast<uint4 *>(&rowbuf[r * SF_MC_PITCH + (r >> 4) * SF_MC_SKEW + 4 * c]) = make_uint4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint4 *>(&rowbuf[r * SF_MC_PITCH + sf_mc_skew(r >> 4) + 4 * c]) = make_uint4(v[0], v[1], v[2], v[3]);
             }
             // ---- this lane's weight as nine 7-bit limbs, written where the A operand's lanes will read them ----
             {
@@ -455,62 +445,57 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
             __builtin_amdgcn_wave_barrier(); // both buffers are private to the wave; LDS operations of a wave stay in order
             v4i A = v4i{0, 0, 0, 0};
             if (a < 9) A = *reinterpret_cast<const v4i *>(&abuf[a * 64 + 16 * kb]); // row a = limb a
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf) + rd_base;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                unsigned d[16];
-#pragma unroll
-                for (int b = 0; b < 16; ++b) d[b] = rowbuf[rd_base + b * SF_MC_PITCH + 16 * h]; // constant offsets off one register
-                unsigned t[4][4]; // t[g][qq]: bin 4a + qq of neighbours 4g .. 4g+3
-#pragma unroll
-                for (int g = 0; g < 4; ++g) tr4x4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3], t[g][0], t[g][1], t[g][2], t[g][3]);
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const v4i B = v4i{(int)t[0][qq], (int)t[1][qq], (int)t[2][qq], (int)t[3][qq]};
-                    acc[h][qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[h][qq], 0, 0, 0);
-                }
+            for (int bb = 0; bb < 8; ++bb) {
+                const v2i_t lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                    (__attribute__((address_space(3))) v2i_t *)(rb + 16 * bb));
+                const v2i_t hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                    (__attribute__((address_space(3))) v2i_t *)(rb + 8 * SF_MC_PITCH * 4 + 16 * bb));
+                const v4i B = v4i{lo[0], lo[1], hi[0], hi[1]};
+                acc[bb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[bb], 0, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // ---- recombination: lane (a, g) holds rows (limbs) 4g .. 4g+3 of column a; bin = 64 h + 4 a + qq ----
+    // ---- recombination: lane (a, g) holds rows (limbs) 4g .. 4g+3 of column a of acc[bb]; bin = 16 bb + a ----
     int rpad[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[1][3][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of (h=1, qq=3) = bin 127
+    for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of bb = 7: bin 127
     const double p0 = ldexp(1.0, 28 * kb - S); // 2^(7 (4 g) - S)
     const double f0 = p0, f1 = p0 * 128.0, f2 = p0 * 16384.0, f3 = p0 * 2097152.0;
     const double kd = (double)k;
     double inv_k = __builtin_amdgcn_rcp(kd);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
-    // partial sums over this lane's four limbs, for its eight bins (h, qq)
-    double part[2][4];
+    // partial sums over this lane's four limbs, for its eight bins
+    double part[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            double v = (double)(acc[h][qq][0] - rpad[0]) * f0;
-            v = __builtin_fma((double)(acc[h][qq][1] - rpad[1]), f1, v);
-            v = __builtin_fma((double)(acc[h][qq][2] - rpad[2]), f2, v);
-            part[h][qq] = __builtin_fma((double)(acc[h][qq][3] - rpad[3]), f3, v);
-        }
+    for (int bb = 0; bb < 8; ++bb) {
+        double v = (double)(acc[bb][0] - rpad[0]) * f0;
+        v = __builtin_fma((double)(acc[bb][1] - rpad[1]), f1, v);
+        v = __builtin_fma((double)(acc[bb][2] - rpad[2]), f2, v);
+        part[bb] = __builtin_fma((double)(acc[bb][3] - rpad[3]), f3, v);
+    }
     // sum over the four limb groups g = kb, transposing as we go: after the exchange with lane ^ 32 a lane keeps only
-    // the half h = kb >> 1, after the one with lane ^ 16 only the pair qq = 2 (kb & 1) + {0, 1} -- the two bins it writes
+    // the blocks bb = 4 (kb >> 1) + {0..3}, after the one with lane ^ 16 only bb = 4 (kb >> 1) + 2 (kb & 1) + {0, 1}
+    // -- the two bins it writes
     const bool up = (kb >> 1) != 0, odd = (kb & 1) != 0;
     double keep[4];
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-        const double mine = up ? part[1][qq] : part[0][qq], send = up ? part[0][qq] : part[1][qq];
-        keep[qq] = mine + __shfl_xor(send, 32);
+    for (int u = 0; u < 4; ++u) {
+        const double mine = up ? part[4 + u] : part[u], send = up ? part[u] : part[4 + u];
+        keep[u] = mine + __shfl_xor(send, 32);
     }
     const double vsel0 = (odd ? keep[2] : keep[0]) + __shfl_xor(odd ? keep[0] : keep[2], 16);
     const double vsel1 = (odd ? keep[3] : keep[1]) + __shfl_xor(odd ? keep[1] : keep[3], 16);
     {
-        const int h = kb >> 1, q0 = 2 * (kb & 1);
-        const int b0 = 64 * h + 4 * a + q0;
+        const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
+        const int b0 = 16 * bb0 + a, b1 = b0 + 16;
         const uint8_t *own = counts + i * 128;
         double *o = out + q * (int64_t)nb3;
         if (b0 < nb3) o[b0] = (double)((unsigned)own[b0] ^ 128u) / kd + vsel0 * inv_k;
-        if (b0 + 1 < nb3) o[b0 + 1] = (double)((unsigned)own[b0 + 1] ^ 128u) / kd + vsel1 * inv_k;
+        if (b1 < nb3) o[b1] = (double)((unsigned)own[b1] ^ 128u) / kd + vsel1 * inv_k;
     }
 }
 
