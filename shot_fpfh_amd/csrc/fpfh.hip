@@ -344,35 +344,62 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
 // --------------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-#define SF_MC_PITCH 36 // dwords per staged row (144 B: 16-byte aligned rows)
-// Extra dwords in front of the four blocks of 16 staged rows.  A transposing read (ds_read_b64_tr_b8) of one 32-lane
-// half touches 8 rows x 16 bytes of block g and of block g + 1; with a 36-dword pitch the eight rows of a block land
-// on half of the 64 banks, and 32 dwords between the two blocks of a half put the other block on the other half.
-__device__ __forceinline__ int sf_mc_skew(int g) { return g == 0 ? 0 : (g == 3 ? 64 : 32); }
-#define SF_MC_SKEW_TOTAL 64
+// Staged rows: 128 B each, no padding -- the image is written by LDS-DMA (global_load_lds_dwordx4: a wave
+// instruction writes its 64 lanes' 16-byte chunks back to back), so the bank spread comes from the SOURCE side:
+// slot s of row r holds chunk s ^ f(r), f(r) = ((r >> 1) & 3) | (((r >> 4) & 1) << 2).  A transposing read of one
+// 32-lane half (8 rows x 16 bytes of block g and of block g + 1, same chunk) then touches all 64 banks once.
 typedef int v2i_t __attribute__((ext_vector_type(2)));
+#ifndef SF_MC_WPB
+#define SF_MC_WPB 2 // waves (= keypoints in flight) per workgroup: 8.6 KB of LDS each, 18 waves per CU
+#endif
 
 template <int NKS>
-__global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+__global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const int32_t *__restrict__ kk, double *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[4][64 * SF_MC_PITCH + SF_MC_SKEW_TOTAL];
-    __shared__ __attribute__((aligned(16))) unsigned char abuf_all[4][9 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][64 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     unsigned *const rowbuf = rowbuf_all[wv_id];
     unsigned char *const abuf = abuf_all[wv_id];
-    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + wv_id);
+    const int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
     if (q >= m) return;
     const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
     const int64_t slot = i - nbrs_begin;
     const int64_t s = offset[slot];
     const int k = cnt[slot];
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
+    // transposing reads: in its 16-lane group (k block kb) lane 2 q + p supplies the address of row 16 kb + 8 t + q,
+    // bytes 8 p .. + 7 of chunk bb (slot bb ^ f(row); f does not depend on t), and receives bin 16 bb + a of those
+    // eight rows -- the B operand's bytes 8 t .. 8 t + 7
+    const int frow = ((a >> 2) & 3) | ((kb & 1) << 2);
+    const int rd_base = (16 * kb + (a >> 1)) * 128 + 8 * (a & 1); // bytes, t = 0
+    int xoff[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) xoff[bb] = rd_base + 16 * (bb ^ frow);
+    // DMA: lane l of instruction u fills slot l & 7 of row 8 u + (l >> 3) with chunk (l & 7) ^ f(row)
+    const int dma_chunk = (lane & 7) ^ ((lane >> 4) & 3); // ^ 4 for the rows 16 .. 31 and 48 .. 63 (u = 2, 3, 6, 7)
+    const unsigned lds_rows = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)rowbuf);
+    // ---- stage the 64 rows of a step in LDS: 8 DMA instructions of 64 x 16 bytes ----
+#define SF_MC_DMA(KS)                                                                                               \
+    {                                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                             \
+            const int jr0 = __shfl(jv[KS], 8 * u + (lane >> 3));                                                    \
+            const int jr = jr0 < 0 ? 0 : jr0; /* idle slots of the last step fetch row 0 */                         \
+            const uint8_t *src = counts + (size_t)jr * 128u + 16u * (unsigned)(dma_chunk ^ (((u >> 1) & 1) << 2)); \
+            unsigned keep_;                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"   \
+                         "s_mov_b32 m0, %0"                                                                         \
+                         : "=&s"(keep_)                                                                             \
+                         : "v"(src), "s"(lds_rows + 1024u * u)                                                      \
+                         : "memory");                                                                               \
+        }                                                                                                           \
+    }
 
     // ---- weights of all neighbours (lane t of step ks <-> neighbour 64 ks + t), as in the vector kernel ----
     int jv[NKS];
@@ -382,6 +409,7 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
         const int t = c * 64 + lane;
         jv[c] = t < k ? idx[s + t] : -1;
     }
+    SF_MC_DMA(0) // in flight while the weights are computed
     double gx[NKS], gy[NKS], gz[NKS];
     int gk[NKS];
 #pragma unroll
@@ -408,9 +436,6 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
     const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
     const int S = 62 - e2;
 
-    // transposing reads: in its 16-lane group (k block kb) lane 2 q + p supplies the address of row 16 kb + 8 t + q,
-    // bytes 16 bb + 8 p .. + 7, and receives bin 16 bb + a of those eight rows -- the B operand's bytes 8 t .. 8 t + 7
-    const int rd_base = 4 * ((16 * kb + (a >> 1)) * SF_MC_PITCH + sf_mc_skew(kb)) + 8 * (a & 1); // bytes, t = 0, bb = 0
     v4i acc[8]; // acc[bb]: column a = bin 16 bb + a, rows = limbs 4 kb .. 4 kb + 3
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) acc[bb] = v4i{0, 0, 0, 0};
@@ -418,14 +443,7 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         if (ks * 64 < k) { // wave-uniform
-            // ---- stage the 64 rows of this step in LDS (8 x 16 bytes per lane) ----
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int p = lane + 64 * u, r = p >> 3, c = p & 7;
-                const int jr = __shfl(jv[ks], r);
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)jr * 128u + (unsigned)c * 16u, 0, 0);
-                *reinterpret_cast<uint4 *>(&rowbuf[r * SF_MC_PITCH + sf_mc_skew(r >> 4) + 4 * c]) = make_uint4(v[0], v[1], v[2], v[3]);
-            }
+            if (ks > 0) SF_MC_DMA(ks) // (step 0 was issued before the weights were computed)
             // ---- this lane's weight as nine 7-bit limbs, written where the A operand's lanes will read them ----
             {
                 const double x = ldexp(wv[ks], S - 32); // < 2^31
@@ -442,19 +460,21 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
                 abuf[7 * 64 + pos] = (unsigned char)((hi >> 17) & 127u);
                 abuf[8 * 64 + pos] = (unsigned char)((hi >> 24) & 127u);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
             __builtin_amdgcn_wave_barrier(); // both buffers are private to the wave; LDS operations of a wave stay in order
             v4i A = v4i{0, 0, 0, 0};
             if (a < 9) A = *reinterpret_cast<const v4i *>(&abuf[a * 64 + 16 * kb]); // row a = limb a
-            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf) + rd_base;
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb) {
                 const v2i_t lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-                    (__attribute__((address_space(3))) v2i_t *)(rb + 16 * bb));
+                    (__attribute__((address_space(3))) v2i_t *)(rb + xoff[bb]));
                 const v2i_t hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-                    (__attribute__((address_space(3))) v2i_t *)(rb + 8 * SF_MC_PITCH * 4 + 16 * bb));
+                    (__attribute__((address_space(3))) v2i_t *)(rb + xoff[bb] + 8 * 128));
                 const v4i B = v4i{lo[0], lo[1], hi[0], hi[1]};
                 acc[bb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[bb], 0, 0, 0);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next step's DMA overwrites the rows
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -498,6 +518,8 @@ __global__ __launch_bounds__(256) void k_fpfh_mc(const double *__restrict__ rec,
         if (b1 < nb3) o[b1] = (double)((unsigned)own[b1] ^ 128u) / kd + vsel1 * inv_k;
     }
 }
+
+#undef SF_MC_DMA
 
 template <typename CT>
 __global__ void k_spfh_export(const CT *__restrict__ counts, const int32_t *__restrict__ kk,
@@ -723,7 +745,7 @@ static int launch_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
 
 static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const int32_t *kp_pos, int64_t m, double *dout)
 {
-    const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_MC_WPB))), block(64 * SF_MC_WPB);
     const size_t tb = (size_t)sp->rows_alloc * 128;
     if (tb >= ((size_t)1 << 32) || sp->stride != 128 || nb->max_count > 255) {
         sf_set_error("sf_fpfh: uint8 SPFH table of %zu bytes / lists of %lld points outside the matrix-core kernel's range", tb,
