@@ -350,7 +350,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // 32-lane half (8 rows x 16 bytes of block g and of block g + 1, same chunk) then touches all 64 banks once.
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 #ifndef SF_MC_WPB
-#define SF_MC_WPB 2 // waves (= keypoints in flight) per workgroup: 8.6 KB of LDS each, 18 waves per CU
+#define SF_MC_WPB 4 // waves (= keypoints in flight) per workgroup: 4.6 KB of LDS each
 #endif
 
 template <int NKS>
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const int32_t *__restrict__ kk, double *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][64 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // 32 rows of 128 B
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     unsigned *const rowbuf = rowbuf_all[wv_id];
@@ -373,25 +373,26 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
     const int k = cnt[slot];
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const int a = lane & 15, kb = lane >> 4;
-    // transposing reads: in its 16-lane group (k block kb) lane 2 q + p supplies the address of row 16 kb + 8 t + q,
-    // bytes 8 p .. + 7 of chunk bb (slot bb ^ f(row); f does not depend on t), and receives bin 16 bb + a of those
-    // eight rows -- the B operand's bytes 8 t .. 8 t + 7
+    // A step covers 32 neighbours (v_mfma_i32_16x16x32_i8: 8 k per 16-lane group).  Transposing reads: in its group
+    // (k block kb) lane 2 q + p supplies the address of row 8 kb + q, bytes 8 p .. + 7 of chunk bb (slot bb ^ f(row),
+    // f(row) = (row >> 1) & 7), and receives bin 16 bb + a of those eight rows -- exactly its B operand.
     const int frow = ((a >> 2) & 3) | ((kb & 1) << 2);
-    const int rd_base = (16 * kb + (a >> 1)) * 128 + 8 * (a & 1); // bytes, t = 0
+    const int rd_base = (8 * kb + (a >> 1)) * 128 + 8 * (a & 1); // bytes
     int xoff[8];
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) xoff[bb] = rd_base + 16 * (bb ^ frow);
     // DMA: lane l of instruction u fills slot l & 7 of row 8 u + (l >> 3) with chunk (l & 7) ^ f(row)
-    const int dma_chunk = (lane & 7) ^ ((lane >> 4) & 3); // ^ 4 for the rows 16 .. 31 and 48 .. 63 (u = 2, 3, 6, 7)
+    const int dma_chunk = (lane & 7) ^ ((lane >> 4) & 3); // ^ 4 for the rows 8 .. 15 and 24 .. 31 (u = 1, 3)
     const unsigned lds_rows = (unsigned)__builtin_amdgcn_readfirstlane(
         (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)rowbuf);
-    // ---- stage the 64 rows of a step in LDS: 8 DMA instructions of 64 x 16 bytes ----
-#define SF_MC_DMA(KS)                                                                                               \
+    // ---- stage the 32 rows of step ST (neighbours 32 ST .. + 31 = lanes 32 (ST & 1) .. of chunk ST >> 1) in LDS:
+    //      4 DMA instructions of 64 x 16 bytes ----
+#define SF_MC_DMA(ST)                                                                                               \
     {                                                                                                               \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                             \
-            const int jr0 = __shfl(jv[KS], 8 * u + (lane >> 3));                                                    \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                             \
+            const int jr0 = __shfl(jv[(ST) >> 1], 32 * ((ST) & 1) + 8 * u + (lane >> 3));                           \
             const int jr = jr0 < 0 ? 0 : jr0; /* idle slots of the last step fetch row 0 */                         \
-            const uint8_t *src = counts + (size_t)jr * 128u + 16u * (unsigned)(dma_chunk ^ (((u >> 1) & 1) << 2)); \
+            const uint8_t *src = counts + (size_t)jr * 128u + 16u * (unsigned)(dma_chunk ^ ((u & 1) << 2));        \
             unsigned keep_;                                                                                         \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"   \
                          "s_mov_b32 m0, %0"                                                                         \
@@ -400,7 +401,6 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
                          : "memory");                                                                               \
         }                                                                                                           \
     }
-
     // ---- weights of all neighbours (lane t of step ks <-> neighbour 64 ks + t), as in the vector kernel ----
     int jv[NKS];
     double wv[NKS];
@@ -441,15 +441,17 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
     for (int bb = 0; bb < 8; ++bb) acc[bb] = v4i{0, 0, 0, 0};
 
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        if (ks * 64 < k) { // wave-uniform
-            if (ks > 0) SF_MC_DMA(ks) // (step 0 was issued before the weights were computed)
-            // ---- this lane's weight as nine 7-bit limbs, written where the A operand's lanes will read them ----
-            {
+    for (int st = 0; st < 2 * NKS; ++st) {
+        if (st * 32 < k) { // wave-uniform
+            if (st > 0) SF_MC_DMA(st) // (step 0 was issued before the weights were computed)
+            if ((st & 1) == 0) {
+                // ---- this lane's weight as nine 7-bit limbs, written where the A operands' lanes will read them:
+                //      abuf[limb][lane]; the two steps of a chunk use the lower / upper 32 columns ----
+                const int ks = st >> 1;
                 const double x = ldexp(wv[ks], S - 32); // < 2^31
                 const unsigned hi = (unsigned)x;
                 const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
-                const int pos = lane; // k slot of this lane's neighbour: block kb, byte a
+                const int pos = lane;
                 abuf[0 * 64 + pos] = (unsigned char)(lo & 127u);
                 abuf[1 * 64 + pos] = (unsigned char)((lo >> 7) & 127u);
                 abuf[2 * 64 + pos] = (unsigned char)((lo >> 14) & 127u);
@@ -462,17 +464,15 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
             __builtin_amdgcn_wave_barrier(); // both buffers are private to the wave; LDS operations of a wave stay in order
-            v4i A = v4i{0, 0, 0, 0};
-            if (a < 9) A = *reinterpret_cast<const v4i *>(&abuf[a * 64 + 16 * kb]); // row a = limb a
+            long A = 0;
+            if (a < 9) A = *reinterpret_cast<const long *>(&abuf[a * 64 + 32 * (st & 1) + 8 * kb]); // row a = limb a
             const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb) {
-                const v2i_t lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                const v2i_t t = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
                     (__attribute__((address_space(3))) v2i_t *)(rb + xoff[bb]));
-                const v2i_t hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-                    (__attribute__((address_space(3))) v2i_t *)(rb + xoff[bb] + 8 * 128));
-                const v4i B = v4i{lo[0], lo[1], hi[0], hi[1]};
-                acc[bb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[bb], 0, 0, 0);
+                const long B = (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
+                acc[bb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, B, acc[bb], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next step's DMA overwrites the rows
             __builtin_amdgcn_wave_barrier();
