@@ -372,6 +372,7 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
     const int64_t s = offset[slot];
     const int k = cnt[slot];
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
     // A step covers 32 neighbours (v_mfma_i32_16x16x32_i8: 8 k per 16-lane group).  Transposing reads: in its group
     // (k block kb) lane 2 q + p supplies the address of row 8 kb + q, bytes 8 p .. + 7 of chunk bb (slot bb ^ f(row),
@@ -392,12 +393,12 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
         _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                             \
             const int jr0 = __shfl(jv[(ST) >> 1], 32 * ((ST) & 1) + 8 * u + (lane >> 3));                           \
             const int jr = jr0 < 0 ? 0 : jr0; /* idle slots of the last step fetch row 0 */                         \
-            const uint8_t *src = counts + (size_t)jr * 128u + 16u * (unsigned)(dma_chunk ^ ((u & 1) << 2));        \
+            const unsigned voff = (unsigned)jr * 128u + 16u * (unsigned)(dma_chunk ^ ((u & 1) << 2));              \
             unsigned keep_;                                                                                         \
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"   \
-                         "s_mov_b32 m0, %0"                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                     \
+                         "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"                              \
                          : "=&s"(keep_)                                                                             \
-                         : "v"(src), "s"(lds_rows + 1024u * u)                                                      \
+                         : "v"(voff), "s"(rsrc), "s"(lds_rows + 1024u * u)                                          \
                          : "memory");                                                                               \
         }                                                                                                           \
     }
