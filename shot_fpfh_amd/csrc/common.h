@@ -171,6 +171,8 @@ struct sf_spfh {
     int bias = 0;        // stored value = count ^ bias (128 for the uint8 table: the byte read as int8 is count - 128)
     void *counts = nullptr; // n x stride, by sorted position
     int32_t *k = nullptr;   // n, neighbourhood size (self included), by sorted position
+    double *p4 = nullptr;   // uint8 table only: n x {x, y, z, (double)k} -- all the matrix-core K7 gathers per neighbour
+                            // besides the table row, in ONE 32-byte record (one cache line per lane instead of three)
 };
 
 static inline int64_t sf_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
-                                              CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias)
+                                              CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias,
+                                              double *__restrict__ p4)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[4][SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS];
@@ -142,7 +143,14 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
     __threadfence_block();
     CT *row = counts + i * (int64_t)stride;
     for (int b = lane; b < stride; b += 64) row[b] = (CT)((b < nb3 ? h[b] : 0u) ^ bias); // (padding bins: count 0)
-    if (lane == 0) kout[i] = k;
+    if (lane == 0) {
+        kout[i] = k;
+        if (p4) { // the per-neighbour record of the matrix-core K7
+            double2 *o = reinterpret_cast<double2 *>(p4 + 4 * i);
+            o[0] = make_double2(rec[6 * i + 0], rec[6 * i + 1]);
+            o[1] = make_double2(rec[6 * i + 2], (double)k);
+        }
+    }
 }
 
 // K7.  The vector-memory pipe of a CU takes 16 cycles per wave instruction whatever the width per lane, so
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
-                                                 const int32_t *__restrict__ kk, double *__restrict__ out)
+                                                 const double *__restrict__ p4, double *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // 32 rows of 128 B
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
@@ -411,20 +419,20 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mc(const double *__rest
         jv[c] = t < k ? idx[s + t] : -1;
     }
     SF_MC_DMA(0) // in flight while the weights are computed
-    double gx[NKS], gy[NKS], gz[NKS];
-    int gk[NKS];
+    double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
 #pragma unroll
     for (int c = 0; c < NKS; ++c) {
         const int j = jv[c] < 0 ? 0 : jv[c];
-        sf_load_xyz(rec, j, gx[c], gy[c], gz[c]);
-        gk[c] = kk[j];
+        const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j); // {x, y}, {z, k}: one 32-byte record
+        const double2 u0 = pp[0], u1 = pp[1];
+        gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
     }
     double wmax = 0.0;
 #pragma unroll
     for (int c = 0; c < NKS; ++c) {
         const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
         const double d2 = (cx * cx + cy * cy) + cz * cz;
-        const double kd = (double)gk[c], xx = d2 * (kd * kd);
+        const double kd = gk[c], xx = d2 * (kd * kd);
         const double y0 = __builtin_amdgcn_rsq(xx);
         const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
         const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
@@ -572,7 +580,8 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     sp->rows_alloc = std::max<int64_t>(sf_div_up(c->n, nr) * nr, 1);
     size_t nn = (size_t)sp->rows_alloc;
     if (hipMalloc(&sp->counts, nn * sp->stride * sp->elem_bytes) != hipSuccess ||
-        hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess) {
+        hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess ||
+        (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess)) {
         sf_set_error("sf_spfh_create: out of device memory");
         sf_spfh_free(ctx, sp);
         return nullptr;
@@ -586,6 +595,7 @@ extern "C" void sf_spfh_free(sf_ctx *ctx, sf_spfh *sp)
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (sp->counts) (void)hipFree(sp->counts);
     if (sp->k) (void)hipFree(sp->k);
+    if (sp->p4) (void)hipFree(sp->p4);
     delete sp;
 }
 
@@ -621,7 +631,7 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
-              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias)
+              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
@@ -670,6 +680,10 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
     char *kb = (char *)sp->k;
     SF_CHECK(sf_comm_allgather(ctx, kb + (size_t)ctx->rank * rows_per_rank * sizeof(int32_t), kb,
                                (size_t)rows_per_rank * sizeof(int32_t)));
+    if (sp->p4) {
+        char *pb = (char *)sp->p4;
+        SF_CHECK(sf_comm_allgather(ctx, pb + (size_t)ctx->rank * rows_per_rank * 32, pb, (size_t)rows_per_rank * 32));
+    }
     return SF_OK;
 }
 
@@ -756,7 +770,7 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     const int nks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
 #define SF_MC_LAUNCH(NKS)                                                                                            \
     SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc<NKS>, grid, block, c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, \
-              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, sp->k, dout)
+              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, (const double *)sp->p4, dout)
     if (nks <= 1) { SF_MC_LAUNCH(1); }
     else if (nks == 2) { SF_MC_LAUNCH(2); }
     else if (nks == 3) { SF_MC_LAUNCH(3); }
