@@ -167,6 +167,16 @@ int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int normal
  * bin counts: bytes up to 255 points (and n_bins <= 5), 16 bits up to 65535, 32 bits beyond. */
 sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_count);
 int sf_spfh_compute(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const double *edges);
+/* Extension for callers that want FPFH and SHOT from the SAME self-search lists (both descriptors of config 3 / 5):
+ * sf_spfh_compute_moments is sf_spfh_compute that also leaves, per query of `self_nbrs`, the weighted covariance of
+ * the SHOT local frame (get_local_rf, shot.py:27-35; 6 doubles c11 c21 c31 c22 c32 c33, device memory) -- the
+ * neighbours are gathered once instead of twice.  sf_shot_from_moments is sf_shot_single_scale starting from those
+ * moments (eigen-solves, then the fused K5); `nbrs` may be a sf_nbrs_slice view with cov advanced accordingly. */
+int sf_spfh_compute_moments(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const double *edges,
+                            double *cov_dev /* m x 6 */);
+int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *cov_dev /* m x 6 */, int normalize,
+                         int64_t min_neighborhood_size, double *lrf /* m x 9, nullable */, double *out /* m x 352 */,
+                         int flags);
 int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *spfh, int64_t rows_per_rank); /* RCCL, in place */
 int sf_spfh_export(sf_ctx *ctx, sf_cloud *cloud, sf_spfh *spfh, double *out /* n x nb^3 */, int flags);
 void sf_spfh_free(sf_ctx *ctx, sf_spfh *spfh);

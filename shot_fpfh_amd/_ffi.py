@@ -64,6 +64,8 @@ SIGNATURES = {
     "sf_shot_single_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),
     "sf_spfh_create": (_vp, [_vp, _vp, _int, _i64]),
     "sf_spfh_compute": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sf_spfh_compute_moments": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "sf_shot_from_moments": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),
     "sf_spfh_allgather": (_int, [_vp, _vp, _i64]),
     "sf_spfh_export": (_int, [_vp, _vp, _vp, _vp, _int]),
     "sf_spfh_free": (None, [_vp, _vp]),

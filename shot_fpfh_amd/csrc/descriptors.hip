@@ -189,27 +189,6 @@ __global__ __launch_bounds__(256) void k_pca(const double *__restrict__ rec, con
 // they fill 64-lane ones (7/8 against 113/128).
 // sqrt here only feeds the continuous weight r - |c| (no bin or sign decision hangs on its last bit), so it
 // is the 8-instruction v_rsq_f64 + Newton form instead of the correctly rounded 22-instruction one.
-__device__ inline double sf_sqrt_fast(double x) // x >= 0, normal range
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    return x > 0.0 ? g : 0.0;
-}
-
-__device__ inline double sf_rcp_fast(double d) // 1/d for normal d, ~1 ulp
-{
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-
 __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec, const double *__restrict__ qx,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
                                                   const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
@@ -1097,6 +1076,23 @@ extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf,
     return SF_OK;
 }
 
+namespace {
+// K4 when the moments come from K6 (sf_spfh_compute_moments): one LAPACK-compatible 3 x 3 eigen-solve per lane, the
+// largest / smallest eigenvectors stored as k_shot_lrf does in its raw mode (the fused K5 completes the frame).
+__global__ __launch_bounds__(256) void k_lrf_from_cov(const double *__restrict__ cov, int64_t m, double *__restrict__ lrf)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const double *c = cov + 6 * q;
+    const sf_eig::eig3 e = sf_eig::eigh3_lower(c[0], c[1], c[2], c[3], c[4], c[5]);
+    double *o = lrf + 9 * q;
+    o[0] = e.v13; o[1] = e.v23; o[2] = e.v33; // eigenvectors[:, 2]
+    o[3] = e.v11; o[4] = e.v21; o[5] = e.v31; // eigenvectors[:, 0]
+    o[6] = 0.0; o[7] = 0.0; o[8] = 0.0;
+}
+
+} // namespace
+
 // Single-scale SHOT in one go (shot_parallelization.py:135-183: frames and descriptor from the SAME search):
 // K4 without its vote sweep, then the fused K5, which votes on the neighbours it gathers anyway.
 extern "C" int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int normalize, int64_t min_nb, double *lrf,
@@ -1119,6 +1115,39 @@ extern "C" int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int n
                   nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, fused ? 1 : 0, dlrf);
     }
     SF_CHECK(launch_shot(ctx, c, nb, dlrf, normalize, min_nb, dout, fused));
+    if (own_lrf && lrf && m) SF_HIP(hipMemcpyAsync(lrf, own_lrf, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
+    if (own_lrf) {
+        if (lrf) SF_HIP(hipStreamSynchronize(ctx->stream));
+        sf_pool_release(ctx, own_lrf);
+    }
+    return SF_OK;
+}
+
+// sf_shot_single_scale with the frame moments already computed by sf_spfh_compute_moments on the SAME lists (self
+// search, every list <= 256 points): eigen-solves only, then the fused K5.  cov: m x 6 on the device.
+extern "C" int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *cov_dev, int normalize, int64_t min_nb,
+                                    double *lrf, double *out, int flags)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_from_moments"));
+    if (!out || !cov_dev) { sf_set_error("sf_shot_from_moments: null argument"); return SF_ERR_ARG; }
+    if (nb->qrow || nb->max_count > 256) {
+        sf_set_error("sf_shot_from_moments: needs a self search with lists of at most 256 points");
+        return SF_ERR_UNSUPPORTED;
+    }
+    SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
+    const int64_t m = nb->m;
+    const bool out_dev = flags & SF_OUT_DEVICE;
+    double *dlrf = lrf, *own_lrf = nullptr, *dout, *oout;
+    if (!out_dev || !lrf) {
+        SF_CHECK(sf_palloc(ctx, &own_lrf, (size_t)m * 9));
+        dlrf = own_lrf;
+    }
+    SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
+    if (m) {
+        SF_LAUNCH(ctx, "k4_lrf_from_cov", k_lrf_from_cov, dim3((unsigned)sf_div_up(m, 256)), dim3(256), cov_dev, m, dlrf);
+    }
+    SF_CHECK(launch_shot(ctx, c, nb, dlrf, normalize, min_nb, dout, true));
     if (own_lrf && lrf && m) SF_HIP(hipMemcpyAsync(lrf, own_lrf, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
     if (own_lrf) {

@@ -130,6 +130,29 @@ __device__ inline void sf_load_pn(const double *__restrict__ rec, int j, double 
     x = a.x; y = a.y; z = b.x; nx = b.y; ny = c.x; nz = c.y;
 }
 
+// 8-instruction v_rsq_f64 + Newton square root and a ~1 ulp reciprocal, for continuous quantities only (weights;
+// no bin or sign decision hangs on their last bit)
+__device__ inline double sf_sqrt_fast(double x) // x >= 0, normal range
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
+__device__ inline double sf_rcp_fast(double d) // 1/d for normal d, ~1 ulp
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 __device__ inline int sf_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ inline long long sf_uniform64(long long v)

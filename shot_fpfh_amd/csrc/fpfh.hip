@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
                                               CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias,
-                                              double *__restrict__ p4)
+                                              double *__restrict__ p4, double mom_radius, double *__restrict__ cov)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[4][SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS];
@@ -115,6 +115,16 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
             if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt], 1u);
         }
     };
+    // Optional by-product (cov != NULL): the weighted covariance of the SHOT frame (shot.py:27-35, w = r - ||c||, the
+    // point itself included), from the neighbours this wave gathers anyway -- K4 then only has its eigen-solves left.
+    double ws = 0, a11 = 0, a21 = 0, a31 = 0, a22 = 0, a32 = 0, a33 = 0;
+    auto moments = [&](double cx, double cy, double cz) {
+        const double w = mom_radius - sf_sqrt_fast((cx * cx + cy * cy) + cz * cz);
+        ws += w;
+        const double wx = cx * w, wy = cy * w, wz = cz * w;
+        a11 += cx * wx; a21 += cy * wx; a31 += cz * wx;
+        a22 += cy * wy; a32 += cz * wy; a33 += cz * wz;
+    };
     if (NCH > 0) {
         constexpr int NC = NCH > 0 ? NCH : 1;
         int jj[NC];
@@ -131,12 +141,25 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            if (jj[c] >= 0) pair(cx[c] - px, cy[c] - py, cz[c] - pz, ax[c], ay[c], az[c]);
+            if (jj[c] >= 0) {
+                if (cov) moments(cx[c] - px, cy[c] - py, cz[c] - pz);
+                pair(cx[c] - px, cy[c] - py, cz[c] - pz, ax[c], ay[c], az[c]);
+            }
     } else {
         for (int t = lane; t < k; t += 64) {
             double x, y, z, a, b, c;
             sf_load_pn(rec, idx[s + t], x, y, z, a, b, c);
+            if (cov) moments(x - px, y - py, z - pz);
             pair(x - px, y - py, z - pz, a, b, c);
+        }
+    }
+    if (cov) {
+        const double iw = sf_rcp_fast(sf_wave_sum(ws));
+        a11 = sf_wave_sum(a11) * iw; a21 = sf_wave_sum(a21) * iw; a31 = sf_wave_sum(a31) * iw;
+        a22 = sf_wave_sum(a22) * iw; a32 = sf_wave_sum(a32) * iw; a33 = sf_wave_sum(a33) * iw;
+        if (lane == 0) {
+            double *o = cov + 6 * q;
+            o[0] = a11; o[1] = a21; o[2] = a31; o[3] = a22; o[4] = a32; o[5] = a33;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -599,7 +622,7 @@ extern "C" void sf_spfh_free(sf_ctx *ctx, sf_spfh *sp)
     delete sp;
 }
 
-extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const double *edges)
+static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const double *edges, double *cov)
 {
     if (!ctx || !c || !nb || !sp || !edges) { sf_set_error("sf_spfh_compute: null argument"); return SF_ERR_ARG; }
     if (!nb->self) { sf_set_error("sf_spfh_compute: needs a sf_radius_search_self result"); return SF_ERR_ARG; }
@@ -631,7 +654,7 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
-              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4)
+              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
@@ -662,6 +685,20 @@ extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *s
 #undef SF_SPFH_LAUNCH
 #undef SF_SPFH_NB
     return SF_OK;
+}
+
+extern "C" int sf_spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const double *edges)
+{
+    return spfh_compute(ctx, c, nb, sp, edges, nullptr);
+}
+
+// SPFH of every query of `nb` AND, from the same sweep over the neighbours, the weighted covariance of the SHOT
+// local frame (6 doubles per query: c11 c21 c31 c22 c32 c33, device memory) for sf_shot_from_moments.
+extern "C" int sf_spfh_compute_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const double *edges,
+                                       double *cov_dev)
+{
+    if (!cov_dev) { sf_set_error("sf_spfh_compute_moments: null cov"); return SF_ERR_ARG; }
+    return spfh_compute(ctx, c, nb, sp, edges, cov_dev);
 }
 
 extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank)

@@ -461,6 +461,18 @@ class Neighbors:
         )
         return res
 
+    def shot_from_moments(self, moments: DeviceArray, first_row: int, normalize: bool, min_neighborhood_size: int,
+                          out: DeviceArray, lrf_out: Optional[DeviceArray] = None) -> DeviceArray:
+        """shot_single_scale from frame moments Spfh.compute(..., moments_out=) left for these lists; `first_row` = row
+        of `moments` that belongs to this object's first query (non-zero for a slice view)."""
+        _ffi.check(
+            self.engine.lib.sf_shot_from_moments(self.engine.h, self.cloud.h, self.h, moments.offset_ptr(first_row * 48),
+                                                 int(bool(normalize)), int(min_neighborhood_size),
+                                                 None if lrf_out is None else lrf_out.ptr, out.ptr, SF_OUT_DEVICE),
+            "sf_shot_from_moments",
+        )
+        return out
+
     def free(self) -> None:
         if getattr(self, "h", None) and self.engine.h:
             self.engine.lib.sf_nbrs_free(self.engine.h, self.h)
@@ -483,7 +495,16 @@ class Spfh:
             self.engine.lib.sf_spfh_create(self.engine.h, cloud.h, self.n_bins, int(max_count)), "sf_spfh_create"
         )
 
-    def compute(self, self_nbrs: Neighbors) -> "Spfh":
+    def compute(self, self_nbrs: Neighbors, moments_out: Optional[DeviceArray] = None) -> "Spfh":
+        """K6 for the queries of `self_nbrs`.  moments_out ((m, 6) device array): also leave the weighted covariance of
+        the SHOT frame of every query there (Neighbors.shot_from_moments consumes it), from the same neighbour sweep."""
+        if moments_out is not None:
+            _ffi.check(
+                self.engine.lib.sf_spfh_compute_moments(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(self.edges),
+                                                        moments_out.ptr),
+                "sf_spfh_compute_moments",
+            )
+            return self
         _ffi.check(
             self.engine.lib.sf_spfh_compute(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(self.edges)), "sf_spfh_compute"
         )

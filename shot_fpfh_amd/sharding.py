@@ -64,12 +64,14 @@ class DescriptorJob:
 
     One `step()` is one pass of the hot path: K1 grid build, K2 radius search (shared by both
     descriptors, their radii being equal), K6 SPFH, K7 FPFH, K4 local frames, K5 SHOT.
+    When both descriptors are wanted, K6 -- which gathers every neighbour of every point anyway -- also accumulates
+    the weighted covariance of the SHOT frame, and K4 shrinks to its eigen-solves (`share_sweep`).
     Rows of the outputs follow cell-sorted order; `block_original_indices()` maps them back.
     """
 
     def __init__(self, engine: Engine, points, normals, radius: float, n_bins: int = 5, normalize: bool = True,
                  min_neighborhood_size: int = 10, world: int = 1, rank: int = 0, spfh_exchange: str = "halo",
-                 do_fpfh: bool = True, do_shot: bool = True, overlap_chains: bool = False):
+                 do_fpfh: bool = True, do_shot: bool = True, overlap_chains: bool = False, share_sweep: bool = True):
         if spfh_exchange not in ("halo", "allgather"):
             raise ValueError("spfh_exchange must be 'halo' or 'allgather'")
         self.engine, self.radius, self.n_bins = engine, float(radius), int(n_bins)
@@ -78,6 +80,8 @@ class DescriptorJob:
         # overlap_chains: run the FPFH chain (K6, K7) and the SHOT chain (K4, K5) on the context's two HIP streams;
         # ~4 % faster at C3, but per-kernel durations then overlap, so the bench keeps it off by default
         self.overlap = bool(overlap_chains)
+        self.share_sweep = bool(share_sweep) and do_fpfh and do_shot
+        self.moments: Optional[DeviceArray] = None
         self.cloud: Cloud = engine.cloud(points, normals)
         self.plan = ShardPlan(self.cloud.n, world, rank)
         m = self.plan.end - self.plan.begin
@@ -118,17 +122,29 @@ class DescriptorJob:
                 two_streams = self.overlap and self.do_fpfh and self.do_shot and hasattr(self.engine, "fork")
                 if self.do_fpfh:
                     spfh = self._spfh_table(nb.max_count)  # (allocates on first use: before forking)
+                shared = self.share_sweep and nb.max_count <= 256  # (the fused K5's limit)
+                if shared:
+                    if self.moments is None or self.moments.shape[0] < nb.m:
+                        if self.moments is not None:
+                            self.moments.free()
+                        self.moments = self.engine.empty((nb.m, 6))
+                    spfh.compute(nb, moments_out=self.moments)  # K6 + frame moments, before the chains part
                 if two_streams:
                     self.engine.fork()  # FPFH chain on the side stream ...
                 if self.do_fpfh:
-                    spfh.compute(nb)
+                    if not shared:
+                        spfh.compute(nb)
                     if self.exchange == "allgather" and self.plan.world > 1:
                         spfh.allgather(self.plan.rows_per_rank)
                     spfh.fpfh(blk, None, out=self.fpfh_out)
                 if two_streams:
                     self.engine.switch(0)  # ... the SHOT chain on the main one, side by side
                 if self.do_shot:
-                    blk.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
+                    if shared:
+                        blk.shot_from_moments(self.moments, b - hb, self.normalize, self.min_nb, out=self.shot_out,
+                                              lrf_out=self.lrf_out)
+                    else:
+                        blk.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
                 if two_streams:
                     self.engine.switch(1)
                     self.engine.join()
@@ -143,10 +159,10 @@ class DescriptorJob:
         return self.cloud.perm()[b:e].astype(np.int64)
 
     def close(self) -> None:
-        for obj in (self.spfh, self.fpfh_out, self.lrf_out, self.shot_out, self.cloud):
+        for obj in (self.spfh, self.fpfh_out, self.lrf_out, self.shot_out, self.moments, self.cloud):
             if obj is not None:
                 obj.free()
-        self.spfh = self.fpfh_out = self.lrf_out = self.shot_out = None
+        self.spfh = self.fpfh_out = self.lrf_out = self.shot_out = self.moments = None
 
 
 class MatchJob:

@@ -59,6 +59,11 @@ class FakeNbrs:
         self.shot_lrf(out=lrf_out)
         return self.shot(lrf_out, normalize, min_neighborhood_size, out=out)
 
+    def shot_from_moments(self, moments, first_row, normalize, min_neighborhood_size, out, lrf_out=None):
+        # the shared-sweep form of the device engine: same result as the two-kernel form (the oracle has no moments)
+        assert moments.a.shape[0] >= first_row + self.m
+        return self.shot_single_scale(normalize, min_neighborhood_size, out=out, lrf_out=lrf_out)
+
     def free(self):
         pass
 
@@ -70,7 +75,7 @@ class FakeSpfh:
         self.k = np.zeros(cloud.n, dtype=np.int64)
         self._full = None
 
-    def compute(self, nb):
+    def compute(self, nb, moments_out=None):
         if self._full is None:  # the oracle's SPFH of the whole cloud, by sorted position
             _, sp = O.compute_fpfh_descriptor(np.zeros(0, dtype=np.int64), self.cloud.ps, self.cloud.ns, nb.radius,
                                               self.n_bins, return_spfh=True)

@@ -927,3 +927,31 @@ def test_match_large_permutation_property(eng, O):
     assert np.array_equal(io, i_h[pick[:40]]) and np.array_equal(do, d_h[pick[:40]])
     for x in (da, db, idx, dist):
         x.free()
+
+
+def test_shared_sweep_frames_equal_the_two_kernel_form(eng, O):
+    """With both descriptors wanted, K6 also accumulates the SHOT frame moments and K4 is reduced to its eigen-solves.
+    The frames and descriptors must equal the separate K4 + K5 ones up to the rounding of a different summation
+    order (and the oracle within the usual tolerance); FPFH must not change at all.  Also through a block view."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    p, nr, rng = synth_cloud(30000, 61)
+    r = 0.07
+    runs = {}
+    for share in (True, False):
+        job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, share_sweep=share)
+        job.step()
+        runs[share] = (job.shot_out.to_host(), job.lrf_out.to_host(), job.fpfh_out.to_host(), job.block_original_indices())
+        job.close()
+    (s1, l1, f1, rows), (s0, l0, f0, _) = runs[True], runs[False]
+    assert np.array_equal(f1, f0)
+    assert np.abs(l1 - l0).max() < 1e-11 and np.abs(s1 - s0).max() < 1e-10
+    pick = rng.choice(30000, 200, replace=False)
+    so = O.shot_single_scale(p, nr, p[rows[pick]], r, normalize=True, min_neighborhood_size=10)
+    assert close(s1[pick], so).all()
+    # a shard (block view of the lists, moments offset by the halo) gives the same rows as the full run, bit for bit
+    part = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=3, rank=1)
+    part.step()
+    b, e = part.plan.block()
+    assert np.array_equal(part.shot_out.to_host(), s1[b:e]) and np.array_equal(part.fpfh_out.to_host(), f1[b:e])
+    part.close()
