@@ -7,8 +7,9 @@ Workload (BASELINE.json metric "descriptors/sec (SHOT+FPFH) on 1M-pt cloud"): a 
 cloud of 1M points PER GPU (seed 3, float32-grid coordinates, random unit normals), every point a
 keypoint, radius 0.03 at N=1 (k ~ 106-113 neighbours); for N>1 the cloud has N*1M points and the radius
 shrinks by N^(-1/3) so the per-GPU work is fixed (weak scaling, BASELINE config 5 at N=8).  One step =
-one pass of the path with inputs resident in HBM: K1 grid build, K2 radius search, K6 SPFH, K7 FPFH
-(1M x 125 float64 out), K4 local frames, K5 SHOT (1M x 352 float64 out); outputs stay in HBM.
+one pass of the path with inputs resident in HBM: K1 grid build, K2 radius search, K6 SPFH (which also accumulates
+the SHOT frame moments from the neighbours it gathers), K7 FPFH (1M x 125 float64 out), K4 frame eigen-solves, K5 SHOT
+(1M x 352 float64 out); outputs stay in HBM.
 value = 2 * (N*1M) descriptors / step time (max over ranks).
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, algorithmic
@@ -35,6 +36,7 @@ ALG_BYTES = {
     "k7_fpfh": 1000 + 1000,  # per descriptor: own SPFH row in, 125 x 8 B FPFH row out
     "k5_shot": 2816 + 24 + 48,  # per descriptor: 352 x 8 B row out, keypoint, cloud share (all points keypoints)
     "k4_shot_lrf": 24 + 72,
+    "k4_lrf_from_cov": 48 + 72,
     "k2_radius_count": 24 + 4,
     "k2_radius_fill": 24,  # + 4 B per pair, added below
 }

@@ -16,7 +16,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHORT = [
-    ("k_shot_lrf", "k4_shot_lrf"), ("k_lrf_", "k4_shot_lrf"), ("k_shot", "k5_shot"), ("k_fpfh", "k7_fpfh"), ("k_spfh_export", "k6_spfh_export"),
+    ("k_lrf_from_cov", "k4_lrf_from_cov"), ("k_shot_lrf", "k4_shot_lrf"), ("k_lrf_", "k4_shot_lrf"), ("k_shot", "k5_shot"), ("k_fpfh", "k7_fpfh"), ("k_spfh_export", "k6_spfh_export"),
     ("k_spfh", "k6_spfh"), ("k_radius<2>", "k2_radius_slots"), ("k_radius<1>", "k2_radius_fill"), ("k_radius<0>", "k2_radius_count"),
     ("k_radius<true>", "k2_radius_fill"), ("k_radius<false>", "k2_radius_count"), ("k_export_lists", "k2_export_lists"),
     ("k_radius", "k2_radius"), ("k_normals", "k3_normals"), ("k_match_tile", "k8_match_tile"), ("k_ransac", "k9_ransac_score"),
