@@ -77,6 +77,45 @@ __device__ inline double sf_wave_max_nonneg(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// Eight sums over the 64 lanes at once, by a transposing butterfly: after the exchanges with lane ^ 32, ^ 16 and ^ 8 a
+// lane keeps ONE of the eight partial sums, v[4 b5 + 2 b4 + b3] (b = bits of the lane number), which three DPP steps
+// then complete over the eight lanes that share those bits.  Returns that total: lane 8 i (and its seven neighbours)
+// holds the sum of v[i].  7 exchange-and-add steps instead of 8 x 6.
+__device__ inline double sf_wave_sum8(const double (&v)[8])
+{
+    const int lane = sf_lane();
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    double k4[4], k2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double mine = b5 ? v[4 + i] : v[i], send = b5 ? v[i] : v[4 + i];
+        k4[i] = mine + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double mine = b4 ? k4[2 + i] : k4[i], send = b4 ? k4[i] : k4[2 + i];
+        k2[i] = mine + __shfl_xor(send, 16);
+    }
+    double r;
+    {
+        const double mine = b3 ? k2[1] : k2[0], send = b3 ? k2[0] : k2[1];
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(send), 0x128, 0xf, 0xf, false); // row_ror:8 = lane ^ 8
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), 0x128, 0xf, 0xf, false);
+        r = mine + __hiloint2double(hi, lo);
+    }
+#define SF_DPP_ADD(ctrl)                                                                                  \
+    {                                                                                                     \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(r), ctrl, 0xf, 0xf, false);          \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(r), ctrl, 0xf, 0xf, false);          \
+        r += __hiloint2double(hi, lo);                                                                    \
+    }
+    SF_DPP_ADD(0xB1)  // quad_perm [1,0,3,2]
+    SF_DPP_ADD(0x4E)  // quad_perm [2,3,0,1]
+    SF_DPP_ADD(0x141) // row_half_mirror: the other quad of the eight
+#undef SF_DPP_ADD
+    return r;
+}
+
 // Sum over each 16-lane DPP row, result in every lane of the row (the first four steps of sf_wave_sum).
 __device__ inline double sf_row16_sum(double v)
 {

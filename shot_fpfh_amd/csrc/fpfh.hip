@@ -154,13 +154,13 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
         }
     }
     if (cov) {
-        const double iw = sf_rcp_fast(sf_wave_sum(ws));
-        a11 = sf_wave_sum(a11) * iw; a21 = sf_wave_sum(a21) * iw; a31 = sf_wave_sum(a31) * iw;
-        a22 = sf_wave_sum(a22) * iw; a32 = sf_wave_sum(a32) * iw; a33 = sf_wave_sum(a33) * iw;
-        if (lane == 0) {
-            double *o = cov + 6 * q;
-            o[0] = a11; o[1] = a21; o[2] = a31; o[3] = a22; o[4] = a32; o[5] = a33;
-        }
+        const double part[8] = {ws, a11, a21, a31, a22, a32, a33, 0.0};
+        const double tot = sf_wave_sum8(part); // lanes 8 i .. 8 i + 7 hold the sum of part[i]
+        const double wsum = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 0),
+                                             __builtin_amdgcn_readlane(__double2loint(tot), 0));
+        const double iw = sf_rcp_fast(wsum);
+        const int e = lane >> 3;
+        if ((lane & 7) == 0 && e >= 1 && e <= 6) cov[6 * q + e - 1] = tot * iw; // c11 c21 c31 c22 c32 c33
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
