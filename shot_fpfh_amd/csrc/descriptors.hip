@@ -743,13 +743,13 @@ __device__ inline void shot_interp(const shot_kept &g, double radius, shot_value
 }
 
 template <int NCH, bool FUSED>
-__global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ rec,
-                                                    const double *__restrict__ qx, const double *__restrict__ qy,
-                                                    const double *__restrict__ qz, const int64_t *__restrict__ offset,
-                                                    const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-                                                    const int32_t *__restrict__ qrow,
-                                                    int64_t m, double radius, double *__restrict__ lrf,
-                                                    int normalize, int64_t min_nb, double *__restrict__ out)
+__device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
+                                                 const double *__restrict__ qx, const double *__restrict__ qy,
+                                                 const double *__restrict__ qz, const int64_t *__restrict__ offset,
+                                                 const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                 const int32_t *__restrict__ qrow, double radius,
+                                                 double *__restrict__ lrf, int normalize, int64_t min_nb,
+                                                 double *__restrict__ out, int64_t q, unsigned long long *slot)
 {
     // FUSED: `lrf` holds the raw axes written by k_shot_lrf(raw = 1); the sign votes (shot.py:40-45) are taken
     // here from the gathered neighbours and the finished frame is written back before it is used.
@@ -759,12 +759,9 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
     // register file, not LDS, set the occupancy.  A CD / EF slot carries ONE value plus a flag in bit 62
     // (unused by doubles below 2.0): the S3/S4 pair of a winner has a single non-zero member, selected by
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
-    __shared__ unsigned long long slot[704];
     unsigned long long *const sA = slot, *const sCD = slot + 352, *const sEF = slot + 528; // phase 1
     unsigned long long *const sB = slot, *const sG = slot + 352;                            // phase 2
     const int lane = threadIdx.x;
-    const int64_t q = sf_xcd_block();
-    if (q >= m) return;
     const int64_t s = offset[q];
     const int k = cnt[q];
     const int64_t row = qrow ? qrow[q] : q;
@@ -932,6 +929,22 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
         const int b = lane + 64 * u;
         if (b < 352) o[b] = vals[u] * scale;
     }
+}
+
+
+template <int NCH, bool FUSED>
+__global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ rec,
+                                                    const double *__restrict__ qx, const double *__restrict__ qy,
+                                                    const double *__restrict__ qz, const int64_t *__restrict__ offset,
+                                                    const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                    const int32_t *__restrict__ qrow,
+                                                    int64_t m, double radius, double *__restrict__ lrf,
+                                                    int normalize, int64_t min_nb, double *__restrict__ out)
+{
+    __shared__ unsigned long long slot[704];
+    const int64_t q = sf_xcd_block();
+    if (q >= m) return;
+    shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, radius, lrf, normalize, min_nb, out, q, slot);
 }
 
 } // namespace

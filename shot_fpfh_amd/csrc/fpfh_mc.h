@@ -1,0 +1,203 @@
+// fpfh_mc.h -- body of K7 on the int8 matrix cores, as a device function: used by k_fpfh_mc (fpfh.hip) and by the
+// kernel that runs K5 and K7 side by side on the same CUs (descriptors.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_util.h"
+
+// --------------------------------------------------------------------------------------------------
+// K7 on the matrix cores (uint8 table: at most 128 bins, neighbourhoods of at most 255 points).
+//
+// fpfh[q][b] - spfh[q][b] = (1/k_q) sum_j w_j c_jb is, per keypoint, the product of a 1 x k row of weights with
+// the k x 128 matrix of its neighbours' integer bin counts.  Done on the vector ALU it costs three instructions
+// per count (extract, convert, FMA).  Here the weights are turned into 63-bit fixed point (scaled by the
+// keypoint's largest weight) and cut into nine 7-bit limbs, and  R[limb][bin] = sum_j limb_j * (c_jb - 128)  is
+// accumulated EXACTLY in int32 by v_mfma_i32_16x16x64_i8: A = limbs x 64 neighbours, B = 64 neighbours x 16 bins,
+// the counts going from the table to the matrix unit as the bytes they are (the table stores count ^ 128, which
+// read as int8 is count - 128; a padding bin holds -128, so its column is -128 * sum_j limb_j and cancels the bias).
+// The sums are recombined in float64 once per keypoint:  sum_j w_j c_jb = 2^-S sum_i 2^(7i) (R[i][b] - R[i][pad]).
+// The only rounding is in the fixed-point weights (2^-62 of the largest one) and in that final recombination.
+//
+// One wave per keypoint, 32 neighbours per step (v_mfma_i32_16x16x32_i8).  Layouts (tools/ubench: probed on the
+// device): operand lane l holds row / column l % 16 and the 8 consecutive k of block l / 16, one per byte; the result
+// lane holds column l % 16 and rows 4 (l / 16) .. + 3.  Per step the 32 rows (128 B each) reach LDS by LDS-DMA; the B
+// operand of the MFMA for bins 16 bb .. 16 bb + 15 -- lane (a, kb): bin 16 bb + a of neighbours 8 kb .. 8 kb + 7, one
+// per byte -- is exactly what ONE transposing read (ds_read_b64_tr_b8: 8 rows x 16 bytes per 16-lane group,
+// delivered column-major) returns, so no byte shuffling is left to the vector pipe.
+// --------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Staged rows: 128 B each, no padding -- the image is written by LDS-DMA (buffer_load_dwordx4 ... lds: a wave
+// instruction writes its 64 lanes' 16-byte chunks back to back), so the bank spread comes from the SOURCE side:
+// slot s of row r holds chunk s ^ f(r), f(r) = (r >> 1) & 7.  A transposing read of one 32-lane half (8 rows x 16
+// bytes of block g and of block g + 1, same chunk) then touches all 64 banks once.
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+#ifndef SF_MC_WPB
+#define SF_MC_WPB 4 // waves (= keypoints in flight) per workgroup: 4.6 KB of LDS each
+#endif
+
+template <int NKS>
+__device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                             const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                             int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                             const uint8_t *__restrict__ counts, unsigned table_bytes,
+                                             const double *__restrict__ p4, double *__restrict__ out, int64_t q,
+                                             unsigned *rowbuf /* 4 KB */, unsigned char *abuf /* 576 B */)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
+    const int64_t slot = i - nbrs_begin;
+    const int64_t s = offset[slot];
+    const int k = cnt[slot];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
+    const int a = lane & 15, kb = lane >> 4;
+    // A step covers 32 neighbours (v_mfma_i32_16x16x32_i8: 8 k per 16-lane group).  Transposing reads: in its group
+    // (k block kb) lane 2 q + p supplies the address of row 8 kb + q, bytes 8 p .. + 7 of chunk bb (slot bb ^ f(row),
+    // f(row) = (row >> 1) & 7), and receives bin 16 bb + a of those eight rows -- exactly its B operand.
+    const int frow = ((a >> 2) & 3) | ((kb & 1) << 2);
+    const int rd_base = (8 * kb + (a >> 1)) * 128 + 8 * (a & 1); // bytes
+    int xoff[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) xoff[bb] = rd_base + 16 * (bb ^ frow);
+    // DMA: lane l of instruction u fills slot l & 7 of row 8 u + (l >> 3) with chunk (l & 7) ^ f(row)
+    const int dma_chunk = (lane & 7) ^ ((lane >> 4) & 3); // ^ 4 for the rows 8 .. 15 and 24 .. 31 (u = 1, 3)
+    const unsigned lds_rows = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)rowbuf);
+    // ---- stage the 32 rows of step ST (neighbours 32 ST .. + 31 = lanes 32 (ST & 1) .. of chunk ST >> 1) in LDS:
+    //      4 DMA instructions of 64 x 16 bytes ----
+#define SF_MC_DMA(ST)                                                                                               \
+    {                                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                             \
+            const int jr0 = __shfl(jv[(ST) >> 1], 32 * ((ST) & 1) + 8 * u + (lane >> 3));                           \
+            const int jr = jr0 < 0 ? 0 : jr0; /* idle slots of the last step fetch row 0 */                         \
+            const unsigned voff = (unsigned)jr * 128u + 16u * (unsigned)(dma_chunk ^ ((u & 1) << 2));              \
+            unsigned keep_;                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                     \
+                         "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"                              \
+                         : "=&s"(keep_)                                                                             \
+                         : "v"(voff), "s"(rsrc), "s"(lds_rows + 1024u * u)                                          \
+                         : "memory");                                                                               \
+        }                                                                                                           \
+    }
+    // ---- weights of all neighbours (lane t of step ks <-> neighbour 64 ks + t), as in the vector kernel ----
+    int jv[NKS];
+    double wv[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const int t = c * 64 + lane;
+        jv[c] = t < k ? idx[s + t] : -1;
+    }
+    SF_MC_DMA(0) // in flight while the weights are computed
+    double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const int j = jv[c] < 0 ? 0 : jv[c];
+        const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j); // {x, y}, {z, k}: one 32-byte record
+        const double2 u0 = pp[0], u1 = pp[1];
+        gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
+    }
+    double wmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
+        const double d2 = (cx * cx + cy * cy) + cz * cz;
+        const double kd = gk[c], xx = d2 * (kd * kd);
+        const double y0 = __builtin_amdgcn_rsq(xx);
+        const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+        const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+        wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0; // 1 / (k_j d_j); d == 0 is masked out (fpfh.py:110-114)
+        jv[c] = jv[c] < 0 ? 0 : jv[c];
+        wmax = fmax(wmax, wv[c]);
+    }
+    wmax = sf_wave_max_nonneg(wmax);
+    // fixed point: W = floor(w 2^S) < 2^63 with S = 62 - floor(log2 wmax)
+    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
+    const int S = 62 - e2;
+
+    v4i acc[8]; // acc[bb]: column a = bin 16 bb + a, rows = limbs 4 kb .. 4 kb + 3
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) acc[bb] = v4i{0, 0, 0, 0};
+
+#pragma unroll
+    for (int st = 0; st < 2 * NKS; ++st) {
+        if (st * 32 < k) { // wave-uniform
+            if (st > 0) SF_MC_DMA(st) // (step 0 was issued before the weights were computed)
+            if ((st & 1) == 0) {
+                // ---- this lane's weight as nine 7-bit limbs, written where the A operands' lanes will read them:
+                //      abuf[limb][lane]; the two steps of a chunk use the lower / upper 32 columns ----
+                const int ks = st >> 1;
+                const double x = ldexp(wv[ks], S - 32); // < 2^31
+                const unsigned hi = (unsigned)x;
+                const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
+                const int pos = lane;
+                abuf[0 * 64 + pos] = (unsigned char)(lo & 127u);
+                abuf[1 * 64 + pos] = (unsigned char)((lo >> 7) & 127u);
+                abuf[2 * 64 + pos] = (unsigned char)((lo >> 14) & 127u);
+                abuf[3 * 64 + pos] = (unsigned char)((lo >> 21) & 127u);
+                abuf[4 * 64 + pos] = (unsigned char)(((lo >> 28) | (hi << 4)) & 127u);
+                abuf[5 * 64 + pos] = (unsigned char)((hi >> 3) & 127u);
+                abuf[6 * 64 + pos] = (unsigned char)((hi >> 10) & 127u);
+                abuf[7 * 64 + pos] = (unsigned char)((hi >> 17) & 127u);
+                abuf[8 * 64 + pos] = (unsigned char)((hi >> 24) & 127u);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
+            __builtin_amdgcn_wave_barrier(); // both buffers are private to the wave; LDS operations of a wave stay in order
+            long A = 0;
+            if (a < 9) A = *reinterpret_cast<const long *>(&abuf[a * 64 + 32 * (st & 1) + 8 * kb]); // row a = limb a
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const v2i_t t = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                    (__attribute__((address_space(3))) v2i_t *)(rb + xoff[bb]));
+                const long B = (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
+                acc[bb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, B, acc[bb], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next step's DMA overwrites the rows
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- recombination: lane (a, g) holds rows (limbs) 4g .. 4g+3 of column a of acc[bb]; bin = 16 bb + a ----
+    int rpad[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of bb = 7: bin 127
+    const double p0 = ldexp(1.0, 28 * kb - S); // 2^(7 (4 g) - S)
+    const double f0 = p0, f1 = p0 * 128.0, f2 = p0 * 16384.0, f3 = p0 * 2097152.0;
+    const double kd = (double)k;
+    double inv_k = __builtin_amdgcn_rcp(kd);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    // partial sums over this lane's four limbs, for its eight bins
+    double part[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+        double v = (double)(acc[bb][0] - rpad[0]) * f0;
+        v = __builtin_fma((double)(acc[bb][1] - rpad[1]), f1, v);
+        v = __builtin_fma((double)(acc[bb][2] - rpad[2]), f2, v);
+        part[bb] = __builtin_fma((double)(acc[bb][3] - rpad[3]), f3, v);
+    }
+    // sum over the four limb groups g = kb, transposing as we go: after the exchange with lane ^ 32 a lane keeps only
+    // the blocks bb = 4 (kb >> 1) + {0..3}, after the one with lane ^ 16 only bb = 4 (kb >> 1) + 2 (kb & 1) + {0, 1}
+    // -- the two bins it writes
+    const bool up = (kb >> 1) != 0, odd = (kb & 1) != 0;
+    double keep[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const double mine = up ? part[4 + u] : part[u], send = up ? part[u] : part[4 + u];
+        keep[u] = mine + __shfl_xor(send, 32);
+    }
+    const double vsel0 = (odd ? keep[2] : keep[0]) + __shfl_xor(odd ? keep[0] : keep[2], 16);
+    const double vsel1 = (odd ? keep[3] : keep[1]) + __shfl_xor(odd ? keep[1] : keep[3], 16);
+    {
+        const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
+        const int b0 = 16 * bb0 + a, b1 = b0 + 16;
+        const uint8_t *own = counts + i * 128;
+        double *o = out + q * (int64_t)nb3;
+        if (b0 < nb3) o[b0] = (double)((unsigned)own[b0] ^ 128u) / kd + vsel0 * inv_k;
+        if (b1 < nb3) o[b1] = (double)((unsigned)own[b1] ^ 128u) / kd + vsel1 * inv_k;
+    }
+}
+
+#undef SF_MC_DMA
