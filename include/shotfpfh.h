@@ -177,6 +177,11 @@ int sf_spfh_compute_moments(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf
 int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *cov_dev /* m x 6 */, int normalize,
                          int64_t min_neighborhood_size, double *lrf /* m x 9, nullable */, double *out /* m x 352 */,
                          int flags);
+/* The two halves of sf_shot_from_moments (device pointers only): the eigen-solves, which leave the raw axes in
+ * lrf_dev, and the fused K5, which completes the frames in place and writes the descriptors. */
+int sf_lrf_raw_from_moments(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *cov_dev, double *lrf_dev);
+int sf_shot_from_raw_lrf(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, double *lrf_dev, int normalize,
+                         int64_t min_neighborhood_size, double *out_dev);
 int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *spfh, int64_t rows_per_rank); /* RCCL, in place */
 int sf_spfh_export(sf_ctx *ctx, sf_cloud *cloud, sf_spfh *spfh, double *out /* n x nb^3 */, int flags);
 void sf_spfh_free(sf_ctx *ctx, sf_spfh *spfh);

@@ -66,6 +66,8 @@ SIGNATURES = {
     "sf_spfh_compute": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "sf_spfh_compute_moments": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sf_shot_from_moments": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),
+    "sf_lrf_raw_from_moments": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sf_shot_from_raw_lrf": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp]),
     "sf_spfh_allgather": (_int, [_vp, _vp, _i64]),
     "sf_spfh_export": (_int, [_vp, _vp, _vp, _vp, _int]),
     "sf_spfh_free": (None, [_vp, _vp]),

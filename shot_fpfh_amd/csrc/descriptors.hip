@@ -1169,3 +1169,27 @@ extern "C" int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const
     }
     return SF_OK;
 }
+
+// The two halves of sf_shot_from_moments as separate calls, for a caller that runs the eigen-solves on the side
+// stream next to K7 (neither needs the other; K5 needs both K6 and the frames): device pointers only.
+extern "C" int sf_lrf_raw_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *cov_dev, double *lrf_dev)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_lrf_raw_from_moments"));
+    if (!cov_dev || !lrf_dev) { sf_set_error("sf_lrf_raw_from_moments: null argument"); return SF_ERR_ARG; }
+    if (nb->qrow) { sf_set_error("sf_lrf_raw_from_moments: needs a self search"); return SF_ERR_UNSUPPORTED; }
+    const int64_t m = nb->m;
+    if (m) {
+        SF_LAUNCH(ctx, "k4_lrf_from_cov", k_lrf_from_cov, dim3((unsigned)sf_div_up(m, 256)), dim3(256), cov_dev, m, lrf_dev);
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_shot_from_raw_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf_dev, int normalize, int64_t min_nb,
+                                    double *out_dev)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_from_raw_lrf"));
+    if (!lrf_dev || !out_dev) { sf_set_error("sf_shot_from_raw_lrf: null argument"); return SF_ERR_ARG; }
+    if (nb->max_count > 256) { sf_set_error("sf_shot_from_raw_lrf: lists of at most 256 points"); return SF_ERR_UNSUPPORTED; }
+    SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
+    return launch_shot(ctx, c, nb, lrf_dev, normalize, min_nb, out_dev, true);
+}

@@ -473,6 +473,23 @@ class Neighbors:
         )
         return out
 
+    def lrf_raw_from_moments(self, moments: DeviceArray, first_row: int, lrf_out: DeviceArray) -> None:
+        """First half of shot_from_moments: the eigen-solves (raw axes into lrf_out)."""
+        _ffi.check(
+            self.engine.lib.sf_lrf_raw_from_moments(self.engine.h, self.cloud.h, self.h, moments.offset_ptr(first_row * 48),
+                                                    lrf_out.ptr),
+            "sf_lrf_raw_from_moments",
+        )
+
+    def shot_from_raw_lrf(self, lrf: DeviceArray, normalize: bool, min_neighborhood_size: int, out: DeviceArray) -> DeviceArray:
+        """Second half: the fused K5 completes the frames in `lrf` and writes the descriptors."""
+        _ffi.check(
+            self.engine.lib.sf_shot_from_raw_lrf(self.engine.h, self.cloud.h, self.h, lrf.ptr, int(bool(normalize)),
+                                                 int(min_neighborhood_size), out.ptr),
+            "sf_shot_from_raw_lrf",
+        )
+        return out
+
     def free(self) -> None:
         if getattr(self, "h", None) and self.engine.h:
             self.engine.lib.sf_nbrs_free(self.engine.h, self.h)

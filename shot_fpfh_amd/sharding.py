@@ -129,6 +129,13 @@ class DescriptorJob:
                             self.moments.free()
                         self.moments = self.engine.empty((nb.m, 6))
                     spfh.compute(nb, moments_out=self.moments)  # K6 + frame moments, before the chains part
+                # the eigen-solves of the frames need only K6's moments and K7 needs only K6's table: side by side (the
+                # small, long-latency eigen kernel disappears under K7); K5 follows both
+                side_eig = shared and not two_streams and hasattr(self.engine, "fork") and hasattr(blk, "lrf_raw_from_moments")
+                if side_eig:
+                    self.engine.fork()
+                    blk.lrf_raw_from_moments(self.moments, b - hb, self.lrf_out)
+                    self.engine.switch(0)
                 if two_streams:
                     self.engine.fork()  # FPFH chain on the side stream ...
                 if self.do_fpfh:
@@ -139,7 +146,11 @@ class DescriptorJob:
                     spfh.fpfh(blk, None, out=self.fpfh_out)
                 if two_streams:
                     self.engine.switch(0)  # ... the SHOT chain on the main one, side by side
-                if self.do_shot:
+                if side_eig:
+                    self.engine.switch(1)
+                    self.engine.join()
+                    blk.shot_from_raw_lrf(self.lrf_out, self.normalize, self.min_nb, self.shot_out)
+                elif self.do_shot:
                     if shared:
                         blk.shot_from_moments(self.moments, b - hb, self.normalize, self.min_nb, out=self.shot_out,
                                               lrf_out=self.lrf_out)
