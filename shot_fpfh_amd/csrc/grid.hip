@@ -20,6 +20,10 @@
 #include "common.h"
 #include "device_util.h"
 
+// rocPRIM's radix sort falls back to a merge sort up to 2^20 items (a 1M-point cloud: block sort + 10 merge passes
+// x 2 kernels = 21 launches, 0.16 ms); Onesweep above 64k items does the 16-17 cell-id bits in a few launches.
+using sf_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+
 namespace {
 
 __global__ void k_bbox_partial(const double *__restrict__ xyz, int64_t n, double *__restrict__ partial)
@@ -375,13 +379,13 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     c->pop_end = base + ns;
     if (ns > 0) {
         size_t tmp_bytes = 0;
-        SF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
+        SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
                                          ctx->stream));
         void *tmp = nullptr;
         SF_CHECK(sf_pool_alloc(ctx, tmp_bytes ? tmp_bytes : 8, &tmp));
         {
             sf_launch_timer t_(ctx, "k1_radix_sort");
-            SF_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
+            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(tmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
                                              ctx->stream));
         }
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,

@@ -32,6 +32,9 @@ sf_grid_desc sf_make_grid_desc(const sf_cloud *c)
     return g;
 }
 
+// (see grid.hip: Onesweep instead of the merge-sort fallback up to 2^20 items)
+using sf_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+
 namespace {
 
 struct to_i64 {
@@ -516,12 +519,12 @@ static int prepare_queries(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *
         int bits = 1;
         while (((int64_t)1 << bits) < c->ncell) ++bits;
         size_t tb = 0;
-        SF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
+        SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
         void *tmp = nullptr;
         SF_CHECK(sf_pool_alloc(ctx, tb ? tb : 8, &tmp));
         {
             sf_launch_timer t_(ctx, "k2_query_sort");
-            SF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
+            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(tmp, tb, cid, cid_s, val, nb->qrow, (size_t)m, 0, bits, ctx->stream));
         }
         SF_LAUNCH(ctx, "k2_gather_queries", k_gather_queries, dim3((unsigned)sf_div_up(m, 256)), dim3(256), dq,
                   nb->qrow, m, nb->qx, nb->qy, nb->qz);
