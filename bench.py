@@ -3,24 +3,38 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric "descriptors/sec (SHOT+FPFH) on 1M-pt cloud"): a synthetic uniform
-cloud of 1M points PER GPU (seed 3, float32-grid coordinates, random unit normals), every point a
-keypoint, radius 0.03 at N=1 (k ~ 106-113 neighbours); for N>1 the cloud has N*1M points and the radius
-shrinks by N^(-1/3) so the per-GPU work is fixed (weak scaling, BASELINE config 5 at N=8).  One step =
-one pass of the path with inputs resident in HBM: K1 grid build, K2 radius search, K6 SPFH (which also accumulates
-the SHOT frame moments from the neighbours it gathers), K7 FPFH (1M x 125 float64 out), K4 frame eigen-solves, K5 SHOT
-(1M x 352 float64 out); outputs stay in HBM.
-value = 2 * (N*1M) descriptors / step time (max over ranks).
+Run directly with N > 1 (no WORLD_SIZE in the environment) it starts N child processes itself, one per GPU, BEFORE
+touching the GPU; under a launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE set) it is one of the ranks.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, algorithmic
-bytes / HIP-event kernel time, measured live on the engine's own stream) and `cpu_baseline` (the CPU
-oracle, single thread, on a bounded sample of the same workload; N=1 only).
+Workload (BASELINE.json metric "descriptors/sec (SHOT+FPFH) on 1M-pt cloud"): a synthetic uniform cloud of 1M points
+PER GPU (seed 3, float32-grid coordinates, random unit normals), every point a keypoint, radius 0.03 at N = 1 (k ~ 110
+neighbours); for N > 1 the cloud has N x 1M points and the radius shrinks by N^(-1/3), so the per-GPU work is fixed
+(weak scaling; BASELINE config 5 at N = 8).
+
+Timed region (`value`): K steps, each ONE pass of the descriptor path over this rank's block with inputs resident in
+HBM -- K1 grid build, K2 radius search, K6 SPFH (+ the SHOT frame moments), K7 FPFH (rows x 125 float64 out), K4 frame
+eigen-solves, K5 SHOT (rows x 352 float64 out); outputs stay in HBM.  value = 2 x (N x 1M) descriptors / step time
+(max over ranks).  Same definition at every N, so the driver's scaling efficiency compares like with like.
+
+After the timed region the SAME process measures the rest of the path north_star names and reports it under extra keys:
+  * `exchange_match`  -- BASELINE config 5's tail: the C4 partner cloud's SHOT rows (one more descriptor pass), a
+    keypoint subset of both descriptor sets gathered per rank, ONE RCCL all-gather of the reference subset rows over
+    xGMI (ncclAllGather is executed at N = 1 too, on a one-rank communicator), the sharded K8 brute-force L2 matching,
+    and the fraction of matches that recover the true correspondence;
+  * `ransac`          -- (N = 1) K9 at 10^4 draws x 10^6 matches through ransac_on_matches, recovered transform checked;
+  * `dropin_host_to_host` -- (N = 1) the reference-signature Python calls on the same cloud, NumPy in / NumPy out;
+  * `parity`          -- 300 rows of the TIMED outputs against the CPU oracle (the timed path is the checked path);
+  * `cpu_baseline`    -- (N = 1) the reference-shaped NumPy restatement (oracle/numpy_shaped.py, calibrated against
+    the reference in the build container) and the scalar C port, on bounded samples, on this box's host cores.
+Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +43,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP16_MFMA_PEAK_TF = 2500.0  # dense FP16 matrix peak (ibid.)
+FP64_VALU_PEAK_TF = 78.6    # FP64 vector peak (ibid.)
 # algorithmic bytes per unit at float64 API widths (DESIGN.md "Measurement")
 ALG_BYTES = {
     "k6_spfh": 48 + 1000,  # per cloud point: xyz+normal in, 125 x 8 B SPFH row out
@@ -40,6 +56,7 @@ ALG_BYTES = {
     "k2_radius_count": 24 + 4,
     "k2_radius_fill": 24,  # + 4 B per pair, added below
 }
+C4_EULER, C4_T = (0.3, -0.2, 0.5), (0.1, -0.3, 0.2)  # SURVEY 8d, config C4's rigid motion
 
 
 def make_cloud(n: int, seed: int):
@@ -50,10 +67,76 @@ def make_cloud(n: int, seed: int):
     return p, nr
 
 
-def cpu_baseline(points_per_gpu: int, radius: float) -> dict:
-    """The CPU oracle (scalar C port of the reference algorithm, one thread) on a bounded sample:
-    a 150k-point cloud at the SAME point density per radius-ball (radius scaled by (n/150k)^(1/3)), all
-    points keypoints, FPFH + SHOT.  ~10 s of CPU work."""
+def c4_partner(points, normals, seed: int):
+    """ref = scan[perm] R^T + t, normals rotated, perm from the given seed."""
+    from scipy.spatial.transform import Rotation
+
+    rot = Rotation.from_euler("xyz", C4_EULER).as_matrix()
+    perm = np.random.default_rng(seed).permutation(points.shape[0])
+    return points[perm] @ rot.T + np.asarray(C4_T), normals[perm] @ rot.T, perm, rot
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: N fresh children, one per GPU, started before this process has
+    made any GPU call (a process that has initialised HIP must never fork + exec).  Rank 0 prints the JSON line."""
+    port = free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---- CPU baselines (N = 1 only) -----------------------------------------------------------------------------------
+def start_numpy_shaped_baseline(points_per_gpu: int, radius: float, sample: int):
+    """The reference-shaped baseline forks a multiprocessing.Pool, so it runs in a child started BEFORE HIP is
+    initialised in this process, and is waited for before any GPU timing starts."""
+    n_procs = min(8, os.cpu_count() or 1)  # the reference's default n_procs = 8 (shot_parallelization.py:26)
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "numpy_shaped.py"), str(points_per_gpu), repr(radius), str(sample), str(n_procs)]
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
+
+
+def finish_numpy_shaped_baseline(proc) -> dict:
+    out, _ = proc.communicate(timeout=900)
+    if proc.returncode != 0:
+        raise RuntimeError("oracle/numpy_shaped.py failed")
+    r = json.loads(out.strip().splitlines()[-1])
+    cal = None
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")))
+    except Exception:
+        pass
+    return {
+        "value": r["desc_per_s"],
+        "unit": "descriptors/s",
+        "cores": r["n_procs"],
+        "kind": "port",
+        "sample": f"{r['points']}-pt uniform cloud, all points keypoints, r={r['radius']:.4f} (same expected neighbours per ball as "
+        f"the GPU workload); reference-shaped NumPy restatement oracle/numpy_shaped.py: sklearn KDTree + per-point NumPy loop, "
+        f"FPFH single process {r['fpfh_s']:.1f}s (as the reference runs it), SHOT through a fork Pool of {r['n_procs']} "
+        f"{r['shot_s']:.1f}s (the reference's default n_procs)",
+        "host_cores_available": os.cpu_count(),
+        "calibration_vs_reference": None if cal is None else {
+            "ratio_time_restatement_over_reference": cal["ratio_total"], "reference_desc_per_s_build_container": cal["ref_desc_per_s"],
+            "max_abs_diff_vs_reference": max(cal["fpfh_max_abs_diff"], cal["shot_max_abs_diff"]),
+            "where": "build container, 8 vCPU (tools/calibrate_cpu_baseline.py; the reference cannot travel to the GPU box)"},
+    }
+
+
+def c_port_baseline(points_per_gpu: int, radius: float) -> dict:
+    """The scalar C oracle (one thread) on a 150k-point sample at the same neighbours per ball: a stricter baseline."""
     from oracle import oracle as O
 
     ns = min(150000, points_per_gpu)
@@ -65,18 +148,38 @@ def cpu_baseline(points_per_gpu: int, radius: float) -> dict:
     t1 = time.perf_counter()
     O.shot_single_scale(p, nr, p, r, True, 10)
     t2 = time.perf_counter()
-    return {
-        "value": 2 * ns / (t2 - t0),
-        "unit": "descriptors/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{ns}-pt uniform cloud, all points keypoints, r={r:.4f} (same neighbours per ball as the GPU "
-        f"workload), FPFH 5 bins {t1 - t0:.1f}s + SHOT {t2 - t1:.1f}s, oracle/shot_fpfh_oracle.c single thread",
-        "host_cores_available": os.cpu_count(),
-    }
+    return {"value": 2 * ns / (t2 - t0), "unit": "descriptors/s", "cores": 1, "kind": "port",
+            "sample": f"{ns}-pt uniform cloud, all points keypoints, r={r:.4f}, FPFH {t1 - t0:.1f}s + SHOT {t2 - t1:.1f}s, "
+            f"oracle/shot_fpfh_oracle.c single thread"}
 
 
-def main() -> None:
+# ---- parity of the timed outputs ---------------------------------------------------------------------------------------
+def parity_sample(job, points, normals, radius, rows: int = 300) -> dict:
+    """`rows` rows of the outputs the TIMED steps left in HBM against the CPU oracle (BASELINE tolerance)."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(5)
+    orig = job.block_original_indices()
+    pick = np.sort(rng.choice(job.m, min(rows, job.m), replace=False))
+    out = {"rows": int(pick.size), "tolerance": "|a-b| <= 1e-5*max(1,|b|)"}
+    ok = True
+    if job.do_fpfh:
+        got = np.stack([job.fpfh_out.rows_to_host(int(i), 1)[0] for i in pick])
+        want = O.compute_fpfh_descriptor_sample(orig[pick], points, normals, radius, job.n_bins)
+        err = np.abs(got - want)
+        out["fpfh_max_abs_err"] = float(err.max())
+        ok &= bool((err <= 1e-5 * np.maximum(1.0, np.abs(want))).all())
+    if job.do_shot:
+        got = np.stack([job.shot_out.rows_to_host(int(i), 1)[0] for i in pick])
+        want = O.shot_single_scale(points, normals, points[orig[pick]], radius, job.normalize, job.min_nb)
+        err = np.abs(got - want)
+        out["shot_max_abs_err"] = float(err.max())
+        ok &= bool((err <= 1e-5 * np.maximum(1.0, np.abs(want))).all())
+    out["ok"] = ok
+    return out
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -85,22 +188,42 @@ def main() -> None:
     ap.add_argument("--radius", type=float, default=0.03)
     ap.add_argument("--spfh-exchange", choices=["halo", "allgather"], default="halo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="points of the reference-shaped CPU baseline's sample")
     ap.add_argument("--only", choices=["both", "fpfh", "shot"], default="both")
     ap.add_argument("--overlap", action="store_true",
                     help="run the FPFH and SHOT chains on two HIP streams (faster; per-kernel times then overlap)")
+    ap.add_argument("--no-match", action="store_true", help="skip the exchange + matching phase (config 5's tail)")
+    ap.add_argument("--match-rows", type=int, default=None,
+                    help="keypoints of the matched subset, whole job (default 262144 at N = 1, 131072 x N otherwise)")
+    ap.add_argument("--match-steps", type=int, default=2)
+    ap.add_argument("--no-ransac", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the host-to-host drop-in timing (N = 1)")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="FUNCTIONAL TEST ONLY: allow more ranks than GPUs; the exchange is then staged through host memory "
+                         "and gloo (RCCL refuses two ranks on one device) and no timing is a scaling result")
     ap.add_argument("--emulate-rank", type=int, default=None, metavar="R",
-                    help="single process, no rendezvous: run rank R's share of a --gpus N job on this GPU (what one "
-                         "GPU of an N-GPU node does per step; for sizing the sharded path on a 1-GPU box)")
+                    help="single process, no rendezvous: run rank R's share of a --gpus N descriptor pass on this GPU")
     args = ap.parse_args()
+
+    emulated = args.emulate_rank is not None
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not emulated:
+        return spawn_ranks(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    emulated = args.emulate_rank is not None
     if emulated:
         world, rank, local_rank = args.gpus, args.emulate_rank, 0
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    lead = rank == 0 or emulated
+    single = world == 1
+
+    shaped = None
+    if single and not args.no_cpu_baseline:  # (forks a Pool: must start before this process touches the GPU)
+        shaped = finish_numpy_shaped_baseline(start_numpy_shaped_baseline(args.points_per_gpu, args.radius, args.cpu_sample))
+
     dist = None
     if world > 1 and not emulated:
         import torch.distributed as dist  # control plane only: rendezvous, barrier, max-reduce of the timing
@@ -109,18 +232,38 @@ def main() -> None:
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import shot_fpfh_amd as s
-    from shot_fpfh_amd.sharding import DescriptorJob
-
     from shot_fpfh_amd import _ffi
+    from shot_fpfh_amd.sharding import DescriptorJob, SubsetMatchJob
 
     n_dev = max(_ffi.load().sf_device_count(), 1)
-    if local_rank >= n_dev and rank == 0:
-        print(f"# warning: {world} ranks share {n_dev} GPU(s) (functional test only, timings are not a scaling result)", file=sys.stderr)
+    oversub = world > n_dev and not emulated
+    if oversub and not args.oversubscribe:
+        raise SystemExit(f"{world} ranks but {n_dev} GPU(s): one process per GPU is the only measured configuration "
+                         f"(--oversubscribe runs a functional test with a host-staged exchange)")
     eng = s.Engine(local_rank % n_dev)
-    if world > 1 and args.spfh_exchange == "allgather" and not emulated:
-        ids = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0], world, rank)
+    exchange = "none (descriptor pass only)"
+    if not emulated:
+        if oversub:
+            exchange = "gloo, staged through host memory (oversubscribed functional test, NOT RCCL)"
+            import torch
+
+            def host_staged_allgather(buf, bytes_per_rank):
+                flat = buf.to_host().reshape(-1).view(np.uint8)
+                mine = torch.from_numpy(flat[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy())
+                parts = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
+                buf.from_host(flat.view(buf.dtype).reshape(buf.shape))
+
+            eng.allgather = host_staged_allgather
+            if args.spfh_exchange == "allgather":
+                raise SystemExit("--oversubscribe supports the halo SPFH exchange only")
+        else:
+            ids = [eng.comm_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(ids, src=0)
+            eng.comm_init(ids[0], world, rank)  # RCCL communicator; one rank too, so ncclAllGather really executes
+            exchange = f"RCCL ncclAllGather over {world} rank(s)"
 
     n_total = args.points_per_gpu * world
     radius = args.radius * world ** (-1.0 / 3.0)
@@ -128,13 +271,22 @@ def main() -> None:
     job = DescriptorJob(eng, points, normals, radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world,
                         rank=rank, spfh_exchange=args.spfh_exchange, do_fpfh=args.only in ("both", "fpfh"),
                         do_shot=args.only in ("both", "shot"), overlap_chains=args.overlap)
-    del points, normals
 
     def barrier():
         eng.sync()
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- timed region: K descriptor passes ---------------------------------------------------------------------------
     for _ in range(args.warmup):
         job.step()
     barrier()
@@ -146,20 +298,16 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     eng.profile(False)
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
+    rep = eng.profile_report()
 
     kinds = (1 if job.do_fpfh else 0) + (1 if job.do_shot else 0)
     n_desc = kinds * n_total
     ms_per_step = 1000.0 * elapsed / args.steps
     value = n_desc / (elapsed / args.steps)
 
-    if rank == 0 or emulated:
-        rep = eng.profile_report()
+    out = {}
+    if lead:
         kern = {k: (v[0], v[1] / max(v[0], 1)) for k, v in rep.items() if v[0] > 0 and v[1] > 0}
         per_step_ms = {k: rep[k][1] / args.steps for k in kern}
         dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: rep[k][1])
@@ -167,11 +315,12 @@ def main() -> None:
         units = job.m  # descriptors of this rank's block per launch (halo SPFH rows are extra work, not counted)
         alg_bytes = ALG_BYTES[dom] * units + (4 * job.last_pairs if dom == "k2_radius_fill" else 0)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic, traffic_src = tj.get(dom), tj.get("_source", "profiles/traffic.json")
             except Exception:
                 traffic = None
         out = {
@@ -194,6 +343,7 @@ def main() -> None:
                 f"mean neighbourhood {job.last_pairs / max(job.plan.end - job.plan.begin, 1):.1f}",
                 "sharding": f"query blocks over {world} GPU(s), cloud replicated, SPFH {args.spfh_exchange}",
                 "points_per_gpu": args.points_per_gpu,
+                "exchange": exchange,
             },
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step_ms.items())},
             "roofline": {
@@ -204,19 +354,168 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                f"NOT measured in this run: per-launch HBM bytes from separate rocprofv3 --pmc passes of this command, {traffic_src}",
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
+            "whole_step_hbm": {"algorithmic_bytes": sum(ALG_BYTES[k] for k in ("k6_spfh", "k7_fpfh", "k5_shot")) * units,
+                               "achieved_gbs": sum(ALG_BYTES[k] for k in ("k6_spfh", "k7_fpfh", "k5_shot")) * units / (ms_per_step * 1e-3) / 1e9}
+            if kinds == 2 else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.points_per_gpu, args.radius)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+
+    # ---- parity of what the timed steps left in HBM ------------------------------------------------------------------
+    if not args.no_parity:
+        par = parity_sample(job, points, normals, radius)
+        if dist is not None:
+            allp = [None] * world
+            dist.all_gather_object(allp, par)
+            par = {"per_rank": allp, "ok": all(p["ok"] for p in allp)}
+        if lead:
+            out["parity"] = par
+
+    # ---- config 5's tail: partner cloud, subset, RCCL all-gather, sharded K8 ------------------------------------------
+    if not args.no_match and job.do_shot and not emulated:
+        total_rows = args.match_rows or (262144 if single else 131072 * world)
+        total_rows = min(total_rows, n_total)
+        ref_pts, ref_nrm, perm, rot = c4_partner(points, normals, 4)
+        t_prep = time.perf_counter()
+        ref_job = DescriptorJob(eng, ref_pts, ref_nrm, radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world,
+                                rank=rank, spfh_exchange="halo", do_fpfh=False, do_shot=True)
+        ref_job.step()
+        eng.sync()
+        t_prep = time.perf_counter() - t_prep
+        scan_orig = job.block_original_indices()            # scan rows of this rank -> scan point
+        ref_label = perm[ref_job.block_original_indices()]  # ref rows of this rank -> the scan point they came from
+        s_sel, r_sel = np.flatnonzero(scan_orig < total_rows), np.flatnonzero(ref_label < total_rows)
+        cap = max_over_ranks(float(max(s_sel.size, r_sel.size, 1)))
+        cap = int(-(-int(cap) // 256) * 256)
+        sub = SubsetMatchJob(eng, 352, cap, world, rank)
+        sub.select(job.shot_out, s_sel, scan_orig[s_sel], ref_job.shot_out, r_sel, ref_label[r_sel])
+        sub.run()  # warm-up (RCCL channel setup, pool growth)
+        barrier()
+        eng.profile_reset()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.match_steps):
+            sub.run()
+        barrier()
+        t_match = max_over_ranks(time.perf_counter() - t0) / max(args.match_steps, 1)
+        eng.profile(False)
+        mrep = eng.profile_report()
+        s_lab, r_lab = sub.matches()
+        stats = np.array([float((s_lab == r_lab).sum()), float(s_lab.size)])
+        if dist is not None:
+            import torch
+
+            tt = torch.from_numpy(stats)
+            dist.all_reduce(tt)
+            stats = tt.numpy()
+        if lead:
+            k8 = {k: v[1] / max(args.match_steps, 1) for k, v in mrep.items() if v[1] > 0}
+            k8_ms = sum(v for k, v in k8.items() if k.startswith("k8_"))
+            gathered = cap * world
+            flop = 2.0 * cap * gathered * 352
+            out["exchange_match"] = {
+                "what": "BASELINE config 5 tail on SHOT rows: subset gather, all-gather of reference rows + labels, sharded K8",
+                "rccl_ranks": world if not oversub else 0,
+                "exchange": exchange,
+                "subset_keypoints_total": int(total_rows),
+                "rows_per_rank_padded": cap,
+                "allgather_bytes_per_rank": cap * 352 * 8,
+                "ms_per_pass": 1000.0 * t_match,
+                "kernels_ms_per_pass": {k: round(v, 4) for k, v in sorted(k8.items())},
+                "k8_pair_dists_per_s": cap * gathered / (k8_ms * 1e-3) if k8_ms > 0 else None,
+                "k8_roofline": {"bound": "mfma", "achieved": flop / (k8_ms * 1e-3) / 1e12 if k8_ms > 0 else None,
+                                "peak": FP16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": flop / (k8_ms * 1e-3) / 1e12 / FP16_MFMA_PEAK_TF if k8_ms > 0 else None,
+                                "note": "2*m1*m2*d flop of the FP16 pre-filter pass; exact FP64 re-ranking of the survivors included in the time"},
+                "matches": int(stats[1]),
+                "matches_recovering_true_correspondence": float(stats[0] / max(stats[1], 1.0)),
+                "partner_cloud_descriptor_pass_s": t_prep,
+            }
+        sub.close()
+        ref_job.close()
+
+        # ---- K9: 10^4 draws x 10^6 matches (N = 1) --------------------------------------------------------------------
+        if single and not args.no_ransac:
+            from shot_fpfh_amd.matching import ransac_on_matches
+            import shot_fpfh_amd.matching.ransac as R
+
+            m = min(1_000_000, n_total)
+            rng = np.random.default_rng(9)
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(perm.size)
+            si = np.arange(m)
+            ri = inv[:m].copy()
+            bad = rng.random(m) < 1.0 / 3.0
+            ri[bad] = rng.integers(0, n_total, int(bad.sum()))  # a third of the matches are wrong
+            R.rng = np.random.default_rng(seed=72)
+            eng.profile_reset()
+            eng.profile(True)
+            t0 = time.perf_counter()
+            ratio, tf = ransac_on_matches(si, ri, points, ref_pts, n_draws=10000, draw_size=4, distance_threshold=0.01,
+                                          disable_progress_bar=True, engine=eng)
+            t_r = time.perf_counter() - t0
+            eng.profile(False)
+            k9 = eng.profile_report().get("k9_ransac_score", (0, 0.0))
+            flop9 = 26.0 * 1e4 * m
+            out["ransac"] = {
+                "draws": 10000, "matches": m, "host_to_host_s": t_r, "k9_ms": k9[1],
+                "k9_pair_draws_per_s": 1e4 * m / (k9[1] * 1e-3) if k9[1] > 0 else None,
+                "k9_roofline": {"bound": "valu_fp64", "achieved": flop9 / (k9[1] * 1e-3) / 1e12 if k9[1] > 0 else None,
+                                "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": flop9 / (k9[1] * 1e-3) / 1e12 / FP64_VALU_PEAK_TF if k9[1] > 0 else None},
+                "inlier_ratio": float(ratio),
+                "rotation_err": float(np.abs(tf.rotation - rot).max()),
+                "translation_err": float(np.abs(tf.translation - np.asarray(C4_T)).max()),
+            }
+
+    # ---- the drop-in calls, host to host (N = 1) ---------------------------------------------------------------------------
+    if single and not args.no_dropin and not emulated:
+        from shot_fpfh_amd.descriptors import ShotMultiprocessor, compute_fpfh_descriptor
+
+        job.close()
+        kp = np.arange(n_total)
+        res = {}
+        for name, call in (
+            ("compute_fpfh_descriptor", lambda: compute_fpfh_descriptor(kp, points, normals, radius, 5, verbose=False)),
+            ("ShotMultiprocessor.compute_descriptor_single_scale", None),
+        ):
+            if call is None:
+                def call():
+                    with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+                        return sm.compute_descriptor_single_scale(points, normals, points, radius)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                arr = call()
+                ts.append(time.perf_counter() - t0)
+                shape = arr.shape
+                del arr
+            res[name] = {"first_call_s": ts[0], "best_s": min(ts), "out_shape": list(shape),
+                         "desc_per_s_best": n_total / min(ts), "out_gb": shape[0] * shape[1] * 8 / 1e9}
+        best = sum(v["best_s"] for v in res.values())
+        out["dropin_host_to_host"] = {
+            "what": "reference-signature Python calls, NumPy arrays in, fresh NumPy arrays out (H2D + kernels + D2H), same cloud",
+            "calls": res, "desc_per_s_both": 2 * n_total / best,
+        }
+    else:
+        job.close()
+
+    if lead:
+        if single and not args.no_cpu_baseline:
+            out["cpu_baseline"] = shaped
+            out["cpu_baseline_c_port"] = c_port_baseline(args.points_per_gpu, args.radius)
+            out["speedup_vs_cpu_baseline"] = value / shaped["value"]
+            out["speedup_vs_c_port"] = value / out["cpu_baseline_c_port"]["value"]
         print(json.dumps(out))
-    job.close()
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -154,6 +154,16 @@ int sf_shot(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *lrf /* m 
 int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int normalize, int64_t min_neighborhood_size,
                          double *lrf /* m x 9, nullable */, double *out /* m x 352 */, int flags);
 
+/* get_azimuth_idx (shot.py:51-70), elementwise: octant 0..7 of (x, y), a boundary ray belonging to the LOWER octant
+ * (+x -> 3, +y -> 5, -x -> 7, -y -> 1, diagonals 4 / 6 / 0 / 2, origin -> 0).  The device function K5 bins with. */
+int sf_azimuth_idx(sf_ctx *ctx, const double *x, const double *y, int64_t n, int64_t *idx, int flags);
+/* compute_shot_descriptor, the reference's serial variant (shot.py:310-499; "debug only", not in descriptors.__all__):
+ * per keypoint the gate `#(rho > 0) > min_neighborhood_size` (:360), the frame from the neighbours at NON-ZERO distance
+ * only (:361-363 -- the keypoint and its duplicates neither weigh in the covariance normaliser nor vote), the ten
+ * statements of sf_shot, and a row that is always L2-normalised (:496-497). */
+int sf_shot_serial(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int64_t min_neighborhood_size, double *out /* m x 352 */,
+                   int flags);
+
 /* ---- FPFH: compute_fpfh_descriptor (fpfh.py:16-117, decorrelated=False) -------------------
  * sf_spfh_create allocates the table for all n cloud points; sf_spfh_compute (K6) fills the rows of
  * the queries of `self_nbrs` (a sf_radius_search_self result); edges = 3 x (n_bins+1) histogram
@@ -200,6 +210,10 @@ int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, i
  * dist(i,j) = min over scales of (a_ok && b_ok ? euclidean distance : max_val); idx = first arg-min over j. */
 /* mask_dev[i] = 1 when row i of the device matrix rows_dev (m x d) has a non-zero entry (np.any(desc, axis=1)). */
 int sf_rows_nonzero(sf_ctx *ctx, const double *rows_dev, int64_t m, int64_t d, unsigned char *mask_dev);
+/* out_dev row i = rows_dev row sel_dev[i] (m x d, all device memory), or a zero row where sel_dev[i] < 0: selects a
+ * keypoint subset of a resident descriptor matrix, padded to the equal per-rank block an all-gather needs (zero rows are
+ * skipped by the matching, matching.py:162-163). */
+int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, const int64_t *sel_dev, int64_t m, int64_t d, double *out_dev);
 /* flags: SF_HOST, or SF_IN_DEVICE | SF_OUT_DEVICE with every pointer (masks included) on the device -- the form
  * the sharded matching uses with n_scales = 1 and max_val = +inf to skip all-zero descriptors in place. */
 int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1, int64_t m2,

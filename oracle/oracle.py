@@ -55,6 +55,14 @@ def lib() -> C.CDLL:
         L.orc_shot_lrf.argtypes = [_f64p, C.c_int64, _f64p, C.c_int64, C.c_double, _f64p]
         L.orc_shot.restype = C.c_int
         L.orc_shot.argtypes = [_f64p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_double, _f64p, C.c_int, C.c_int64, _f64p]
+        L.orc_azimuth_idx.restype = C.c_int
+        L.orc_azimuth_idx.argtypes = [C.c_double, C.c_double]
+        L.orc_shot_single.restype = None
+        L.orc_shot_single.argtypes = [_f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_double, _f64p, C.c_int, C.c_int64, _f64p]
+        L.orc_shot_serial.restype = C.c_int
+        L.orc_shot_serial.argtypes = [_f64p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_double, C.c_int64, _f64p]
+        L.orc_fpfh_sample.restype = C.c_int
+        L.orc_fpfh_sample.argtypes = [_f64p, _f64p, C.c_int64, _i64p, C.c_int64, C.c_double, C.c_int, _f64p, _f64p]
         L.orc_fpfh.restype = C.c_int
         L.orc_fpfh.argtypes = [_f64p, _f64p, C.c_int64, _i64p, C.c_int64, C.c_double, C.c_int, _f64p, _f64p, C.c_void_p]
         L.orc_match_argmin.restype = None
@@ -196,6 +204,12 @@ def knn_lists(cloud, queries, k, radius_hint=None):
 # --------------------------------------------------------------------------------------------
 # (a3, a7, a9) SHOT
 # --------------------------------------------------------------------------------------------
+def azimuth_idx(x, y):
+    """get_azimuth_idx (shot.py:51-70), elementwise."""
+    L = lib()
+    return np.array([L.orc_azimuth_idx(float(a), float(b)) for a, b in zip(np.ravel(x), np.ravel(y))], dtype=np.int64)
+
+
 def shot_lrf(cloud, keypoints, radius):
     p, q = _f64(cloud), _f64(keypoints)
     out = np.zeros((q.shape[0], 3, 3))
@@ -211,6 +225,15 @@ def shot(cloud, normals, keypoints, radius, lrf, normalize=True, min_neighborhoo
     return out
 
 
+def shot_single(point, neighbors, normals, radius, lrf, normalize=True, min_neighborhood_size=100):
+    """compute_single_shot_descriptor on one explicit neighbourhood (shot.py:175-306)."""
+    nbh, nrm = _f64(neighbors), _f64(normals)
+    out = np.zeros(352)
+    lib().orc_shot_single(_f64(point), nbh, nrm, np.arange(nbh.shape[0], dtype=np.int32), nbh.shape[0], float(radius),
+                          _f64(lrf).reshape(9), int(bool(normalize)), int(min_neighborhood_size), out)
+    return out
+
+
 def shot_single_scale(point_cloud, normals, keypoints, radius, normalize=True, min_neighborhood_size=100, support=None):
     """ShotMultiprocessor.compute_descriptor_single_scale (shot_parallelization.py:135-183);
     `support` is the index array grid_subsampling would return (or None)."""
@@ -218,6 +241,16 @@ def shot_single_scale(point_cloud, normals, keypoints, radius, normalize=True, m
     nr = _f64(normals) if support is None else _f64(np.asarray(normals)[support])
     lrf = shot_lrf(pc, keypoints, radius)
     return shot(pc, nr, keypoints, radius, lrf, normalize, min_neighborhood_size)
+
+
+def compute_shot_descriptor(keypoints, cloud_points, normals, radius, min_neighborhood_size=10):
+    """The serial / debug variant compute_shot_descriptor (shot.py:310-499): frames from the neighbours at
+    non-zero distance only, rows always normalised."""
+    p, nrm, q = _f64(cloud_points), _f64(normals), _f64(keypoints)
+    out = np.zeros((q.shape[0], 352))
+    rc = lib().orc_shot_serial(p, nrm, p.shape[0], q, q.shape[0], radius, int(min_neighborhood_size), out)
+    assert rc == 0
+    return out
 
 
 # --------------------------------------------------------------------------------------------
@@ -244,6 +277,17 @@ def compute_fpfh_descriptor(keypoints_indices, cloud_points, normals, radius, n_
     rc = lib().orc_fpfh(p, nrm, p.shape[0], kp, kp.shape[0], radius, n_bins, fpfh_edges(n_bins), out, _ptr(spfh))
     assert rc == 0
     return (out, spfh) if return_spfh else out
+
+
+def compute_fpfh_descriptor_sample(keypoints_indices, cloud_points, normals, radius, n_bins):
+    """compute_fpfh_descriptor for a SAMPLE of keypoints of a large cloud: the SPFH rows are evaluated only for the
+    sample's keypoints and their neighbours (bit-identical rows; affordable at 1M / 8M points)."""
+    p, nrm = _f64(cloud_points), _f64(normals)
+    kp = np.ascontiguousarray(keypoints_indices, dtype=np.int64)
+    out = np.zeros((kp.shape[0], n_bins**3))
+    rc = lib().orc_fpfh_sample(p, nrm, p.shape[0], kp, kp.shape[0], radius, n_bins, fpfh_edges(n_bins), out)
+    assert rc == 0
+    return out
 
 
 # --------------------------------------------------------------------------------------------

@@ -691,6 +691,8 @@ static int azimuth_idx(double x, double y)
     return 4 * a + 2 * bsel + csel;
 }
 
+int orc_azimuth_idx(double x, double y) { return azimuth_idx(x, y); } /* exported for the boundary-table test */
+
 typedef struct {
     double rho;
     int64_t pos;
@@ -848,6 +850,43 @@ int orc_shot(const double *xyz, const double *normals, int64_t n, const double *
 }
 
 /* ------------------------------------------------------------------------------------------
+ * (a8) compute_shot_descriptor, the serial / debug variant (shot.py:310-499).
+ * Differences from the ShotMultiprocessor path: the gate comes first (:360), the neighbours at
+ * distance zero are dropped BEFORE the frame is computed (:361-363: neither their weight
+ * `radius` in the covariance normaliser nor their ">= 0" sign vote exists), and the row is
+ * always divided by its norm (:496-497).  The ten statements are those of
+ * compute_single_shot_descriptor (same text at :376-494), so orc_shot_single serves both.
+ * ---------------------------------------------------------------------------------------- */
+int orc_shot_serial(const double *xyz, const double *normals, int64_t n, const double *q, int64_t m, double radius,
+                    int64_t min_nb, double *out)
+{
+    int64_t *off = (int64_t *)malloc((size_t)(m + 1) * sizeof(int64_t));
+    int64_t total = orc_radius_search(xyz, n, q, m, radius, off, NULL, NULL); /* 340-341 */
+    if (total < 0) return -1;
+    int32_t *idx = (int32_t *)malloc((size_t)(total ? total : 1) * sizeof(int32_t));
+    int32_t *pos = (int32_t *)malloc((size_t)(total ? total : 1) * sizeof(int32_t));
+    orc_radius_search(xyz, n, q, m, radius, off, idx, NULL);
+    for (int64_t i = 0; i < m; ++i) {
+        const double *point = q + 3 * i;
+        double *row = out + 352 * i;
+        int64_t k = off[i + 1] - off[i], kp = 0;
+        for (int64_t t = 0; t < k; ++t) { /* distances > 0 (:359-361) */
+            int32_t j = idx[off[i] + t];
+            if (sqrt(sq_dist3(xyz + 3 * (int64_t)j, point)) > 0.0) pos[kp++] = j;
+        }
+        for (int b = 0; b < 352; ++b) row[b] = 0.0; /* all_descriptors = np.zeros (:343-348) */
+        if (!(kp > min_nb)) continue;              /* :360 */
+        double lrf[9];
+        orc_lrf_single(point, xyz, pos, kp, radius, lrf); /* :362 */
+        orc_shot_single(point, xyz, normals, pos, kp, radius, lrf, 1, min_nb, row);
+    }
+    free(pos);
+    free(idx);
+    free(off);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * (a10) compute_fpfh_descriptor  (fpfh.py:16-117), decorrelated=False.
  * edges: 3 x (n_bins+1) doubles = np.linspace(lo, hi, n_bins+1) for (-1,1), (-1,1),
  * (-pi/2, pi/2), exactly what np.histogramdd builds (fpfh.py:82-87).
@@ -866,6 +905,52 @@ static int hist_bin(const double *edges, int n_bins, double x)
     return lo - 1;
 }
 
+/* SPFH row of cloud point i from its neighbour list (fpfh.py:44-90): pairs at distance zero skipped,
+ * out-of-range samples dropped by the histogram, counts divided by the FULL list length. */
+static void spfh_row(const double *xyz, const double *normals, int64_t i, const int32_t *idx, int64_t k, int n_bins,
+                     const double *edges, double *row /* n_bins^3, zeroed here */)
+{
+    const int64_t nb3 = (int64_t)n_bins * n_bins * n_bins;
+    const double *ea = edges, *ep = edges + (n_bins + 1), *et = edges + 2 * (n_bins + 1);
+    for (int64_t b = 0; b < nb3; ++b) row[b] = 0.0;
+    if (k == 0) return;
+    const double *pi_ = xyz + 3 * i, *u = normals + 3 * i;
+    for (int64_t t = 0; t < k; ++t) {
+        int64_t j = idx[t];
+        const double *pj = xyz + 3 * j, *nj = normals + 3 * j;
+        double c[3] = {pj[0] - pi_[0], pj[1] - pi_[1], pj[2] - pi_[2]};
+        double dist = sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]); /* 48 */
+        if (!(dist > 0.0)) continue;
+        /* v = cross(c, u) (50); w = cross(u, v) (51) */
+        double v[3] = {c[1] * u[2] - c[2] * u[1], c[2] * u[0] - c[0] * u[2], c[0] * u[1] - c[1] * u[0]};
+        double w[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+        double alpha = (v[0] * nj[0] + v[1] * nj[1]) + v[2] * nj[2];          /* 52 */
+        double phi = ((c[0] * u[0] + c[1] * u[1]) + c[2] * u[2]) / dist;      /* 53 */
+        double theta = atan2((nj[0] * w[0] + nj[1] * w[1]) + nj[2] * w[2],    /* 54-57 */
+                             (nj[0] * u[0] + nj[1] * u[1]) + nj[2] * u[2]);
+        int ba = hist_bin(ea, n_bins, alpha), bp = hist_bin(ep, n_bins, phi), bt = hist_bin(et, n_bins, theta);
+        if (ba < 0 || bp < 0 || bt < 0) continue;
+        row[((int64_t)ba * n_bins + bp) * n_bins + bt] += 1.0;
+    }
+    for (int64_t b = 0; b < nb3; ++b) row[b] = row[b] / (double)k; /* 88 */
+}
+
+/* FPFH row of keypoint i (fpfh.py:101-116) given a function-like access to SPFH rows: spfh_of[j] is the row of
+ * cloud point j. */
+static void fpfh_row(const double *xyz, int64_t i, const int32_t *idx, int64_t k, int64_t nb3, const double *own,
+                     const double *const *rows /* rows[t] = SPFH row of idx[t] */, double *o)
+{
+    for (int64_t b = 0; b < nb3; ++b) o[b] = 0.0;
+    for (int64_t t = 0; t < k; ++t) {
+        int64_t j = idx[t];
+        double dist = sqrt(sq_dist3(xyz + 3 * j, xyz + 3 * i));
+        if (!(dist > 0.0)) continue;
+        const double *rj = rows[t];
+        for (int64_t b = 0; b < nb3; ++b) o[b] += rj[b] / dist;
+    }
+    for (int64_t b = 0; b < nb3; ++b) o[b] = own[b] + o[b] / (double)k;
+}
+
 int orc_fpfh(const double *xyz, const double *normals, int64_t n, const int64_t *kp_idx, int64_t m,
              double radius, int n_bins, const double *edges, double *out /* m x n_bins^3 */,
              double *spfh_out /* nullable n x n_bins^3 */)
@@ -877,49 +962,80 @@ int orc_fpfh(const double *xyz, const double *normals, int64_t n, const int64_t 
     int32_t *idx = (int32_t *)malloc((size_t)(total ? total : 1) * sizeof(int32_t));
     orc_radius_search(xyz, n, xyz, n, radius, off, idx, NULL);
     double *spfh = spfh_out ? spfh_out : (double *)malloc((size_t)(n * nb3 ? n * nb3 : 1) * sizeof(double));
-    memset(spfh, 0, (size_t)(n * nb3) * sizeof(double));
-    const double *ea = edges, *ep = edges + (n_bins + 1), *et = edges + 2 * (n_bins + 1);
-    for (int64_t i = 0; i < n; ++i) { /* 38-90 */
-        int64_t s = off[i], k = off[i + 1] - s;
-        if (k == 0) continue;
-        const double *pi_ = xyz + 3 * i, *u = normals + 3 * i;
-        double *row = spfh + i * nb3;
-        for (int64_t t = 0; t < k; ++t) {
-            int64_t j = idx[s + t];
-            const double *pj = xyz + 3 * j, *nj = normals + 3 * j;
-            double c[3] = {pj[0] - pi_[0], pj[1] - pi_[1], pj[2] - pi_[2]};
-            double dist = sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]); /* 48 */
-            if (!(dist > 0.0)) continue;
-            /* v = cross(c, u) (50); w = cross(u, v) (51) */
-            double v[3] = {c[1] * u[2] - c[2] * u[1], c[2] * u[0] - c[0] * u[2], c[0] * u[1] - c[1] * u[0]};
-            double w[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
-            double alpha = (v[0] * nj[0] + v[1] * nj[1]) + v[2] * nj[2];          /* 52 */
-            double phi = ((c[0] * u[0] + c[1] * u[1]) + c[2] * u[2]) / dist;      /* 53 */
-            double theta = atan2((nj[0] * w[0] + nj[1] * w[1]) + nj[2] * w[2],    /* 54-57 */
-                                 (nj[0] * u[0] + nj[1] * u[1]) + nj[2] * u[2]);
-            int ba = hist_bin(ea, n_bins, alpha), bp = hist_bin(ep, n_bins, phi), bt = hist_bin(et, n_bins, theta);
-            if (ba < 0 || bp < 0 || bt < 0) continue;
-            row[((int64_t)ba * n_bins + bp) * n_bins + bt] += 1.0;
-        }
-        for (int64_t b = 0; b < nb3; ++b) row[b] = row[b] / (double)k; /* 88 */
-    }
+    for (int64_t i = 0; i < n; ++i) /* 38-90 */
+        spfh_row(xyz, normals, i, idx + off[i], off[i + 1] - off[i], n_bins, edges, spfh + i * nb3);
+    int64_t kmax = 1;
+    for (int64_t i = 0; i < n; ++i)
+        if (off[i + 1] - off[i] > kmax) kmax = off[i + 1] - off[i];
+    const double **rows = (const double **)malloc((size_t)kmax * sizeof(double *));
     for (int64_t q = 0; q < m; ++q) { /* 101-116 */
         int64_t i = kp_idx[q], s = off[i], k = off[i + 1] - s;
-        double *o = out + q * nb3;
-        for (int64_t b = 0; b < nb3; ++b) o[b] = 0.0;
-        for (int64_t t = 0; t < k; ++t) {
-            int64_t j = idx[s + t];
-            double dist = sqrt(sq_dist3(xyz + 3 * j, xyz + 3 * i));
-            if (!(dist > 0.0)) continue;
-            const double *rj = spfh + j * nb3;
-            for (int64_t b = 0; b < nb3; ++b) o[b] += rj[b] / dist;
-        }
-        const double *ri = spfh + i * nb3;
-        for (int64_t b = 0; b < nb3; ++b) o[b] = ri[b] + o[b] / (double)k;
+        for (int64_t t = 0; t < k; ++t) rows[t] = spfh + (int64_t)idx[s + t] * nb3;
+        fpfh_row(xyz, i, idx + s, k, nb3, spfh + i * nb3, rows, out + q * nb3);
     }
+    free(rows);
     if (!spfh_out) free(spfh);
     free(idx);
     free(off);
+    return 0;
+}
+
+/* The same function for a SAMPLE of keypoints of a large cloud: identical arithmetic, but the SPFH rows are
+ * evaluated only for the points the sample needs (the keypoints and their neighbours) instead of for all n -- what
+ * makes a full-size check of a 1M / 8M-point cloud affordable.  Results are bit-identical to orc_fpfh's. */
+int orc_fpfh_sample(const double *xyz, const double *normals, int64_t n, const int64_t *kp_idx, int64_t m,
+                    double radius, int n_bins, const double *edges, double *out /* m x n_bins^3 */)
+{
+    const int64_t nb3 = (int64_t)n_bins * n_bins * n_bins;
+    orc_grid g;
+    if (grid_build(&g, xyz, n, radius > 0 ? radius : 1.0)) return -1;
+    int64_t *slot = (int64_t *)malloc((size_t)(n ? n : 1) * sizeof(int64_t)); /* point -> cached row, -1 = none */
+    for (int64_t i = 0; i < n; ++i) slot[i] = -1;
+    int64_t cap = 1024, cap2 = 1024, nrows = 0, rows_cap = 4096;
+    int32_t *buf = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+    int32_t *buf2 = (int32_t *)malloc((size_t)cap2 * sizeof(int32_t));
+    double *cache = (double *)malloc((size_t)rows_cap * nb3 * sizeof(double));
+    const double **rows = (const double **)malloc((size_t)cap * sizeof(double *));
+    int64_t *need = (int64_t *)malloc((size_t)(cap + 1) * sizeof(int64_t));
+    for (int64_t q = 0; q < m; ++q) {
+        const int64_t i = kp_idx[q];
+        int64_t k = grid_query(&g, xyz + 3 * i, radius, buf, cap);
+        if (k > cap) {
+            cap = k;
+            buf = (int32_t *)realloc(buf, (size_t)cap * sizeof(int32_t));
+            rows = (const double **)realloc(rows, (size_t)cap * sizeof(double *));
+            need = (int64_t *)realloc(need, (size_t)(cap + 1) * sizeof(int64_t));
+            k = grid_query(&g, xyz + 3 * i, radius, buf, cap);
+        }
+        /* SPFH rows of the keypoint and of every neighbour, computed once each */
+        for (int64_t t = 0; t <= k; ++t) {
+            const int64_t j = t < k ? (int64_t)buf[t] : i;
+            if (slot[j] < 0) {
+                int64_t kj = grid_query(&g, xyz + 3 * j, radius, buf2, cap2);
+                if (kj > cap2) {
+                    cap2 = kj;
+                    buf2 = (int32_t *)realloc(buf2, (size_t)cap2 * sizeof(int32_t));
+                    kj = grid_query(&g, xyz + 3 * j, radius, buf2, cap2);
+                }
+                if (nrows == rows_cap) {
+                    rows_cap *= 2;
+                    cache = (double *)realloc(cache, (size_t)rows_cap * nb3 * sizeof(double));
+                }
+                spfh_row(xyz, normals, j, buf2, kj, n_bins, edges, cache + nrows * nb3);
+                slot[j] = nrows++;
+            }
+            need[t] = slot[j];
+        }
+        for (int64_t t = 0; t < k; ++t) rows[t] = cache + need[t] * nb3; /* (after any realloc of the cache) */
+        fpfh_row(xyz, i, buf, k, nb3, cache + need[k] * nb3, rows, out + q * nb3);
+    }
+    free(need);
+    free(rows);
+    free(cache);
+    free(buf2);
+    free(buf);
+    free(slot);
+    grid_free(&g);
     return 0;
 }
 

@@ -62,6 +62,8 @@ SIGNATURES = {
     "sf_shot_lrf": (_int, [_vp, _vp, _vp, _vp, _int]),
     "sf_shot": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _int]),
     "sf_shot_single_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),
+    "sf_azimuth_idx": (_int, [_vp, _vp, _vp, _i64, _vp, _int]),
+    "sf_shot_serial": (_int, [_vp, _vp, _vp, _i64, _vp, _int]),
     "sf_spfh_create": (_vp, [_vp, _vp, _int, _i64]),
     "sf_spfh_compute": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "sf_spfh_compute_moments": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -74,6 +76,7 @@ SIGNATURES = {
     "sf_fpfh": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _int]),
     "sf_match_argmin": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int]),
     "sf_rows_nonzero": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "sf_rows_gather": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "sf_match_argmin_multiscale": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _f64, _vp, _vp, _int]),
     "sf_ransac_score": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _int]),
     "sf_comm_unique_id": (_int, [_vp]),

@@ -69,14 +69,15 @@ def solver_point_to_point(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.flo
     return RigidTransform(rot, ref_center - rot.dot(scan_center))
 
 
-def solver_point_to_point_batched(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.float64]):
+def solver_point_to_point_batched(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.float64], return_reflected: bool = False):
     """`solver_point_to_point` for a stack of draws: scan, ref of shape (n, k, 3) -> rotations (n, 3, 3),
     translations (n, 3).
 
     Same operations on the same operands as the per-draw function, through NumPy's stacked forms of the same
     routines (`matmul` -> the same BLAS call per matrix, `linalg.svd` / `det` -> the same LAPACK call per matrix), so
-    every transform comes out bit-identical to the per-draw one; `ransac_on_matches` verifies that on the first
-    draws of every call and falls back to the per-draw loop otherwise.  ~10x less host time at 10 000 draws.
+    every transform comes out bit-identical to the per-draw one; `ransac_on_matches` verifies that on a sample of
+    draws and on every reflected draw of every call and falls back to the per-draw loop otherwise.  ~8x less host
+    time at 10 000 draws.
     """
     scan_center, ref_center = scan.mean(axis=1), ref.mean(axis=1)
     cross_cov = np.matmul((scan - scan_center[:, None, :]).transpose(0, 2, 1), ref - ref_center[:, None, :])
@@ -88,8 +89,10 @@ def solver_point_to_point_batched(scan: npt.NDArray[np.float64], ref: npt.NDArra
         ut = ut.copy()
         ut[neg, -1] *= -1
         rot[neg] = np.matmul(vt[neg].transpose(0, 2, 1), ut[neg])
-    translation = ref_center - np.matmul(rot, scan_center[:, :, None])[:, :, 0]
-    return rot, translation
+    # rot.dot(centre) one draw at a time: the reference's call (solvers.py:28, a dgemv); a stacked matmul may round
+    # differently on some BLAS builds, and a one-ulp translation changes that draw's inlier count
+    translation = ref_center - np.array([r.dot(c) for r, c in zip(rot, scan_center)]).reshape(-1, 3)
+    return (rot, translation, neg) if return_reflected else (rot, translation)
 
 
 def solver_point_to_plane(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.float64],

@@ -44,12 +44,16 @@ extern "C" int sf_comm_init(sf_ctx *ctx, const char id[128], int nranks, int ran
 extern "C" int sf_comm_allgather(sf_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank)
 {
     if (!ctx || !send || !recv) { sf_set_error("sf_comm_allgather: null argument"); return SF_ERR_ARG; }
-    if (ctx->nranks == 1) {
+    // Without a communicator a lone context has nothing to exchange: the block only has to be in place.  Once
+    // sf_comm_init has run -- with ONE rank too -- every call goes through ncclAllGather, so a single-GPU box
+    // exercises the very RCCL path the N-rank job uses.
+    if (!ctx->comm) {
+        if (ctx->nranks != 1) { sf_set_error("sf_comm_allgather: communicator not initialised"); return SF_ERR_STATE; }
         if (send != recv && bytes_per_rank)
             SF_HIP(hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
         return SF_OK;
     }
-    if (!ctx->comm) { sf_set_error("sf_comm_allgather: communicator not initialised"); return SF_ERR_STATE; }
+    if (!bytes_per_rank) return SF_OK;
     sf_launch_timer t_(ctx, "c_allgather");
     SF_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclChar, (ncclComm_t)ctx->comm, ctx->stream));
     return SF_OK;

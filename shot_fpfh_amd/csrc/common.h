@@ -81,6 +81,34 @@ static inline int sf_palloc(sf_ctx *ctx, T **out, size_t count)
     return rc;
 }
 
+// Temporaries of one entry point: every block goes back to the pool when the guard leaves scope, on the error
+// returns of SF_HIP / SF_CHECK / SF_LAUNCH as well as on success.  Releasing is stream-ordered (the block is only
+// handed to later launches on the same stream), so it needs no synchronisation.
+struct sf_pool_guard {
+    sf_ctx *ctx;
+    std::vector<void *> held;
+    explicit sf_pool_guard(sf_ctx *c) : ctx(c) {}
+    sf_pool_guard(const sf_pool_guard &) = delete;
+    sf_pool_guard &operator=(const sf_pool_guard &) = delete;
+    template <typename T>
+    int alloc(T **out, size_t count)
+    {
+        const int rc = sf_palloc(ctx, out, count);
+        if (rc == SF_OK) held.push_back((void *)*out);
+        return rc;
+    }
+    void release(void *p) // early release of one block
+    {
+        for (auto &h : held)
+            if (h == p) { sf_pool_release(ctx, p); h = nullptr; }
+    }
+    ~sf_pool_guard()
+    {
+        for (void *p : held)
+            if (p) sf_pool_release(ctx, p);
+    }
+};
+
 int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out);
 #define SF_PINNED_BYTES 4096
 int sf_ctx_pinned(sf_ctx *ctx, void **out);

@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
                                                   const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
                                                   const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
-                                                  int64_t m, double radius, int raw, double *__restrict__ lrf)
+                                                  int64_t m, double radius, int raw, int skip_zero,
+                                                  double *__restrict__ lrf)
 {
+    // skip_zero != 0: the support is the list minus its points at distance zero -- the serial compute_shot_descriptor
+    // drops them BEFORE get_local_rf (shot.py:361-363), so neither their weight r nor their ">= 0" vote counts.
     // raw != 0: stop after the eigen-decomposition and store the largest / smallest eigenvectors (x in slots
     // 0..2, z in slots 3..5) as returned; the fused SHOT kernel does the sign votes from the neighbours it has
     // in registers anyway and completes the frame in place.
@@ -233,8 +236,9 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
             for (int c = 0; c < 8; ++c) {
                 if (base + 16 * c < kmax) {
                     const double cx = x[c] - px, cy = y[c] - py, cz = z[c] - pz;
-                    const double wv = radius - sf_sqrt_fast((cx * cx + cy * cy) + cz * cz);
-                    const double w = j[c] < 0 ? 0.0 : wv;
+                    const double d2 = (cx * cx + cy * cy) + cz * cz;
+                    const double wv = radius - sf_sqrt_fast(d2);
+                    const double w = (j[c] < 0) | ((skip_zero != 0) & (d2 == 0.0)) ? 0.0 : wv;
                     ws += w;
                     const double wx = cx * w, wy = cy * w, wz = cz * w;
                     a11 += cx * wx; a21 += cy * wx; a31 += cz * wx;
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
     }
     // phase C: sign votes (shot.py:40-45): flip when strictly more neighbours project negative than >= 0
     bool flipx = false, flipz = false;
+    int nvote = 0;
     for (int r = 0; r < 16; ++r) {
         const int src = 16 * rw + r; // lane holding this row's header and axes
         const int64_t s = __shfl(smine, src);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
         const int kmax = sf_rows_max(k);
         const double bx0 = lane_bcast(x0, src), bx1 = lane_bcast(x1, src), bx2 = lane_bcast(x2, src);
         const double bz0 = lane_bcast(z0, src), bz1 = lane_bcast(z1, src), bz2 = lane_bcast(z2, src);
-        int xneg = 0, zneg = 0;
+        int xneg = 0, zneg = 0, nzero = 0;
         for (int base = 0; base < kmax; base += 64) {
             int j[4];
 #pragma unroll
@@ -296,18 +301,20 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
                 const double zo = (cx * bz0 + cy * bz1) + cz * bz2;
                 xneg += ((j[c] >= 0) & (xo < 0.0)) ? 1 : 0;
                 zneg += ((j[c] >= 0) & (zo < 0.0)) ? 1 : 0;
+                nzero += ((j[c] >= 0) & (((cx * cx + cy * cy) + cz * cz) == 0.0)) ? 1 : 0;
             }
         }
         xneg = sf_row16_sum(xneg);
         zneg = sf_row16_sum(zneg);
-        // coordinates are finite (checked at upload), so the ">= 0" voters are the remaining k - neg
-        if (sl == r) { flipx = xneg > k - xneg; flipz = zneg > k - zneg; }
+        const int kv = k - (skip_zero ? sf_row16_sum(nzero) : 0); // voters
+        // coordinates are finite (checked at upload), so the ">= 0" voters are the remaining kv - neg
+        if (sl == r) { flipx = xneg > kv - xneg; flipz = zneg > kv - zneg; nvote = kv; }
     }
     if (lane < nq) {
         const int64_t q = q0 + lane;
         const int64_t row = qrow ? qrow[q] : q;
         double *o = lrf + 9 * row;
-        if (kmine == 0) { // shot.py:24-25
+        if (nvote == 0) { // empty support: shot.py:24-25
             o[0] = 1.0; o[1] = 0.0; o[2] = 0.0;
             o[3] = 0.0; o[4] = 1.0; o[5] = 0.0;
             o[6] = 0.0; o[7] = 0.0; o[8] = 1.0;
@@ -351,6 +358,13 @@ __device__ inline int azimuth_octant(double x, double y) // get_azimuth_idx, sho
     const bool b = ((x > 0.0) || ((x == 0.0) && (y > 0.0))) != a;
     const bool c = ((x * y > 0.0) || (x == 0.0)) ? (fabs(x) < fabs(y)) : (fabs(x) > fabs(y));
     return 4 * (int)a + 2 * (int)b + (int)c;
+}
+
+// get_azimuth_idx as an elementwise function (shot.py:51-70): the very device function K5 bins with
+__global__ void k_azimuth_idx(const double *__restrict__ x, const double *__restrict__ y, int64_t n, int64_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = azimuth_octant(x[i], y[i]);
 }
 
 template <bool VALUES>
@@ -957,34 +971,36 @@ static int check_nbrs(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const char *who)
     return SF_OK;
 }
 
-// stage an optional host input (rows x cols doubles) on the device
-static int stage_in(sf_ctx *ctx, const double *src, size_t count, int flags, const double **dev, double **owned)
+// Host <-> device staging of one entry point.  Buffers come from the context pool through the caller's guard (released on
+// every return path); copies are asynchronous on the context stream and stage_sync() closes the call when any host
+// buffer was involved.
+static int stage_in(sf_pool_guard &g, const double *src, size_t count, int flags, const double **dev)
 {
-    *owned = nullptr;
     if (!src) { *dev = nullptr; return SF_OK; }
     if (flags & SF_IN_DEVICE) { *dev = src; return SF_OK; }
-    SF_HIP(hipMalloc(owned, (count ? count : 1) * sizeof(double)));
-    if (count) SF_HIP(hipMemcpyAsync(*owned, src, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    *dev = *owned;
+    double *owned = nullptr;
+    SF_CHECK(g.alloc(&owned, count));
+    if (count) SF_HIP(hipMemcpyAsync(owned, src, count * sizeof(double), hipMemcpyHostToDevice, g.ctx->stream));
+    *dev = owned;
     return SF_OK;
 }
 
-static int stage_out(sf_ctx *ctx, double *dst, size_t count, int flags, double **dev, double **owned)
+static int stage_out(sf_pool_guard &g, double *dst, size_t count, int flags, double **dev)
 {
-    *owned = nullptr;
     if (flags & SF_OUT_DEVICE) { *dev = dst; return SF_OK; }
-    SF_HIP(hipMalloc(owned, (count ? count : 1) * sizeof(double)));
-    *dev = *owned;
+    return g.alloc(dev, count);
+}
+
+static int finish_out(sf_ctx *ctx, double *dst, size_t count, int flags, const double *dev)
+{
+    if (!(flags & SF_OUT_DEVICE) && count)
+        SF_HIP(hipMemcpyAsync(dst, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return SF_OK;
 }
 
-static int finish_out(sf_ctx *ctx, double *dst, size_t count, double *dev, double *owned)
+static int stage_sync(sf_ctx *ctx, int flags)
 {
-    if (owned) {
-        if (count) SF_HIP(hipMemcpyAsync(dst, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(owned));
-    }
+    if ((flags & (SF_IN_DEVICE | SF_OUT_DEVICE)) != (SF_IN_DEVICE | SF_OUT_DEVICE)) SF_HIP(hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }
 
@@ -993,18 +1009,18 @@ extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *p
     SF_CHECK(check_nbrs(ctx, c, nb, "sf_normals"));
     if (!out) { sf_set_error("sf_normals: null output"); return SF_ERR_ARG; }
     const int64_t m = nb->m;
+    sf_pool_guard tmp(ctx);
     const double *dpre;
-    double *opre, *dout, *oout;
-    SF_CHECK(stage_in(ctx, pre, (size_t)m * 3, flags, &dpre, &opre));
-    SF_CHECK(stage_out(ctx, out, (size_t)m * 3, flags, &dout, &oout));
+    double *dout;
+    SF_CHECK(stage_in(tmp, pre, (size_t)m * 3, flags, &dpre));
+    SF_CHECK(stage_out(tmp, out, (size_t)m * 3, flags, &dout));
     if (m) {
         SF_LAUNCH(ctx, "k3_normals", k_pca<0>, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx,
                   nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, dpre, dout, (double *)nullptr,
                   (double *)nullptr, (double *)nullptr);
     }
-    SF_CHECK(finish_out(ctx, out, (size_t)m * 3, dout, oout));
-    if (opre) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(opre)); }
-    return SF_OK;
+    SF_CHECK(finish_out(ctx, out, (size_t)m * 3, flags, dout));
+    return stage_sync(ctx, flags);
 }
 
 extern "C" int sf_pca(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *eigenvalues, double *eigenvectors, double *moments,
@@ -1013,10 +1029,11 @@ extern "C" int sf_pca(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *eigenvalues
     SF_CHECK(check_nbrs(ctx, c, nb, "sf_pca"));
     if (!eigenvalues || !eigenvectors) { sf_set_error("sf_pca: null output"); return SF_ERR_ARG; }
     const int64_t m = nb->m;
-    double *dw, *ow, *dv, *ov, *dm = nullptr, *om = nullptr;
-    SF_CHECK(stage_out(ctx, eigenvalues, (size_t)m * 3, flags, &dw, &ow));
-    SF_CHECK(stage_out(ctx, eigenvectors, (size_t)m * 9, flags, &dv, &ov));
-    if (moments) SF_CHECK(stage_out(ctx, moments, (size_t)m * 8, flags, &dm, &om));
+    sf_pool_guard tmp(ctx);
+    double *dw, *dv, *dm = nullptr;
+    SF_CHECK(stage_out(tmp, eigenvalues, (size_t)m * 3, flags, &dw));
+    SF_CHECK(stage_out(tmp, eigenvectors, (size_t)m * 9, flags, &dv));
+    if (moments) SF_CHECK(stage_out(tmp, moments, (size_t)m * 8, flags, &dm));
     if (m) {
         const dim3 grid(sf_xcd_grid(sf_div_up(m, 256))), block(256);
         if (moments) {
@@ -1027,10 +1044,10 @@ extern "C" int sf_pca(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *eigenvalues
                       nb->idx, nb->qrow, m, (const double *)nullptr, (double *)nullptr, dw, dv, (double *)nullptr);
         }
     }
-    SF_CHECK(finish_out(ctx, eigenvalues, (size_t)m * 3, dw, ow));
-    SF_CHECK(finish_out(ctx, eigenvectors, (size_t)m * 9, dv, ov));
-    if (moments) SF_CHECK(finish_out(ctx, moments, (size_t)m * 8, dm, om));
-    return SF_OK;
+    SF_CHECK(finish_out(ctx, eigenvalues, (size_t)m * 3, flags, dw));
+    SF_CHECK(finish_out(ctx, eigenvectors, (size_t)m * 9, flags, dv));
+    if (moments) SF_CHECK(finish_out(ctx, moments, (size_t)m * 8, flags, dm));
+    return stage_sync(ctx, flags);
 }
 
 extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, int flags)
@@ -1038,13 +1055,15 @@ extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, i
     SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_lrf"));
     if (!lrf) { sf_set_error("sf_shot_lrf: null output"); return SF_ERR_ARG; }
     const int64_t m = nb->m;
-    double *dout, *oout;
-    SF_CHECK(stage_out(ctx, lrf, (size_t)m * 9, flags, &dout, &oout));
+    sf_pool_guard tmp(ctx);
+    double *dout;
+    SF_CHECK(stage_out(tmp, lrf, (size_t)m * 9, flags, &dout));
     if (m) {
         SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec,
-                  nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, 0, dout);
+                  nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, 0, 0, dout);
     }
-    return finish_out(ctx, lrf, (size_t)m * 9, dout, oout);
+    SF_CHECK(finish_out(ctx, lrf, (size_t)m * 9, flags, dout));
+    return stage_sync(ctx, flags);
 }
 
 // launch K5 on resident buffers; fused != 0: dlrf holds raw axes (k_shot_lrf raw mode) and receives the frames
@@ -1079,13 +1098,55 @@ extern "C" int sf_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *lrf,
     if (!lrf || !out) { sf_set_error("sf_shot: null lrf/out"); return SF_ERR_ARG; }
     SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
     const int64_t m = nb->m;
+    sf_pool_guard tmp(ctx);
     const double *dlrf;
-    double *olrf, *dout, *oout;
-    SF_CHECK(stage_in(ctx, lrf, (size_t)m * 9, flags, &dlrf, &olrf));
-    SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
+    double *dout;
+    SF_CHECK(stage_in(tmp, lrf, (size_t)m * 9, flags, &dlrf));
+    SF_CHECK(stage_out(tmp, out, (size_t)m * SF_SHOT_LEN, flags, &dout));
     SF_CHECK(launch_shot(ctx, c, nb, const_cast<double *>(dlrf), normalize, min_nb, dout, false));
-    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
-    if (olrf) { SF_HIP(hipStreamSynchronize(ctx->stream)); SF_HIP(hipFree(olrf)); }
+    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, dout));
+    return stage_sync(ctx, flags);
+}
+
+extern "C" int sf_azimuth_idx(sf_ctx *ctx, const double *x, const double *y, int64_t n, int64_t *idx, int flags)
+{
+    if (!ctx || !x || !y || !idx || n < 0) { sf_set_error("sf_azimuth_idx: bad argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    sf_pool_guard tmp(ctx);
+    const double *dx, *dy;
+    SF_CHECK(stage_in(tmp, x, (size_t)n, flags, &dx));
+    SF_CHECK(stage_in(tmp, y, (size_t)n, flags, &dy));
+    int64_t *dout = idx;
+    if (!(flags & SF_OUT_DEVICE)) SF_CHECK(tmp.alloc(&dout, (size_t)n));
+    if (n) {
+        SF_LAUNCH(ctx, "k5_azimuth_idx", k_azimuth_idx, dim3((unsigned)sf_div_up(n, 256)), dim3(256), dx, dy, n, dout);
+        if (dout != idx) SF_HIP(hipMemcpyAsync(idx, dout, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return stage_sync(ctx, flags);
+}
+
+// compute_shot_descriptor, the reference's serial variant (shot.py:310-499): the frame of a keypoint is computed on its
+// neighbours at NON-ZERO distance only (the keypoint itself and its duplicates are dropped first, :361-363) and the
+// descriptor is always normalised (:496-497).  K4 with skip_zero, then the plain K5.
+extern "C" int sf_shot_serial(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t min_nb, double *out, int flags)
+{
+    SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_serial"));
+    if (!out) { sf_set_error("sf_shot_serial: null out"); return SF_ERR_ARG; }
+    SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
+    const int64_t m = nb->m;
+    sf_pool_guard guard(ctx);
+    double *dlrf = nullptr, *dout = out;
+    SF_CHECK(guard.alloc(&dlrf, (size_t)m * 9));
+    if (!(flags & SF_OUT_DEVICE)) SF_CHECK(guard.alloc(&dout, (size_t)m * SF_SHOT_LEN));
+    if (m) {
+        SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx, nb->qy,
+                  nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, 0, 1, dlrf);
+    }
+    SF_CHECK(launch_shot(ctx, c, nb, dlrf, 1, min_nb, dout, false));
+    if (dout != out) {
+        if (m) SF_HIP(hipMemcpyAsync(out, dout, (size_t)m * SF_SHOT_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return SF_OK;
 }
 
@@ -1116,24 +1177,22 @@ extern "C" int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int n
     SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
     const int64_t m = nb->m;
     const bool out_dev = flags & SF_OUT_DEVICE;
-    double *dlrf = lrf, *own_lrf = nullptr, *dout, *oout;
+    sf_pool_guard tmp(ctx);
+    double *dlrf = lrf, *own_lrf = nullptr, *dout;
     if (!out_dev || !lrf) { // frames wanted on the host, or not wanted at all: scratch on the device
-        SF_CHECK(sf_palloc(ctx, &own_lrf, (size_t)m * 9));
+        SF_CHECK(tmp.alloc(&own_lrf, (size_t)m * 9));
         dlrf = own_lrf;
     }
-    SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
+    SF_CHECK(stage_out(tmp, out, (size_t)m * SF_SHOT_LEN, flags, &dout));
     const bool fused = nb->max_count <= 256;
     if (m) {
         SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx, nb->qy,
-                  nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, fused ? 1 : 0, dlrf);
+                  nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, fused ? 1 : 0, 0, dlrf);
     }
     SF_CHECK(launch_shot(ctx, c, nb, dlrf, normalize, min_nb, dout, fused));
     if (own_lrf && lrf && m) SF_HIP(hipMemcpyAsync(lrf, own_lrf, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
-    if (own_lrf) {
-        if (lrf) SF_HIP(hipStreamSynchronize(ctx->stream));
-        sf_pool_release(ctx, own_lrf);
-    }
+    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, dout));
+    if (!out_dev) SF_HIP(hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }
 
@@ -1151,22 +1210,20 @@ extern "C" int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const
     SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
     const int64_t m = nb->m;
     const bool out_dev = flags & SF_OUT_DEVICE;
-    double *dlrf = lrf, *own_lrf = nullptr, *dout, *oout;
+    sf_pool_guard tmp(ctx);
+    double *dlrf = lrf, *own_lrf = nullptr, *dout;
     if (!out_dev || !lrf) {
-        SF_CHECK(sf_palloc(ctx, &own_lrf, (size_t)m * 9));
+        SF_CHECK(tmp.alloc(&own_lrf, (size_t)m * 9));
         dlrf = own_lrf;
     }
-    SF_CHECK(stage_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, &dout, &oout));
+    SF_CHECK(stage_out(tmp, out, (size_t)m * SF_SHOT_LEN, flags, &dout));
     if (m) {
         SF_LAUNCH(ctx, "k4_lrf_from_cov", k_lrf_from_cov, dim3((unsigned)sf_div_up(m, 256)), dim3(256), cov_dev, m, dlrf);
     }
     SF_CHECK(launch_shot(ctx, c, nb, dlrf, normalize, min_nb, dout, true));
     if (own_lrf && lrf && m) SF_HIP(hipMemcpyAsync(lrf, own_lrf, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, dout, oout));
-    if (own_lrf) {
-        if (lrf) SF_HIP(hipStreamSynchronize(ctx->stream));
-        sf_pool_release(ctx, own_lrf);
-    }
+    SF_CHECK(finish_out(ctx, out, (size_t)m * SF_SHOT_LEN, flags, dout));
+    if (!out_dev) SF_HIP(hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }
 

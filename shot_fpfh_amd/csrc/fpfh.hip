@@ -523,7 +523,7 @@ extern "C" int sf_spfh_compute_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf
 extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank)
 {
     if (!ctx || !sp) { sf_set_error("sf_spfh_allgather: null argument"); return SF_ERR_ARG; }
-    if (ctx->nranks == 1) return SF_OK;
+    if (ctx->nranks == 1 && !ctx->comm) return SF_OK;
     if (rows_per_rank <= 0 || rows_per_rank * ctx->nranks > sp->rows_alloc || rows_per_rank * ctx->nranks < sp->n) {
         sf_set_error("sf_spfh_allgather: %lld rows/rank x %d ranks does not tile a table of %lld (+pad %lld) rows",
                      (long long)rows_per_rank, ctx->nranks, (long long)sp->n, (long long)sp->rows_alloc);
@@ -548,9 +548,10 @@ extern "C" int sf_spfh_export(sf_ctx *ctx, sf_cloud *c, sf_spfh *sp, double *out
     if (!ctx || !c || !sp || !out) { sf_set_error("sf_spfh_export: null argument"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
     const int64_t n = sp->n, tot = n * sp->nb3;
+    sf_pool_guard tmp(ctx);
     double *dout = out, *owned = nullptr;
     if (!(flags & SF_OUT_DEVICE)) {
-        SF_HIP(hipMalloc(&owned, (size_t)(tot ? tot : 1) * sizeof(double)));
+        SF_CHECK(tmp.alloc(&owned, (size_t)tot));
         dout = owned;
     }
     if (tot) {
@@ -569,7 +570,6 @@ extern "C" int sf_spfh_export(sf_ctx *ctx, sf_cloud *c, sf_spfh *sp, double *out
     if (owned) {
         if (tot) SF_HIP(hipMemcpyAsync(out, owned, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(owned));
     }
     return SF_OK;
 }
@@ -646,28 +646,26 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
         return SF_ERR_ARG;
     }
     SF_HIP(hipSetDevice(ctx->device));
+    sf_pool_guard tmp(ctx);
     int32_t *pos = nullptr;
-    int64_t *dkp = nullptr;
-    int *dbad = nullptr;
     if (kp_idx && m) {
         const int64_t *src = kp_idx;
+        int64_t *dkp = nullptr;
+        int *dbad = nullptr;
         if (!(flags & SF_IN_DEVICE)) {
-            SF_HIP(hipMalloc(&dkp, (size_t)m * sizeof(int64_t)));
+            SF_CHECK(tmp.alloc(&dkp, (size_t)m));
             SF_HIP(hipMemcpyAsync(dkp, kp_idx, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
             src = dkp;
         }
-        SF_HIP(hipMalloc(&pos, (size_t)m * sizeof(int32_t)));
-        SF_HIP(hipMalloc(&dbad, sizeof(int)));
+        SF_CHECK(tmp.alloc(&pos, (size_t)m));
+        SF_CHECK(tmp.alloc(&dbad, 1));
         SF_HIP(hipMemsetAsync(dbad, 0, sizeof(int), ctx->stream));
         SF_LAUNCH(ctx, "k7_map_positions", k_map_positions, dim3((unsigned)sf_div_up(m, 256)), dim3(256), src,
                   c->inv_perm, m, c->n, pos, dbad);
         int bad = 0;
         SF_HIP(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(dbad));
-        if (dkp) SF_HIP(hipFree(dkp));
         if (bad) {
-            SF_HIP(hipFree(pos));
             sf_set_error("sf_fpfh: keypoint index out of range for a cloud of %lld points", (long long)c->n);
             return SF_ERR_ARG;
         }
@@ -675,7 +673,7 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
     const int64_t tot = m * sp->nb3;
     double *dout = out, *owned = nullptr;
     if (!(flags & SF_OUT_DEVICE)) {
-        SF_HIP(hipMalloc(&owned, (size_t)(tot ? tot : 1) * sizeof(double)));
+        SF_CHECK(tmp.alloc(&owned, (size_t)tot));
         dout = owned;
     }
     int rc = SF_OK;
@@ -684,9 +682,7 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
                                       : launch_fpfh<uint32_t>(ctx, c, nb, sp, pos, m, dout);
     if (rc == SF_OK && owned) {
         if (tot) SF_HIP(hipMemcpyAsync(out, owned, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
     }
-    if (owned || pos) SF_HIP(hipStreamSynchronize(ctx->stream));
-    if (owned) SF_HIP(hipFree(owned));
-    if (pos) SF_HIP(hipFree(pos));
     return rc;
 }

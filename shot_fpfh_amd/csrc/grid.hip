@@ -225,6 +225,12 @@ int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
     if (np > 0) {
         SF_LAUNCH(ctx, "k1_gather_normals", k_gather_normals, dim3((unsigned)sf_div_up(np, 256)), dim3(256),
                   c->nrm_orig, c->perm, c->pop_begin, np, c->rec);
+        // The flag below is per cloud, not per stream: while the context is forked (sf_fork) a consumer on the OTHER
+        // stream would see it set and read rec[3..5] with nothing ordering that read after this gather.  Make the
+        // other stream wait for it.
+        hipStream_t other = ctx->stream == ctx->streams[0] ? ctx->streams[1] : ctx->streams[0];
+        SF_HIP(hipEventRecord(ctx->join_event, ctx->stream));
+        SF_HIP(hipStreamWaitEvent(other, ctx->join_event, 0));
     }
     c->normals_sorted = true;
     return SF_OK;

@@ -140,6 +140,18 @@ __global__ __launch_bounds__(256) void k_rows_nonzero(const double *__restrict__
     if (lane == 0) mask[i] = any != 0ull;
 }
 
+// dst row i = src row sel[i], or a zero row when sel[i] < 0 (the padding of an equal-sized per-rank block): picks the
+// descriptors of a keypoint subset out of a resident descriptor matrix before the exchange that precedes K8
+__global__ __launch_bounds__(256) void k_rows_gather(const double *__restrict__ src, const int64_t *__restrict__ sel,
+                                                     int64_t m, int64_t d, double *__restrict__ dst)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int64_t r = sel[i];
+    for (int64_t t = lane; t < d; t += 64) dst[i * d + t] = r < 0 ? 0.0 : src[r * d + t];
+}
+
 __global__ void k_match_merge(const double *__restrict__ pdist, const int64_t *__restrict__ pidx, int64_t m1, int nsplit,
                               int64_t *__restrict__ idx, double *__restrict__ dist)
 {
@@ -226,16 +238,15 @@ static int match_one_way(sf_ctx *ctx, const double *da, int64_t m1, const double
     if (nsplit > 65535) nsplit = 65535;
     const int64_t tiles_per_split = sf_div_up(col_tiles, nsplit);
     nsplit = sf_div_up(col_tiles, tiles_per_split);
+    sf_pool_guard tmp(ctx); // stream-ordered release: safe to reuse by later launches on this stream
     double *pdist = nullptr;
     int64_t *pidx = nullptr;
-    SF_CHECK(sf_palloc(ctx, &pdist, (size_t)(nsplit * m1)));
-    SF_CHECK(sf_palloc(ctx, &pidx, (size_t)(nsplit * m1)));
+    SF_CHECK(tmp.alloc(&pdist, (size_t)(nsplit * m1)));
+    SF_CHECK(tmp.alloc(&pidx, (size_t)(nsplit * m1)));
     SF_LAUNCH(ctx, name, k_match_tile, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(256), da, m1, db, m2, d,
               n_scales, a_ok, b_ok, max_val, tiles_per_split, pdist, pidx);
     SF_LAUNCH(ctx, "k8_match_merge", k_match_merge, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), pdist, pidx, m1,
               (int)nsplit, didx, ddist);
-    sf_pool_release(ctx, pdist); // stream-ordered: safe to reuse by later launches on this stream
-    sf_pool_release(ctx, pidx);
     return SF_OK;
 }
 
@@ -245,14 +256,13 @@ int sf_match_exact(sf_ctx *ctx, const double *da, int64_t m1, const double *db, 
 {
     if (!a_ok && !b_ok) return match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name);
     // masked form: a row whose mask is 0 is at distance +inf from everything (the scan side only if given)
+    sf_pool_guard tmp(ctx);
     unsigned char *ones = nullptr;
     if (!a_ok) {
-        SF_CHECK(sf_palloc(ctx, &ones, (size_t)m1));
+        SF_CHECK(tmp.alloc(&ones, (size_t)m1));
         SF_HIP(hipMemsetAsync(ones, 1, (size_t)(m1 ? m1 : 1), ctx->stream));
     }
-    int rc = match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name, 1, a_ok ? a_ok : ones, b_ok, INFINITY);
-    if (ones) sf_pool_release(ctx, ones);
-    return rc;
+    return match_one_way(ctx, da, m1, db, m2, d, didx, ddist, name, 1, a_ok ? a_ok : ones, b_ok, INFINITY);
 }
 
 int sf_match_gemm(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int64_t m2, int64_t d, int64_t *didx,
@@ -277,19 +287,20 @@ extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const d
     if (m2 == 0 && m1 > 0) { sf_set_error("sf_match_argmin: empty reference set (argmin of an empty sequence)"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
     const bool in_dev = flags & SF_IN_DEVICE, out_dev = flags & SF_OUT_DEVICE;
+    sf_pool_guard tmp(ctx); // staging buffers: back in the pool on every return path
     double *da = const_cast<double *>(a), *db = const_cast<double *>(b);
     if (!in_dev) {
-        SF_HIP(hipMalloc(&da, (size_t)std::max<int64_t>(m1 * d, 1) * sizeof(double)));
-        SF_HIP(hipMalloc(&db, (size_t)std::max<int64_t>(m2 * d, 1) * sizeof(double)));
+        SF_CHECK(tmp.alloc(&da, (size_t)std::max<int64_t>(m1 * d, 1)));
+        SF_CHECK(tmp.alloc(&db, (size_t)std::max<int64_t>(m2 * d, 1)));
         if (m1) SF_HIP(hipMemcpyAsync(da, a, (size_t)(m1 * d) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (m2) SF_HIP(hipMemcpyAsync(db, b, (size_t)(m2 * d) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }
     int64_t *didx = idx, *dcol = col_idx;
     double *ddist = dist;
     if (!out_dev) {
-        SF_HIP(hipMalloc(&didx, (size_t)std::max<int64_t>(m1, 1) * sizeof(int64_t)));
-        if (dist) SF_HIP(hipMalloc(&ddist, (size_t)std::max<int64_t>(m1, 1) * sizeof(double)));
-        if (col_idx) SF_HIP(hipMalloc(&dcol, (size_t)std::max<int64_t>(m2, 1) * sizeof(int64_t)));
+        SF_CHECK(tmp.alloc(&didx, (size_t)std::max<int64_t>(m1, 1)));
+        if (dist) SF_CHECK(tmp.alloc(&ddist, (size_t)std::max<int64_t>(m1, 1)));
+        if (col_idx) SF_CHECK(tmp.alloc(&dcol, (size_t)std::max<int64_t>(m2, 1)));
     }
     if (m1) SF_CHECK(match_dispatch(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_tile", "k8_match_gemm"));
     if (col_idx && m2 && m1)
@@ -298,16 +309,8 @@ extern "C" int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const d
         if (m1) SF_HIP(hipMemcpyAsync(idx, didx, (size_t)m1 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         if (dist && m1) SF_HIP(hipMemcpyAsync(dist, ddist, (size_t)m1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (col_idx && m2) SF_HIP(hipMemcpyAsync(col_idx, dcol, (size_t)m2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(didx));
-        if (dist) SF_HIP(hipFree(ddist));
-        if (col_idx) SF_HIP(hipFree(dcol));
     }
-    if (!in_dev) {
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(da));
-        SF_HIP(hipFree(db));
-    }
+    if (!out_dev || !in_dev) SF_HIP(hipStreamSynchronize(ctx->stream)); // host buffers are the caller's again
     return SF_OK;
 }
 
@@ -318,6 +321,18 @@ extern "C" int sf_rows_nonzero(sf_ctx *ctx, const double *rows_dev, int64_t m, i
     if (m) {
         SF_LAUNCH(ctx, "k8_rows_nonzero", k_rows_nonzero, dim3((unsigned)sf_div_up(m, 4)), dim3(256), rows_dev, m, d,
                   mask_dev);
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, const int64_t *sel_dev, int64_t m, int64_t d,
+                              double *out_dev)
+{
+    if (!ctx || !rows_dev || !sel_dev || !out_dev || m < 0 || d <= 0) { sf_set_error("sf_rows_gather: bad argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    if (m) {
+        SF_LAUNCH(ctx, "k8_rows_gather", k_rows_gather, dim3((unsigned)sf_div_up(m, 4)), dim3(256), rows_dev, sel_dev, m, d,
+                  out_dev);
     }
     return SF_OK;
 }
@@ -346,12 +361,13 @@ extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const do
     double *da = nullptr, *db = nullptr, *ddist = nullptr;
     unsigned char *dao = nullptr, *dbo = nullptr;
     int64_t *didx = nullptr;
-    SF_CHECK(sf_palloc(ctx, &da, na));
-    SF_CHECK(sf_palloc(ctx, &db, nbv));
-    SF_CHECK(sf_palloc(ctx, &dao, (size_t)n_scales * m1));
-    SF_CHECK(sf_palloc(ctx, &dbo, (size_t)n_scales * m2));
-    SF_CHECK(sf_palloc(ctx, &didx, (size_t)m1));
-    SF_CHECK(sf_palloc(ctx, &ddist, (size_t)m1));
+    sf_pool_guard tmp(ctx);
+    SF_CHECK(tmp.alloc(&da, na));
+    SF_CHECK(tmp.alloc(&db, nbv));
+    SF_CHECK(tmp.alloc(&dao, (size_t)n_scales * m1));
+    SF_CHECK(tmp.alloc(&dbo, (size_t)n_scales * m2));
+    SF_CHECK(tmp.alloc(&didx, (size_t)m1));
+    SF_CHECK(tmp.alloc(&ddist, (size_t)m1));
     if (na) SF_HIP(hipMemcpyAsync(da, a, na * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     SF_HIP(hipMemcpyAsync(db, b, nbv * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (m1) SF_HIP(hipMemcpyAsync(dao, a_ok, (size_t)n_scales * m1, hipMemcpyHostToDevice, ctx->stream));
@@ -362,8 +378,6 @@ extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const do
         if (dist) SF_HIP(hipMemcpyAsync(dist, ddist, (size_t)m1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    sf_pool_release(ctx, da); sf_pool_release(ctx, db); sf_pool_release(ctx, dao); sf_pool_release(ctx, dbo);
-    sf_pool_release(ctx, didx); sf_pool_release(ctx, ddist);
     return SF_OK;
 }
 
@@ -373,11 +387,12 @@ extern "C" int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, in
     if (!ctx || !a || !b || !Rt || !inliers || m < 0 || n_draws < 0) { sf_set_error("sf_ransac_score: bad argument"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
     const bool in_dev = flags & SF_IN_DEVICE, out_dev = flags & SF_OUT_DEVICE;
+    sf_pool_guard tmp(ctx);
     double *da = const_cast<double *>(a), *db = const_cast<double *>(b), *dR = const_cast<double *>(Rt);
     if (!in_dev) {
-        SF_HIP(hipMalloc(&da, (size_t)std::max<int64_t>(m * 3, 1) * sizeof(double)));
-        SF_HIP(hipMalloc(&db, (size_t)std::max<int64_t>(m * 3, 1) * sizeof(double)));
-        SF_HIP(hipMalloc(&dR, (size_t)std::max<int64_t>(n_draws * 12, 1) * sizeof(double)));
+        SF_CHECK(tmp.alloc(&da, (size_t)std::max<int64_t>(m * 3, 1)));
+        SF_CHECK(tmp.alloc(&db, (size_t)std::max<int64_t>(m * 3, 1)));
+        SF_CHECK(tmp.alloc(&dR, (size_t)std::max<int64_t>(n_draws * 12, 1)));
         if (m) {
             SF_HIP(hipMemcpyAsync(da, a, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
             SF_HIP(hipMemcpyAsync(db, b, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
@@ -385,7 +400,7 @@ extern "C" int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, in
         if (n_draws) SF_HIP(hipMemcpyAsync(dR, Rt, (size_t)n_draws * 96, hipMemcpyHostToDevice, ctx->stream));
     }
     int64_t *dinl = inliers;
-    if (!out_dev) SF_HIP(hipMalloc(&dinl, (size_t)std::max<int64_t>(n_draws, 1) * sizeof(int64_t)));
+    if (!out_dev) SF_CHECK(tmp.alloc(&dinl, (size_t)std::max<int64_t>(n_draws, 1)));
     if (n_draws) {
         SF_HIP(hipMemsetAsync(dinl, 0, (size_t)n_draws * sizeof(int64_t), ctx->stream));
         if (m) {
@@ -409,16 +424,8 @@ extern "C" int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, in
                       n_draws, dps, thr, lo, hi, reinterpret_cast<unsigned long long *>(dinl));
         }
     }
-    if (!out_dev) {
-        if (n_draws) SF_HIP(hipMemcpyAsync(inliers, dinl, (size_t)n_draws * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(dinl));
-    }
-    if (!in_dev) {
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        SF_HIP(hipFree(da));
-        SF_HIP(hipFree(db));
-        SF_HIP(hipFree(dR));
-    }
+    if (!out_dev && n_draws)
+        SF_HIP(hipMemcpyAsync(inliers, dinl, (size_t)n_draws * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (!out_dev || !in_dev) SF_HIP(hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }

@@ -332,9 +332,10 @@ int sf_match_gemm_f64(sf_ctx *ctx, const double *da, int64_t m1, const double *d
 {
     if (n_slow) *n_slow = 0;
     if (!m1) return SF_OK;
+    sf_pool_guard tmp(ctx);
     double *nb = nullptr, *part = nullptr;
-    SF_CHECK(sf_palloc(ctx, &nb, (size_t)m2));
-    SF_CHECK(sf_palloc(ctx, &part, (size_t)256));
+    SF_CHECK(tmp.alloc(&nb, (size_t)m2));
+    SF_CHECK(tmp.alloc(&part, (size_t)256));
     SF_LAUNCH(ctx, "k8_row_sqnorm", k_row_sqnorm, dim3((unsigned)sf_div_up(m2, 4)), dim3(256), db, m2, d, b_ok, nb);
     SF_LAUNCH(ctx, "k8_max_partial", k_max_partial, dim3(256), dim3(256), (const double *)nb, m2, part);
     const int64_t row_tiles = sf_div_up(m1, GM), col_tiles = sf_div_up(m2, GN);
@@ -346,11 +347,11 @@ int sf_match_gemm_f64(sf_ctx *ctx, const double *da, int64_t m1, const double *d
     double *pm1 = nullptr, *pm2 = nullptr;
     int64_t *pj1 = nullptr;
     int *flag = nullptr, *nflag = nullptr;
-    SF_CHECK(sf_palloc(ctx, &pm1, (size_t)(nsplit * m1)));
-    SF_CHECK(sf_palloc(ctx, &pm2, (size_t)(nsplit * m1)));
-    SF_CHECK(sf_palloc(ctx, &pj1, (size_t)(nsplit * m1)));
-    SF_CHECK(sf_palloc(ctx, &flag, (size_t)m1));
-    SF_CHECK(sf_palloc(ctx, &nflag, (size_t)1));
+    SF_CHECK(tmp.alloc(&pm1, (size_t)(nsplit * m1)));
+    SF_CHECK(tmp.alloc(&pm2, (size_t)(nsplit * m1)));
+    SF_CHECK(tmp.alloc(&pj1, (size_t)(nsplit * m1)));
+    SF_CHECK(tmp.alloc(&flag, (size_t)m1));
+    SF_CHECK(tmp.alloc(&nflag, (size_t)1));
     SF_HIP(hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream));
     const bool vec = (d % 2 == 0) && ((uintptr_t)da % 16 == 0) && ((uintptr_t)db % 16 == 0);
     if (vec) {
@@ -384,10 +385,10 @@ int sf_match_gemm_f64(sf_ctx *ctx, const double *da, int64_t m1, const double *d
         const int64_t nr = (int64_t)rows.size();
         int64_t *drows = nullptr, *sidx = nullptr;
         double *sub = nullptr, *sdist = nullptr;
-        SF_CHECK(sf_palloc(ctx, &drows, (size_t)nr));
-        SF_CHECK(sf_palloc(ctx, &sidx, (size_t)nr));
-        SF_CHECK(sf_palloc(ctx, &sdist, (size_t)nr));
-        SF_CHECK(sf_palloc(ctx, &sub, (size_t)(nr * d)));
+        SF_CHECK(tmp.alloc(&drows, (size_t)nr));
+        SF_CHECK(tmp.alloc(&sidx, (size_t)nr));
+        SF_CHECK(tmp.alloc(&sdist, (size_t)nr));
+        SF_CHECK(tmp.alloc(&sub, (size_t)(nr * d)));
         SF_HIP(hipMemcpyAsync(drows, rows.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
         SF_LAUNCH(ctx, "k8_gather_rows", k_gather_rows, dim3((unsigned)sf_div_up(nr * d, 256)), dim3(256), da, d,
                   (const int64_t *)drows, nr, sub);
@@ -397,11 +398,8 @@ int sf_match_gemm_f64(sf_ctx *ctx, const double *da, int64_t m1, const double *d
                       (const int64_t *)drows, nr, (const int64_t *)sidx, (const double *)sdist, didx, ddist);
         }
         SF_HIP(hipStreamSynchronize(ctx->stream)); // rows.data() is a host buffer
-        sf_pool_release(ctx, drows); sf_pool_release(ctx, sidx); sf_pool_release(ctx, sdist); sf_pool_release(ctx, sub);
         if (n_slow) *n_slow = nr;
     }
-    sf_pool_release(ctx, nb); sf_pool_release(ctx, part); sf_pool_release(ctx, pm1); sf_pool_release(ctx, pm2);
-    sf_pool_release(ctx, pj1); sf_pool_release(ctx, flag); sf_pool_release(ctx, nflag);
     return rc;
 }
 

@@ -464,14 +464,8 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     float *nbf = nullptr, *win = nullptr, *candk = nullptr, *thr = nullptr;
     int *cnt = nullptr, *flag = nullptr, *nflag = nullptr;
     int32_t *candj = nullptr;
-    std::vector<void *> held;
-    auto release = [&]() { for (void *p : held) sf_pool_release(ctx, p); held.clear(); };
-#define SF_HALLOC(ptr, count)                                   \
-    {                                                           \
-        int rc_ = sf_palloc(ctx, &ptr, (size_t)(count));        \
-        if (rc_ != SF_OK) { release(); return rc_; }            \
-        held.push_back(ptr);                                    \
-    }
+    sf_pool_guard tmp(ctx); // every block returns to the pool on any exit, error returns of SF_LAUNCH / SF_HIP included
+#define SF_HALLOC(ptr, count) SF_CHECK(tmp.alloc(&ptr, (size_t)(count)))
     SF_HALLOC(part, 256);
     SF_HALLOC(nb2, m2p); SF_HALLOC(eb, m2p); SF_HALLOC(qb, m2p); SF_HALLOC(nbf, m2p);
     SF_HALLOC(na2, m1p); SF_HALLOC(ea, m1p); SF_HALLOC(qa, m1p);
@@ -485,12 +479,12 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
                   1.0, b_ok, (_Float16 *)nullptr, eb, qb, nb2, (float *)nullptr, 1.0);
         int rc = host_max(ctx, na2, m1, part, &namax);
         if (rc == SF_OK) rc = host_max(ctx, nb2, m2, part, &nbmax);
-        if (rc != SF_OK) { release(); return rc; }
+        if (rc != SF_OK) return rc;
     }
-    if (!pick_scale(namax, &sa) || !pick_scale(nbmax, &sb)) { release(); return SF_OK; }
+    if (!pick_scale(namax, &sa) || !pick_scale(nbmax, &sb)) return SF_OK;
     // accumulator units: 1 / 2s = sa sb / 2.  ||b||^2 / 2s ~ 2^27 ||b||max / ||a||max must stay a normal float
     const double unit = 0.5 * sa * sb;
-    if (!(nbmax * unit < 1e30) || !(nbmax * unit > 1e-20)) { release(); return SF_OK; }
+    if (!(nbmax * unit < 1e30) || !(nbmax * unit > 1e-20)) return SF_OK;
     SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m1p, 4)), dim3(256), da, m1, m1p, d, dp, sa,
               (const unsigned char *)nullptr, ah, ea, qa, na2, (float *)nullptr, 1.0);
     SF_LAUNCH(ctx, "k8_half_convert", k_half_convert, dim3((unsigned)sf_div_up(m2p, 4)), dim3(256), db, m2, m2p, d, dp, sb,
@@ -499,9 +493,9 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     {
         int rc = host_max(ctx, eb, m2, part, &ebmax);
         if (rc == SF_OK) rc = host_max(ctx, qb, m2, part, &qbmax);
-        if (rc != SF_OK) { release(); return rc; }
+        if (rc != SF_OK) return rc;
     }
-    if (!std::isfinite(ebmax) || !std::isfinite(qbmax)) { release(); return SF_OK; }
+    if (!std::isfinite(ebmax) || !std::isfinite(qbmax)) return SF_OK;
     // column splits: enough workgroups for two per CU's worth of the chip, each with at least 32 tiles to scan
     const int64_t row_blocks = m1p / HM, col_tiles = m2p / HN;
     int64_t nsplit = 1;
@@ -560,7 +554,6 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
         SF_HIP(hipStreamSynchronize(ctx->stream)); // rows.data() is a host buffer
         if (n_slow) *n_slow = nr;
     }
-    release();
 #undef SF_HALLOC
     *used = 1;
     return rc;

@@ -608,9 +608,15 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
     std::vector<int32_t> hstatus((size_t)m), pending;
     int64_t msel = m;
     bool subset = false;
-    for (int round = 0; round < 64; ++round) {
+    // Each round answers the queries that have k points within R; the others are retried with R doubled on a coarser
+    // grid.  A query far outside the cloud's bounding box (KDTree.query answers those too: ICP feeds it scans that are
+    // not yet aligned) stays pending until the grid has shrunk to ONE cell; that round drops the radius test, so every
+    // cloud point is a candidate and, k being at most n, every remaining query is answered.
+    bool resolved = false;
+    for (int round = 0; round < 2200 && !resolved; ++round) { // R doubles: a double overflows long before 2200 rounds
         sf_grid_desc g = sf_make_grid_desc(c);
-        const double R2 = R * R;
+        const bool one_cell = g.dim[0] == 1 && g.dim[1] == 1 && g.dim[2] == 1;
+        const double R2 = one_cell ? INFINITY : R * R;
         const dim3 grid(sf_xcd_grid(msel)), block(64);
         const int32_t *sel = subset ? qsel : nullptr;
         sf_launch_timer *tm = new sf_launch_timer(ctx, "k2_knn");
@@ -628,13 +634,9 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         pending.clear();
         for (int64_t i = 0; i < m; ++i)
             if (hstatus[(size_t)i] != 0) pending.push_back((int32_t)i);
-        if (pending.empty()) break;
-        if (R > 2.0 * diag) { // cannot happen for k <= n: a single cell already holds every point
-            sf_set_error("sf_knn_search: internal error, %zu queries unresolved", pending.size());
-            sf_pool_release(ctx, status); sf_pool_release(ctx, qsel);
-            return fail();
-        }
-        R *= 2.0; // sparse regions: retry only the unresolved queries on a coarser grid
+        if (pending.empty()) { resolved = true; break; }
+        if (one_cell) break; // cannot happen for k <= n (reported below)
+        R = std::max(2.0 * R, std::min(diag, 1e300) * 1e-6); // sparse regions: retry only the unresolved queries on a coarser grid
         if (sf_cloud_build_grid(ctx, c, R) != SF_OK ||
             hipMemcpyAsync(qsel, pending.data(), pending.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -646,6 +648,10 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
     }
     sf_pool_release(ctx, status);
     sf_pool_release(ctx, qsel);
+    if (!resolved) { // never return lists with unwritten rows
+        sf_set_error("sf_knn_search: internal error, %zu queries unresolved", pending.size());
+        return fail();
+    }
     {
         sf_launch_timer t_(ctx, "k2_knn_to_positions");
         hipLaunchKernelGGL(k_knn_to_positions, dim3((unsigned)sf_div_up(nb->total, 256)), dim3(256), 0, ctx->stream, nb->total,

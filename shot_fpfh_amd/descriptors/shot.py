@@ -19,7 +19,7 @@ import numpy.typing as npt
 from ..core import grid_subsampling
 from ..engine import Cloud, Engine, default_engine
 
-__all__ = ["ShotMultiprocessor"]
+__all__ = ["ShotMultiprocessor", "compute_shot_descriptor", "get_azimuth_idx"]
 
 
 @dataclass
@@ -170,3 +170,43 @@ class ShotMultiprocessor:
             finally:
                 cloud.free()
         return stack.reshape(m, 352 * n_scales)
+
+
+def get_azimuth_idx(x: npt.NDArray[np.float64], y: npt.NDArray[np.float64]) -> npt.NDArray[np.int64]:
+    """Drop-in for shot.py:51-70: octant index 0..7 of (x, y); a point exactly on a boundary ray falls in the LOWER
+    octant.  Evaluated on the GPU by the same device function the SHOT kernel bins its neighbours with."""
+    return default_engine().azimuth_idx(x, y)
+
+
+def compute_shot_descriptor(
+    keypoints: npt.NDArray[np.float64],
+    cloud_points: npt.NDArray[np.float64],
+    normals: npt.NDArray[np.float64],
+    radius: float,
+    min_neighborhood_size: int = 10,
+    n_cosine_bins: int = 11,
+    n_azimuth_bins: int = 8,
+    n_elevation_bins: int = 2,
+    n_radial_bins: int = 2,
+    debug_mode: bool = False,
+    disable_progress_bars: bool = True,
+) -> npt.NDArray[np.float64]:
+    """Drop-in for the reference's serial SHOT (shot.py:310-499, "kept for debugging purposes"): not the same function
+    as ShotMultiprocessor's -- the frame of a keypoint is computed WITHOUT the keypoint itself (and without any
+    duplicate of it) in the support (:361-363), and the rows are always normalised (:496-497).  One K2 search, K4 with
+    the zero-distance neighbours left out, K5.  `debug_mode` only adds assertions / warnings in the reference and
+    `disable_progress_bars` a tqdm bar; both are accepted and have nothing to act on here."""
+    assert n_azimuth_bins == 8, "Generic function for other than 8 azimuth divisions not implemented"
+    assert n_elevation_bins == 2, "Generic function for other than 2 elevation divisions not implemented"
+    assert n_radial_bins == 2, "Generic function for other than 2 radial divisions not implemented"
+    if n_cosine_bins != 11:
+        raise NotImplementedError("the device SHOT kernel has the 11 cosine bins of ShotMultiprocessor (352-bin rows)")
+    cloud = Cloud(default_engine(), cloud_points, normals)
+    try:
+        nb = cloud.radius_search(keypoints, radius)
+        try:
+            return nb.shot_serial(min_neighborhood_size)
+        finally:
+            nb.free()
+    finally:
+        cloud.free()

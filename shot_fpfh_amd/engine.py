@@ -153,6 +153,15 @@ class Engine:
     def spfh(self, cloud: "Cloud", n_bins: int, max_count: int) -> "Spfh":
         return Spfh(cloud, n_bins, max_count)
 
+    def azimuth_idx(self, x, y) -> np.ndarray:
+        """get_azimuth_idx (shot.py:51-70) evaluated by the device function K5 bins with."""
+        x, y = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+        if x.shape != y.shape:
+            raise ValueError("x and y must have the same shape")
+        out = np.zeros(x.shape, dtype=np.int64)
+        _ffi.check(self.lib.sf_azimuth_idx(self.h, _ptr(x), _ptr(y), x.size, _ptr(out), SF_HOST), "sf_azimuth_idx")
+        return out
+
     # ---- matching (K8) / RANSAC scoring (K9) ------------------------------------------------------
     def match_argmin(self, a, b, want_dist=True, want_col=False):
         """Row arg-min of cdist(a, b) (first minimum), winners' distances, optional column arg-min."""
@@ -209,6 +218,15 @@ class Engine:
         m = rows.shape[0] if n_rows is None else n_rows
         out = out if out is not None else self.empty((rows.shape[0],), np.uint8)
         _ffi.check(self.lib.sf_rows_nonzero(self.h, rows.ptr, m, rows.shape[1], out.ptr), "sf_rows_nonzero")
+        return out
+
+    def rows_gather_device(self, rows: DeviceArray, sel: DeviceArray, out: DeviceArray) -> DeviceArray:
+        """out[i] = rows[sel[i]] (a zero row where sel[i] < 0), all resident: a keypoint subset of a descriptor
+        matrix, padded to the equal per-rank block an all-gather needs."""
+        m = sel.shape[0]
+        if out.shape[0] < m or out.shape[1] != rows.shape[1] or sel.dtype != np.int64:
+            raise ValueError("rows_gather_device: int64 selection and an (>= len(sel), d) output expected")
+        _ffi.check(self.lib.sf_rows_gather(self.h, rows.ptr, sel.ptr, m, rows.shape[1], out.ptr), "sf_rows_gather")
         return out
 
     def match_masked_device(self, a: DeviceArray, a_ok: DeviceArray, b: DeviceArray, b_ok: DeviceArray, idx: DeviceArray,
@@ -458,6 +476,15 @@ class Neighbors:
             self.engine.lib.sf_shot_single_scale(self.engine.h, self.cloud.h, self.h, int(bool(normalize)),
                                                  int(min_neighborhood_size), None, _ptr(res), SF_HOST),
             "sf_shot_single_scale",
+        )
+        return res
+
+    def shot_serial(self, min_neighborhood_size: int = 10) -> np.ndarray:
+        """compute_shot_descriptor (shot.py:310-499): frames from the neighbours at non-zero distance, rows normalised."""
+        res = np.zeros((self.m, _ffi.SHOT_LEN))
+        _ffi.check(
+            self.engine.lib.sf_shot_serial(self.engine.h, self.cloud.h, self.h, int(min_neighborhood_size), _ptr(res), SF_HOST),
+            "sf_shot_serial",
         )
         return res
 

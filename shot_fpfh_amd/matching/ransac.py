@@ -4,7 +4,7 @@
 Host: the draws (same module-level np.random.default_rng(seed=72) stream as ransac.py:14, so draw
 k of a process equals the reference's draw k) and one Kabsch fit per draw -- solved as one stack through
 the same BLAS / LAPACK routines (bit-identical transforms, checked against the per-draw solver on the
-first draws of every call).  Device (K9): the O(n_draws x n_matches) inlier count of every candidate
+a sample of the draws and every reflected draw of every call).  Device (K9): the O(n_draws x n_matches) inlier count of every candidate
 transform in ONE launch, instead of one NumPy pass over all matches per draw.
 """
 from __future__ import annotations
@@ -52,10 +52,14 @@ def ransac_on_matches(
         draws[d] = rng.choice(n_matches, draw_size, replace=False, shuffle=False)
     records = np.empty((n_draws, 12), dtype=np.float64)
     if n_draws:
-        rot, tr = solver_point_to_point_batched(scan_pts[draws], ref_pts[draws])
+        rot, tr, reflected = solver_point_to_point_batched(scan_pts[draws], ref_pts[draws], return_reflected=True)
         records[:, :9] = rot.reshape(n_draws, 9)
         records[:, 9:] = tr
-        for d in range(min(n_draws, 8)):  # the stacked solve must reproduce the per-draw one bit for bit
+        # the stacked solve must reproduce the per-draw one bit for bit: checked on the first draws, on an evenly
+        # spread sample and on the draws that took the reflection branch (det < 0: rare, and the likeliest to differ)
+        check = set(range(min(n_draws, 8))) | set(np.linspace(0, n_draws - 1, min(n_draws, 56)).astype(int).tolist())
+        check |= set(reflected[:256].tolist())
+        for d in sorted(check):
             if not np.array_equal(records[d], solver_point_to_point(scan_pts[draws[d]], ref_pts[draws[d]]).as_row12()):
                 logging.warning("stacked Kabsch differs from the per-draw solver on this NumPy build: using the per-draw loop")
                 for e in range(n_draws):

@@ -26,7 +26,7 @@ import numpy as np
 
 from .engine import Cloud, DeviceArray, Engine, Neighbors, Spfh
 
-__all__ = ["ShardPlan", "DescriptorJob", "MatchJob"]
+__all__ = ["ShardPlan", "DescriptorJob", "MatchJob", "SubsetMatchJob"]
 
 
 @dataclass(frozen=True)
@@ -119,7 +119,7 @@ class DescriptorJob:
             self.last_pairs = nb.total
             blk = nb if (hb, he) == (b, e) else nb.slice(b - hb, e - b)
             try:
-                two_streams = self.overlap and self.do_fpfh and self.do_shot and hasattr(self.engine, "fork")
+                two_streams = self.overlap and self.do_fpfh and self.do_shot
                 if self.do_fpfh:
                     spfh = self._spfh_table(nb.max_count)  # (allocates on first use: before forking)
                 shared = self.share_sweep and nb.max_count <= 256  # (the fused K5's limit)
@@ -131,34 +131,38 @@ class DescriptorJob:
                     spfh.compute(nb, moments_out=self.moments)  # K6 + frame moments, before the chains part
                 # the eigen-solves of the frames need only K6's moments and K7 needs only K6's table: side by side (the
                 # small, long-latency eigen kernel disappears under K7); K5 follows both
-                side_eig = shared and not two_streams and hasattr(self.engine, "fork") and hasattr(blk, "lrf_raw_from_moments")
-                if side_eig:
-                    self.engine.fork()
-                    blk.lrf_raw_from_moments(self.moments, b - hb, self.lrf_out)
-                    self.engine.switch(0)
-                if two_streams:
-                    self.engine.fork()  # FPFH chain on the side stream ...
-                if self.do_fpfh:
-                    if not shared:
-                        spfh.compute(nb)
-                    if self.exchange == "allgather" and self.plan.world > 1:
-                        spfh.allgather(self.plan.rows_per_rank)
-                    spfh.fpfh(blk, None, out=self.fpfh_out)
-                if two_streams:
-                    self.engine.switch(0)  # ... the SHOT chain on the main one, side by side
-                if side_eig:
-                    self.engine.switch(1)
-                    self.engine.join()
-                    blk.shot_from_raw_lrf(self.lrf_out, self.normalize, self.min_nb, self.shot_out)
-                elif self.do_shot:
-                    if shared:
-                        blk.shot_from_moments(self.moments, b - hb, self.normalize, self.min_nb, out=self.shot_out,
-                                              lrf_out=self.lrf_out)
-                    else:
-                        blk.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
-                if two_streams:
-                    self.engine.switch(1)
-                    self.engine.join()
+                side_eig = shared and not two_streams
+                forked = False
+                try:
+                    if side_eig:
+                        self.engine.fork()
+                        forked = True
+                        blk.lrf_raw_from_moments(self.moments, b - hb, self.lrf_out)
+                        self.engine.switch(0)
+                    if two_streams:
+                        self.engine.fork()  # FPFH chain on the side stream ...
+                        forked = True
+                    if self.do_fpfh:
+                        if not shared:
+                            spfh.compute(nb)
+                        if self.exchange == "allgather" and self.plan.world > 1:
+                            spfh.allgather(self.plan.rows_per_rank)
+                        spfh.fpfh(blk, None, out=self.fpfh_out)
+                    if two_streams:
+                        self.engine.switch(0)  # ... the SHOT chain on the main one, side by side
+                    if side_eig:
+                        self.engine.join()
+                        forked = False
+                        blk.shot_from_raw_lrf(self.lrf_out, self.normalize, self.min_nb, self.shot_out)
+                    elif self.do_shot:
+                        if shared:
+                            blk.shot_from_moments(self.moments, b - hb, self.normalize, self.min_nb, out=self.shot_out,
+                                                  lrf_out=self.lrf_out)
+                        else:
+                            blk.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
+                finally:
+                    if forked:  # also after an error: never leave the context on its side stream
+                        self.engine.join()
             finally:
                 if blk is not nb:
                     blk.free()
@@ -206,8 +210,9 @@ class MatchJob:
         row_bytes = self.d * 8
         b, e = plan.block()
         self.ref_all.copy_from_device(ref_block, dst_byte_offset=b * row_bytes, nbytes=(e - b) * row_bytes)
-        if plan.world > 1:
-            eng.allgather(self.ref_all, plan.rows_per_rank * row_bytes)
+        # (a lone context without a communicator has nothing to exchange and the call returns at once; with a
+        # communicator -- of ONE rank too -- this is ncclAllGather)
+        eng.allgather(self.ref_all, plan.rows_per_rank * row_bytes)
         eng.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=plan.n)
         if self.m:
             eng.rows_nonzero_device(scan_block, self.scan_ok, n_rows=self.m)
@@ -225,4 +230,67 @@ class MatchJob:
 
     def close(self) -> None:
         for a in (self.ref_all, self.ref_ok, self.scan_ok, self.idx, self.dist):
+            a.free()
+
+
+class SubsetMatchJob:
+    """The tail of BASELINE config 5: match a keypoint SUBSET of two sharded descriptor sets.
+
+    Every rank holds its block of the scan descriptors and its block of the reference descriptors (`DescriptorJob`
+    outputs, rows in the cell-sorted order of their clouds).  `select()` picks the rows of the subset out of both
+    blocks on the device (`sf_rows_gather`) into blocks of exactly `rows_per_rank` rows -- zero rows pad a rank that
+    owns fewer, and zero descriptors are skipped by the matching like the reference's empty ones (matching.py:162-163)
+    -- together with a caller-chosen int64 label per row (the original point index, say).  `run()` is the exchange
+    + K8: one RCCL all-gather of the reference subset rows, one of their labels, then the row arg-min of this rank's
+    scan subset over the gathered set.  `matches()` returns label pairs, so ranks need no common row numbering.
+    """
+
+    def __init__(self, engine: Engine, length: int, rows_per_rank: int, world: int = 1, rank: int = 0):
+        if rows_per_rank < 1:
+            raise ValueError("rows_per_rank must be positive")
+        self.engine, self.d, self.rows, self.world, self.rank = engine, int(length), int(rows_per_rank), world, rank
+        total = self.rows * world
+        self.job = MatchJob(engine, length, total, total, world, rank)
+        self.scan_sub: DeviceArray = engine.empty((self.rows, self.d))
+        self.ref_sub: DeviceArray = engine.empty((self.rows, self.d))
+        self.sel: DeviceArray = engine.empty((self.rows,), np.int64)
+        self.ref_labels: DeviceArray = engine.empty((total,), np.int64)
+        self.scan_labels = np.full(self.rows, -1, dtype=np.int64)
+
+    def _padded(self, values, what: str) -> np.ndarray:
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        if v.ndim != 1 or v.shape[0] > self.rows:
+            raise ValueError(f"{what}: at most {self.rows} rows per rank, got shape {v.shape}")
+        out = np.full(self.rows, -1, dtype=np.int64)
+        out[: v.shape[0]] = v
+        return out
+
+    def select(self, scan_rows: DeviceArray, scan_sel, scan_labels, ref_rows: DeviceArray, ref_sel, ref_labels) -> None:
+        """scan_sel / ref_sel: local row numbers (into this rank's blocks) of the subset; *_labels: one int64 each."""
+        eng = self.engine
+        if len(scan_sel) != len(scan_labels) or len(ref_sel) != len(ref_labels):
+            raise ValueError("one label per selected row expected")
+        self.scan_labels = self._padded(scan_labels, "scan_labels")
+        eng.rows_gather_device(scan_rows, self.sel.from_host(self._padded(scan_sel, "scan_sel")), self.scan_sub)
+        eng.rows_gather_device(ref_rows, self.sel.from_host(self._padded(ref_sel, "ref_sel")), self.ref_sub)
+        mine = eng.empty((self.rows,), np.int64).from_host(self._padded(ref_labels, "ref_labels"))
+        try:
+            self.ref_labels.copy_from_device(mine, dst_byte_offset=self.rank * self.rows * 8)
+            eng.sync()
+        finally:
+            mine.free()
+
+    def run(self) -> None:
+        self.job.run(self.scan_sub, self.ref_sub)                 # all-gather of descriptor rows (C2) + K8
+        self.engine.allgather(self.ref_labels, self.rows * 8)     # all-gather of the small label vector (C3)
+
+    def matches(self) -> tuple[np.ndarray, np.ndarray]:
+        """(labels of this rank's non-empty scan subset rows, labels of the reference rows they matched)."""
+        rows, idx = self.job.matches()
+        labels = self.ref_labels.to_host()
+        return self.scan_labels[rows - self.job.scan_plan.begin], labels[idx]
+
+    def close(self) -> None:
+        self.job.close()
+        for a in (self.scan_sub, self.ref_sub, self.sel, self.ref_labels):
             a.free()

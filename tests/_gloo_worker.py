@@ -37,12 +37,46 @@ def match_main(out_path, rank, world):
     dist.destroy_process_group()
 
 
+def subset_main(out_path, rank, world):
+    """Config-5 tail on two ranks: every rank owns a block of scan and of reference descriptors; a keypoint subset
+    (chosen by label) is gathered out of both, the reference part all-gathered with its labels, and matched."""
+    from shot_fpfh_amd.sharding import ShardPlan, SubsetMatchJob
+
+    rng = np.random.default_rng(17)
+    n, d = 400, 24
+    scan = rng.random((n, d)) * (rng.random((n, d)) < 0.5)
+    perm = rng.permutation(n)
+    ref = scan[perm] + 0.004 * rng.standard_normal((n, d))  # reference row j corresponds to scan row perm[j]
+    scan[[3, 77]] = 0.0
+    ref[[10]] = 0.0
+    in_subset = rng.random(n) < 0.3  # by SCAN label
+    eng = FakeEngine()
+    sb, se = ShardPlan(n, world, rank).block()
+    s_sel = np.flatnonzero(in_subset[sb:se])
+    r_lab_block = perm[sb:se]
+    r_sel = np.flatnonzero(in_subset[r_lab_block])
+    rows = int(in_subset.sum())  # generous per-rank capacity: exercises the zero-row padding
+    job = SubsetMatchJob(eng, d, rows, world, rank)
+    job.select(eng.empty((se - sb, d)).from_host(scan[sb:se]), s_sel, s_sel + sb,
+               eng.empty((se - sb, d)).from_host(ref[sb:se]), r_sel, r_lab_block[r_sel])
+    job.run()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, job.matches())
+    if rank == 0:
+        np.savez(out_path, s=np.concatenate([g[0] for g in gathered]), r=np.concatenate([g[1] for g in gathered]),
+                 scan=scan, ref=ref, perm=perm, in_subset=in_subset)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out_path, mode = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if mode == "match":
         return match_main(out_path, rank, world)
+    if mode == "subset":
+        return subset_main(out_path, rank, world)
     p, nr, _ = synth_cloud(1500, 41)
     job = DescriptorJob(FakeEngine(), p, nr, 0.15, n_bins=5, normalize=True, min_neighborhood_size=5, world=world,
                         rank=rank, spfh_exchange=mode)

@@ -59,6 +59,14 @@ class FakeNbrs:
         self.shot_lrf(out=lrf_out)
         return self.shot(lrf_out, normalize, min_neighborhood_size, out=out)
 
+    def lrf_raw_from_moments(self, moments, first_row, lrf_out):
+        # first half of the shared-sweep form (the device engine leaves raw axes here; the stand-in the frames)
+        assert moments.a.shape[0] >= first_row + self.m
+        self.shot_lrf(out=lrf_out)
+
+    def shot_from_raw_lrf(self, lrf, normalize, min_neighborhood_size, out):
+        return self.shot(lrf, normalize, min_neighborhood_size, out=out)
+
     def shot_from_moments(self, moments, first_row, normalize, min_neighborhood_size, out, lrf_out=None):
         # the shared-sweep form of the device engine: same result as the two-kernel form (the oracle has no moments)
         assert moments.a.shape[0] >= first_row + self.m
@@ -151,6 +159,16 @@ class FakeCloud:
 
 
 class FakeEngine:
+    # the two-stream interface of the device engine: the stand-in runs everything in program order
+    def fork(self):
+        pass
+
+    def switch(self, side):
+        pass
+
+    def join(self):
+        pass
+
     def cloud(self, points, normals=None):
         return FakeCloud(points, normals)
 
@@ -167,6 +185,14 @@ class FakeEngine:
         parts = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
+
+    def sync(self):
+        pass
+
+    def rows_gather_device(self, rows, sel, out):
+        pick = sel.a.astype(np.int64)
+        out.a[: pick.shape[0]] = np.where((pick >= 0)[:, None], np.nan_to_num(rows.a, nan=0.0)[np.maximum(pick, 0)], 0.0)
+        return out
 
     def rows_nonzero_device(self, rows, out=None, n_rows=None):
         m = rows.shape[0] if n_rows is None else n_rows

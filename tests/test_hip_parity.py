@@ -210,8 +210,9 @@ def test_config_c2_shot_fpfh_vs_oracle(O):
         d = sm.compute_descriptor_single_scale(p, nr, p[kp], r)
     do = O.shot_single_scale(p, nr, p[kp], r, True, 10)
     bad_rows = np.flatnonzero((~close(d, do)).any(axis=1))
-    # a bin decision that sits on a rounding boundary may flip; such rows are counted, not hidden
-    assert bad_rows.size <= 2, f"{bad_rows.size} SHOT rows outside tolerance: {bad_rows[:10]}"
+    # a bin decision that sits on a rounding boundary could flip a row; the observed number on MI355X is 0 and the
+    # test holds the kernel to it (a flipped row would be listed here, not hidden)
+    assert bad_rows.size == 0, f"{bad_rows.size} SHOT rows outside tolerance: {bad_rows[:10]}"
     nz = d.any(axis=1)  # corner keypoints with <= 10 neighbours stay all-zero (shot.py:212)
     assert np.array_equal(nz, do.any(axis=1)) and nz.sum() > 9900
     assert np.abs(np.linalg.norm(d[nz], axis=1) - 1.0).max() < 1e-12

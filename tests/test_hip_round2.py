@@ -1,0 +1,308 @@
+"""GPU parity tests added in round 2 (all through the C ABI):
+
+  * a8  serial compute_shot_descriptor against the reference's golden and the oracle;
+  * a4  get_azimuth_idx on the device against the reference's boundary table; a SHOT row whose neighbours all sit ON bin
+        boundaries;
+  * C3  FPFH at full size (1M points, k ~ 110) against the oracle on a sample;  C5: one rank's block of the 8M-point
+        cloud (r = 0.015) on one device against the oracle on a sample;
+  * C4  at full size: 2 x 1M SHOT -> basic_matching -> RANSAC, with a sample of match rows re-derived on the CPU;
+  * the exchange layer: ncclAllGather really executed (one-rank communicator), SubsetMatchJob on the device;
+  * regressions for the advisor's findings (k-NN queries far outside the cloud, two-stream overlap with unshared sweeps).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, synth_cloud
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL):
+    return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import shot_fpfh_amd as s
+
+    return s.default_engine()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+# ---- a8 --------------------------------------------------------------------------------------------------------------
+def test_serial_shot_descriptor_golden(O):
+    """compute_shot_descriptor (shot.py:310-499): frame WITHOUT the keypoint in its support, always normalised."""
+    from shot_fpfh_amd.descriptors.shot import compute_shot_descriptor
+
+    g = load_golden("shot_150.npz")
+    kp, r = g["keypoints"][:60], float(g["radius"])
+    d = compute_shot_descriptor(kp, g["cloud"], g["normals"], r, min_neighborhood_size=10)
+    assert d.shape == g["serial"].shape and d.dtype == np.float64
+    assert close(d, g["serial"]).all(), np.abs(d - g["serial"]).max()
+    assert np.abs(d - O.compute_shot_descriptor(kp, g["cloud"], g["normals"], r, 10)).max() < 1e-9
+    with pytest.raises(AssertionError):
+        compute_shot_descriptor(kp, g["cloud"], g["normals"], r, n_azimuth_bins=4)
+
+
+def test_serial_shot_descriptor_vs_oracle_with_duplicates_and_sparse_rows(O):
+    """Duplicated keypoints (several zero-distance neighbours leave the support), keypoints off the cloud (the keypoint
+    is not a cloud point: nothing to drop), sparse corners (gate fails -> zero row) and min_neighborhood_size extremes."""
+    from shot_fpfh_amd.descriptors.shot import compute_shot_descriptor
+
+    p, nr, rng = synth_cloud(5000, 61)
+    p = np.vstack([p, p[:40], p[:15]])  # duplicates (and triplicates) of cloud points
+    nr = np.vstack([nr, nr[:40], nr[:15]])
+    kp = np.vstack([p[:80], p[2000:2100], rng.random((50, 3)), [[5.0, 5.0, 5.0]]])
+    for mn in (10, 60, 0):
+        d = compute_shot_descriptor(kp, p, nr, 0.13, min_neighborhood_size=mn)
+        do = O.compute_shot_descriptor(kp, p, nr, 0.13, mn)
+        assert np.array_equal(d.any(axis=1), do.any(axis=1))
+        assert np.abs(d - do).max() < 1e-9
+    assert not d[-1].any()  # the far keypoint has an empty neighbourhood
+
+
+# ---- a4 --------------------------------------------------------------------------------------------------------------
+def test_azimuth_idx_device_function_matches_the_reference_table():
+    from shot_fpfh_amd.descriptors.shot import get_azimuth_idx
+
+    g = load_golden("azimuth_table.npz")
+    got = get_azimuth_idx(g["x"], g["y"])
+    assert got.dtype == np.int64 and np.array_equal(got, g["idx"])
+    named = {(1, 0): 3, (0, 1): 5, (-1, 0): 7, (0, -1): 1, (1, 1): 4, (-1, 1): 6, (-1, -1): 0, (1, -1): 2, (0, 0): 0}
+    xy = np.array(list(named), dtype=np.float64)
+    assert get_azimuth_idx(xy[:, 0], xy[:, 1]).tolist() == list(named.values())
+
+
+def test_shot_row_with_every_neighbour_on_a_bin_boundary(eng):
+    """One keypoint at the origin, identity frame, neighbours exactly ON octant / elevation / radial boundaries and
+    cosines on the half-way points of the cosine bins (reference output: tests/golden/shot_boundary.npz)."""
+    g = load_golden("shot_boundary.npz")
+    cloud = eng.cloud(g["neighbors"], g["normals"])
+    nb = cloud.radius_search(g["point"][None, :], float(g["radius"]))
+    assert nb.total == g["neighbors"].shape[0]
+    for key, normalize in (("desc_n1", True), ("desc_n0", False)):
+        d = nb.shot(np.eye(3)[None], normalize, 5)[0]
+        assert np.abs(d - g[key]).max() < 1e-9, np.abs(d - g[key]).max()
+    nb.free()
+    cloud.free()
+
+
+# ---- C2 tightened: DESIGN.md claims 0 rows outside tolerance; hold it to that -------------------------------------------
+def test_config_c2_has_no_row_outside_tolerance(O):
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    p, nr, rng = synth_cloud(100000, 2)
+    kp = np.sort(rng.choice(100000, 10000, replace=False))
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+        d = sm.compute_descriptor_single_scale(p, nr, p[kp], 0.05)
+    do = O.shot_single_scale(p, nr, p[kp], 0.05, True, 10)
+    bad = np.flatnonzero((~close(d, do)).any(axis=1))
+    assert bad.size == 0, f"SHOT rows outside tolerance: {bad.tolist()}"
+    assert np.abs(d - do).max() < 1e-9
+    f = s.compute_fpfh_descriptor(kp, p, nr, 0.05, 5, verbose=False)
+    fo = O.compute_fpfh_descriptor(kp, p, nr, 0.05, 5)
+    assert np.abs(f - fo).max() < 1e-9
+
+
+# ---- C3 / C5 at full size against the oracle ------------------------------------------------------------------------------
+def test_config_c3_fpfh_and_shot_rows_vs_oracle_at_full_size(eng, O):
+    """BASELINE config 3 (1M points, all keypoints, r = 0.03, k ~ 110): 300 FPFH rows and 300 SHOT rows of the
+    resident outputs against the oracle, which evaluates SPFH only for the sample's neighbours (bit-identical rows)."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    n, r = 1_000_000, 0.03
+    p, nr, rng = synth_cloud(n, 3)
+    job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10)
+    job.step()
+    assert 100 < job.last_pairs / n < 120
+    orig = job.block_original_indices()
+    pick = np.sort(rng.choice(n, 300, replace=False))
+    f = np.stack([job.fpfh_out.rows_to_host(int(i), 1)[0] for i in pick])
+    fo = O.compute_fpfh_descriptor_sample(orig[pick], p, nr, r, 5)
+    assert close(f, fo).all() and np.abs(f - fo).max() < 1e-9, np.abs(f - fo).max()
+    d = np.stack([job.shot_out.rows_to_host(int(i), 1)[0] for i in pick])
+    do = O.shot_single_scale(p, nr, p[orig[pick]], r, True, 10)
+    assert close(d, do).all() and np.abs(d - do).max() < 1e-9
+    # the drop-in call returns the same rows (original numbering) as the resident job
+    import shot_fpfh_amd as s
+
+    fd = s.compute_fpfh_descriptor(orig[pick], p, nr, r, 5, verbose=False)
+    assert np.array_equal(fd, f)
+    job.close()
+
+
+@pytest.mark.parametrize("rank", [3])
+def test_config_c5_rank_block_of_the_8m_cloud_vs_oracle(eng, O, rank):
+    """BASELINE config 5's descriptor pass as ONE of its 8 ranks executes it: the 8M-point cloud (seed 5, r = 0.015)
+    replicated, rank `rank`'s block of 1M cell-sorted positions, block grid build with halo SPFH recompute.
+    A sample of FPFH and SHOT rows against the oracle (which searches the whole 8M cloud), and the block's row -> point
+    map must be a slice of a permutation."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    n, r, world = 8_000_000, 0.015, 8
+    p, nr, rng = synth_cloud(n, 5)
+    job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=rank)
+    job.step()
+    assert job.m == n // world
+    orig = job.block_original_indices()
+    assert np.unique(orig).size == job.m and orig.min() >= 0 and orig.max() < n
+    pick = np.sort(rng.choice(job.m, 200, replace=False))
+    f = np.stack([job.fpfh_out.rows_to_host(int(i), 1)[0] for i in pick])
+    fo = O.compute_fpfh_descriptor_sample(orig[pick], p, nr, r, 5)
+    assert close(f, fo).all() and np.abs(f - fo).max() < 1e-9, np.abs(f - fo).max()
+    d = np.stack([job.shot_out.rows_to_host(int(i), 1)[0] for i in pick])
+    do = O.shot_single_scale(p, nr, p[orig[pick]], r, True, 10)
+    assert close(d, do).all() and np.abs(d - do).max() < 1e-9
+    job.close()
+
+
+# ---- C4 at full size ---------------------------------------------------------------------------------------------------------
+def _exact_first_argmin(O, a_rows, b, chunk=65536):
+    """Row arg-min of cdist(a_rows, b) with scipy's first-minimum rule, affordable for a few hundred rows against 10^6:
+    float64 BLAS keys ||b||^2 - 2 a.b locate every column within 1e-7 of the minimum (the GEMM's rounding is ~1e-13),
+    the oracle's sequential sum then decides among those candidates in index order."""
+    bn = np.einsum("ij,ij->i", b, b)
+    best = np.full(a_rows.shape[0], np.inf)
+    keys = []
+    for c0 in range(0, b.shape[0], chunk):
+        k = bn[None, c0:c0 + chunk] - 2.0 * (a_rows @ b[c0:c0 + chunk].T)
+        best = np.minimum(best, k.min(axis=1))
+        keys.append(k)
+    keys = np.concatenate(keys, axis=1)
+    idx, dist = np.zeros(a_rows.shape[0], np.int64), np.zeros(a_rows.shape[0])
+    for i in range(a_rows.shape[0]):
+        cand = np.flatnonzero(keys[i] <= best[i] + 1e-7)
+        j, dd = O.match_argmin(a_rows[i:i + 1], b[cand])
+        idx[i], dist[i] = cand[j[0]], dd[0]
+    return idx, dist
+
+
+def test_config_c4_full_size_chain_with_cpu_checked_match_rows(eng, O):
+    """BASELINE config 4: two 1M-point clouds (ref = scan[perm] R^T + t), SHOT r = 0.03 on both, basic_matching
+    scan -> ref, RANSAC with 10 000 draws at threshold 0.01.
+      * a sample of 256 match rows equals the exact first-minimum arg-min over all 10^6 reference rows (and its distance),
+        re-derived on the CPU;
+      * the chain recovers R, t; the share of matches equal to the true correspondence is reported against the measured
+        level (SHOT rows are only rotation-invariant up to the sign votes of get_local_rf, shot.py:40-45)."""
+    import shot_fpfh_amd.matching.ransac as R
+    from scipy.spatial.transform import Rotation
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+    from shot_fpfh_amd.matching import basic_matching
+
+    n, r = 1_000_000, 0.03
+    scan, nrm, rng = synth_cloud(n, 4)
+    perm = rng.permutation(n)
+    rot = Rotation.from_euler("xyz", [0.3, -0.2, 0.5]).as_matrix()
+    t = np.array([0.1, -0.3, 0.2])
+    ref, ref_n = scan[perm] @ rot.T + t, nrm[perm] @ rot.T
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+        ds = sm.compute_descriptor_single_scale(scan, nrm, scan, r)
+        dr = sm.compute_descriptor_single_scale(ref, ref_n, ref, r)
+    si, ri = basic_matching(ds, dr)
+    assert si.dtype == np.int64 and ri.dtype == np.int64
+    assert np.array_equal(si, np.flatnonzero(ds.any(axis=1)))
+    pick = np.sort(rng.choice(si.size, 256, replace=False))
+    nz_r = np.flatnonzero(dr.any(axis=1))
+    want, _ = _exact_first_argmin(O, ds[si[pick]], dr[nz_r])
+    assert np.array_equal(ri[pick], nz_r[want])
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    correct = float((ri == inv[si]).mean())
+    assert correct > 0.85, correct
+    R.rng = np.random.default_rng(seed=72)
+    ratio, tf = R.ransac_on_matches(si, ri, scan, ref, n_draws=10000, draw_size=4, distance_threshold=0.01,
+                                    disable_progress_bar=True)
+    assert abs(ratio - correct) < 0.02  # inliers are the correct matches (wrong ones land far away)
+    assert np.abs(tf.rotation - rot).max() < 5e-3 and np.abs(tf.translation - t).max() < 5e-3
+    # the winning draw's inlier count equals the NumPy expression of ransac.py:60-67 for that transform
+    best_inl = (np.linalg.norm((scan[si] @ tf.rotation.T + tf.translation) - ref[ri], axis=1) <= 0.01).sum()
+    assert abs(best_inl / si.size - ratio) < 1e-3
+
+
+# ---- exchange layer -----------------------------------------------------------------------------------------------------
+def test_nccl_allgather_is_really_executed_on_a_one_rank_communicator(O):
+    """Once sf_comm_init has run, sf_comm_allgather goes through ncclAllGather -- also with ONE rank, which is what a
+    single-GPU box can execute of the N-rank exchange: in-place form (send inside recv), out-of-place form through
+    MatchJob / SubsetMatchJob, and the HIP-event timer 'c_allgather' counts the launches."""
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.sharding import SubsetMatchJob
+
+    e2 = s.Engine(0)
+    e2.comm_init(e2.comm_unique_id(), 1, 0)
+    e2.profile_reset()
+    e2.profile(True)
+    a = e2.empty((1000, 352)).from_host(np.arange(352000.0).reshape(1000, 352))
+    e2.allgather(a, a.nbytes)
+    assert np.array_equal(a.to_host(), np.arange(352000.0).reshape(1000, 352))
+    rng = np.random.default_rng(3)
+    scan = rng.random((900, 352)) * (rng.random((900, 352)) < 0.3)
+    perm = rng.permutation(900)
+    ref = scan[perm] + 1e-3 * rng.standard_normal((900, 352))
+    scan[[5, 6]] = 0.0
+    sub = SubsetMatchJob(e2, 352, 512, 1, 0)
+    s_sel = np.flatnonzero(np.arange(900) % 2 == 0)
+    r_sel = np.flatnonzero(perm % 2 == 0)
+    sub.select(e2.empty((900, 352)).from_host(scan), s_sel, s_sel, e2.empty((900, 352)).from_host(ref), r_sel, perm[r_sel])
+    sub.run()
+    s_lab, r_lab = sub.matches()
+    si, ri = O.basic_matching(scan[s_sel], ref[r_sel])
+    assert np.array_equal(s_lab, s_sel[si]) and np.array_equal(r_lab, perm[r_sel][ri])
+    assert (s_lab == r_lab).mean() > 0.99
+    e2.profile(False)
+    rep = e2.profile_report()
+    assert rep["c_allgather"][0] >= 3 and rep["c_allgather"][1] > 0.0  # rows, rows, labels: ncclAllGather launches
+    sub.close()
+    a.free()
+    e2.close()
+
+
+# ---- advisor regressions -----------------------------------------------------------------------------------------------------
+def test_knn_answers_queries_far_outside_the_cloud(eng, O):
+    """KDTree.query returns the nearest points for ANY query; ICP feeds it scans that are not aligned yet.  Queries 10
+    and 1000 bounding-box diagonals away (and a mix with inside queries) against brute force."""
+    p, _, rng = synth_cloud(3000, 12)
+    inside = rng.random((50, 3))
+    far = np.array([[11.0, 12.0, -9.0], [1000.0, 0.5, 0.5], [-1e3, -1e3, -1e3], [0.5, 0.5, 40.0]])
+    q = np.vstack([inside, far, inside + 25.0])
+    cloud = eng.cloud(p)
+    for k in (1, 7):
+        nb = cloud.knn_search(q, k)
+        off, idx = nb.export()
+        d2 = ((p[None, :, :] - q[:, None, :]) ** 2).sum(axis=2)
+        want = np.sort(np.argsort(d2, axis=1, kind="stable")[:, :k], axis=1)
+        got = np.sort(idx.reshape(q.shape[0], k), axis=1)
+        assert np.array_equal(got, want)
+        nb.free()
+    cloud.free()
+
+
+@pytest.mark.parametrize("share", [False, True])
+def test_two_stream_overlap_with_unshared_sweep_and_long_lists(eng, share):
+    """The --overlap path when K6 does NOT run before the fork (share_sweep off, or a list longer than 256 points):
+    the normals are then sorted by whichever chain gets there first and the other stream must wait for that gather."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    rng = np.random.default_rng(8)
+    sparse = rng.random((20000, 3), dtype=np.float32).astype(np.float64)
+    dense = (0.5 + 0.01 * rng.standard_normal((600, 3))).astype(np.float32).astype(np.float64)  # lists > 256 points
+    p = np.vstack([sparse, dense]) if not share else sparse
+    nr = rng.standard_normal(p.shape)
+    nr /= np.linalg.norm(nr, axis=1)[:, None]
+    outs = []
+    for overlap in (False, True):
+        job = DescriptorJob(eng, p, nr, 0.06, overlap_chains=overlap, share_sweep=share)
+        for _ in range(3):  # every step rebuilds the grid, which clears the sorted-normals flag
+            job.step()
+        outs.append((job.fpfh_out.to_host(), job.shot_out.to_host(), job.lrf_out.to_host()))
+        job.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

@@ -70,3 +70,29 @@ def test_two_rank_gloo_sharded_matching_equals_basic_matching(tmp_path):
     got = np.load(out)
     s, r = O.basic_matching(got["a"], got["b"])
     assert np.array_equal(got["s"], s) and np.array_equal(got["r"], r)
+
+
+def test_two_rank_gloo_subset_matching_by_label(tmp_path):
+    """SubsetMatchJob (the tail of BASELINE config 5) over two gloo ranks: a keypoint subset picked out of every rank's
+    blocks, reference subset + labels all-gathered, sharded K8; the label pairs must be those of basic_matching on the
+    subset rows taken in label order."""
+    from oracle import oracle as O
+
+    out = str(tmp_path / "subset.npz")
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, "subset"], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    scan, ref, perm, sub = got["scan"], got["ref"], got["perm"], got["in_subset"]
+    s_lab = np.flatnonzero(sub)                       # scan subset, label = scan row
+    r_rows = np.flatnonzero(sub[perm])                # reference rows whose label is in the subset
+    si, ri = O.basic_matching(scan[s_lab], ref[r_rows])
+    want = dict(zip(s_lab[si].tolist(), perm[r_rows[ri]].tolist()))
+    have = dict(zip(got["s"].tolist(), got["r"].tolist()))
+    assert have == want
+    assert np.mean([k == v for k, v in have.items()]) > 0.9  # and the matches do recover the correspondence

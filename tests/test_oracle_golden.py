@@ -188,3 +188,60 @@ def test_config1_plumbing_case_fpfh_matches_reference_golden():
     assert np.abs(normals[:200] - g["normals_head"]).max() < 1e-9
     f = O.compute_fpfh_descriptor(g["kp_idx"], p, normals, float(g["radius"]), 5)
     assert np.abs(f - g["fpfh"]).max() <= 1e-10 * max(1.0, np.abs(g["fpfh"]).max())
+
+
+def test_azimuth_idx_boundary_table():
+    """get_azimuth_idx on the reference's own outputs for every exact octant boundary, the doubles
+    one ulp either side of each, signed zeros, subnormal / huge magnitudes and 20 000 random points."""
+    g = load_golden("azimuth_table.npz")
+    with np.errstate(over="ignore"):
+        got = O.azimuth_idx(g["x"], g["y"])
+    assert np.array_equal(got, g["idx"])
+    # the table SURVEY 8a quotes: boundaries belong to the LOWER octant
+    named = {(1, 0): 3, (0, 1): 5, (-1, 0): 7, (0, -1): 1, (1, 1): 4, (-1, 1): 6, (-1, -1): 0, (1, -1): 2, (0, 0): 0}
+    for (x, y), k in named.items():
+        assert O.azimuth_idx([float(x)], [float(y)])[0] == k
+
+
+def test_shot_row_with_every_neighbour_on_a_bin_boundary():
+    """compute_single_shot_descriptor with an identity frame and neighbours exactly ON the octant, elevation and radial
+    boundaries (rho == r/2, r/4, 3r/4; z == 0; axes and diagonals) and cosines on the half-way points of the cosine bins."""
+    g = load_golden("shot_boundary.npz")
+    for key, normalize in (("desc_n1", True), ("desc_n0", False)):
+        d = O.shot_single(g["point"], g["neighbors"], g["normals"], float(g["radius"]), np.eye(3), normalize, 5)
+        assert np.abs(d - g[key]).max() <= TOL, np.abs(d - g[key]).max()
+
+
+def test_serial_shot_descriptor():
+    """compute_shot_descriptor (shot.py:310-499): the frame is computed without the keypoint in its support, so rows
+    differ from ShotMultiprocessor's wherever a sign vote was within one of a tie."""
+    g = load_golden("shot_150.npz")
+    kp = g["keypoints"][:60]
+    d = O.compute_shot_descriptor(kp, g["cloud"], g["normals"], float(g["radius"]), 10)
+    assert np.abs(d - g["serial"]).max() <= TOL
+    par = O.shot_single_scale(g["cloud"], g["normals"], kp, float(g["radius"]), True, 10)
+    assert (np.abs(par - g["serial"]).max(axis=1) > 1e-6).sum() >= 1  # the fixture does tell the two variants apart
+
+
+def test_fpfh_sample_helper_equals_the_full_function():
+    from conftest import synth_cloud
+
+    p, nr, rng = synth_cloud(6000, 77)
+    kp = np.sort(rng.choice(6000, 150, replace=False))
+    full = O.compute_fpfh_descriptor(kp, p, nr, 0.09, 5)
+    assert np.array_equal(O.compute_fpfh_descriptor_sample(kp, p, nr, 0.09, 5), full)
+    g = load_golden("fpfh_200.npz")
+    f = O.compute_fpfh_descriptor_sample(g["kp_idx"], g["cloud"], g["normals"], float(g["radius"]), 5)
+    assert np.abs(f - g["fpfh5"]).max() <= 1e-10 * max(1.0, np.abs(g["fpfh5"]).max())
+
+
+def test_numpy_shaped_cpu_baseline_reproduces_the_reference():
+    """oracle/numpy_shaped.py (the reference-shaped CPU baseline bench.py times) against the reference's goldens."""
+    from oracle import numpy_shaped as NS
+
+    g = load_golden("fpfh_200.npz")
+    f = NS.fpfh_numpy_shaped(g["kp_idx"], g["cloud"], g["normals"], float(g["radius"]), 5)
+    assert np.abs(f - g["fpfh5"]).max() <= TOL
+    s = load_golden("shot_150.npz")
+    d = NS.shot_numpy_shaped(s["cloud"], s["normals"], s["keypoints"], float(s["radius"]), True, 10, n_procs=2)
+    assert np.abs(d - s["single_n1_m10"]).max() <= TOL

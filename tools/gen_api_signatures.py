@@ -20,6 +20,7 @@ TARGETS = {
                               "ShotMultiprocessor.compute_descriptor_multiscale", "ShotMultiprocessor.compute_local_rf",
                               "ShotMultiprocessor.compute_descriptor"],
     "shot_fpfh.descriptors.pca_based_descriptors": ["compute_local_pca_with_moments"],
+    "shot_fpfh.descriptors.shot": ["compute_shot_descriptor"],
     "shot_fpfh.matching": ["match_descriptors", "basic_matching", "double_matching_with_rejects", "ransac_on_matches",
                            "threshold_filter", "quantile_filter", "left_median_filter"],
     "shot_fpfh.keypoint_selection": ["select_keypoints_iteratively", "select_keypoints_subsampling", "select_keypoints_randomly",
