@@ -219,6 +219,11 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     lead = rank == 0 or emulated
     single = world == 1
+    # stdout carries exactly ONE line, the JSON record: libraries that print there (RCCL's version banner) are sent to
+    # stderr for the rest of the run, and the record goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     shaped = None
     if single and not args.no_cpu_baseline:  # (forks a Pool: must start before this process touches the GPU)
@@ -509,8 +514,8 @@ def main() -> int:
             out["cpu_baseline_c_port"] = c_port_baseline(args.points_per_gpu, args.radius)
             out["speedup_vs_cpu_baseline"] = value / shaped["value"]
             out["speedup_vs_c_port"] = value / out["cpu_baseline_c_port"]["value"]
-        print(json.dumps(out))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -71,6 +71,11 @@ int sf_join(sf_ctx *ctx);
 /* ---- raw device memory (for callers that keep results resident) ------------------------- */
 void *sf_dev_alloc(sf_ctx *ctx, size_t bytes);
 int sf_dev_free(sf_ctx *ctx, void *dev_ptr);
+/* Page-locked host memory: host output pointers of any call may point into it, and the device-to-host copy is then one
+ * DMA at PCIe speed instead of a staged copy into pageable memory.  Pinning is slow: allocate once, reuse.
+ * sf_host_free may be called after sf_destroy (ctx is ignored). */
+void *sf_host_alloc(sf_ctx *ctx, size_t bytes);
+int sf_host_free(sf_ctx *ctx, void *host_ptr);
 int sf_h2d(sf_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int sf_d2h(sf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int sf_d2d(sf_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* stream-ordered, asynchronous */

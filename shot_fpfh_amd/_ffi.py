@@ -37,6 +37,8 @@ SIGNATURES = {
     "sf_join": (_int, [_vp]),
     "sf_dev_alloc": (_vp, [_vp, _sz]),
     "sf_dev_free": (_int, [_vp, _vp]),
+    "sf_host_alloc": (_vp, [_vp, _sz]),
+    "sf_host_free": (_int, [_vp, _vp]),
     "sf_h2d": (_int, [_vp, _vp, _vp, _sz]),
     "sf_d2h": (_int, [_vp, _vp, _vp, _sz]),
     "sf_d2d": (_int, [_vp, _vp, _vp, _sz]),

@@ -132,6 +132,27 @@ extern "C" int sf_dev_free(sf_ctx *ctx, void *p)
     return SF_OK;
 }
 
+// Page-locked host memory for callers that want their results at PCIe speed: a device-to-host copy into pageable
+// memory is staged by the runtime through its own pinned buffers (~10-25 GB/s with first-touch page faults on a
+// fresh array); into memory from sf_host_alloc it is one DMA (~55 GB/s).  Allocation pins pages and is slow, so
+// callers keep and reuse these blocks (shot_fpfh_amd.engine does: NumPy outputs above 32 MiB live in them).
+extern "C" void *sf_host_alloc(sf_ctx *ctx, size_t bytes)
+{
+    if (!ctx) { sf_set_error("null ctx"); return nullptr; }
+    void *p = nullptr;
+    SF_HIP_NULL(hipSetDevice(ctx->device));
+    SF_HIP_NULL(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault));
+    return p;
+}
+
+extern "C" int sf_host_free(sf_ctx *ctx, void *p)
+{
+    (void)ctx; // (valid after the context is gone: outputs may outlive their engine)
+    if (!p) return SF_OK;
+    SF_HIP(hipHostFree(p));
+    return SF_OK;
+}
+
 extern "C" int sf_h2d(sf_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }

@@ -701,7 +701,12 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     const unsigned base = cd * 2 + ri;
     const unsigned bcos = (unsigned)(((cin * 8 + ti) * 2 + pi_) * 2 + ri);
     const unsigned bth = (unsigned)(((ci * 8 + tin) * 2 + pi_) * 2 + ri);
-    o.rho = rho; o.dc = dc; o.tcross = cross; o.tdot = dot; o.lzr = lz * inv_rho;
+    // lz / rho through the reciprocal, then one residual correction: acos has an unbounded derivative at +-1, so for a
+    // neighbour on the frame's z axis a one-ulp error of the quotient would be a 1.5e-8 error of phi (the reference's
+    // correctly rounded division gives exactly +-1 there)
+    double lzr = lz * inv_rho;
+    lzr = __builtin_fma(__builtin_fma(-lzr, rho, lz), inv_rho, lzr);
+    o.rho = rho; o.dc = dc; o.tcross = cross; o.tdot = dot; o.lzr = lzr;
     o.bins0 = base | (bcos << 9) | (bth << 18);
     o.bins1 = cd | (ef << 8) | 0x80000000u;
 }

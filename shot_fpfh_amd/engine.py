@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -101,6 +102,50 @@ class DeviceArray:
             pass
 
 
+class _PinnedPool:
+    """Page-locked host blocks (sf_host_alloc) behind the NumPy arrays `Engine.host_empty` hands out."""
+
+    THRESHOLD = 32 << 20      # smaller results use ordinary NumPy memory
+    KEEP_BYTES = 16 << 30     # cached (unused) blocks beyond this are unpinned at once
+
+    def __init__(self, lib, ctx):
+        self.lib, self.ctx = lib, ctx
+        self.free: list[tuple[int, int]] = []  # (nbytes, address)
+        self.cached = 0
+        self.lock = threading.Lock()
+
+    def array(self, shape, dtype, count, nbytes) -> np.ndarray:
+        with self.lock:
+            fit = [b for b in self.free if nbytes <= b[0] <= nbytes + nbytes // 2 + (1 << 20)]
+            blk = min(fit) if fit else None
+            if blk is not None:
+                self.free.remove(blk)
+                self.cached -= blk[0]
+        if blk is None:
+            size = (nbytes + 4095) & ~4095
+            addr = self.lib.sf_host_alloc(self.ctx, size)
+            if not addr:
+                return np.empty(shape, dtype=dtype)  # pinning refused (ulimit, memory pressure): plain memory works too
+            blk = (size, addr)
+        buf = (C.c_char * blk[0]).from_address(blk[1])
+        weakref.finalize(buf, self._give_back, blk)  # `buf` lives exactly as long as the array and its views
+        return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+    def _give_back(self, blk) -> None:
+        with self.lock:
+            if self.ctx is not None and self.cached + blk[0] <= self.KEEP_BYTES:
+                self.free.append(blk)
+                self.cached += blk[0]
+                return
+        self.lib.sf_host_free(None, blk[1])
+
+    def drain(self) -> None:
+        with self.lock:
+            blocks, self.free, self.cached, self.ctx = self.free, [], 0, None
+        for _, addr in blocks:
+            self.lib.sf_host_free(None, addr)
+
+
 class Engine:
     """One GPU: a libshotfpfh context with its own HIP stream.  Fails loudly when the native library
     or the GPU is missing -- there is no CPU path."""
@@ -116,12 +161,27 @@ class Engine:
         self.h = _ffi.check_handle(self.lib.sf_create(device), f"sf_create({device})")
         self.pid = os.getpid()
         self.nranks, self.rank = 1, 0
+        self._pinned = _PinnedPool(self.lib, self.h)
 
     # ---- lifetime -----------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "h", None) and os.getpid() == self.pid:
+            self._pinned.drain()
             self.lib.sf_destroy(self.h)
         self.h = None
+
+    def host_empty(self, shape, dtype=np.float64) -> np.ndarray:
+        """A fresh, writable, C-contiguous NumPy array for a result coming back from the GPU.  Large ones (the
+        (M, 352) / (M, n_bins^3) descriptor matrices) live in page-locked memory, so the device-to-host copy that
+        fills them is ONE DMA at PCIe speed; the block goes back to a per-engine pool when the array (and every view
+        of it) has been garbage-collected, and is pinned again only if a later result does not fit a cached one."""
+        dtype = np.dtype(dtype)
+        shape = tuple(int(v) for v in np.atleast_1d(shape)) if not isinstance(shape, tuple) else tuple(int(v) for v in shape)
+        count = int(np.prod(shape, dtype=np.int64))
+        nbytes = count * dtype.itemsize
+        if nbytes < _PinnedPool.THRESHOLD:
+            return np.empty(shape, dtype=dtype)
+        return self._pinned.array(shape, dtype, count, nbytes)
 
     def __del__(self):
         try:
@@ -452,7 +512,7 @@ class Neighbors:
         lrf = _f64(lrf).reshape(-1, 9)
         if lrf.shape[0] != self.m:
             raise ValueError("one local reference frame per keypoint expected")
-        res = np.zeros((self.m, _ffi.SHOT_LEN))
+        res = self.engine.host_empty((self.m, _ffi.SHOT_LEN))
         _ffi.check(
             self.engine.lib.sf_shot(self.engine.h, self.cloud.h, self.h, _ptr(lrf), int(bool(normalize)),
                                     int(min_neighborhood_size), _ptr(res), SF_HOST),
@@ -471,7 +531,7 @@ class Neighbors:
                 "sf_shot_single_scale",
             )
             return out
-        res = np.zeros((self.m, _ffi.SHOT_LEN))
+        res = self.engine.host_empty((self.m, _ffi.SHOT_LEN))
         _ffi.check(
             self.engine.lib.sf_shot_single_scale(self.engine.h, self.cloud.h, self.h, int(bool(normalize)),
                                                  int(min_neighborhood_size), None, _ptr(res), SF_HOST),
@@ -481,7 +541,7 @@ class Neighbors:
 
     def shot_serial(self, min_neighborhood_size: int = 10) -> np.ndarray:
         """compute_shot_descriptor (shot.py:310-499): frames from the neighbours at non-zero distance, rows normalised."""
-        res = np.zeros((self.m, _ffi.SHOT_LEN))
+        res = self.engine.host_empty((self.m, _ffi.SHOT_LEN))
         _ffi.check(
             self.engine.lib.sf_shot_serial(self.engine.h, self.cloud.h, self.h, int(min_neighborhood_size), _ptr(res), SF_HOST),
             "sf_shot_serial",
@@ -575,7 +635,7 @@ class Spfh:
                 "sf_fpfh",
             )
             return out
-        res = np.zeros((m, nb3))
+        res = self.engine.host_empty((m, nb3))
         _ffi.check(
             self.engine.lib.sf_fpfh(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(kp), m, _ptr(res), SF_HOST), "sf_fpfh"
         )

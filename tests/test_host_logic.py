@@ -261,3 +261,51 @@ def test_stacked_kabsch_is_bit_identical_to_the_per_draw_solver():
             ref = [solver_point_to_point(a[d], b[d]) for d in draws]
             assert np.array_equal(rot, np.array([t.rotation for t in ref]))
             assert np.array_equal(tr, np.array([t.translation for t in ref]))
+
+
+def test_pinned_output_pool_reuses_blocks_after_garbage_collection():
+    """Engine.host_empty's pool (engine._PinnedPool) with malloc standing in for hipHostMalloc: arrays are writable and
+    C-contiguous, a block returns to the pool only when the array AND its views are gone, and is then reused."""
+    import ctypes
+    import gc
+
+    from shot_fpfh_amd.engine import _PinnedPool
+
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = ctypes.c_void_p, [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+
+    class Lib:
+        allocs, frees = [], []
+
+        def sf_host_alloc(self, ctx, size):
+            p = libc.malloc(size)
+            self.allocs.append(p)
+            return p
+
+        def sf_host_free(self, ctx, p):
+            self.frees.append(p)
+            libc.free(p)
+            return 0
+
+    lib = Lib()
+    pool = _PinnedPool(lib, ctx=object())
+    a = pool.array((1000, 352), np.dtype(np.float64), 352000, 352000 * 8)
+    assert a.flags.c_contiguous and a.flags.writeable and a.shape == (1000, 352)
+    a[:] = 3.0
+    view = a[10:20]
+    del a
+    gc.collect()
+    assert not pool.free  # the view keeps the block alive
+    assert view[0, 0] == 3.0
+    del view
+    gc.collect()
+    assert len(pool.free) == 1 and len(lib.allocs) == 1
+    b = pool.array((999, 352), np.dtype(np.float64), 999 * 352, 999 * 352 * 8)  # fits the cached block
+    assert len(lib.allocs) == 1 and not pool.free
+    c = pool.array((10, 352), np.dtype(np.float64), 3520, 3520 * 8)  # far smaller: its own block
+    assert len(lib.allocs) == 2
+    pool.drain()
+    del b, c
+    gc.collect()
+    assert sorted(lib.frees) == sorted(lib.allocs)  # after drain(), returning blocks are unpinned at once
