@@ -51,6 +51,7 @@ typedef struct sf_ctx sf_ctx;     /* one GPU: device id, stream, scratch, option
 typedef struct sf_cloud sf_cloud; /* resident point cloud + uniform grid (replaces KDTree(X))  */
 typedef struct sf_nbrs sf_nbrs;   /* resident CSR radius-neighbour lists of a query set        */
 typedef struct sf_spfh sf_spfh;   /* resident SPFH table (integer bin counts + list lengths)   */
+typedef struct sf_voxels sf_voxels; /* voxel partition of a point set (grid_subsampling)       */
 
 /* ---- library / context ---------------------------------------------------------------- */
 const char *sf_last_error(void);
@@ -229,6 +230,36 @@ int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, in
  * a, b: m x 3 matched points; Rt: n_draws x 12 (row-major R, then t); counts ||a R^T + t - b|| <= thr. */
 int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, int64_t m, const double *Rt, int64_t n_draws,
                     double thr, int64_t *inliers, int flags);
+
+/* ---- voxel subsampling: grid_subsampling (core/subsampling.py:5-39) and the voxel loop of
+ * select_keypoints_with_density_threshold (keypoint_selection.py:80-101) ---------------------------------
+ * sf_voxels_build: keys ((p - min p) // voxel).astype(int) with NumPy's floor_divide, voxels ranked in np.unique's
+ *   lexicographic key order (stable device sort).  xyz: n x 3, host or (SF_IN_DEVICE) device memory that must stay valid.
+ * sf_voxels_count: number of occupied voxels.
+ * sf_voxels_inverse: np.unique's `inverse` (voxel rank of every point, n, host).
+ * sf_voxels_select: per voxel the point closest to the voxel's barycentre (first minimum) and, optionally, the voxel
+ *   populations (np.unique's counts).  `order` (nullable, n, host) is the visiting order of the points, grouped by voxel
+ *   in voxel order -- the reference uses np.argsort(inverse), an UNSTABLE sort whose order decides exact distance ties
+ *   (every two-point voxel is one); NULL = ascending point index inside a voxel. */
+sf_voxels *sf_voxels_build(sf_ctx *ctx, const double *xyz, int64_t n, double voxel_size, int flags);
+int64_t sf_voxels_count(const sf_voxels *vox);
+int sf_voxels_inverse(sf_ctx *ctx, sf_voxels *vox, int64_t *inverse /* n */);
+int sf_voxels_select(sf_ctx *ctx, sf_voxels *vox, const int64_t *order /* nullable, n */, int64_t *selected /* count */,
+                     int64_t *counts /* nullable, count */);
+void sf_voxels_free(sf_ctx *ctx, sf_voxels *vox);
+
+/* ---- ICP: one iteration's device work (icp.py:64-72, 108-124, 160-183; core/solvers.py:17-18, 38-46) --------
+ * sf_icp_accumulate: rows sel_dev[0..m) (or 0..m when NULL) of the resident points pts_dev are moved by Rt (12 host
+ *   doubles: R row-major then t; NULL = identity), their nearest reference point found (KDTree.query, k = 1), pairs
+ *   with distance <= d_max kept, and the sums of the iteration's solver returned in sums[40] (host):
+ *     [0] inlier count, [1..3] sum of inlier points p, [4..6] sum of their neighbours q,
+ *     mode 0 (point to point): [8..16] sum (p - pbar)(q - qbar)^T row-major, [17] sum |p - q|^2
+ *     mode 1 (point to plane; the cloud needs normals): [8..28] upper triangle of G^T G row by row, [29..34] G^T h,
+ *       [35] sum |h|, with g = [p x n, n], h = (q - p) . n.
+ * sf_transform_points: p <- p R^T + t in place on resident points (RigidTransform.__getitem__). */
+int sf_icp_accumulate(sf_ctx *ctx, sf_cloud *ref, const double *pts_dev, const int64_t *sel_dev, int64_t m, const double *Rt,
+                      double d_max, int mode, double *sums /* 40 */);
+int sf_transform_points(sf_ctx *ctx, double *pts_dev, int64_t n, const double *Rt /* 12 */);
 
 /* ---- multi-GPU: RCCL over xGMI (no counterpart in the reference) --------------------------
  * One process per GPU.  Rank 0 calls sf_comm_unique_id, ships the 128 bytes to the other ranks by

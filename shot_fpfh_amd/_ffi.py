@@ -81,6 +81,13 @@ SIGNATURES = {
     "sf_rows_gather": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "sf_match_argmin_multiscale": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _f64, _vp, _vp, _int]),
     "sf_ransac_score": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _int]),
+    "sf_voxels_build": (_vp, [_vp, _vp, _i64, _f64, _int]),
+    "sf_voxels_count": (_i64, [_vp]),
+    "sf_voxels_inverse": (_int, [_vp, _vp, _vp]),
+    "sf_voxels_select": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sf_voxels_free": (None, [_vp, _vp]),
+    "sf_icp_accumulate": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f64, _int, _vp]),
+    "sf_transform_points": (_int, [_vp, _vp, _i64, _vp]),
     "sf_comm_unique_id": (_int, [_vp]),
     "sf_comm_init": (_int, [_vp, _vp, _int, _int]),
     "sf_comm_allgather": (_int, [_vp, _vp, _vp, _sz]),

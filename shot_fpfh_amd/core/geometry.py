@@ -1,9 +1,10 @@
-"""Host-side geometry that rides with the hot path: rigid transforms, the Kabsch solver RANSAC uses
-per draw, and voxel-grid support subsampling.
+"""Geometry that rides with the hot path: rigid transforms, the Kabsch solver RANSAC uses per draw, and voxel-grid
+support subsampling.
 
-These stay on the host on purpose: a RANSAC run needs 10^4 3x3 SVDs whose results must
-equal NumPy/LAPACK's bit for bit for the draw-by-draw inlier counts to match, and they cost
-microseconds each; only the O(draws x matches) scoring is a kernel (K9).
+The small dense solves stay on the host on purpose: a RANSAC run needs 10^4 3x3 SVDs whose results must
+equal NumPy/LAPACK's bit for bit for the draw-by-draw inlier counts to match, and they cost microseconds each; only
+the O(draws x matches) scoring is a kernel (K9).  Voxel subsampling -- O(N), in front of every subsampled SHOT call --
+runs on the device (csrc/voxel.hip).
 """
 from __future__ import annotations
 
@@ -105,32 +106,57 @@ def solver_point_to_plane(scan: npt.NDArray[np.float64], ref: npt.NDArray[np.flo
     return RigidTransform(Rotation.from_euler("xyz", solution[:3]).as_matrix(), solution[3:6])
 
 
-def voxel_closest_to_barycentre(points: npt.NDArray[np.float64], voxel_size: float):
+def voxel_closest_to_barycentre(points: npt.NDArray[np.float64], voxel_size: float, *, within_voxel_order: str = "numpy",
+                                engine=None):
     """Per occupied voxel (np.unique's lexicographic key order): the index of the point closest to the voxel's
     barycentre, and the number of points in the voxel (shot_fpfh/core/subsampling.py:12-37 and the identical
-    loop of keypoint_selection.py:80-101).
+    loop of keypoint_selection.py:80-101) -- on the GPU: voxel keys, stable sort, run detection, one thread per voxel
+    for barycentre / distances / first minimum (csrc/voxel.hip).
 
-    Segment-vectorised (no per-voxel Python loop).  The within-voxel visiting order is the one
-    np.argsort(inverse) yields, as in the reference, because the first minimum wins on distance ties
-    (two-point voxels tie by construction).
+    The reference visits a voxel's points in the order `np.argsort(inverse)` gives them -- an UNSTABLE sort -- and a
+    two-point voxel is an exact distance tie (both points are equally far from their midpoint), so which of the two it
+    returns is decided by NumPy's sort implementation.  `within_voxel_order="numpy"` (default) takes that order from the
+    same call on the same array (one host argsort of the device-computed `inverse`) and feeds it to the device
+    selection: results identical to the reference's on the same NumPy build, ties included.  `"index"` visits a voxel's
+    points by ascending index, entirely on the device and independent of the platform; it differs from the reference
+    only on exact ties and last-bit barycentre rounding.
     """
-    points = np.asarray(points)
-    keys = ((points - np.min(points, axis=0)) // voxel_size).astype(int)
-    _, inverse, counts = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
-    inverse = np.asarray(inverse).reshape(-1)
-    order = np.argsort(inverse)
-    starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
-    grouped = points[order]
-    bary = np.add.reduceat(grouped, starts, axis=0) / counts[:, None]
-    seg = np.repeat(np.arange(counts.shape[0]), counts)
-    dist = np.linalg.norm(grouped - bary[seg], axis=1)
-    seg_min = np.minimum.reduceat(dist, starts)
-    hit = np.flatnonzero(dist == seg_min[seg])
-    first = hit[np.unique(seg[hit], return_index=True)[1]]
-    return order[first], counts
+    import ctypes as C
+
+    from .. import _ffi
+    from ..engine import default_engine
+
+    if within_voxel_order not in ("numpy", "index"):
+        raise ValueError("within_voxel_order must be 'numpy' or 'index'")
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    if pts.ndim != 2 or pts.shape[1] != 3:
+        raise ValueError(f"expected an (N, 3) array, got shape {pts.shape}")
+    n = pts.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    eng = engine or default_engine()
+    lib = eng.lib
+    vox = _ffi.check_handle(lib.sf_voxels_build(eng.h, pts.ctypes.data_as(C.c_void_p), n, float(voxel_size), _ffi.SF_HOST),
+                            "sf_voxels_build")
+    try:
+        count = int(lib.sf_voxels_count(vox))
+        order_ptr = None
+        if within_voxel_order == "numpy":
+            inverse = np.empty(n, dtype=np.int64)
+            _ffi.check(lib.sf_voxels_inverse(eng.h, vox, inverse.ctypes.data_as(C.c_void_p)), "sf_voxels_inverse")
+            order = np.ascontiguousarray(np.argsort(inverse), dtype=np.int64)  # the reference's call (subsampling.py:19)
+            order_ptr = order.ctypes.data_as(C.c_void_p)
+        picked, counts = np.empty(count, dtype=np.int64), np.empty(count, dtype=np.int64)
+        _ffi.check(lib.sf_voxels_select(eng.h, vox, order_ptr, picked.ctypes.data_as(C.c_void_p),
+                                        counts.ctypes.data_as(C.c_void_p)), "sf_voxels_select")
+    finally:
+        lib.sf_voxels_free(eng.h, vox)
+    return picked, counts
 
 
-def grid_subsampling(points: npt.NDArray[np.float64], voxel_size: float) -> npt.NDArray[np.int64]:
+def grid_subsampling(points: npt.NDArray[np.float64], voxel_size: float, *, within_voxel_order: str = "numpy",
+                     engine=None) -> npt.NDArray[np.int64]:
     """Voxel subsampling: per occupied voxel keep the point closest to the voxel's barycentre; voxels
-    come out in np.unique's lexicographic key order (shot_fpfh/core/subsampling.py:5-39)."""
-    return voxel_closest_to_barycentre(points, voxel_size)[0]
+    come out in np.unique's lexicographic key order (shot_fpfh/core/subsampling.py:5-39).  Runs on the GPU; see
+    `voxel_closest_to_barycentre` for `within_voxel_order`."""
+    return voxel_closest_to_barycentre(points, voxel_size, within_voxel_order=within_voxel_order, engine=engine)[0]

@@ -236,16 +236,16 @@ int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
     return SF_OK;
 }
 
-// min / max of the cloud's coordinates (block partials on the device, 1024 x 6 values finished on the host)
-int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3])
+// min / max of n x 3 coordinates on the device (block partials, folded by one more block; 6 values read back through
+// page-locked memory)
+int sf_cloud_bbox_raw(sf_ctx *ctx, const double *xyz_dev, int64_t n, double lo[3], double hi[3])
 {
-    const int64_t n = c->n;
     for (int a = 0; a < 3; ++a) lo[a] = hi[a] = 0.0;
     if (!n) return SF_OK;
     const int nb = 1024;
     void *scr = nullptr;
     SF_CHECK(sf_ctx_scratch(ctx, ((size_t)nb * 6 + 8) * sizeof(double), &scr));
-    SF_LAUNCH(ctx, "k1_bbox", k_bbox_partial, dim3(nb), dim3(256), c->xyz_orig, n, (double *)scr);
+    SF_LAUNCH(ctx, "k1_bbox", k_bbox_partial, dim3(nb), dim3(256), xyz_dev, n, (double *)scr);
     double *fin = (double *)scr + (size_t)nb * 6;
     SF_LAUNCH(ctx, "k1_bbox", k_bbox_final, dim3(1), dim3(384), (const double *)scr, nb, fin);
     void *pin = nullptr;
@@ -261,6 +261,8 @@ int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3])
         }
     return SF_OK;
 }
+
+int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3]) { return sf_cloud_bbox_raw(ctx, c->xyz_orig, c->n, lo, hi); }
 
 // Common grid build.  block_end < 0: the whole cloud.  Otherwise only the z-layers of cells that the queries at
 // cell-sorted positions [block_begin, block_end) can reach within `reach` cells are sorted and gathered -- the

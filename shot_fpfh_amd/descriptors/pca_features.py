@@ -65,65 +65,62 @@ def compute_local_pca_with_moments(
     return w, v, mo, [int(n) for n in sizes]
 
 
+class _Spectrum:
+    """Eigen-decomposition of every neighbourhood in the form the feature formulas consume.  The reference bumps the
+    LARGEST eigenvalue by 1e-6 in place before anything else reads the eigenvalue array (pca_based_descriptors.py:172,
+    207), so the sums, the product and the entropy below all see the bumped value; that is reproduced by bumping a copy
+    once, here."""
+
+    def __init__(self, eigenvalues: np.ndarray, eigenvectors: np.ndarray):
+        self.values = np.array(eigenvalues, dtype=np.float64, copy=True)
+        self.values[:, 2] += 1e-6
+        self.smallest, self.middle, self.largest = self.values[:, 0], self.values[:, 1], self.values[:, 2]
+        self.normal = eigenvectors[:, :, 0]  # eigenvector of the smallest eigenvalue
+        self.axis = eigenvectors[:, :, 2]    # ... of the largest
+
+
+def _tilt(component: np.ndarray) -> np.ndarray:
+    """|component| of a unit vector as an angle fraction of a right angle."""
+    return 2 * np.arcsin(np.abs(component)) / np.pi
+
+
+# name -> formula; the 12 leading columns of compute_pca_based_features in the reference's order
+# (pca_based_descriptors.py:222-243), the four of compute_pca_based_basic_features picked by name (:174-179)
+_SHAPE_FEATURES = {
+    "eigensum": lambda s: s.values.sum(axis=-1),
+    "eigen_square_sum": lambda s: (s.values**2).sum(axis=-1),
+    "omnivariance": lambda s: np.cbrt(s.values.prod(axis=-1)),
+    "eigenentropy": lambda s: (-s.values * np.log(s.values + 1e-6)).sum(axis=-1),
+    "linearity": lambda s: 1 - s.middle / s.largest,
+    "planarity": lambda s: (s.middle - s.smallest) / s.largest,
+    "sphericity": lambda s: s.smallest / s.largest,
+    "curvature_change": lambda s: s.smallest / s.values.sum(axis=-1),
+    "verticality": lambda s: _tilt(s.normal[:, 2]),
+    "lin_verticality": lambda s: _tilt(s.axis[:, 2]),
+    "horizontalityx": lambda s: _tilt(s.normal[:, 0]),
+    "horizontalityy": lambda s: _tilt(s.normal[:, 1]),
+}
+
+
 def compute_pca_based_basic_features(
     query_points: npt.NDArray[np.float64], cloud_points: npt.NDArray[np.float64], radius: float
 ) -> tuple[npt.NDArray[np.float64], npt.NDArray[np.float64], npt.NDArray[np.float64], npt.NDArray[np.float64]]:
     """(verticality, linearity, planarity, sphericity), pca_based_descriptors.py:150-187."""
-    all_eigenvalues, all_eigenvectors, _ = _local_pca(query_points, cloud_points, radius=radius)
-    lbd3, lbd2, lbd1 = all_eigenvalues[:, 0], all_eigenvalues[:, 1], all_eigenvalues[:, 2]
-    lbd1 += 1e-6
-    normals = all_eigenvectors[:, :, 0]
-    verticality = 2 * np.arcsin(np.abs(normals[:, 2])) / np.pi
-    linearity = 1 - lbd2 / lbd1
-    planarity = (lbd2 - lbd3) / lbd1
-    sphericity = lbd3 / lbd1
-    return verticality, linearity, planarity, sphericity
+    eigenvalues, eigenvectors, _ = _local_pca(query_points, cloud_points, radius=radius)
+    spectrum = _Spectrum(eigenvalues, eigenvectors)
+    return tuple(_SHAPE_FEATURES[name](spectrum) for name in ("verticality", "linearity", "planarity", "sphericity"))
 
 
 def compute_pca_based_features(
     query_points: npt.NDArray[np.float64], cloud_points: npt.NDArray[np.float64], radius: float
 ) -> npt.NDArray[np.float64]:
-    """(N, 21) feature matrix, columns in the reference's order (pca_based_descriptors.py:190-244).  As there,
-    lambda_1 is bumped by 1e-6 IN PLACE before the eigenvalue sums are formed."""
-    all_eigenvalues, all_eigenvectors, moments, neighborhood_sizes = compute_local_pca_with_moments(
-        query_points, cloud_points, radius=radius
-    )
-    lbd3, lbd2, lbd1 = all_eigenvalues[:, 0], all_eigenvalues[:, 1], all_eigenvalues[:, 2]
-    lbd1 += 1e-6
-
-    normals = all_eigenvectors[:, :, 0]
-    principal_axis = all_eigenvectors[:, :, 2]
-
-    eigensum = all_eigenvalues.sum(axis=-1)
-    eigen_square_sum = (all_eigenvalues**2).sum(axis=-1)
-    omnivariance = np.cbrt(all_eigenvalues.prod(axis=-1))
-    eigenentropy = (-all_eigenvalues * np.log(all_eigenvalues + 1e-6)).sum(axis=-1)
-
-    linearity = 1 - lbd2 / lbd1
-    planarity = (lbd2 - lbd3) / lbd1
-    sphericity = lbd3 / lbd1
-    curvature_change = lbd3 / eigensum
-
-    verticality = 2 * np.arcsin(np.abs(normals[:, 2])) / np.pi
-    lin_verticality = 2 * np.arcsin(np.abs(principal_axis[:, 2])) / np.pi
-    horizontalityx = 2 * np.arcsin(np.abs(normals[:, 0])) / np.pi
-    horizontalityy = 2 * np.arcsin(np.abs(normals[:, 1])) / np.pi
-
-    return np.hstack(
-        (
-            eigensum[:, None],
-            eigen_square_sum[:, None],
-            omnivariance[:, None],
-            eigenentropy[:, None],
-            linearity[:, None],
-            planarity[:, None],
-            sphericity[:, None],
-            curvature_change[:, None],
-            verticality[:, None],
-            lin_verticality[:, None],
-            horizontalityx[:, None],
-            horizontalityy[:, None],
-            moments,
-            np.array(neighborhood_sizes)[:, None],
-        )
-    )
+    """(N, 21) feature matrix (pca_based_descriptors.py:187-244): the twelve shape features above, the eight moments of
+    compute_local_pca_with_moments, the neighbourhood size."""
+    eigenvalues, eigenvectors, moments, sizes = compute_local_pca_with_moments(query_points, cloud_points, radius=radius)
+    spectrum = _Spectrum(eigenvalues, eigenvectors)
+    out = np.empty((eigenvalues.shape[0], len(_SHAPE_FEATURES) + moments.shape[1] + 1))
+    for col, formula in enumerate(_SHAPE_FEATURES.values()):
+        out[:, col] = formula(spectrum)
+    out[:, len(_SHAPE_FEATURES):-1] = moments
+    out[:, -1] = sizes
+    return out

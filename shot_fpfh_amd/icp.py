@@ -1,51 +1,136 @@
-"""ICP refinement, the step after RANSAC in the reference pipeline (mirrors shot_fpfh/icp.py and
-core/solvers.py:51-62).
+"""ICP refinement on the GPU -- drop-in for shot_fpfh.icp (icp.py:20-189) and core.solvers.compute_point_to_point_error
+(solvers.py:51-62).
 
-Each iteration's nearest-neighbour query (`KDTree(ref).query(points)`) runs on the MI355X: the reference
-cloud is uploaded once and searched with the grid k-NN kernel (k = 1).  The 3x3 Kabsch / 6x6 point-to-plane
-solves on the inliers stay NumPy calls, written exactly as the reference writes them, so the iterates are the
-reference's iterates.
+How an iteration is split.  The reference does everything in NumPy around a KDTree query: transform the working points,
+query their nearest reference points, mask the pairs farther than `d_max`, build the centred 3x3 cross-covariance
+(point-to-point) or the 6x6 normal equations (point-to-plane) from the masked arrays, solve, compose.  Here the working
+points and the reference cloud live in HBM for the whole run and ONE device call per iteration (`sf_icp_accumulate`,
+csrc/icp.hip) does the transform, the nearest-neighbour search (grid k-NN kernel, k = 1), the `d_max` filter and the
+reductions; what crosses the bus per iteration is a 12-number transform one way and ~30 sums the other.  The host keeps
+only the tiny dense step -- a 3x3 SVD (`_rigid_fit`) or a 6x6 solve (`_plane_fit`) on those sums -- and the bookkeeping of
+the running transform.  `_Registration` is that device state; the three public functions differ only in which rows they
+feed it, which fit they ask for and what they return.
 
-Deviation, on purpose: the reference's `icp_point_to_point` computes its RMS from `ref[neighbors]` (all
-queried points, shape (n, 1, 3)) instead of `ref[inliers_neighbors]` (icp.py:122-124); the broadcast yields an
-array, and formatting it for the progress bar raises TypeError on the first iteration, so that function cannot
-run there at all.  Here the RMS is taken over the inlier pairs, as in `icp_point_to_point_with_sampling`.
+Deviation, on purpose: the reference's `icp_point_to_point` computes its RMS from `ref[neighbors]` (all queried points,
+shape (n, 1, 3)) instead of `ref[inliers_neighbors]` (icp.py:122-124); the broadcast yields an array, and formatting it for
+the progress bar raises TypeError on the first iteration, so that function cannot run there at all.  Here the RMS is taken
+over the inlier pairs, as in `icp_point_to_point_with_sampling`.
 """
 from __future__ import annotations
 
+import ctypes as C
 import logging
 from typing import Optional
 
 import numpy as np
 import numpy.typing as npt
+from scipy.spatial.transform import Rotation
 
-from .core import RigidTransform, grid_subsampling, solver_point_to_plane, solver_point_to_point
-from .engine import Cloud, Engine, default_engine
+from . import _ffi
+from .core import RigidTransform, grid_subsampling
+from .engine import Cloud, DeviceArray, Engine, default_engine
 
 __all__ = [
     "icp_point_to_point_with_sampling",
     "icp_point_to_point",
     "icp_point_to_plane",
     "compute_point_to_point_error",
+    "nearest_within",
 ]
 
+_POINT, _PLANE = 0, 1
+_TRIU = np.triu_indices(6)
 
-class _NearestNeighbour:
-    """KDTree(ref).query(points) on the device: (distances (n,), indices (n,))."""
 
-    def __init__(self, ref, engine: Optional[Engine] = None):
-        self.cloud = Cloud(engine or default_engine(), ref)
+class _PairSums:
+    """What one device pass returns about the inlier pairs (p = moved working point, q = its nearest reference point)."""
 
-    def query(self, points):
-        nbrs = self.cloud.knn_search(points, 1)
-        try:
-            _, idx, dist = nbrs.export(return_distance=True)
-        finally:
-            nbrs.free()
-        return dist, idx.astype(np.int64)
+    def __init__(self, raw: np.ndarray, mode: int):
+        self.count = int(raw[0])
+        self.sum_p, self.sum_q = raw[1:4], raw[4:7]
+        if mode == _POINT:
+            self.cross_cov = raw[8:17].reshape(3, 3)  # sum (p - pbar)(q - qbar)^T
+            self.sq_dist = float(raw[17])             # sum |p - q|^2
+        else:
+            self.gtg = np.zeros((6, 6))
+            self.gtg[_TRIU] = raw[8:29]
+            self.gtg = self.gtg + np.triu(self.gtg, 1).T
+            self.gth = raw[29:35]
+            self.abs_h = float(raw[35])               # sum |(q - p) . n|
 
-    def close(self):
-        self.cloud.free()
+    def require_pairs(self) -> None:
+        if self.count == 0:
+            raise np.linalg.LinAlgError("ICP: no scan point has a reference point within d_max")
+
+
+def _rigid_fit(s: _PairSums) -> RigidTransform:
+    """Kabsch from the centred cross-covariance (core/solvers.py:9-30: same SVD, same reflection rule)."""
+    s.require_pairs()
+    u, _, vt = np.linalg.svd(s.cross_cov)
+    rot = vt.T @ u.T
+    if np.linalg.det(rot) < 0:
+        ut = u.T.copy()
+        ut[-1] *= -1
+        rot = vt.T @ ut
+    return RigidTransform(rot, s.sum_q / s.count - rot.dot(s.sum_p / s.count))
+
+
+def _plane_fit(s: _PairSums) -> RigidTransform:
+    """Linearised point-to-plane step from G^T G and G^T h (core/solvers.py:33-48)."""
+    s.require_pairs()
+    sol = np.linalg.solve(s.gtg, s.gth)
+    return RigidTransform(Rotation.from_euler("xyz", sol[:3]).as_matrix(), sol[3:6])
+
+
+class _Registration:
+    """Working points + reference cloud resident on one GPU for the length of an ICP run."""
+
+    def __init__(self, points, ref, ref_normals=None, engine: Optional[Engine] = None):
+        self.engine = engine or default_engine()
+        self.ref = Cloud(self.engine, ref, ref_normals)
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError(f"expected an (N, 3) array, got shape {pts.shape}")
+        self.n = pts.shape[0]
+        self.points: DeviceArray = self.engine.empty((max(self.n, 1), 3)).from_host(pts if self.n else np.zeros((1, 3)))
+        self.rows: Optional[DeviceArray] = None
+
+    def pairs(self, mode: int, d_max: float, moved_by: Optional[RigidTransform] = None, rows=None) -> _PairSums:
+        """Inlier-pair sums of the working points (all of them, or the given `rows`) after `moved_by`."""
+        m, sel = self.n, None
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+            m = rows.shape[0]
+            if self.rows is None or self.rows.shape[0] < m:
+                if self.rows is not None:
+                    self.rows.free()
+                self.rows = self.engine.empty((max(m, 1),), np.int64)
+            if m:
+                _ffi.check(self.engine.lib.sf_h2d(self.engine.h, self.rows.ptr, rows.ctypes.data_as(C.c_void_p), m * 8), "sf_h2d")
+            sel = self.rows.ptr
+        rt = None if moved_by is None else np.ascontiguousarray(moved_by.as_row12())
+        raw = np.zeros(40)
+        _ffi.check(
+            self.engine.lib.sf_icp_accumulate(self.engine.h, self.ref.h, self.points.ptr, sel, m,
+                                              None if rt is None else rt.ctypes.data_as(C.c_void_p), float(d_max), mode,
+                                              raw.ctypes.data_as(C.c_void_p)),
+            "sf_icp_accumulate",
+        )
+        return _PairSums(raw, mode)
+
+    def move(self, transform: RigidTransform) -> None:
+        """points <- transform[points], in place in HBM."""
+        rt = np.ascontiguousarray(transform.as_row12())
+        _ffi.check(self.engine.lib.sf_transform_points(self.engine.h, self.points.ptr, self.n, rt.ctypes.data_as(C.c_void_p)),
+                   "sf_transform_points")
+
+    def download(self) -> np.ndarray:
+        return self.points.to_host()[: self.n]
+
+    def close(self) -> None:
+        for obj in (self.points, self.rows, self.ref):
+            if obj is not None:
+                obj.free()
 
 
 def icp_point_to_point_with_sampling(
@@ -57,29 +142,45 @@ def icp_point_to_point_with_sampling(
     sampling_limit: int = 100,
     disable_progress_bar: bool = False,
 ) -> tuple[npt.NDArray[np.float64], float, bool]:
-    """Point-to-point ICP on a fresh random subset per iteration (icp.py:19-77).  Subsets come from NumPy's
-    global generator, as in the reference.  Returns (aligned points, rms, converged)."""
-    points_aligned = np.copy(scan)
-    nn = _NearestNeighbour(ref)
-    sampling_limit = min(sampling_limit, scan.shape[0])
+    """Point-to-point ICP fitted on a fresh random subset per iteration and applied to ALL points (icp.py:20-78).
+    Subsets are drawn from NumPy's global generator exactly as the reference draws them.
+    Returns (aligned points, rms of the last fit = sqrt(sum of squared inlier distances), converged)."""
+    reg = _Registration(scan, ref)
+    limit = min(sampling_limit, reg.n)
     rms = 0.0
     try:
         for _ in range(max_iter):
-            indexes = np.random.choice(scan.shape[0], sampling_limit, replace=False)
-            points_aligned_subset = points_aligned[indexes]
-            distances, neighbors = nn.query(points_aligned_subset)
-            inlier_points = points_aligned_subset[distances <= d_max]
-            neighbors = neighbors[distances <= d_max]
-            transformation = solver_point_to_point(inlier_points, ref[neighbors])
-            rms = np.sqrt((np.linalg.norm(inlier_points - ref[neighbors], axis=1) ** 2).sum(axis=0))
-            points_aligned = transformation[points_aligned]
+            subset = np.random.choice(reg.n, limit, replace=False)
+            found = reg.pairs(_POINT, d_max, rows=subset)
+            reg.move(_rigid_fit(found))
+            rms = float(np.sqrt(found.sq_dist))
             if rms < rms_threshold:
                 break
     except KeyboardInterrupt:
         logging.info("ICP interrupted by user.")
+    try:
+        return reg.download(), rms, rms < rms_threshold
     finally:
-        nn.close()
-    return points_aligned, rms, rms < rms_threshold
+        reg.close()
+
+
+def _refine(reg: _Registration, start: RigidTransform, mode: int, d_max: float, max_iter: int, rms_threshold: float):
+    """The loop shared by icp_point_to_point and icp_point_to_plane: the working points stay where they are, the
+    running transform is what moves (icp.py:103-130, 155-189)."""
+    total, rms = start, 0.0
+    fit = _rigid_fit if mode == _POINT else _plane_fit
+    try:
+        for _ in range(max_iter):
+            found = reg.pairs(mode, d_max, moved_by=total)
+            total = fit(found) @ total
+            # residual of the pairs the fit was computed FROM (before this iteration's update), as in the reference
+            rms = float(np.sqrt(found.sq_dist)) if mode == _POINT else found.abs_h / found.count
+            if rms < rms_threshold:
+                logging.info("RMS threshold reached.")
+                break
+    except KeyboardInterrupt:
+        logging.info("ICP interrupted by user.")
+    return total, rms, rms < rms_threshold
 
 
 def icp_point_to_point(
@@ -92,28 +193,13 @@ def icp_point_to_point(
     rms_threshold: float = 1e-2,
     disable_progress_bar: bool = False,
 ) -> tuple[RigidTransform, float, bool]:
-    """Point-to-point ICP on a voxel-subsampled scan (icp.py:80-135; see the module note on its RMS)."""
-    nn = _NearestNeighbour(ref)
-    subsampled_indices = grid_subsampling(scan, voxel_size)
-    transformation_icp = transformation_init
-    rms = 0.0
+    """Point-to-point ICP on the voxel-subsampled scan (icp.py:81-130; see the module note on its RMS)."""
+    scan = np.asarray(scan)
+    reg = _Registration(scan[grid_subsampling(scan, voxel_size)], ref)
     try:
-        for _ in range(max_iter):
-            points_aligned = transformation_icp[scan[subsampled_indices]]
-            distances, neighbors = nn.query(points_aligned)
-            inliers = points_aligned[distances <= d_max]
-            inliers_neighbors = neighbors[distances <= d_max]
-            transformation_aligned_to_ref = solver_point_to_point(inliers, ref[inliers_neighbors])
-            rms = np.sqrt((np.linalg.norm(inliers - ref[inliers_neighbors], axis=1) ** 2).sum(axis=0))
-            transformation_icp = transformation_aligned_to_ref @ transformation_icp
-            if rms < rms_threshold:
-                logging.info("RMS threshold reached.")
-                break
-    except KeyboardInterrupt:
-        logging.info("ICP interrupted by user.")
+        return _refine(reg, transformation_init, _POINT, d_max, max_iter, rms_threshold)
     finally:
-        nn.close()
-    return transformation_icp, rms, rms < rms_threshold
+        reg.close()
 
 
 def icp_point_to_plane(
@@ -127,44 +213,34 @@ def icp_point_to_plane(
     rms_threshold: float = 1e-2,
     disable_progress_bar: bool = False,
 ) -> tuple[RigidTransform, float, bool]:
-    """Point-to-plane ICP (icp.py:138-189): linearised 6-dof solve per iteration; the returned rms is the mean
-    |(inlier - neighbour) . normal| measured BEFORE the iteration's update, as in the reference."""
-    nn = _NearestNeighbour(ref)
-    subsampled_indices = grid_subsampling(scan, voxel_size)
-    transformation_icp = transformation_init
-    rms = 0.0
+    """Point-to-plane ICP (icp.py:133-189): the returned rms is the mean |(inlier - neighbour) . normal| of the pairs
+    the last step was fitted on."""
+    scan = np.asarray(scan)
+    reg = _Registration(scan[grid_subsampling(scan, voxel_size)], ref, ref_normals)
     try:
-        for _ in range(max_iter):
-            points_aligned = transformation_icp[scan[subsampled_indices]]
-            distances, neighbors = nn.query(points_aligned)
-            inliers = points_aligned[distances <= d_max]
-            inliers_neighbors = neighbors[distances <= d_max]
-            transformation_aligned_to_ref = solver_point_to_plane(
-                inliers, ref[inliers_neighbors], ref_normals[inliers_neighbors]
-            )
-            transformation_icp = transformation_aligned_to_ref @ transformation_icp
-            rms = np.abs(
-                np.einsum("ij, ij->i", inliers - ref[inliers_neighbors], ref_normals[inliers_neighbors])
-            ).mean(axis=0)
-            if rms < rms_threshold:
-                logging.info("RMS threshold reached.")
-                break
-    except KeyboardInterrupt:
-        logging.info("ICP interrupted by user.")
+        return _refine(reg, transformation_init, _PLANE, d_max, max_iter, rms_threshold)
     finally:
-        nn.close()
-    return transformation_icp, rms, rms < rms_threshold
+        reg.close()
 
 
 def compute_point_to_point_error(
     scan: npt.NDArray[np.float64], ref: npt.NDArray[np.float64], transformation: RigidTransform
 ) -> tuple[float, npt.NDArray[np.float64]]:
     """RMS nearest-neighbour distance of the transformed scan to the reference cloud, and the transformed scan
-    (core/solvers.py:51-62)."""
-    transformed_data = transformation[scan]
-    nn = _NearestNeighbour(ref)
+    (core/solvers.py:51-62).  Every point counts: no d_max."""
+    reg = _Registration(scan, ref)
     try:
-        distances, _ = nn.query(transformed_data)
+        found = reg.pairs(_POINT, np.inf, moved_by=transformation)
     finally:
-        nn.close()
-    return np.sqrt((distances**2).mean()), transformed_data
+        reg.close()
+    return float(np.sqrt(found.sq_dist / max(found.count, 1))), transformation[np.asarray(scan)]
+
+
+def nearest_within(points: npt.NDArray[np.float64], against: npt.NDArray[np.float64], distance: float) -> int:
+    """How many of `points` have a point of `against` within `distance` (the `KDTree(ref).query(...)[0] <= thr` masks
+    of pipeline.py:560-587, summed) -- counted on the device."""
+    reg = _Registration(points, against)
+    try:
+        return reg.pairs(_POINT, distance).count
+    finally:
+        reg.close()

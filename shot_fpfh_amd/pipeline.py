@@ -19,7 +19,7 @@ from . import keypoint_selection as _ks
 from .core import RigidTransform
 from .descriptors import ShotMultiprocessor, compute_fpfh_descriptor
 from .helpers import write_ply
-from .icp import _NearestNeighbour, icp_point_to_plane, icp_point_to_point
+from .icp import icp_point_to_plane, icp_point_to_point, nearest_within
 from .matching import (
     basic_matching,
     double_matching_with_rejects,
@@ -206,16 +206,9 @@ class RegistrationPipeline:
         """(overlap of the aligned scan with ref, ratio of aligned scan keypoints that have a ref keypoint within
         the threshold)."""
         aligned = transformation_icp[self.scan]
-
-        def inlier_count(points, against) -> int:
-            nn = _NearestNeighbour(against)
-            try:
-                return int((nn.query(points)[0] <= distance_threshold).sum())
-            finally:
-                nn.close()
-
-        return (inlier_count(aligned, self.ref) / aligned.shape[0],
-                inlier_count(aligned[self.scan_keypoints], self.ref[self.ref_keypoints]) / self.scan_keypoints.shape[0])
+        return (nearest_within(aligned, self.ref, distance_threshold) / aligned.shape[0],
+                nearest_within(aligned[self.scan_keypoints], self.ref[self.ref_keypoints], distance_threshold)
+                / self.scan_keypoints.shape[0])
 
     def write_alignments(self, *args: tuple[str, RigidTransform]) -> None:
         """One PLY per (file_name, transform): the transformed scan stacked on ref, with an `is_scan` column."""

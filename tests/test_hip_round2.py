@@ -306,3 +306,68 @@ def test_two_stream_overlap_with_unshared_sweep_and_long_lists(eng, share):
         job.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+# ---- voxel subsampling on the device -------------------------------------------------------------------
+def test_grid_subsampling_device_matches_reference_goldens():
+    """grid_subsampling / select_keypoints_subsampling / the voxel-count density threshold against the reference's
+    outputs (20k uniform cloud at voxel 0.05: 5 694 multi-point voxels, 2 042 exact two-point ties; the SHOT supports)."""
+    import shot_fpfh_amd.keypoint_selection as ks
+    from shot_fpfh_amd.core import grid_subsampling, voxel_closest_to_barycentre
+
+    g = load_golden("grid_sub_20k.npz")
+    p, _, _ = synth_cloud(int(g["n"]), int(g["seed"]))
+    got = grid_subsampling(p, float(g["voxel"]))
+    assert got.dtype == np.int64 and np.array_equal(got, g["idx"])
+    s = load_golden("shot_150.npz")
+    assert np.array_equal(grid_subsampling(s["cloud"], float(s["voxel"])), s["support"])
+    assert np.array_equal(grid_subsampling(s["cloud"], 0.008), s["support_008"])
+    k = load_golden("keypoints_6k.npz")
+    assert np.array_equal(ks.select_keypoints_subsampling(k["cloud"], float(k["voxel"])), k["subsampling"])
+    assert np.array_equal(ks.select_keypoints_with_density_threshold(k["cloud"], float(k["voxel"]), int(k["density_value"])),
+                          k["density_voxel"])
+    # the platform-independent order: same voxels, same populations; a different representative only where the
+    # reference's own choice hangs on its unstable sort (equal distances to the barycentre, or last-bit barycentres)
+    pick_i, cnt_i = voxel_closest_to_barycentre(p, float(g["voxel"]), within_voxel_order="index")
+    pick_n, cnt_n = voxel_closest_to_barycentre(p, float(g["voxel"]))
+    assert np.array_equal(cnt_i, cnt_n) and pick_i.shape == pick_n.shape
+    keys = lambda idx: ((p[idx] - p.min(axis=0)) // float(g["voxel"])).astype(int)
+    assert np.array_equal(keys(pick_i), keys(pick_n))
+    diff = np.flatnonzero(pick_i != pick_n)
+    assert 0 < diff.size < cnt_n.size
+    # every differing voxel is a tie within rounding: both candidates are equally close to the barycentre
+    allk = keys(np.arange(p.shape[0]))
+    for v in diff[:100]:
+        members = np.flatnonzero((allk == allk[pick_n[v]]).all(axis=1))
+        bary = p[members].mean(axis=0)
+        da, db = np.linalg.norm(p[pick_i[v]] - bary), np.linalg.norm(p[pick_n[v]] - bary)
+        assert abs(da - db) <= 1e-12 * max(da, 1e-300) + 1e-15, (v, da, db)
+    with pytest.raises(Exception):
+        grid_subsampling(p, 0.0)
+    assert grid_subsampling(np.zeros((0, 3)), 0.1).size == 0
+    one = grid_subsampling(p[:1], 0.1)
+    assert one.tolist() == [0]
+
+
+def test_grid_subsampling_device_at_one_million_points():
+    """1M points, voxel = radius / 10 of config 3 (0.003): mostly one-point voxels; and a coarse voxel (0.02, ~8 points
+    each).  Against the NumPy expression of subsampling.py:12-37 evaluated with the same visiting order."""
+    from shot_fpfh_amd.core import voxel_closest_to_barycentre
+
+    p, _, _ = synth_cloud(1_000_000, 3)
+    for voxel in (0.003, 0.02):
+        picked, counts = voxel_closest_to_barycentre(p, voxel)
+        keys = ((p - np.min(p, axis=0)) // voxel).astype(int)
+        _, inverse, cnt = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
+        inverse = np.asarray(inverse).reshape(-1)
+        assert np.array_equal(counts, cnt)
+        order = np.argsort(inverse)
+        starts = np.concatenate(([0], np.cumsum(cnt)[:-1]))
+        grouped = p[order]
+        bary = np.add.reduceat(grouped, starts, axis=0) / cnt[:, None]
+        seg = np.repeat(np.arange(cnt.shape[0]), cnt)
+        dist = np.linalg.norm(grouped - bary[seg], axis=1)
+        seg_min = np.minimum.reduceat(dist, starts)
+        hit = np.flatnonzero(dist == seg_min[seg])
+        first = hit[np.unique(seg[hit], return_index=True)[1]]
+        assert np.array_equal(picked, order[first])
