@@ -45,7 +45,8 @@ extern "C" {
 #define SF_IN_DEVICE 2
 
 #define SF_SHOT_LEN 352 /* 11 cosine x 8 azimuth x 2 elevation x 2 radial bins (shot.py:195) */
-#define SF_MAX_FPFH_BINS 8 /* n_bins^3 <= 512 histogram cells per point */
+#define SF_FAST_FPFH_BINS 8 /* n_bins up to here: LDS-histogram K6 and the matrix-core / streaming K7 */
+#define SF_MAX_FPFH_BINS 32 /* any n_bins up to here (the reference takes any, fpfh.py:16): generic K6 / K7, 32-bit counts */
 
 typedef struct sf_ctx sf_ctx;     /* one GPU: device id, stream, scratch, optional RCCL comm  */
 typedef struct sf_cloud sf_cloud; /* resident point cloud + uniform grid (replaces KDTree(X))  */
@@ -122,7 +123,7 @@ sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, i
                           int flags);
 sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *cloud, double radius, int64_t begin, int64_t end);
 /* k nearest neighbours: replaces KDTree.query(Q, k=k, return_distance=False) (pca_based_descriptors.py:46).
- * Every list has exactly k entries, nearest first (ties: lower cell-sorted position).  1 <= k <= min(n, 448). */
+ * Every list has exactly k entries, nearest first (ties: lower cell-sorted position).  1 <= k <= min(n, 1984). */
 sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, int k, int flags);
 /* non-owning view of queries [first, first+count) of `nbrs` (free it before the parent) */
 sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nbrs, int64_t first, int64_t count);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libshotfpfh.so")
 
 SF_HOST, SF_OUT_DEVICE, SF_IN_DEVICE = 0, 1, 2
 SHOT_LEN = 352
-MAX_FPFH_BINS = 8
+MAX_FPFH_BINS = 32  # SF_MAX_FPFH_BINS (n_bins above 8 take the generic kernels)
 
 
 class ShotFpfhError(RuntimeError):

@@ -25,8 +25,8 @@
 namespace {
 
 struct fpfh_edges {
-    double a[SF_MAX_FPFH_BINS + 1], p[SF_MAX_FPFH_BINS + 1], t[SF_MAX_FPFH_BINS + 1];
-    double tan_t[SF_MAX_FPFH_BINS + 1]; // tan of the interior theta edges (index 1..nb-1)
+    double a[SF_FAST_FPFH_BINS + 1], p[SF_FAST_FPFH_BINS + 1], t[SF_FAST_FPFH_BINS + 1];
+    double tan_t[SF_FAST_FPFH_BINS + 1]; // tan of the interior theta edges (index 1..nb-1)
 };
 
 // np.histogramdd bin of x: searchsorted(edges, x, 'right') - 1, x == last edge -> last bin, out of
@@ -36,7 +36,7 @@ __device__ inline int hist_bin(const double *e, int nb, double x)
     if (!(x >= e[0]) || x > e[nb]) return -1;
     int b = 0;
 #pragma unroll
-    for (int i = 1; i < SF_MAX_FPFH_BINS; ++i)
+    for (int i = 1; i < SF_FAST_FPFH_BINS; ++i)
         if (i < nb && x >= e[i]) b = i;
     return b;
 }
@@ -53,7 +53,7 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
         int bin = 0;
         double gap = 1.0e300; // smallest |a - tan(e_i) b| over the interior edges
 #pragma unroll
-        for (int i = 1; i < SF_MAX_FPFH_BINS; ++i)
+        for (int i = 1; i < SF_FAST_FPFH_BINS; ++i)
             if (i < nb) {
                 const double tb = ed.tan_t[i] * b;
                 bin += a >= tb ? 1 : 0;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
                                               double *__restrict__ p4, double mom_radius, double *__restrict__ cov)
 {
     const int nb = NB > 0 ? NB : nb_rt;
-    __shared__ unsigned int hist[4][SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS * SF_MAX_FPFH_BINS];
+    __shared__ unsigned int hist[4][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = sf_uniform64(sf_xcd_block() * 4 + wave);
     if (q >= m) return; // whole wave exits together; no block-wide barrier below
@@ -384,6 +384,104 @@ __global__ void k_spfh_export(const CT *__restrict__ counts, const int32_t *__re
     out[(int64_t)perm[i] * nb3 + b] = (double)((unsigned)counts[i * stride + b] ^ bias) / (double)kk[i];
 }
 
+// ---- any bin count (n_bins > SF_FAST_FPFH_BINS): the reference takes whatever `n_bins` it is given (fpfh.py:16) ---------
+// K6g: one wave per point, edges from memory with a binary search (np.histogramdd's searchsorted rule), theta from
+// atan2 as the reference computes it; the row of the (uint32) table is private to the wave, so the counts go straight
+// into it with global atomics (the row is zeroed first).  K7g: one workgroup per keypoint, neighbours staged through
+// LDS in tiles (index, 1 / d_j, k_j), every thread owns bins tid, tid + 256, ... and sums the neighbours in list
+// order.  Plain and bandwidth-hungry on purpose: n_bins^3 bins per point leave no room for the LDS / matrix-core
+// schemes above, and the configurations the pipeline uses (n_bins <= 8) never come here.
+__device__ inline int hist_bin_search(const double *__restrict__ e, int nb, double x)
+{
+    if (!(x >= e[0]) || x > e[nb]) return -1;
+    if (x == e[nb]) return nb - 1;
+    int lo = 0, hi = nb + 1; // first index with e[i] > x
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (e[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+
+__global__ __launch_bounds__(256) void k_spfh_generic(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                                      const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx, int64_t m,
+                                                      int64_t self_begin, const double *__restrict__ edges, int nb, int nb3,
+                                                      int stride, unsigned *__restrict__ counts, int32_t *__restrict__ kk)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
+    if (q >= m) return;
+    const int64_t i = self_begin + q, s = offset[q];
+    const int k = cnt[q];
+    unsigned *row = counts + i * (int64_t)stride;
+    for (int b = lane; b < stride; b += 64) row[b] = 0u;
+    if (lane == 0) kk[i] = k;
+    __threadfence(); // the zeroed row is in memory before any lane's atomic reaches it
+    double px, py, pz, ux, uy, uz;
+    sf_load_pn(rec, (int)i, px, py, pz, ux, uy, uz);
+    const double *ea = edges, *ep = edges + (nb + 1), *et = edges + 2 * (nb + 1);
+    for (int t = lane; t < k; t += 64) {
+        double x, y, z, nx, ny, nz;
+        sf_load_pn(rec, idx[s + t], x, y, z, nx, ny, nz);
+        const double cx = x - px, cy = y - py, cz = z - pz;
+        const double dist = sqrt((cx * cx + cy * cy) + cz * cz); // fpfh.py:48
+        if (!(dist > 0.0)) continue;
+        const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)  :50
+        const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)  :51
+        const double alpha = (vx * nx + vy * ny) + vz * nz;                                   // :52
+        const double phi = ((cx * ux + cy * uy) + cz * uz) / dist;                            // :53
+        const double theta = atan2((nx * wx + ny * wy) + nz * wz, (nx * ux + ny * uy) + nz * uz); // :54-57
+        const int ba = hist_bin_search(ea, nb, alpha), bp = hist_bin_search(ep, nb, phi), bt = hist_bin_search(et, nb, theta);
+        if (ba < 0 || bp < 0 || bt < 0) continue;
+        atomicAdd(&row[(ba * nb + bp) * nb + bt], 1u);
+    }
+}
+
+constexpr int FG_TILE = 512;
+__global__ __launch_bounds__(256) void k_fpfh_generic(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                                      const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                      int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m, int nb3,
+                                                      int stride, const unsigned *__restrict__ counts,
+                                                      const int32_t *__restrict__ kk, double *__restrict__ out)
+{
+    __shared__ int tj[FG_TILE];
+    __shared__ double tinvd[FG_TILE], tk[FG_TILE];
+    const int64_t q = blockIdx.x;
+    if (q >= m) return;
+    const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q; // cell-sorted position of the keypoint
+    const int64_t lq = i - nbrs_begin, s = offset[lq];
+    const int k = cnt[lq];
+    double px, py, pz;
+    sf_load_xyz(rec, (int)i, px, py, pz);
+    double *o = out + q * (int64_t)nb3;
+    for (int t0 = 0; t0 < k || t0 == 0; t0 += FG_TILE) {
+        const int nt = min(FG_TILE, k - t0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += 256) {
+            const int j = idx[s + t0 + t];
+            double x, y, z;
+            sf_load_xyz(rec, j, x, y, z);
+            const double cx = x - px, cy = y - py, cz = z - pz;
+            const double d = sqrt((cx * cx + cy * cy) + cz * cz);
+            tj[t] = j;
+            tinvd[t] = d > 0.0 ? d : 0.0; // 0 marks "skip" (fpfh.py:113: distances > 0)
+            tk[t] = (double)kk[j];
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb3; b += 256) {
+            double acc = t0 ? o[b] : 0.0;
+            for (int t = 0; t < nt; ++t)
+                if (tinvd[t] > 0.0) acc += ((double)counts[(int64_t)tj[t] * stride + b] / tk[t]) / tinvd[t]; // spfh[j] / d_j
+            o[b] = acc;
+        }
+        if (k == 0) break;
+    }
+    __syncthreads();
+    const double kd = (double)k;
+    for (int b = threadIdx.x; b < nb3; b += 256)
+        o[b] = (double)counts[i * (int64_t)stride + b] / kd + o[b] / kd; // spfh[kp] + sum / len(neighbourhood)  :109-115
+}
+
 __global__ void k_map_positions(const int64_t *__restrict__ kp_idx, const int32_t *__restrict__ inv_perm, int64_t m,
                                 int64_t n, int32_t *__restrict__ pos, int *__restrict__ bad)
 {
@@ -401,7 +499,7 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
 {
     if (!ctx || !c) { sf_set_error("sf_spfh_create: null argument"); return nullptr; }
     if (n_bins < 1 || n_bins > SF_MAX_FPFH_BINS) {
-        sf_set_error("sf_spfh_create: n_bins=%d unsupported on device (1..%d)", n_bins, SF_MAX_FPFH_BINS);
+        sf_set_error("sf_spfh_create: n_bins=%d outside 1..%d (n_bins^3 bins per point)", n_bins, SF_MAX_FPFH_BINS);
         return nullptr;
     }
     if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
@@ -412,15 +510,22 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     // neighbourhoods of at most 255 points and at most 128 bins: one BYTE per bin, biased by 128 (a 128-byte row the
     // matrix-core K7 consumes as int8); else uint16, uint32 beyond 65535
     sp->elem_bytes = (max_count <= 255 && sp->nb3 <= 128) ? 1 : (max_count > 65535 ? 4 : 2);
+    if (n_bins > SF_FAST_FPFH_BINS) sp->elem_bytes = 4; // the generic kernels keep 32-bit counts
     sp->bias = sp->elem_bytes == 1 ? 128 : 0;
     // rows padded to a multiple of 128 elements: lane l of a wave owns elements 2l, 2l+1 of each 128-element
     // slice, so no lane of the K7 row loads ever falls outside its row (256 B rows for 125 uint16 bins)
     sp->stride = 128; // ... and to a power of two, so that a row is 256 B, 512 B, 1 KiB or 2 KiB (the K7 row shapes)
     while (sp->stride < sp->nb3) sp->stride *= 2;
+    if (n_bins > SF_FAST_FPFH_BINS) sp->stride = (sp->nb3 + 3) & ~3; // generic kernels: no shape constraint
     // room for ceil(n / nranks) rows per rank so the table can be all-gathered in place
     const int64_t nr = ctx->nranks > 0 ? ctx->nranks : 1;
     sp->rows_alloc = std::max<int64_t>(sf_div_up(c->n, nr) * nr, 1);
     size_t nn = (size_t)sp->rows_alloc;
+    if ((double)nn * sp->stride * sp->elem_bytes > 2.0e11) {
+        sf_set_error("sf_spfh_create: an SPFH table of %lld x %d bins does not fit the device", (long long)nn, sp->nb3);
+        delete sp;
+        return nullptr;
+    }
     if (hipMalloc(&sp->counts, nn * sp->stride * sp->elem_bytes) != hipSuccess ||
         hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess ||
         (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess)) {
@@ -458,9 +563,23 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     }
     SF_HIP(hipSetDevice(ctx->device));
     SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
+    if (sp->n_bins > SF_FAST_FPFH_BINS) {
+        if (cov) { sf_set_error("sf_spfh_compute_moments: n_bins=%d has no shared-sweep form (use sf_spfh_compute)", sp->n_bins); return SF_ERR_UNSUPPORTED; }
+        const int64_t mg = nb->m;
+        if (!mg) return SF_OK;
+        sf_pool_guard tmp(ctx);
+        double *dedges = nullptr;
+        const size_t ne = (size_t)3 * (sp->n_bins + 1);
+        SF_CHECK(tmp.alloc(&dedges, ne));
+        SF_HIP(hipMemcpyAsync(dedges, edges, ne * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SF_LAUNCH(ctx, "k6_spfh", k_spfh_generic, dim3(sf_xcd_grid(sf_div_up(mg, 4))), dim3(256), c->rec, nb->offset, nb->count,
+                  nb->idx, mg, nb->self_begin, (const double *)dedges, sp->n_bins, sp->nb3, sp->stride, (unsigned *)sp->counts, sp->k);
+        SF_HIP(hipStreamSynchronize(ctx->stream)); // `edges` is a host buffer
+        return SF_OK;
+    }
     fpfh_edges ed;
     const int nbn = sp->n_bins;
-    for (int i = 0; i <= SF_MAX_FPFH_BINS; ++i) {
+    for (int i = 0; i <= SF_FAST_FPFH_BINS; ++i) {
         ed.a[i] = edges[i <= nbn ? i : nbn];
         ed.p[i] = edges[(nbn + 1) + (i <= nbn ? i : nbn)];
         ed.t[i] = edges[2 * (nbn + 1) + (i <= nbn ? i : nbn)];
@@ -677,9 +796,14 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
         dout = owned;
     }
     int rc = SF_OK;
-    if (m) rc = sp->elem_bytes == 1   ? launch_fpfh_mc(ctx, c, nb, sp, pos, m, dout)
-                : sp->elem_bytes == 2 ? launch_fpfh<uint16_t>(ctx, c, nb, sp, pos, m, dout)
-                                      : launch_fpfh<uint32_t>(ctx, c, nb, sp, pos, m, dout);
+    if (m && sp->n_bins > SF_FAST_FPFH_BINS) {
+        if (m > 2147483000LL) { sf_set_error("sf_fpfh: too many keypoints for one launch"); return SF_ERR_UNSUPPORTED; }
+        SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_generic, dim3((unsigned)m), dim3(256), c->rec, nb->offset, nb->count, nb->idx,
+                  nb->self_begin, (const int32_t *)pos, m, sp->nb3, sp->stride, (const unsigned *)sp->counts, sp->k, dout);
+    } else if (m)
+        rc = sp->elem_bytes == 1   ? launch_fpfh_mc(ctx, c, nb, sp, pos, m, dout)
+             : sp->elem_bytes == 2 ? launch_fpfh<uint16_t>(ctx, c, nb, sp, pos, m, dout)
+                                   : launch_fpfh<uint32_t>(ctx, c, nb, sp, pos, m, dout);
     if (rc == SF_OK && owned) {
         if (tot) SF_HIP(hipMemcpyAsync(out, owned, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));

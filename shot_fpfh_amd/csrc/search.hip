@@ -573,7 +573,7 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         sf_set_error("sf_knn_search: k=%d must be in 1..%lld (the number of cloud points)", k, (long long)c->n);
         return nullptr;
     }
-    if (k > 448) { sf_set_error("sf_knn_search: k=%d > 448 unsupported on the device path", k); return nullptr; }
+    if (k > 1984) { sf_set_error("sf_knn_search: k=%d > 1984 exceeds the candidate buffer of the k-NN kernel", k); return nullptr; }
     if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
     double lo[3], hi[3];
     if (sf_cloud_bbox(ctx, c, lo, hi) != SF_OK) return nullptr;
@@ -620,9 +620,13 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         const dim3 grid(sf_xcd_grid(msel)), block(64);
         const int32_t *sel = subset ? qsel : nullptr;
         sf_launch_timer *tm = new sf_launch_timer(ctx, "k2_knn");
-        if (k <= 64) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status);
-        else if (k <= 192) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status);
-        else hipLaunchKernelGGL(k_knn<8>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status);
+#define SF_KNN_LAUNCH(EPL) hipLaunchKernelGGL(k_knn<EPL>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status)
+        if (k <= 64) SF_KNN_LAUNCH(2);         // buffer of 64 * EPL candidates >= k + 64
+        else if (k <= 192) SF_KNN_LAUNCH(4);
+        else if (k <= 448) SF_KNN_LAUNCH(8);
+        else if (k <= 960) SF_KNN_LAUNCH(16);
+        else SF_KNN_LAUNCH(32);
+#undef SF_KNN_LAUNCH
         delete tm;
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

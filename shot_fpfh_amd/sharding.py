@@ -80,7 +80,7 @@ class DescriptorJob:
         # overlap_chains: run the FPFH chain (K6, K7) and the SHOT chain (K4, K5) on the context's two HIP streams;
         # ~4 % faster at C3, but per-kernel durations then overlap, so the bench keeps it off by default
         self.overlap = bool(overlap_chains)
-        self.share_sweep = bool(share_sweep) and do_fpfh and do_shot
+        self.share_sweep = bool(share_sweep) and do_fpfh and do_shot and self.n_bins <= 8  # (the fast K6 only)
         self.moments: Optional[DeviceArray] = None
         self.cloud: Cloud = engine.cloud(points, normals)
         self.plan = ShardPlan(self.cloud.n, world, rank)
