@@ -12,6 +12,7 @@
 #include "common.h"
 #include "device_util.h"
 #include "eigh3.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
@@ -614,54 +615,60 @@ __device__ inline double sf_sgpr(double c)
 }
 #define SF_HORNER(p, s, c) p = __builtin_fma(p, s, sf_sgpr(c))
 
-__device__ inline double sf_atan_small(double t) // atan(t), 0 <= t <= tan(pi/8) (1 + 1e-3)
+// atan(t) / (pi/4) for 0 <= t <= tan(pi/8) (1 + 1e-3): the minimax polynomial of tools/fit_poly.py with 4/pi folded into its
+// coefficients at compile time -- the azimuth weight is |dth| = angle / (pi/4), so the angle itself is never needed
+__device__ inline double sf_atan_octant_fraction(double t)
 {
+    constexpr double K = 1.2732395447351628; // 4 / pi
     const double s = t * t;
-    double p = sf_sgpr(0.021102961440831885);
-    SF_HORNER(p, s, -0.04345403041920663);
-    SF_HORNER(p, s, 0.05687431322104835);
-    SF_HORNER(p, s, -0.06640058350060206);
-    SF_HORNER(p, s, 0.07689933264608774);
-    SF_HORNER(p, s, -0.09090771637100807);
-    SF_HORNER(p, s, 0.11111106118508882);
-    SF_HORNER(p, s, -0.14285714179450393);
-    SF_HORNER(p, s, 0.19999999998836118);
-    SF_HORNER(p, s, -0.33333333333328347);
-    return __builtin_fma(t * s, p, t);
+    double p = sf_sgpr(0.021102961440831885 * K);
+    SF_HORNER(p, s, -0.04345403041920663 * K);
+    SF_HORNER(p, s, 0.05687431322104835 * K);
+    SF_HORNER(p, s, -0.06640058350060206 * K);
+    SF_HORNER(p, s, 0.07689933264608774 * K);
+    SF_HORNER(p, s, -0.09090771637100807 * K);
+    SF_HORNER(p, s, 0.11111106118508882 * K);
+    SF_HORNER(p, s, -0.14285714179450393 * K);
+    SF_HORNER(p, s, 0.19999999998836118 * K);
+    SF_HORNER(p, s, -0.33333333333328347 * K);
+    SF_HORNER(p, s, K);
+    return t * p;
 }
 
-__device__ inline double sf_acos(double z) // acos(z), -1 <= z <= 1
+// acos(z) / (pi/2) for -1 <= z <= 1 (result in [0, 2]): sf_acos with 2/pi folded into the coefficients -- the elevation
+// weights are linear in phi / (pi/2).  z = 0 gives exactly 1, z = +-1 exactly 0 / 2.
+__device__ inline double sf_acos_quadrants(double z)
 {
+    constexpr double K = 0.6366197723675814; // 2 / pi
     const double az = fabs(z);
     const bool big = az > 0.5;
-    // straight-line on purpose (both forms are evaluated, then selected): the two Horner chains of sweep 2
-    // interleave only if no branch separates them
     const double xb = __builtin_fma(-0.5, az, 0.5), xs = az * az; // (1 - |z|) / 2 is exact
     const double rb = sf_sqrt_small(fmin(xb, 0.25));
     const double x = big ? xb : xs;
     const double r = big ? rb : az;
-    double p = sf_sgpr(0.028169218060881414); // asin(r) = r + r s R(s), s = r^2 <= 1/4
-    SF_HORNER(p, x, -0.010749050339697808);
-    SF_HORNER(p, x, 0.01603551434914882);
-    SF_HORNER(p, x, 0.0078029494773533175);
-    SF_HORNER(p, x, 0.011875494382636922);
-    SF_HORNER(p, x, 0.013929652902326633);
-    SF_HORNER(p, x, 0.017355259955786323);
-    SF_HORNER(p, x, 0.02237204763174451);
-    SF_HORNER(p, x, 0.03038194736709848);
-    SF_HORNER(p, x, 0.044642857103423646);
-    SF_HORNER(p, x, 0.07500000000020764);
-    SF_HORNER(p, x, 0.1666666666666665);
-    const double as = __builtin_fma(r * x, p, r);
-    // |z| <= 1/2: pi/2 -+ asin|z| ;  z > 1/2: 2 asin(sqrt((1-z)/2)) ;  z < -1/2: pi - 2 asin(sqrt((1+z)/2))
+    double p = sf_sgpr(0.028169218060881414 * K); // asin(r) = r + r s R(s), s = r^2 <= 1/4
+    SF_HORNER(p, x, -0.010749050339697808 * K);
+    SF_HORNER(p, x, 0.01603551434914882 * K);
+    SF_HORNER(p, x, 0.0078029494773533175 * K);
+    SF_HORNER(p, x, 0.011875494382636922 * K);
+    SF_HORNER(p, x, 0.013929652902326633 * K);
+    SF_HORNER(p, x, 0.017355259955786323 * K);
+    SF_HORNER(p, x, 0.02237204763174451 * K);
+    SF_HORNER(p, x, 0.03038194736709848 * K);
+    SF_HORNER(p, x, 0.044642857103423646 * K);
+    SF_HORNER(p, x, 0.07500000000020764 * K);
+    SF_HORNER(p, x, 0.1666666666666665 * K);
+    SF_HORNER(p, x, K);
+    const double as = r * p; // asin(r) / (pi/2)
+    // |z| <= 1/2: 1 -+ as ;  z > 1/2: 2 as ;  z < -1/2: 2 - 2 as
     const bool neg = z < 0.0;
-    const double a = big ? (neg ? SHOT_PI : 0.0) : SHOT_PI / 2;
+    const double a = big ? (neg ? 2.0 : 0.0) : 1.0;
     const double b = big ? (neg ? -2.0 : 2.0) : (neg ? 1.0 : -1.0);
     return __builtin_fma(b, as, a);
 }
 
 __device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
-                                     const double *E, double radius, shot_kept &o)
+                                     const double *E, double half_r, shot_kept &o)
 {
     double rho, inv_rho;
     sf_sqrt_rsqrt(d2, rho, inv_rho);
@@ -675,18 +682,20 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     const int ci = (int)cf;
     const int ti = azimuth_octant(lx, ly);
     const int pi_ = lz > 0.0 ? 1 : 0;
-    const int ri = rho > radius / 2 ? 1 : 0;
+    const int ri = rho > half_r ? 1 : 0; // (radius / 2 is exact: the host passes that very double)
     const double dc = cpos - cf;
     const int sc = (dc > 0.0) - (dc < 0.0);
     int cin = (ci + sc) % 11;
     if (cin < 0) cin += 11;
-    // sign of the azimuth offset from the octant centre -pi + (ti + 1/2) pi/4
+    // Offset from the octant's centre ray, in the octant's own frame: with a >= b the larger / smaller of |lx|, |ly|, the
+    // point sits atan(b / a) in [0, pi/4] off the nearest axis and the centre ray pi/8 off it, so rotating (a, b) by
+    // -pi/8 gives cross' / dot' = tan(angle off the centre).  Whether theta grows or shrinks with that angle alternates
+    // from octant to octant (even octants: grows).
     const double C8 = 0.9238795325112867, S8 = 0.3826834323650898; // cos, sin of pi/8
-    const bool cos_is_c = (((ti ^ (ti >> 1)) & 1) == 0);
-    const double ac = cos_is_c ? C8 : S8, as = cos_is_c ? S8 : C8;
-    const double ctr_x = ((ti + 2) & 4) ? ac : -ac, ctr_y = ti >= 4 ? as : -as;
-    const double cross = ctr_x * ly - ctr_y * lx;
-    const double dot = ctr_x * lx + ctr_y * ly;
+    const double am = fmax(fabs(lx), fabs(ly)), bm = fmin(fabs(lx), fabs(ly));
+    const double crs = __builtin_fma(C8, bm, -(S8 * am));
+    const double dot = __builtin_fma(C8, am, S8 * bm);
+    const double cross = (ti & 1) ? -crs : crs;
     int sth;
     if (fabs(cross) > 1e-9 * (fabs(lx) + fabs(ly))) {
         sth = cross > 0.0 ? 1 : -1;
@@ -711,54 +720,51 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     o.bins1 = cd | (ef << 8) | 0x80000000u;
 }
 
-struct shot_values { double vA, vB, vG, vC, vD, vE, vF; };
+// Radius-derived constants of the interpolation, computed once on the host (as kernel arguments they live in SGPRs;
+// computed in the kernel the wave-uniform division 1 / (r/2) was a 14-instruction vector sequence per chunk)
+struct shot_consts {
+    double radius, half_r, q1, q3, inv_hr;
+};
 
-__device__ inline void shot_interp(const shot_kept &g, double radius, shot_values &o)
+// The interpolation weights of one neighbour (shot.py:73-171, 244-298), reduced to what the elections consume:
+//   vA   = S2 + S5 + S8 + S10 = (1 - |dc|) + current radial + current elevation + (1 - |dth|)
+//   v_cd = S3's `outer` if the neighbour is in the inner shell, S4's `inner` if in the outer one (the other is 0)
+//   v_ef = S6's `upper` if it is in the lower half space, S7's `lower` if in the upper one (the other is 0)
+//   adth = |dth| (S9's value; S1's is |dc|, already in g)
+// Written so that only the shell / half-space the neighbour is actually in gets evaluated: the centre of ITS bin is
+// selected first, the distance to that centre computed once.  theta and phi enter as fractions of their bin size
+// (sf_atan_octant_fraction, sf_acos_quadrants).  All weights are continuous in rho / phi / theta except at
+// rho = r/2 (decided on rho itself, as the reference does) and phi = pi/2 (decided by the sign of z inside the
+// reference's 1e-10 band), so last-bit differences of the short polynomial forms cannot flip a term.
+__device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, double &vA, double &v_cd, double &v_ef, double &adth)
 {
-    // Same interpolation weights as shot_eval<true> (shot.py:73-171, 282-298); the divisions by the constant
-    // bin sizes (r/2, pi/2, pi/4) are multiplications by their reciprocals and theta / phi come from the short
-    // helpers above (all within ~1e-15 of the reference's libm expressions).  Written as straight-line code
-    // (values first, selects after) so that no branch separates the independent dependency chains.
     const unsigned base = g.bins0 & 511u;
-    const int ri = base & 1, pi_ = (base >> 1) & 1;
+    const bool ri = base & 1u, z_pos = base & 2u; // rho > r/2 ; lz > 0 -- both decided in shot_geometry
     const double rho = g.rho;
     const double adc = fabs(g.dc);
-    // |dth| of shot.py:283-288 = (angle between (lx, ly) and the octant's centre ray) / (pi/4), clipped to 1/2.
-    // lx = ly = 0 has dot = 0: the reference's atan2(0, 0) = 0 sits 3.5 octants from octant 0's start -> 1/2.
-    const double inv_tsz = 1.2732395447351628; // 1 / (pi/4)
+    // |dth|: angle off the octant's centre ray as a fraction of the octant, clipped to 1/2.  lx = ly = 0 has dot = 0:
+    // the reference's atan2(0, 0) = 0 sits 3.5 octants from octant 0's start -> 1/2.
     const bool fwd = g.tdot > 0.0;
     const double tq = fmin(fabs(g.tcross) * sf_rcp(fwd ? g.tdot : 1.0), 0.4146);
-    const double at = fmin(sf_atan_small(tq) * inv_tsz, 0.5);
-    const double adth = fwd ? at : 0.5;
-    const double half_r = radius / 2, q1 = radius / 4, q3 = radius * 3 / 4;
-    const double inv_hr = 1.0 / half_r; // wave-uniform
-    const double in_v = (q3 - rho) * inv_hr, out_v = (rho - q1) * inv_hr;
-    const double cur_lo = 1 - fabs(rho - q1) * inv_hr, cur_hi = 1 - fabs(rho - q3) * inv_hr;
-    const bool lo = rho < half_r, hi = rho > half_r;
-    const double inner = (hi & (rho < q3)) ? in_v : 0.0;
-    const double outer = (lo & (rho > q1)) ? out_v : 0.0;
-    const double cur_h = hi ? cur_hi : 0.0;
-    const double cur = lo ? cur_lo : cur_h;
-    const double lzr = fmin(fmax(g.lzr, -1.0), 1.0);
-    const bool z_pos = pi_ != 0; // lz > 0, decided in sweep 1 on lz itself
-    const double phi = sf_acos(lzr);
-    const double hpi = SHOT_PI / 2, pi34 = SHOT_PI * 3 / 4, pi4 = SHOT_PI / 4;
-    const double inv_hpi = 0.6366197723675814; // 1 / (pi/2)
-    const bool near_eq = fabs(phi - hpi) < 1e-10;
-    const bool up_on = ((phi > hpi) | (near_eq & !z_pos)) & (phi <= pi34);
-    const bool lw_on = ((phi < hpi) & (!near_eq | z_pos)) & (phi >= pi4);
-    const double up_v = (pi34 - phi) * inv_hpi, lw_v = (phi - pi4) * inv_hpi;
-    const double upper = up_on ? up_v : 0.0;
-    const double lower = lw_on ? lw_v : 0.0;
-    const double cv_lo = 1 - fabs(phi - pi4) * inv_hpi, cv_hi = 1 - fabs(phi - pi34) * inv_hpi;
-    const double curv = phi < hpi ? cv_lo : cv_hi;
-    o.vB = adc; // the reference's mask (cf > -0.5) & (cf < 10.5) is always true for cf in 0..10
-    o.vA = (((1 - adc) + cur) + curv) + (1 - adth);
-    o.vC = ri == 0 ? outer : 0.0;
-    o.vD = ri == 1 ? inner : 0.0;
-    o.vE = pi_ == 0 ? upper : 0.0;
-    o.vF = pi_ == 1 ? lower : 0.0;
-    o.vG = adth;
+    const double at = fmin(sf_atan_octant_fraction(tq), 0.5);
+    adth = fwd ? at : 0.5;
+    // radial shells (interpolate_on_adjacent_husks): rho == r/2 belongs to neither and gets all three terms zero
+    const bool off_half = rho != k.half_r;
+    const double dr = rho - (ri ? k.q3 : k.q1);
+    const double cur = off_half ? 1.0 - fabs(dr) * k.inv_hr : 0.0;
+    const double toward = ri ? -dr : dr; // (3r/4 - rho) in the outer shell, (rho - r/4) in the inner one
+    v_cd = off_half ? fmax(toward, 0.0) * k.inv_hr : 0.0;
+    // elevation (interpolate_vertical_volumes), u = phi / (pi/2) in [0, 2]
+    const double u = sf_acos_quadrants(fmin(fmax(g.lzr, -1.0), 1.0));
+    const bool below = u < 1.0;                                  // phi < pi/2
+    const bool near_eq = fabs(u - 1.0) < 1e-10 * 0.6366197723675814; // |phi - pi/2| < 1e-10
+    const double curv = 1.0 - fabs(u - (below ? 0.5 : 1.5));
+    // upper = [(phi > pi/2 or (near and z <= 0)) and phi <= 3pi/4] (3pi/4 - phi)/(pi/2), counted for z <= 0 writers;
+    // lower = [(phi < pi/2 and (not near or z > 0)) and phi >= pi/4] (phi - pi/4)/(pi/2), counted for z > 0 writers
+    const double e = z_pos ? u - 0.5 : 1.5 - u;
+    const bool side = z_pos ? below : ((u > 1.0) | near_eq);
+    v_ef = side ? fmax(e, 0.0) : 0.0;
+    vA = (((1.0 - adc) + cur) + curv) + (1.0 - adth);
 }
 
 template <int NCH, bool FUSED>
@@ -766,7 +772,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
                                                  const double *__restrict__ qx, const double *__restrict__ qy,
                                                  const double *__restrict__ qz, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-                                                 const int32_t *__restrict__ qrow, double radius,
+                                                 const int32_t *__restrict__ qrow, const shot_consts &K,
                                                  double *__restrict__ lrf, int normalize, int64_t min_nb,
                                                  double *__restrict__ out, int64_t q, unsigned long long *slot)
 {
@@ -778,8 +784,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // register file, not LDS, set the occupancy.  A CD / EF slot carries ONE value plus a flag in bit 62
     // (unused by doubles below 2.0): the S3/S4 pair of a winner has a single non-zero member, selected by
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
-    unsigned long long *const sA = slot, *const sCD = slot + 352, *const sEF = slot + 528; // phase 1
-    unsigned long long *const sB = slot, *const sG = slot + 352;                            // phase 2
+    unsigned long long *const sA = slot;
     const int lane = threadIdx.x;
     const int64_t s = offset[q];
     const int k = cnt[q];
@@ -852,92 +857,90 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         return;
     }
     __syncthreads();
-    // phase 1, sweep 1: geometry + election of the max-rho writer of every (key, bin) of A / CD / EF
+    // Election and accumulation.  sA (352 slots) first elects the writers of S2+S5+S8+S10 by rho, then becomes the
+    // ACCUMULATOR of the row: its winners store their (negated) value, and every other statement's winner adds its own
+    // (negated) value to the bin it feeds with an LDS float64 atomic add -- the LDS pipe does the additions, the bins are
+    // never assembled by the vector ALU.  sX (352 slots) is the election table of the other statements in turn:
+    // S3/S4 (CD, 176) + S6/S7 (EF, 176), then S1 (B, 352), then S9 (G, 352).  A workgroup is ONE wave, whose LDS
+    // instructions execute in program order, so the order of the additions into a bin -- hence every bit of the row --
+    // is the same in every run.
+    unsigned long long *const sX = slot + 352;
+    double *const acc = reinterpret_cast<double *>(slot);
+    constexpr unsigned long long SHOT_CLAIMED = ~0ull; // no rho has this bit pattern
     shot_kept g[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         g[c].bins1 = 0u;
         if (d2[c] > 0.0) {
-            shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, radius, g[c]);
+            shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, K.half_r, g[c]);
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             atomicMax(&sA[g[c].bins0 & 511u], key);
-            atomicMax(&sCD[g[c].bins1 & 255u], key);
-            atomicMax(&sEF[(g[c].bins1 >> 8) & 255u], key);
+            atomicMax(&sX[g[c].bins1 & 255u], key);
+            atomicMax(&sX[176 + ((g[c].bins1 >> 8) & 255u)], key);
         }
     }
     __syncthreads();
-    // phase 1, sweep 2: winners replace their key by their (tagged) value; |dth| is kept for phase 2
+    // the winners of A store; every neighbour keeps what its other statements may have to add
+    double v_cd[NCH], v_ef[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        v_cd[c] = 0.0;
+        v_ef[c] = 0.0;
+        if (g[c].bins1 >> 31) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            const unsigned iA = g[c].bins0 & 511u;
+            double vA, adth;
+            shot_weights(g[c], K, vA, v_cd[c], v_ef[c], adth);
+            g[c].tdot = adth;
+            if (sA[iA] == key) sA[iA] = tag_value(vA);
+        }
+    }
+    __syncthreads();
+    // S3/S4 and S6/S7: the elected writer adds into the bin with the OTHER radial / elevation bit than its own
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (g[c].bins1 >> 31) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             const unsigned iA = g[c].bins0 & 511u, iCD = g[c].bins1 & 255u, iEF = (g[c].bins1 >> 8) & 255u;
-            const bool wA = sA[iA] == key, wCD = sCD[iCD] == key, wEF = sEF[iEF] == key;
-            shot_values v;
-            shot_interp(g[c], radius, v);
-            g[c].tdot = v.vG;
-            if (wA) sA[iA] = tag_value(v.vA);
-            const unsigned long long ri_w = iA & 1u, pi_w = (iA >> 1) & 1u; // the winner's own radial / elevation bin
-            if (wCD) sCD[iCD] = tag_value(ri_w ? v.vD : v.vC) | (ri_w << 62);
-            if (wEF) sEF[iEF] = tag_value(pi_w ? v.vF : v.vE) | (pi_w << 62);
+            // compare-and-swap, not a plain comparison: two neighbours at exactly the same distance (duplicated points)
+            // hold the same key, and an ADD must come from one of them only (their values are equal; which one of two
+            // distinct equidistant neighbours writes last is undefined in the reference too: unstable argsort, shot.py:218)
+            if (atomicCAS(&sX[iCD], key, SHOT_CLAIMED) == key && v_cd[c] != 0.0) unsafeAtomicAdd(&acc[iA ^ 1u], -v_cd[c]);
+            if (atomicCAS(&sX[176 + iEF], key, SHOT_CLAIMED) == key && v_ef[c] != 0.0) unsafeAtomicAdd(&acc[iA ^ 2u], -v_ef[c]);
         }
     }
     __syncthreads();
-    // Every claimed slot has been resolved by its winner, so a slot is now either +0 (empty) or a tagged
-    // (negated) value: A is subtracted as it is; a CD / EF slot feeds the bin whose radial / elevation bit
-    // differs from the winner's flag (bit 62), selected with an all-ones / all-zeros mask.
+    // S1 (value |dc|) and S9 (value |dth|): elect in sX, add into the accumulator
+#pragma unroll
+    for (int stmt = 0; stmt < 2; ++stmt) {
+        for (int b = lane; b < 352; b += 64) sX[b] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (g[c].bins1 >> 31) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+                atomicMax(&sX[(g[c].bins0 >> (stmt ? 18 : 9)) & 511u], key);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (g[c].bins1 >> 31) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+                const unsigned iW = (g[c].bins0 >> (stmt ? 18 : 9)) & 511u;
+                const double val = stmt ? g[c].tdot : fabs(g[c].dc); // S1's range mask is always true for cf in 0..10
+                if (atomicCAS(&sX[iW], key, SHOT_CLAIMED) == key && val != 0.0) unsafeAtomicAdd(&acc[iW], -val);
+            }
+        }
+        __syncthreads();
+    }
+    // every slot of the accumulator is +0 (nothing written) or minus the bin's value
     double vals[6];
-    const unsigned rb30 = (unsigned)(lane & 1) << 30, pb30 = (unsigned)((lane >> 1) & 1) << 30; // 64 u keeps both bits
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int b = lane + 64 * u;
-        double v = 0.0;
-        if (b < 352) {
-            const int cdi = b >> 1, efi = ((b >> 2) << 1) | (b & 1);
-            const unsigned long long cd = sCD[cdi], ef = sEF[efi];
-            const unsigned hcd = (unsigned)(cd >> 32), hef = (unsigned)(ef >> 32);
-            const unsigned mcd = (unsigned)((int)((hcd ^ rb30) << 1) >> 31), mef = (unsigned)((int)((hef ^ pb30) << 1) >> 31);
-            const double vcd = __hiloint2double((int)(hcd & 0x3fffffffu & mcd), (int)((unsigned)cd & mcd));
-            const double vef = __hiloint2double((int)(hef & 0x3fffffffu & mef), (int)((unsigned)ef & mef));
-            v = 0.0 - __longlong_as_double((long long)sA[b]);
-            v += vcd;
-            v += vef;
-        }
-        vals[u] = v;
-    }
-    __syncthreads();
-    for (int b = lane; b < 704; b += 64) slot[b] = 0;
-    __syncthreads();
-    // phase 2: S1 (B, value |dc|) and S9 (G, value |dth|) through the same slots
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if (g[c].bins1 >> 31) {
-            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
-            atomicMax(&sB[(g[c].bins0 >> 9) & 511u], key);
-            atomicMax(&sG[(g[c].bins0 >> 18) & 511u], key);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if (g[c].bins1 >> 31) {
-            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
-            const unsigned iB = (g[c].bins0 >> 9) & 511u, iG = (g[c].bins0 >> 18) & 511u;
-            const bool wB = sB[iB] == key, wG = sG[iG] == key;
-            if (wB) sB[iB] = tag_value(fabs(g[c].dc)); // S1: |dc|; the reference's range mask is always true
-            if (wG) sG[iG] = tag_value(g[c].tdot);
-        }
-    }
-    __syncthreads();
     double ss = 0.0;
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int b = lane + 64 * u;
-        double v = vals[u];
-        if (b < 352) {
-            v -= __longlong_as_double((long long)sB[b]);
-            v -= __longlong_as_double((long long)sG[b]);
-        }
+        const double v = b < 352 ? 0.0 - acc[b] : 0.0;
         vals[u] = v;
         ss += v * v;
     }
@@ -957,13 +960,13 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
                                                     const double *__restrict__ qz, const int64_t *__restrict__ offset,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                     const int32_t *__restrict__ qrow,
-                                                    int64_t m, double radius, double *__restrict__ lrf,
+                                                    int64_t m, shot_consts K, double *__restrict__ lrf,
                                                     int normalize, int64_t min_nb, double *__restrict__ out)
 {
     __shared__ unsigned long long slot[704];
     const int64_t q = sf_xcd_block();
     if (q >= m) return;
-    shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, radius, lrf, normalize, min_nb, out, q, slot);
+    shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
 }
 
 } // namespace
@@ -1078,18 +1081,20 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     const int64_t m = nb->m;
     if (!m) return SF_OK;
     const dim3 grid(sf_xcd_grid(m)), block(64);
-#define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius
+#define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m
+    const double r_ = nb->radius;
+    const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2)}; // the reference's own expressions (shot.py:95-117, 235)
     const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
 #define SF_SHOT_CASE(N)                                                                                              \
-    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, dlrf, normalize, min_nb, dout); } \
-    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, dlrf, normalize, min_nb, dout); }
+    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout); } \
+    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout); }
     if (chunks <= 1) { SF_SHOT_CASE(1) }
     else if (chunks == 2) { SF_SHOT_CASE(2) }
     else if (chunks == 3) { SF_SHOT_CASE(3) }
     else if (chunks == 4) { SF_SHOT_CASE(4) }
     else {
         if (fused) { sf_set_error("internal: fused SHOT needs neighbourhoods of at most 256 points"); return SF_ERR_STATE; }
-        SF_LAUNCH(ctx, "k5_shot", k_shot, grid, block, SF_SHOT_ARGS, (const double *)dlrf, normalize, min_nb, dout); // streaming
+        SF_LAUNCH(ctx, "k5_shot", k_shot, grid, block, SF_SHOT_ARGS, r_, (const double *)dlrf, normalize, min_nb, dout); // streaming
     }
 #undef SF_SHOT_CASE
 #undef SF_SHOT_ARGS
