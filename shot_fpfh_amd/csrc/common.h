@@ -157,7 +157,8 @@ struct sf_cloud {
     double cell = 0.0;              // actual cell edge used
     double inv_cell = 0.0;
     double lo[3] = {0, 0, 0};
-    int dim[3] = {1, 1, 1};
+    int dim[3] = {1, 1, 1};         // cells per axis; dim[0] counts the FINE cells along x (xsub per grid edge)
+    int xsub = 1;                   // x is subdivided xsub times finer than y / z (see grid.hip)
     int64_t ncell = 0;
     int32_t *cell_start = nullptr;  // ncell + 1
     int32_t *perm = nullptr;        // sorted position -> original index

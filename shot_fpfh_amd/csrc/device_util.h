@@ -8,8 +8,11 @@ struct sf_cloud;
 
 struct sf_grid_desc {
     double lo[3];
-    double inv_cell;
-    int dim[3];
+    double inv_cell;   // 1 / edge of a cell along y and z
+    double inv_cell_x; // xsub / edge: cells are xsub times finer along x
+    double cell;       // the edge
+    int dim[3];        // dim[0] counts fine x cells
+    int xsub;
 };
 
 #ifdef __HIPCC__

@@ -77,7 +77,7 @@ __global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_de
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int cx = sf_cell_coord(xyz[3 * i + 0], g.lo[0], g.inv_cell, g.dim[0]);
+    int cx = sf_cell_coord(xyz[3 * i + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
     int cy = sf_cell_coord(xyz[3 * i + 1], g.lo[1], g.inv_cell, g.dim[1]);
     int cz = sf_cell_coord(xyz[3 * i + 2], g.lo[2], g.inv_cell, g.dim[2]);
     cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
@@ -293,6 +293,16 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         }
         if (!too_long && tot <= 67108864.0) { ncell = (int64_t)tot; break; }
         edge *= 2.0; // coarser cells stay correct (edge >= radius), only slower
+    }
+    // Along x the cells are cut xsub times finer (a power of two, so a fine cell index / xsub is exactly the index of
+    // the edge-sized cell): the radius search clips each of its nine runs to the x range its ball can reach in that
+    // row of cells (search.hip), which needs cell boundaries every edge / xsub.  Rows stay contiguous runs of positions
+    // and z-layers stay slabs, so nothing else changes but the row stride.
+    c->xsub = 1;
+    while (c->xsub < 4 && (double)ncell * 2.0 <= 67108864.0 && c->dim[0] * 2 <= 2097152) {
+        c->xsub *= 2;
+        c->dim[0] *= 2;
+        ncell *= 2;
     }
     c->cell = edge;
     c->inv_cell = 1.0 / edge;

@@ -29,6 +29,9 @@ sf_grid_desc sf_make_grid_desc(const sf_cloud *c)
         g.dim[a] = c->dim[a];
     }
     g.inv_cell = c->inv_cell;
+    g.inv_cell_x = c->inv_cell * c->xsub; // (xsub is a power of two: exact)
+    g.cell = c->cell;
+    g.xsub = c->xsub;
     return g;
 }
 
@@ -77,13 +80,11 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
     const int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
     if (q >= m) return;
     const double px = qx[q], py = qy[q], pz = qz[q];
-    int x0, x1, y0, y1, z0, z1;
-    stencil_bounds(px, g.lo[0], g.inv_cell, g.dim[0], x0, x1);
+    int y0, y1, z0, z1;
     stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
     stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
     // the bounds are wave-uniform but were computed with (vector) float64 instructions: hand them to the
-    // scalar unit so the cell_start look-ups below are scalar loads, not 64-lane vector loads of one address
-    x0 = sf_uniform(x0); x1 = sf_uniform(x1);
+    // scalar unit so that everything derived from them is scalar
     y0 = sf_uniform(y0); y1 = sf_uniform(y1);
     z0 = sf_uniform(z0); z1 = sf_uniform(z1);
     int total = 0;
@@ -102,12 +103,26 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
     {
         const int r = lane < 9 ? lane : 8;
         const int cz = z0 + r / 3, cy = y0 + r % 3;
-        const bool ok = lane < 9 && cz <= z1 && cy <= y1;
+        bool ok = lane < 9 && cz <= z1 && cy <= y1;
         const int64_t row = ((int64_t)(ok ? cz : z0) * g.dim[1] + (ok ? cy : y0)) * g.dim[0];
+        // The row (cy, cz) of cells is the band [lo + c edge, lo + (c + 1) edge) in y and in z.  A point of it within r
+        // of the query is at least (dy, dz) away in those two axes -- the gaps between the query and the bands -- so
+        // its x lies within w = sqrt(r^2 - dy^2 - dz^2) of the query's: only the FINE x cells (xsub per edge) that
+        // [px - w, px + w] touches are swept, 12-15 edge-lengths of cells per query instead of 27.  The cell of a
+        // coordinate is a monotone function of it, so every point with px - w <= x <= px + w lies in a cell between
+        // the cells of the two ends; the gaps shrink and w grows by 1e-9 relative, far above any rounding of the
+        // band edges, so the sweep can only be wider than necessary, never narrower.
+        const double slack = 1e-9 * g.cell;
+        const double by0 = g.lo[1] + (double)cy * g.cell, bz0 = g.lo[2] + (double)cz * g.cell;
+        const double dy = fmax(fmax(by0 - py, py - (by0 + g.cell)) - slack, 0.0);
+        const double dz = fmax(fmax(bz0 - pz, pz - (bz0 + g.cell)) - slack, 0.0);
+        const double w2 = (r2 * (1.0 + 1e-9) - dy * dy) - dz * dz;
+        ok = ok && w2 >= 0.0;
+        const double w = sf_sqrt_fast(fmax(w2, 0.0)) * (1.0 + 1e-9) + slack;
         int s = 0, e = 0;
         if (lane < 9) {
-            s = cell_start[row + x0];
-            e = cell_start[row + x1 + 1];
+            s = cell_start[row + sf_cell_coord(px - w, g.lo[0], g.inv_cell_x, g.dim[0])];
+            e = cell_start[row + sf_cell_coord(px + w, g.lo[0], g.inv_cell_x, g.dim[0]) + 1];
         }
         if (!ok) { s = 0; e = 0; }
         const int base = s & ~1; // pairs start at an EVEN position: every 16-byte load is naturally aligned
@@ -171,7 +186,7 @@ __global__ void k_query_cells(const double *__restrict__ q, int64_t m, sf_grid_d
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    int cx = sf_cell_coord(q[3 * i + 0], g.lo[0], g.inv_cell, g.dim[0]);
+    int cx = sf_cell_coord(q[3 * i + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
     int cy = sf_cell_coord(q[3 * i + 1], g.lo[1], g.inv_cell, g.dim[1]);
     int cz = sf_cell_coord(q[3 * i + 2], g.lo[2], g.inv_cell, g.dim[2]);
     cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
@@ -246,7 +261,9 @@ __global__ __launch_bounds__(64) void k_knn(sf_grid_desc g, const int32_t *__res
     const int64_t q = qsel ? qsel[slot] : slot;
     const double px = qx[q], py = qy[q], pz = qz[q];
     int x0, x1, y0, y1, z0, z1;
-    stencil_bounds(px, g.lo[0], g.inv_cell, g.dim[0], x0, x1);
+    stencil_bounds(px, g.lo[0], g.inv_cell, g.dim[0] / g.xsub, x0, x1); // edge-sized cells along x ...
+    x0 *= g.xsub;                                                      // ... as a range of fine ones
+    x1 = x1 * g.xsub + (g.xsub - 1);
     stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
     stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
     x0 = sf_uniform(x0); x1 = sf_uniform(x1);
@@ -405,7 +422,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     // capacity from the mean density of the bounding box (x2.25 + 32, multiple of 32); skipped when the slots
     // would take more than 24 GiB or the estimate is meaningless
     double vol = 1.0;
-    for (int a = 0; a < 3; ++a) vol *= std::max((double)c->dim[a] * c->cell, 1e-300);
+    for (int a = 0; a < 3; ++a) vol *= std::max((double)(a == 0 ? c->dim[0] / c->xsub : c->dim[a]) * c->cell, 1e-300);
     const double expect = (double)c->n * 4.18879020478639 * nb->radius * nb->radius * nb->radius / vol;
     int64_t cap = (int64_t)(expect * 2.25) + 32;
     cap = std::min<int64_t>(((cap + 31) / 32) * 32, std::max<int64_t>(c->n, 32));
@@ -615,7 +632,7 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
     bool resolved = false;
     for (int round = 0; round < 2200 && !resolved; ++round) { // R doubles: a double overflows long before 2200 rounds
         sf_grid_desc g = sf_make_grid_desc(c);
-        const bool one_cell = g.dim[0] == 1 && g.dim[1] == 1 && g.dim[2] == 1;
+        const bool one_cell = g.dim[0] == g.xsub && g.dim[1] == 1 && g.dim[2] == 1;
         const double R2 = one_cell ? INFINITY : R * R;
         const dim3 grid(sf_xcd_grid(msel)), block(64);
         const int32_t *sel = subset ? qsel : nullptr;
