@@ -299,7 +299,8 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     // row of cells (search.hip), which needs cell boundaries every edge / xsub.  Rows stay contiguous runs of positions
     // and z-layers stay slabs, so nothing else changes but the row stride.
     c->xsub = 1;
-    while (c->xsub < 4 && (double)ncell * 2.0 <= 67108864.0 && c->dim[0] * 2 <= 2097152) {
+    static const int xsub_max = [] { const char *e = getenv("SF_XSUB"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 16 ? v : 4; }();
+    while (c->xsub < xsub_max && (double)ncell * 2.0 <= 67108864.0 && c->dim[0] * 2 <= 2097152) {
         c->xsub *= 2;
         c->dim[0] *= 2;
         ncell *= 2;
