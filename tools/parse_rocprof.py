@@ -16,6 +16,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHORT = [
+    ("k_rows_gather", "k8_rows_gather"), ("k_rows_nonzero", "k8_rows_nonzero"), ("k_icp_", "i1_icp"), ("k_transform", "i0_transform"),
+    ("k_voxel", "v_voxel"), ("k_azimuth", "k5_azimuth_idx"), ("k_spfh_generic", "k6_spfh_generic"), ("k_fpfh_generic", "k7_fpfh_generic"),
     ("k_lrf_from_cov", "k4_lrf_from_cov"), ("k_shot_lrf", "k4_shot_lrf"), ("k_lrf_", "k4_shot_lrf"), ("k_shot", "k5_shot"), ("k_fpfh", "k7_fpfh"), ("k_spfh_export", "k6_spfh_export"),
     ("k_spfh", "k6_spfh"), ("k_radius<2>", "k2_radius_slots"), ("k_radius<1>", "k2_radius_fill"), ("k_radius<0>", "k2_radius_count"),
     ("k_radius<true>", "k2_radius_fill"), ("k_radius<false>", "k2_radius_count"), ("k_export_lists", "k2_export_lists"),
@@ -49,7 +51,7 @@ def read_counter(path, counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    cmd = sys.argv[2] if len(sys.argv) > 2 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+    cmd = sys.argv[2] if len(sys.argv) > 2 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dropin --no-parity"
     bench_run = len(sys.argv) <= 2  # only the bench profile feeds bench.py's roofline.traffic
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     stats = defaultdict(lambda: [0, 0.0])
@@ -85,6 +87,7 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     if bench_run:
+        traffic["_source"] = f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{cmd}`)"
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
