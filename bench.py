@@ -247,28 +247,54 @@ def main() -> int:
                          f"(--oversubscribe runs a functional test with a host-staged exchange)")
     eng = s.Engine(local_rank % n_dev)
     exchange = "none (descriptor pass only)"
+    rccl_ranks = 0
+
+    def make_host_staged_allgather():
+        import torch
+
+        def host_staged_allgather(buf, bytes_per_rank):
+            flat = buf.to_host().reshape(-1).view(np.uint8)
+            mine = torch.from_numpy(flat[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy())
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
+            buf.from_host(flat.view(buf.dtype).reshape(buf.shape))
+
+        return host_staged_allgather
+
     if not emulated:
         if oversub:
             exchange = "gloo, staged through host memory (oversubscribed functional test, NOT RCCL)"
-            import torch
-
-            def host_staged_allgather(buf, bytes_per_rank):
-                flat = buf.to_host().reshape(-1).view(np.uint8)
-                mine = torch.from_numpy(flat[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy())
-                parts = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(parts, mine)
-                flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
-                buf.from_host(flat.view(buf.dtype).reshape(buf.shape))
-
-            eng.allgather = host_staged_allgather
+            eng.allgather = make_host_staged_allgather()
             if args.spfh_exchange == "allgather":
                 raise SystemExit("--oversubscribe supports the halo SPFH exchange only")
         else:
-            ids = [eng.comm_unique_id() if rank == 0 else None]
+            # RCCL communicator -- one rank too, so that ncclAllGather really executes.  The descriptor pass (`value`)
+            # needs no collective; if the communicator cannot be built on this node the exchange phase still runs,
+            # staged through host memory, and the record says so instead of the whole bench dying.
+            err = ""
+            try:
+                ids = [eng.comm_unique_id() if rank == 0 else None]
+                if dist is not None:
+                    dist.broadcast_object_list(ids, src=0)
+                eng.comm_init(ids[0], world, rank)
+            except Exception as exc:  # noqa: BLE001 -- reported in the record
+                err = f"{type(exc).__name__}: {exc}"
+            errs = [err]
             if dist is not None:
-                dist.broadcast_object_list(ids, src=0)
-            eng.comm_init(ids[0], world, rank)  # RCCL communicator; one rank too, so ncclAllGather really executes
-            exchange = f"RCCL ncclAllGather over {world} rank(s)"
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+            if any(errs):
+                first = next(e for e in errs if e)
+                if dist is None:
+                    raise SystemExit(f"RCCL communicator: {first}")
+                exchange = f"gloo, staged through host memory -- RCCL communicator failed ({first[:200]})"
+                eng.allgather = make_host_staged_allgather()
+                if args.spfh_exchange == "allgather":
+                    raise SystemExit("SPFH all-gather needs RCCL: " + first)
+            else:
+                exchange = f"RCCL ncclAllGather over {world} rank(s)"
+                rccl_ranks = world
 
     n_total = args.points_per_gpu * world
     radius = args.radius * world ** (-1.0 / 3.0)
@@ -423,7 +449,7 @@ def main() -> int:
             flop = 2.0 * cap * gathered * 352
             out["exchange_match"] = {
                 "what": "BASELINE config 5 tail on SHOT rows: subset gather, all-gather of reference rows + labels, sharded K8",
-                "rccl_ranks": world if not oversub else 0,
+                "rccl_ranks": rccl_ranks,
                 "exchange": exchange,
                 "subset_keypoints_total": int(total_rows),
                 "rows_per_rank_padded": cap,
