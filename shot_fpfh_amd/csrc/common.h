@@ -153,6 +153,11 @@ struct sf_cloud {
     // original order (as uploaded)
     double *xyz_orig = nullptr;     // n x 3 AoS
     double *nrm_orig = nullptr;     // n x 3 AoS or null
+    // bounding box of the uploaded points: a property of the (immutable) cloud, computed by the first grid build and
+    // kept -- every later build (another radius, a k-NN retry, the next pass over a resident cloud) skips the
+    // reduction kernels and the device-to-host read-back of their six numbers
+    bool bbox_known = false;
+    double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
     // grid
     double cell = 0.0;              // actual cell edge used
     double inv_cell = 0.0;

@@ -262,7 +262,15 @@ int sf_cloud_bbox_raw(sf_ctx *ctx, const double *xyz_dev, int64_t n, double lo[3
     return SF_OK;
 }
 
-int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3]) { return sf_cloud_bbox_raw(ctx, c->xyz_orig, c->n, lo, hi); }
+int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3])
+{
+    if (!c->bbox_known) {
+        SF_CHECK(sf_cloud_bbox_raw(ctx, c->xyz_orig, c->n, c->bbox_lo, c->bbox_hi));
+        c->bbox_known = true; // (sf_cloud_upload is the only writer of xyz_orig)
+    }
+    for (int a = 0; a < 3; ++a) { lo[a] = c->bbox_lo[a]; hi[a] = c->bbox_hi[a]; }
+    return SF_OK;
+}
 
 // Common grid build.  block_end < 0: the whole cloud.  Otherwise only the z-layers of cells that the queries at
 // cell-sorted positions [block_begin, block_end) can reach within `reach` cells are sorted and gathered -- the
