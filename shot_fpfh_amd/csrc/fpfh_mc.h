@@ -163,8 +163,13 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     int rpad[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of bb = 7: bin 127
+    // A lane's four limb rows are combined in INTEGER arithmetic first: |R| <= 127 * 128 * 255 < 2^22, so
+    // (R[r+1] << 7) + R[r] and the same combination of the padding column stay below 2^30 and their difference fits an
+    // int32 exactly -- two shift-adds and a subtraction per pair of limbs instead of a subtraction, a conversion and a
+    // float64 FMA per limb.
+    const int pad01 = (rpad[1] << 7) + rpad[0], pad23 = (rpad[3] << 7) + rpad[2];
     const double p0 = ldexp(1.0, 28 * kb - S); // 2^(7 (4 g) - S)
-    const double f0 = p0, f1 = p0 * 128.0, f2 = p0 * 16384.0, f3 = p0 * 2097152.0;
+    const double f0 = p0, f2 = p0 * 16384.0;
     const double kd = (double)k;
     double inv_k = __builtin_amdgcn_rcp(kd);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
@@ -173,10 +178,9 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     double part[8];
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) {
-        double v = (double)(acc[bb][0] - rpad[0]) * f0;
-        v = __builtin_fma((double)(acc[bb][1] - rpad[1]), f1, v);
-        v = __builtin_fma((double)(acc[bb][2] - rpad[2]), f2, v);
-        part[bb] = __builtin_fma((double)(acc[bb][3] - rpad[3]), f3, v);
+        const int e01 = ((acc[bb][1] << 7) + acc[bb][0]) - pad01;
+        const int e23 = ((acc[bb][3] << 7) + acc[bb][2]) - pad23;
+        part[bb] = __builtin_fma((double)e23, f2, (double)e01 * f0);
     }
     // sum over the four limb groups g = kb, transposing as we go: after the exchange with lane ^ 32 a lane keeps only
     // the blocks bb = 4 (kb >> 1) + {0..3}, after the one with lane ^ 16 only bb = 4 (kb >> 1) + 2 (kb & 1) + {0, 1}
