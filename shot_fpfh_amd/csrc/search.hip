@@ -76,34 +76,31 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
                                                 int64_t m, double r2, int cap, int32_t *__restrict__ count,
                                                 int64_t *__restrict__ offset, int32_t *__restrict__ idx)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
-    if (q >= m) return;
-    const double px = qx[q], py = qy[q], pz = qz[q];
+    // A wave serves FOUR consecutive queries.  The run tables of all four are built at once, one query per 16-lane
+    // DPP row (lanes 0..8 of a row describe its query's nine runs): the ~150 instructions of that set-up -- band gaps,
+    // square root, cell look-ups, scan -- are executed once per four queries instead of once per query, where they were
+    // 40 % of the kernel's (issue-bound) vector instructions.  The candidate sweeps then run query after query with the
+    // whole wave, as before.
+    const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
+    const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 4);
+    if (q0 >= m) return;
+    const int nq = (int)(m - q0 < 4 ? m - q0 : 4);
+    const int64_t qm = q0 + (rw < nq ? rw : 0);
+    const double pxv = qx[qm], pyv = qy[qm], pzv = qz[qm]; // this row's query
     int y0, y1, z0, z1;
-    stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
-    stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
-    // the bounds are wave-uniform but were computed with (vector) float64 instructions: hand them to the
-    // scalar unit so that everything derived from them is scalar
-    y0 = sf_uniform(y0); y1 = sf_uniform(y1);
-    z0 = sf_uniform(z0); z1 = sf_uniform(z1);
-    int total = 0;
-    const int64_t out = MODE == 1 ? offset[q] : q * (int64_t)cap;
-    const int room = MODE == 2 ? cap : 0x7fffffff;
-    // The stencil is up to 9 runs of consecutive positions, one per (cz, cy) row of cells, ~80 candidates each at
-    // C3.  Swept run by run, 128 candidates per step, a step is barely half full; so the runs are laid end to end
-    // in units of candidate PAIRS (a pair = one even-aligned 16-byte load) and every step takes the next 64 pairs,
-    // whichever runs they fall in: ~6 full steps instead of ~10 partial ones.  Everything a lane needs to find its
-    // pair is vector work -- lanes 0..8 each describe one run, a DPP scan gives the runs' first pair slots, the
-    // eight interior boundaries go to SGPRs once per query -- because the scalar unit is shared by the whole CU
-    // and per-step scalar bookkeeping is what sank an earlier packed variant.
-    __shared__ int4 runs[4][12];
-    int4 *const tab = runs[threadIdx.x >> 6];
-    int first_slot = 0; // lane r < 9: first pair slot of run r; lane 8 + 1 ... : total
+    stencil_bounds(pyv, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
+    stencil_bounds(pzv, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
+    // The stencil is up to 9 runs of consecutive positions, one per (cz, cy) row of cells.  The runs are laid end to
+    // end in units of candidate PAIRS (a pair = one even-aligned 16-byte load) and every step of a sweep takes the next
+    // 64 pairs, whichever runs they fall in.  Everything a lane needs to find its pair is vector work -- a DPP scan
+    // gives the runs' first pair slots, the table goes to LDS -- because the scalar unit is shared by the whole CU.
+    __shared__ int4 runs[4][4][12];
+    int4(*const tabs)[12] = runs[threadIdx.x >> 6];
+    int first_slot = 0; // lane r < 9 of a row: first pair slot of run r; lane 9: the total
     {
-        const int r = lane < 9 ? lane : 8;
+        const int r = sl < 9 ? sl : 8;
         const int cz = z0 + r / 3, cy = y0 + r % 3;
-        bool ok = lane < 9 && cz <= z1 && cy <= y1;
+        bool ok = sl < 9 && rw < nq && cz <= z1 && cy <= y1;
         const int64_t row = ((int64_t)(ok ? cz : z0) * g.dim[1] + (ok ? cy : y0)) * g.dim[0];
         // The row (cy, cz) of cells is the band [lo + c edge, lo + (c + 1) edge) in y and in z.  A point of it within r
         // of the query is at least (dy, dz) away in those two axes -- the gaps between the query and the bands -- so
@@ -114,69 +111,77 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
         // band edges, so the sweep can only be wider than necessary, never narrower.
         const double slack = 1e-9 * g.cell;
         const double by0 = g.lo[1] + (double)cy * g.cell, bz0 = g.lo[2] + (double)cz * g.cell;
-        const double dy = fmax(fmax(by0 - py, py - (by0 + g.cell)) - slack, 0.0);
-        const double dz = fmax(fmax(bz0 - pz, pz - (bz0 + g.cell)) - slack, 0.0);
+        const double dy = fmax(fmax(by0 - pyv, pyv - (by0 + g.cell)) - slack, 0.0);
+        const double dz = fmax(fmax(bz0 - pzv, pzv - (bz0 + g.cell)) - slack, 0.0);
         const double w2 = (r2 * (1.0 + 1e-9) - dy * dy) - dz * dz;
         ok = ok && w2 >= 0.0;
         const double w = sf_sqrt_fast(fmax(w2, 0.0)) * (1.0 + 1e-9) + slack;
         int s = 0, e = 0;
-        if (lane < 9) {
-            s = cell_start[row + sf_cell_coord(px - w, g.lo[0], g.inv_cell_x, g.dim[0])];
-            e = cell_start[row + sf_cell_coord(px + w, g.lo[0], g.inv_cell_x, g.dim[0]) + 1];
+        if (sl < 9) {
+            s = cell_start[row + sf_cell_coord(pxv - w, g.lo[0], g.inv_cell_x, g.dim[0])];
+            e = cell_start[row + sf_cell_coord(pxv + w, g.lo[0], g.inv_cell_x, g.dim[0]) + 1];
         }
         if (!ok) { s = 0; e = 0; }
         const int base = s & ~1; // pairs start at an EVEN position: every 16-byte load is naturally aligned
         const int npairs = (e - base + 1) >> 1;
-        // inclusive scan of npairs over lanes 0..15 (row_shr DPP steps), then exclusive = inclusive - own
+        // inclusive scan of npairs inside the 16-lane row (row_shr DPP steps), then exclusive = inclusive - own
         int inc = npairs;
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false); // row_shr:1
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false); // row_shr:2
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false); // row_shr:4
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false); // row_shr:8
         first_slot = inc - npairs;
-        if (lane < 12) tab[lane] = make_int4(base - 2 * first_slot, s, e, first_slot); // j = .x + 2 * slot; .w: first slot
+        if (sl < 12) tabs[rw][sl] = make_int4(base - 2 * first_slot, s, e, first_slot); // j = .x + 2 * slot; .w: first slot
     }
-    // two of the boundaries between runs and the number of pair slots, as scalars
-    const int b4 = __builtin_amdgcn_readlane(first_slot, 4), b8 = __builtin_amdgcn_readlane(first_slot, 8);
-    const int nslots = __builtin_amdgcn_readlane(first_slot, 9); // lane 9 has npairs = 0: its exclusive sum is the total
-    __builtin_amdgcn_wave_barrier(); // the table is written and read by this wave only
-    for (int f0 = 0; f0 < nslots; f0 += 64) {
-        const int f = f0 + lane;
-        // run of slot f = last run whose first slot is <= f: a three-level binary search, the first level against a
-        // scalar, the other two against the first-slot column of the table in LDS (an LDS read costs the vector
-        // pipe one instruction; eight compare-and-add pairs cost it sixteen and more)
-        int r = f >= b4 ? 4 : 0;
-        r += f >= tab[r + 2].w ? 2 : 0;
-        r += f >= tab[r + 1].w ? 1 : 0;
-        r = f >= b8 ? 8 : r;
-        const int4 t = tab[r];
-        const bool live = f < nslots;
-        const int j = live ? t.x + 2 * f : 0; // idle lanes of the last step load pair 0 (always there)
-        const bool in0 = live & (j >= t.y), in1 = live & (j + 1 < t.z);
-        const double2 X = *reinterpret_cast<const double2 *>(xs + j);
-        const double2 Y = *reinterpret_cast<const double2 *>(ys + j);
-        const double2 Z = *reinterpret_cast<const double2 *>(zs + j);
-        const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
-        const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
-        // both distances are evaluated unconditionally (bitwise &): a short-circuit would let the compiler
-        // sink half of each 16-byte load into a branch and split it into two 8-byte loads
-        const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
-        const bool hit0 = in0 & (d2a <= r2);
-        const bool hit1 = in1 & (d2b <= r2);
-        const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-        if (MODE != 0) {
-            const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
-            if (hit0 && pos < room) idx[out + pos] = j;
-            const int pos1 = pos + (hit0 ? 1 : 0);
-            if (hit1 && pos1 < room) idx[out + pos1] = j + 1;
+    __builtin_amdgcn_wave_barrier(); // the tables are written and read by this wave only
+    for (int qi = 0; qi < nq; ++qi) {
+        const int64_t q = q0 + qi;
+        const int4 *const tab = tabs[qi];
+        const double px = __shfl(pxv, 16 * qi), py = __shfl(pyv, 16 * qi), pz = __shfl(pzv, 16 * qi);
+        // two of the boundaries between runs and the number of pair slots, as scalars
+        const int b4 = __shfl(first_slot, 16 * qi + 4), b8 = __shfl(first_slot, 16 * qi + 8);
+        const int nslots = sf_uniform(__shfl(first_slot, 16 * qi + 9)); // lane 9 has npairs = 0: its exclusive sum is the total
+        int total = 0;
+        const int64_t out = MODE == 1 ? offset[q] : q * (int64_t)cap;
+        const int room = MODE == 2 ? cap : 0x7fffffff;
+        for (int f0 = 0; f0 < nslots; f0 += 64) {
+            const int f = f0 + lane;
+            // run of slot f = last run whose first slot is <= f: a three-level binary search, the first level against a
+            // scalar, the other two against the first-slot column of the table in LDS (an LDS read costs the vector
+            // pipe one instruction; eight compare-and-add pairs cost it sixteen and more)
+            int r = f >= b4 ? 4 : 0;
+            r += f >= tab[r + 2].w ? 2 : 0;
+            r += f >= tab[r + 1].w ? 1 : 0;
+            r = f >= b8 ? 8 : r;
+            const int4 t = tab[r];
+            const bool live = f < nslots;
+            const int j = live ? t.x + 2 * f : 0; // idle lanes of the last step load pair 0 (always there)
+            const bool in0 = live & (j >= t.y), in1 = live & (j + 1 < t.z);
+            const double2 X = *reinterpret_cast<const double2 *>(xs + j);
+            const double2 Y = *reinterpret_cast<const double2 *>(ys + j);
+            const double2 Z = *reinterpret_cast<const double2 *>(zs + j);
+            const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
+            const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
+            // both distances are evaluated unconditionally (bitwise &): a short-circuit would let the compiler
+            // sink half of each 16-byte load into a branch and split it into two 8-byte loads
+            const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
+            const bool hit0 = in0 & (d2a <= r2);
+            const bool hit1 = in1 & (d2b <= r2);
+            const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+            if (MODE != 0) {
+                const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
+                if (hit0 && pos < room) idx[out + pos] = j;
+                const int pos1 = pos + (hit0 ? 1 : 0);
+                if (hit1 && pos1 < room) idx[out + pos1] = j + 1;
+            }
+            total += __popcll(m0) + __popcll(m1);
         }
-        total += __popcll(m0) + __popcll(m1);
-    }
-    if (lane == 0) {
-        if (MODE != 1) count[q] = total;
-        if (MODE == 2) {
-            offset[q] = out;
-            if (q == m - 1) offset[m] = out + cap;
+        if (lane == 0) {
+            if (MODE != 1) count[q] = total;
+            if (MODE == 2) {
+                offset[q] = out;
+                if (q == m - 1) offset[m] = out + cap;
+            }
         }
     }
 }
@@ -413,7 +418,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     SF_HIP(hipMemsetAsync(nb->count, 0, (size_t)(m + 1) * sizeof(int32_t), ctx->stream));
     SF_HIP(hipMemsetAsync(nb->offset, 0, (size_t)(m + 1) * sizeof(int64_t), ctx->stream));
     sf_grid_desc g = sf_make_grid_desc(c);
-    const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4))), block(256);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 16))), block(256); // 4 waves x 4 queries
     if (!m) {
         SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)8));
         return SF_OK;
