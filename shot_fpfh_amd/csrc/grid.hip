@@ -302,12 +302,12 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         if (!too_long && tot <= 67108864.0) { ncell = (int64_t)tot; break; }
         edge *= 2.0; // coarser cells stay correct (edge >= radius), only slower
     }
-    // Along x the cells are cut xsub times finer (a power of two, so a fine cell index / xsub is exactly the index of
+    // Along x the cells are cut xsub times finer (up to 16, SF_XSUB overrides; a power of two, so a fine cell index / xsub is exactly the index of
     // the edge-sized cell): the radius search clips each of its nine runs to the x range its ball can reach in that
     // row of cells (search.hip), which needs cell boundaries every edge / xsub.  Rows stay contiguous runs of positions
     // and z-layers stay slabs, so nothing else changes but the row stride.
     c->xsub = 1;
-    static const int xsub_max = [] { const char *e = getenv("SF_XSUB"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 16 ? v : 4; }();
+    static const int xsub_max = [] { const char *e = getenv("SF_XSUB"); const int v = e ? atoi(e) : 16; return v >= 1 && v <= 16 ? v : 16; }();
     while (c->xsub < xsub_max && (double)ncell * 2.0 <= 67108864.0 && c->dim[0] * 2 <= 2097152) {
         c->xsub *= 2;
         c->dim[0] *= 2;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
         // The row (cy, cz) of cells is the band [lo + c edge, lo + (c + 1) edge) in y and in z.  A point of it within r
         // of the query is at least (dy, dz) away in those two axes -- the gaps between the query and the bands -- so
         // its x lies within w = sqrt(r^2 - dy^2 - dz^2) of the query's: only the FINE x cells (xsub per edge) that
-        // [px - w, px + w] touches are swept, 12-15 edge-lengths of cells per query instead of 27.  The cell of a
+        // [px - w, px + w] touches are swept, 12-14 edge-lengths of cells per query instead of 27.  The cell of a
         // coordinate is a monotone function of it, so every point with px - w <= x <= px + w lies in a cell between
         // the cells of the two ends; the gaps shrink and w grows by 1e-9 relative, far above any rounding of the
         // band edges, so the sweep can only be wider than necessary, never narrower.
