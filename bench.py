@@ -442,13 +442,33 @@ def main() -> int:
             tt = torch.from_numpy(stats)
             dist.all_reduce(tt)
             stats = tt.numpy()
+        # the (scan, reference) pairs of every rank on every rank (one more small all-gather), then the registration
+        # they are for: RANSAC over the WHOLE match set, scored on this rank's GPU (K9)
+        t0 = time.perf_counter()
+        all_s, all_r = sub.gather_matches()
+        t_pairs = time.perf_counter() - t0
+        reg = None
+        if lead and all_s.size >= 4:
+            import shot_fpfh_amd.matching.ransac as R
+            from shot_fpfh_amd.matching import ransac_on_matches
+
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(perm.size)
+            R.rng = np.random.default_rng(seed=72)
+            t0 = time.perf_counter()
+            ratio_m, tf_m = ransac_on_matches(all_s, inv[all_r], points, ref_pts, n_draws=2000, draw_size=4,
+                                              distance_threshold=0.01, disable_progress_bar=True, engine=eng)
+            reg = {"matches": int(all_s.size), "draws": 2000, "seconds": time.perf_counter() - t0, "inlier_ratio": float(ratio_m),
+                   "rotation_err": float(np.abs(tf_m.rotation - rot).max()),
+                   "translation_err": float(np.abs(tf_m.translation - np.asarray(C4_T)).max())}
         if lead:
             k8 = {k: v[1] / max(args.match_steps, 1) for k, v in mrep.items() if v[1] > 0}
             k8_ms = sum(v for k, v in k8.items() if k.startswith("k8_"))
             gathered = cap * world
             flop = 2.0 * cap * gathered * 352
             out["exchange_match"] = {
-                "what": "BASELINE config 5 tail on SHOT rows: subset gather, all-gather of reference rows + labels, sharded K8",
+                "what": "BASELINE config 5 tail on SHOT rows: subset gather, all-gather of reference rows + labels, sharded K8, "
+                        "all-gather of the match pairs, RANSAC over all of them",
                 "rccl_ranks": rccl_ranks,
                 "exchange": exchange,
                 "subset_keypoints_total": int(total_rows),
@@ -463,6 +483,8 @@ def main() -> int:
                                 "note": "2*m1*m2*d flop of the FP16 pre-filter pass; exact FP64 re-ranking of the survivors included in the time"},
                 "matches": int(stats[1]),
                 "matches_recovering_true_correspondence": float(stats[0] / max(stats[1], 1.0)),
+                "match_pairs_allgather_s": t_pairs,
+                "registration_from_all_matches": reg,
                 "partner_cloud_descriptor_pass_s": t_prep,
             }
         sub.close()

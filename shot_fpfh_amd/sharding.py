@@ -256,6 +256,7 @@ class SubsetMatchJob:
         self.sel: DeviceArray = engine.empty((self.rows,), np.int64)
         self.ref_labels: DeviceArray = engine.empty((total,), np.int64)
         self.scan_labels = np.full(self.rows, -1, dtype=np.int64)
+        self._pairs: Optional[DeviceArray] = None
 
     def _padded(self, values, what: str) -> np.ndarray:
         v = np.ascontiguousarray(values, dtype=np.int64)
@@ -290,7 +291,27 @@ class SubsetMatchJob:
         labels = self.ref_labels.to_host()
         return self.scan_labels[rows - self.job.scan_plan.begin], labels[idx]
 
+    def gather_matches(self) -> tuple[np.ndarray, np.ndarray]:
+        """Every rank's matches on every rank: one more all-gather, of `rows_per_rank` (scan label, reference label)
+        pairs per rank (-1 marks an empty scan row).  What a caller needs to run RANSAC on the whole match set."""
+        eng = self.engine
+        s_lab, r_lab = self.matches()
+        mine = np.full((self.rows, 2), -1, dtype=np.int64)
+        mine[: s_lab.shape[0], 0], mine[: s_lab.shape[0], 1] = s_lab, r_lab
+        if self._pairs is None:
+            self._pairs = eng.empty((self.rows * self.world, 2), np.int64)
+        block = eng.empty((self.rows, 2), np.int64).from_host(mine)
+        try:
+            self._pairs.copy_from_device(block, dst_byte_offset=self.rank * self.rows * 16)
+            eng.allgather(self._pairs, self.rows * 16)
+            allp = self._pairs.to_host()
+        finally:
+            block.free()
+        keep = allp[:, 0] >= 0
+        return allp[keep, 0], allp[keep, 1]
+
     def close(self) -> None:
         self.job.close()
-        for a in (self.scan_sub, self.ref_sub, self.sel, self.ref_labels):
-            a.free()
+        for a in (self.scan_sub, self.ref_sub, self.sel, self.ref_labels, self._pairs):
+            if a is not None:
+                a.free()

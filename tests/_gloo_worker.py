@@ -62,6 +62,9 @@ def subset_main(out_path, rank, world):
     job.run()
     gathered = [None] * world
     dist.all_gather_object(gathered, job.matches())
+    all_s, all_r = job.gather_matches()  # the same pairs through the engine's own all-gather, on every rank
+    assert np.array_equal(all_s, np.concatenate([g[0] for g in gathered]))
+    assert np.array_equal(all_r, np.concatenate([g[1] for g in gathered]))
     if rank == 0:
         np.savez(out_path, s=np.concatenate([g[0] for g in gathered]), r=np.concatenate([g[1] for g in gathered]),
                  scan=scan, ref=ref, perm=perm, in_subset=in_subset)

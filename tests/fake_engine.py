@@ -23,6 +23,10 @@ class FakeArray:
         self.a[...] = x
         return self
 
+    @property
+    def dtype(self):
+        return self.a.dtype
+
     def copy_from_device(self, src, dst_byte_offset=0, nbytes=None):
         flat, sflat = self.a.reshape(-1).view(np.uint8), src.a.reshape(-1).view(np.uint8)
         nbytes = src.nbytes if nbytes is None else nbytes
