@@ -966,6 +966,13 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
     __shared__ unsigned long long slot[704];
     const int64_t q = sf_xcd_block();
     if (q >= m) return;
+    // The kernel is instantiated for the LONGEST list of the launch (a 1M-point uniform cloud at 110 neighbours on average
+    // has one of 160+), but nearly every keypoint fits one chunk less: a wave-uniform branch picks the body that
+    // matches THIS keypoint, so the gather, votes and distance tests of an empty last chunk are never issued.
+    if (NCH >= 3 && sf_uniform(cnt[q]) <= 64 * (NCH - 1)) {
+        shot_cached_body<(NCH >= 3 ? NCH - 1 : NCH), FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
+        return;
+    }
     shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
 }
 
