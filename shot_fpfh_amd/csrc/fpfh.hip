@@ -355,11 +355,12 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
 
 #include "fpfh_mc.h"
 
-// waves_per_eu(7, 8): the 3- and 4-chunk instantiations need 74 registers left to themselves, two more than seven waves
-// per SIMD allow; asked for seven the allocator fits them into 72 without spilling, and the kernel -- which lives on
-// the number of waves that cover its LDS-DMA round trips -- runs 8.5 % faster at C3 (1.48 -> 1.36 ms).
+// waves_per_eu(8, 8): left to itself the allocator gives the 3-chunk instantiation 74 registers (6 waves per SIMD); asked
+// for eight waves it fits 64 without spilling (the 4-chunk form spills five dwords), and the kernel -- which lives on the
+// number of waves that cover its LDS-DMA round trips -- runs 11 % faster at C3 (1.48 -> 1.31 ms).  LDS (4.6 KB per wave)
+// allows 8.5 waves per SIMD.  The same request made K5 and K6 spill and lose (2.13 / 0.98 ms instead of 1.70 / 0.82).
 template <int NKS>
-__global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+__global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
