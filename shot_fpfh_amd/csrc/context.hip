@@ -38,7 +38,12 @@ extern "C" sf_ctx *sf_create(int device)
     sf_ctx *ctx = new sf_ctx();
     ctx->device = device;
     e = hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->streams[1], hipStreamNonBlocking);
+    // the side stream carries small, latency-bound kernels that are meant to disappear under a large one on the main
+    // stream (the frame eigen-solves under K7): at equal priority the large kernel's waves crowd them out and the small
+    // kernel ends AFTER it, delaying whatever joins both -- so the side stream gets the higher priority
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->streams[1], hipStreamNonBlocking, prio_hi);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming);
     if (e != hipSuccess) {
         sf_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));

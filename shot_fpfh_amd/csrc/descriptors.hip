@@ -1170,7 +1170,10 @@ extern "C" int sf_shot_serial(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t min
 namespace {
 // K4 when the moments come from K6 (sf_spfh_compute_moments): one LAPACK-compatible 3 x 3 eigen-solve per lane, the
 // largest / smallest eigenvectors stored as k_shot_lrf does in its raw mode (the fused K5 completes the frame).
-__global__ __launch_bounds__(256) void k_lrf_from_cov(const double *__restrict__ cov, int64_t m, double *__restrict__ lrf)
+// It is meant to run on the side stream UNDER K7, which holds eight 64-register waves on every SIMD: a wave of this kernel
+// only ever finds room if it fits the hole ONE retiring K7 wave leaves (<= 64 VGPRs, single-wave workgroups) -- at 84
+// registers in 4-wave workgroups it was starved until K7's tail and ended after it (1.43 ms against K7's 1.33 ms).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lrf_from_cov(const double *__restrict__ cov, int64_t m, double *__restrict__ lrf)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= m) return;
@@ -1235,7 +1238,7 @@ extern "C" int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const
     }
     SF_CHECK(stage_out(tmp, out, (size_t)m * SF_SHOT_LEN, flags, &dout));
     if (m) {
-        SF_LAUNCH(ctx, "k4_lrf_from_cov", k_lrf_from_cov, dim3((unsigned)sf_div_up(m, 256)), dim3(256), cov_dev, m, dlrf);
+        SF_LAUNCH(ctx, "k4_lrf_from_cov", k_lrf_from_cov, dim3((unsigned)sf_div_up(m, 64)), dim3(64), cov_dev, m, dlrf);
     }
     SF_CHECK(launch_shot(ctx, c, nb, dlrf, normalize, min_nb, dout, true));
     if (own_lrf && lrf && m) SF_HIP(hipMemcpyAsync(lrf, own_lrf, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1253,7 +1256,7 @@ extern "C" int sf_lrf_raw_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, co
     if (nb->qrow) { sf_set_error("sf_lrf_raw_from_moments: needs a self search"); return SF_ERR_UNSUPPORTED; }
     const int64_t m = nb->m;
     if (m) {
-        SF_LAUNCH(ctx, "k4_lrf_from_cov", k_lrf_from_cov, dim3((unsigned)sf_div_up(m, 256)), dim3(256), cov_dev, m, lrf_dev);
+        SF_LAUNCH(ctx, "k4_lrf_from_cov", k_lrf_from_cov, dim3((unsigned)sf_div_up(m, 64)), dim3(64), cov_dev, m, lrf_dev);
     }
     return SF_OK;
 }
