@@ -361,6 +361,17 @@ __device__ inline int azimuth_octant(double x, double y) // get_azimuth_idx, sho
     return 4 * (int)a + 2 * (int)b + (int)c;
 }
 
+// The same function for a whole wave with the special cases (a zero coordinate, |x| = |y|, a product that underflows)
+// moved behind a wave-uniform test: off them the three bits are two sign tests and one magnitude comparison.
+__device__ inline int azimuth_octant_wave(double x, double y)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const bool special = !(fmin(ax, ay) > 1e-150) || ax == ay; // (also catches NaN)
+    if (__ballot(special)) return azimuth_octant(x, y);
+    const bool a = y > 0.0, xp = x > 0.0, lt = ax < ay;
+    return 4 * (int)a + 2 * (int)(xp != a) + (int)(xp == a ? lt : !lt);
+}
+
 // get_azimuth_idx as an elementwise function (shot.py:51-70): the very device function K5 bins with
 __global__ void k_azimuth_idx(const double *__restrict__ x, const double *__restrict__ y, int64_t n, int64_t *__restrict__ out)
 {
@@ -667,26 +678,33 @@ __device__ inline double sf_acos_quadrants(double z)
     return __builtin_fma(b, as, a);
 }
 
+__device__ inline double sf_dot3(double a0, double a1, double a2, double b0, double b1, double b2)
+{
+    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+}
+
 __device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
                                      const double *E, double half_r, shot_kept &o)
 {
     double rho, inv_rho;
     sf_sqrt_rsqrt(d2, rho, inv_rho);
-    const double lx = (cx * E[0] + cy * E[3]) + cz * E[6];
-    const double ly = (cx * E[1] + cy * E[4]) + cz * E[7];
-    const double lz = (cx * E[2] + cy * E[5]) + cz * E[8];
-    double cosine = (nx * E[2] + ny * E[5]) + nz * E[8];
+    // (neighbors - point) @ eigenvectors and normals @ eigenvectors[:, 2] (shot.py:214-215) as the multiply-add chain an
+    // FMA BLAS kernel runs over the inner index -- what the reference's NumPy does on any current x86 / OpenBLAS
+    const double lx = sf_dot3(cx, cy, cz, E[0], E[3], E[6]);
+    const double ly = sf_dot3(cx, cy, cz, E[1], E[4], E[7]);
+    const double lz = sf_dot3(cx, cy, cz, E[2], E[5], E[8]);
+    double cosine = sf_dot3(nx, ny, nz, E[2], E[5], E[8]);
     cosine = fmin(fmax(cosine, -1.0), 1.0);
     const double cpos = (cosine + 1.0) * 11.0 / 2.0 - 0.5;
     const double cf = rint(cpos);
     const int ci = (int)cf;
-    const int ti = azimuth_octant(lx, ly);
+    const int ti = azimuth_octant_wave(lx, ly);
     const int pi_ = lz > 0.0 ? 1 : 0;
     const int ri = rho > half_r ? 1 : 0; // (radius / 2 is exact: the host passes that very double)
     const double dc = cpos - cf;
     const int sc = (dc > 0.0) - (dc < 0.0);
-    int cin = (ci + sc) % 11;
-    if (cin < 0) cin += 11;
+    int cin = ci + sc; // -1 .. 11, wrapped as the reference's % 11 does
+    cin = cin < 0 ? 10 : (cin > 10 ? 0 : cin);
     // Offset from the octant's centre ray, in the octant's own frame: with a >= b the larger / smaller of |lx|, |ly|, the
     // point sits atan(b / a) in [0, pi/4] off the nearest axis and the centre ray pi/8 off it, so rotating (a, b) by
     // -pi/8 gives cross' / dot' = tan(angle off the centre).  Whether theta grows or shrinks with that angle alternates
@@ -815,8 +833,8 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const bool on = c * 64 + lane < k; // the query itself (c = 0) votes ">= 0", as in the reference
-            const double xo = (cx[c] * x0 + cy[c] * x1) + cz[c] * x2;
-            const double zo = (cx[c] * z0 + cy[c] * z1) + cz[c] * z2;
+            const double xo = sf_dot3(cx[c], cy[c], cz[c], x0, x1, x2);
+            const double zo = sf_dot3(cx[c], cy[c], cz[c], z0, z1, z2);
             xneg += __popcll(__ballot(on & (xo < 0.0)));
             zneg += __popcll(__ballot(on & (zo < 0.0)));
         }
@@ -944,8 +962,9 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         vals[u] = v;
         ss += v * v;
     }
-    const double nrm = sqrt(sf_wave_sum(ss));
-    const double scale = nrm > 0.0 ? (normalize ? 1.0 / nrm : 1.0) : 0.0; // shot.py:301-305
+    double nrm, inv_nrm; // (the short root / inverse-root pair: ~1 ulp each, a third of sqrt() followed by a division)
+    sf_sqrt_rsqrt(sf_wave_sum(ss), nrm, inv_nrm);
+    const double scale = nrm > 0.0 ? (normalize ? inv_nrm : 1.0) : 0.0; // shot.py:301-305
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int b = lane + 64 * u;
