@@ -127,21 +127,28 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
     };
     if (NCH > 0) {
         constexpr int NC = NCH > 0 ? NCH : 1;
+        // (instantiated for the longest list of the launch; a chunk past THIS point's list -- the last one for nine points
+        // in ten at C3 -- is skipped wave-uniformly: no index load, no gather)
+        const int ku = sf_uniform(k);
         int jj[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int t = c * 64 + lane;
-            jj[c] = t < k ? idx[s + t] : -1;
+            jj[c] = -1;
+            if (c == 0 || c * 64 < ku) jj[c] = t < k ? idx[s + t] : -1;
         }
         double cx[NC], cy[NC], cz[NC], ax[NC], ay[NC], az[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int j = jj[c] < 0 ? 0 : jj[c];
-            sf_load_pn(rec, j, cx[c], cy[c], cz[c], ax[c], ay[c], az[c]);
+            cx[c] = cy[c] = cz[c] = ax[c] = ay[c] = az[c] = 0.0;
+            if (c == 0 || c * 64 < ku) {
+                const int j = jj[c] < 0 ? 0 : jj[c];
+                sf_load_pn(rec, j, cx[c], cy[c], cz[c], ax[c], ay[c], az[c]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            if (jj[c] >= 0) {
+            if ((c == 0 || c * 64 < ku) && jj[c] >= 0) {
                 if (cov) moments(cx[c] - px, cy[c] - py, cz[c] - pz);
                 pair(cx[c] - px, cy[c] - py, cz[c] - pz, ax[c], ay[c], az[c]);
             }

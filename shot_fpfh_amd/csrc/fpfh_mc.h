@@ -86,31 +86,40 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     int jv[NKS];
     double wv[NKS];
 #pragma unroll
+    // (the kernel is instantiated for the longest list of the launch; the chunks past THIS keypoint's list -- the last one
+    // for nine keypoints in ten -- are skipped wave-uniformly: no index load, no gather, no weight)
     for (int c = 0; c < NKS; ++c) {
         const int t = c * 64 + lane;
-        jv[c] = t < k ? idx[s + t] : -1;
+        jv[c] = -1;
+        if (c == 0 || c * 64 < k) jv[c] = t < k ? idx[s + t] : -1;
     }
     SF_MC_DMA(0) // in flight while the weights are computed
     double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
 #pragma unroll
     for (int c = 0; c < NKS; ++c) {
-        const int j = jv[c] < 0 ? 0 : jv[c];
-        const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j); // {x, y}, {z, k}: one 32-byte record
-        const double2 u0 = pp[0], u1 = pp[1];
-        gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
+        gx[c] = gy[c] = gz[c] = gk[c] = 0.0;
+        if (c == 0 || c * 64 < k) {
+            const int j = jv[c] < 0 ? 0 : jv[c];
+            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j); // {x, y}, {z, k}: one 32-byte record
+            const double2 u0 = pp[0], u1 = pp[1];
+            gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
+        }
     }
     double wmax = 0.0;
 #pragma unroll
     for (int c = 0; c < NKS; ++c) {
-        const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
-        const double d2 = (cx * cx + cy * cy) + cz * cz;
-        const double kd = gk[c], xx = d2 * (kd * kd);
-        const double y0 = __builtin_amdgcn_rsq(xx);
-        const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
-        const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
-        wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0; // 1 / (k_j d_j); d == 0 is masked out (fpfh.py:110-114)
+        wv[c] = 0.0;
+        if (c == 0 || c * 64 < k) {
+            const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
+            const double d2 = (cx * cx + cy * cy) + cz * cz;
+            const double kd = gk[c], xx = d2 * (kd * kd);
+            const double y0 = __builtin_amdgcn_rsq(xx);
+            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+            wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0; // 1 / (k_j d_j); d == 0 is masked out (fpfh.py:110-114)
+            wmax = fmax(wmax, wv[c]);
+        }
         jv[c] = jv[c] < 0 ? 0 : jv[c];
-        wmax = fmax(wmax, wv[c]);
     }
     wmax = sf_wave_max_nonneg(wmax);
     // fixed point: W = floor(w 2^S) < 2^63 with S = 62 - floor(log2 wmax)
