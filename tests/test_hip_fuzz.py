@@ -14,6 +14,8 @@ What is compared, and how strictly:
 import numpy as np
 import pytest
 
+from conftest import FAMILIES, _unit, family, load_golden
+
 pytestmark = pytest.mark.gpu
 
 
@@ -29,53 +31,6 @@ def O():
     from oracle import oracle
 
     return oracle
-
-
-def _unit(v):
-    return v / np.linalg.norm(v, axis=1)[:, None]
-
-
-def _f32grid(a):
-    return np.ascontiguousarray(a, dtype=np.float32).astype(np.float64)
-
-
-def family(name, n, rng):
-    """(points, normals, has_distance_ties, is_flat)"""
-    if name == "uniform":
-        p = rng.random((n, 3))
-    elif name == "clustered":  # a few tight blobs in a sparse background: densities two orders of magnitude apart
-        centres = rng.random((6, 3))
-        p = np.vstack([centres[rng.integers(0, 6, n - n // 5)] + 0.02 * rng.standard_normal((n - n // 5, 3)),
-                       rng.random((n // 5, 3))])
-    elif name == "lattice":  # spacing 1/16: squared distances are exact multiples of 2^-8 -> ties and on-radius points
-        side = int(round(n ** (1 / 3)))
-        g = np.arange(side) / 16.0
-        p = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
-    elif name == "plane":  # exactly z = 0.25
-        p = np.column_stack([rng.random((n, 2)), np.full(n, 0.25)])
-    elif name == "rough_plane":  # a tilted plane with 1e-3 roughness: flat but with a well-defined frame
-        uv = rng.random((n, 2))
-        p = np.column_stack([uv, 0.3 * uv[:, 0] - 0.2 * uv[:, 1] + 1e-3 * rng.standard_normal(n)])
-    elif name == "line":  # collinear points plus a little cloud around them so that lists are not all degenerate
-        t = rng.random((n, 1))
-        p = np.vstack([(t * np.array([[1.0, 0.5, 0.25]]))[: n // 2], rng.random((n - n // 2, 3))])
-    elif name == "duplicates":  # a fifth of the points occur two or three times
-        base = rng.random((n - 2 * (n // 5), 3))
-        p = np.vstack([base, base[: n // 5], base[: n // 5]])
-    elif name == "far_origin":  # 4 decimal digits of the mantissa eaten by the offset
-        p = rng.random((n, 3)) + np.array([[4096.0, -2048.0, 1024.0]])
-    elif name == "slab":  # one cell thick along z, a few along y
-        p = rng.random((n, 3)) * np.array([[1.0, 0.3, 0.004]])
-    else:
-        raise KeyError(name)
-    p = _f32grid(p) if name not in ("far_origin",) else np.ascontiguousarray(p)
-    nr = _unit(rng.standard_normal((p.shape[0], 3)))
-    if name in ("plane", "rough_plane"):
-        nr[: p.shape[0] // 2] = np.array([0.0, 0.0, 1.0])  # half the normals exactly along the plane's: alpha, theta on edges
-    return p, nr, name in ("lattice", "duplicates"), name in ("plane", "line", "lattice", "slab")
-
-
-FAMILIES = ["uniform", "clustered", "lattice", "plane", "rough_plane", "line", "duplicates", "far_origin", "slab"]
 
 
 def _radius_for(p, rng, target):
@@ -279,3 +234,28 @@ def test_grid_subsampling_partition_properties(eng, name):
         best = np.full(uniq.shape[0], np.inf)
         np.minimum.at(best, inv, d2)
         assert np.all(d2[sel] <= best[inv[sel]] * (1 + 1e-12) + 1e-300)
+
+
+# ---- the same families against the REFERENCE's own outputs (tests/golden/degenerate_families.npz, tools/gen_golden_r2b.py) ----
+@pytest.mark.parametrize("name", ["lattice", "plane", "rough_plane", "duplicates", "far_origin"])
+def test_degenerate_families_golden(eng, name):
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    g = load_golden("degenerate_families.npz")
+    p, nr, r = g[f"{name}_cloud"], g[f"{name}_normals"], float(g[f"{name}_radius"])
+    off, idx, dist = eng.cloud(p).radius_search(p, r).export(return_distance=True)
+    assert np.array_equal(off, g[f"{name}_offsets"]) and np.array_equal(idx, g[f"{name}_idx"])
+    assert np.array_equal(dist, g[f"{name}_dist"])
+    for nb in (4, 5):
+        got = s.compute_fpfh_descriptor(g[f"{name}_kp"], p, nr, r, nb)
+        assert np.abs(got - g[f"{name}_fpfh{nb}"]).max() < 1e-9, (name, nb)
+    if f"{name}_shot" in g.files:
+        kq = g[f"{name}_shot_kp"]
+        cloud = eng.cloud(p, nr)
+        nbq = cloud.radius_search(kq, r)
+        framed = nbq.counts() >= 5
+        assert np.abs(nbq.shot_lrf() - g[f"{name}_lrf"])[framed].max() < 1e-9
+        with ShotMultiprocessor(normalize=True, min_neighborhood_size=5, verbose=False) as sm:
+            d = sm.compute_descriptor_single_scale(p, nr, kq, r)
+        assert np.abs(d - g[f"{name}_shot"])[framed].max() < 1e-9

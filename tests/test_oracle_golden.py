@@ -245,3 +245,29 @@ def test_numpy_shaped_cpu_baseline_reproduces_the_reference():
     s = load_golden("shot_150.npz")
     d = NS.shot_numpy_shaped(s["cloud"], s["normals"], s["keypoints"], float(s["radius"]), True, 10, n_procs=2)
     assert np.abs(d - s["single_n1_m10"]).max() <= TOL
+
+
+# ---- degenerate cloud families against the reference's own outputs (tools/gen_golden_r2b.py) ---------------------------
+@pytest.mark.parametrize("name", ["lattice", "plane", "rough_plane", "duplicates", "far_origin"])
+def test_degenerate_families_golden(name):
+    """Lattice (neighbours exactly ON the radius, distance ties), exact plane with normals along the plane's (alpha = 0,
+    theta = 0 on histogram edges), rough plane, duplicated points, a cloud 4096 units from the origin: neighbour lists bit
+    for bit, FPFH (4 and 5 bins), local frames and SHOT rows as the reference produced them."""
+    from oracle import oracle as O
+
+    g = load_golden("degenerate_families.npz")
+    p, nr, r = g[f"{name}_cloud"], g[f"{name}_normals"], float(g[f"{name}_radius"])
+    off, idx, dist = O.radius_search(p, p, r, return_distance=True)
+    assert np.array_equal(off, g[f"{name}_offsets"]) and np.array_equal(idx, g[f"{name}_idx"])
+    assert np.array_equal(dist, g[f"{name}_dist"])
+    if name == "lattice":
+        assert (dist == np.sqrt(5.0 / 256.0)).any()  # the shell at exactly the radius is in the lists
+    for nb in (4, 5):
+        got = O.compute_fpfh_descriptor(g[f"{name}_kp"], p, nr, r, nb)
+        assert np.abs(got - g[f"{name}_fpfh{nb}"]).max() < 1e-12
+    if f"{name}_shot" in g.files:
+        kq = g[f"{name}_shot_kp"]
+        framed = np.diff(O.radius_search(p, kq, r)[0]) >= 5  # fewer points span no frame (two zero eigenvalues)
+        assert np.abs(O.shot_lrf(p, kq, r) - g[f"{name}_lrf"])[framed].max() < 1e-12
+        d = O.shot_single_scale(p, nr, kq, r, normalize=True, min_neighborhood_size=5)
+        assert np.abs(d - g[f"{name}_shot"])[framed].max() < 1e-12
