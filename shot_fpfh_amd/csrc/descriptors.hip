@@ -596,7 +596,7 @@ __device__ inline void sf_sqrt_rsqrt(double x, double &root, double &inv)
 
 struct shot_kept {
     double rho, dc, tcross, tdot, lzr; // tcross / tdot: (lx, ly) against the octant's centre ray; lzr = lz / rho
-    unsigned bins0, bins1;            // base | bcos << 9 | bth << 18 ; cd | ef << 8 ; bins1 bit 31 = valid
+    unsigned bins0, bins1;            // base | bcos << 9 | bth << 18 ; bins1: bit 31 = valid, bits 28-30 = election flags
 };
 
 // ---- short double-precision helpers for sweep 2 (coefficients: tools/fit_poly.py) ------------------------
@@ -724,8 +724,7 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
         sth = (dth > 0.0) - (dth < 0.0);
     }
     const int tin = (ti + sth) & 7;
-    const unsigned cd = (unsigned)((ci * 8 + ti) * 2 + pi_), ef = (unsigned)((ci * 8 + ti) * 2 + ri);
-    const unsigned base = cd * 2 + ri;
+    const unsigned base = (unsigned)(((ci * 8 + ti) * 2 + pi_) * 2 + ri);
     const unsigned bcos = (unsigned)(((cin * 8 + ti) * 2 + pi_) * 2 + ri);
     const unsigned bth = (unsigned)(((ci * 8 + tin) * 2 + pi_) * 2 + ri);
     // lz / rho through the reciprocal, then one residual correction: acos has an unbounded derivative at +-1, so for a
@@ -735,7 +734,7 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     lzr = __builtin_fma(__builtin_fma(-lzr, rho, lz), inv_rho, lzr);
     o.rho = rho; o.dc = dc; o.tcross = cross; o.tdot = dot; o.lzr = lzr;
     o.bins0 = base | (bcos << 9) | (bth << 18);
-    o.bins1 = cd | (ef << 8) | 0x80000000u;
+    o.bins1 = 0x80000000u;
 }
 
 // Radius-derived constants of the interpolation, computed once on the host (as kernel arguments they live in SGPRs;
@@ -810,7 +809,8 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     double *o = out + (int64_t)SF_SHOT_LEN * row;
     const double px = qx[q], py = qy[q], pz = qz[q];
 
-    for (int b = lane; b < 704; b += 64) slot[b] = 0;
+    // (only the election / accumulator half: sX is cleared before each of its two uses; 16 bytes per lane and store)
+    for (int b = lane; b < 176; b += 64) reinterpret_cast<ulonglong2 *>(slot)[b] = make_ulonglong2(0ull, 0ull);
 
     // one gather for all chunks
     double cx[NCH], cy[NCH], cz[NCH], nx[NCH], ny[NCH], nz[NCH];
@@ -878,13 +878,18 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // Election and accumulation.  sA (352 slots) first elects the writers of S2+S5+S8+S10 by rho, then becomes the
     // ACCUMULATOR of the row: its winners store their (negated) value, and every other statement's winner adds its own
     // (negated) value to the bin it feeds with an LDS float64 atomic add -- the LDS pipe does the additions, the bins are
-    // never assembled by the vector ALU.  sX (352 slots) is the election table of the other statements in turn:
-    // S3/S4 (CD, 176) + S6/S7 (EF, 176), then S1 (B, 352), then S9 (G, 352).  A workgroup is ONE wave, whose LDS
-    // instructions execute in program order, so the order of the additions into a bin -- hence every bit of the row --
-    // is the same in every run.
+    // never assembled by the vector ALU.  A workgroup is ONE wave, whose LDS instructions execute in program order, so
+    // the order of the additions into a bin -- hence every bit of the row -- is the same in every run.
+    // S3/S4 and S6/S7 need no election of their own: their writer is the farthest neighbour of a cell (cosine, azimuth,
+    // half-space) over BOTH radial shells, resp. of a cell (cosine, azimuth, shell) over both half-spaces -- i.e. the
+    // farther of the two S2 winners of bins base ^ 1, resp. base ^ 2.  The four S2 keys of the aligned group of bins
+    // {base & ~3 ..} are read back after the election (two 16-byte reads) and compared: that replaces two 64-bit LDS
+    // atomic maxima and two compare-and-swaps per neighbour (the LDS pipe was 77 % busy, more than half of it bank
+    // conflicts of the random 8-byte atomics -- tools/pmc_k5.sh).  sX (352 slots) serves S1 (B), then S9 (G).
     unsigned long long *const sX = slot + 352;
     double *const acc = reinterpret_cast<double *>(slot);
     constexpr unsigned long long SHOT_CLAIMED = ~0ull; // no rho has this bit pattern
+    constexpr unsigned WON_A = 1u << 28, WON_CD = 1u << 29, WON_EF = 1u << 30; // flags kept in bins1 (bit 31 = valid)
     shot_kept g[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -893,11 +898,32 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
             shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, K.half_r, g[c]);
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             atomicMax(&sA[g[c].bins0 & 511u], key);
-            atomicMax(&sX[g[c].bins1 & 255u], key);
-            atomicMax(&sX[176 + ((g[c].bins1 >> 8) & 255u)], key);
         }
     }
     __syncthreads();
+    // who writes what (all reads of the keys come before the first winner replaces its key by a value)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (g[c].bins1 >> 31) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            const unsigned iA = g[c].bins0 & 511u;
+            const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(&sA[iA & ~3u]);
+            const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(&sA[(iA & ~3u) + 2u]);
+            const bool up = iA & 2u, odd = iA & 1u; // (bit 1: z > 0, bit 0: outer shell)
+            const unsigned long long own = up ? (odd ? hi.y : hi.x) : (odd ? lo.y : lo.x);
+            const unsigned long long other_shell = up ? (odd ? hi.x : hi.y) : (odd ? lo.x : lo.y); // bin base ^ 1
+            const unsigned long long other_half = up ? (odd ? lo.y : lo.x) : (odd ? hi.y : hi.x);  // bin base ^ 2
+            unsigned f = 0u;
+            if (own == key) {
+                f = WON_A;
+                // every rho of the outer shell exceeds every rho of the inner one
+                if (odd || other_shell == 0ull) f |= WON_CD;
+                // equal distances in the two half-spaces: undefined in the reference (unstable argsort, shot.py:218); z > 0 here
+                if (key > other_half || (key == other_half && up)) f |= WON_EF;
+            }
+            g[c].bins1 |= f;
+        }
+    }
     // the winners of A store; every neighbour keeps what its other statements may have to add
     double v_cd[NCH], v_ef[NCH];
 #pragma unroll
@@ -910,28 +936,27 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
             double vA, adth;
             shot_weights(g[c], K, vA, v_cd[c], v_ef[c], adth);
             g[c].tdot = adth;
-            if (sA[iA] == key) sA[iA] = tag_value(vA);
+            // compare-and-swap, not a plain store: two neighbours at exactly the same distance (duplicated points) hold the
+            // same key, and the ADDS below must come from one of them only (their values are equal; which one of two
+            // distinct equidistant neighbours writes last is undefined in the reference too)
+            if ((g[c].bins1 & WON_A) && atomicCAS(&sA[iA], key, tag_value(vA)) != key) g[c].bins1 &= ~(WON_A | WON_CD | WON_EF);
         }
     }
     __syncthreads();
-    // S3/S4 and S6/S7: the elected writer adds into the bin with the OTHER radial / elevation bit than its own
+    // S3/S4 and S6/S7: the writer adds into the bin with the OTHER radial / elevation bit than its own
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (g[c].bins1 >> 31) {
-            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
-            const unsigned iA = g[c].bins0 & 511u, iCD = g[c].bins1 & 255u, iEF = (g[c].bins1 >> 8) & 255u;
-            // compare-and-swap, not a plain comparison: two neighbours at exactly the same distance (duplicated points)
-            // hold the same key, and an ADD must come from one of them only (their values are equal; which one of two
-            // distinct equidistant neighbours writes last is undefined in the reference too: unstable argsort, shot.py:218)
-            if (atomicCAS(&sX[iCD], key, SHOT_CLAIMED) == key && v_cd[c] != 0.0) unsafeAtomicAdd(&acc[iA ^ 1u], -v_cd[c]);
-            if (atomicCAS(&sX[176 + iEF], key, SHOT_CLAIMED) == key && v_ef[c] != 0.0) unsafeAtomicAdd(&acc[iA ^ 2u], -v_ef[c]);
+        if (g[c].bins1 & WON_A) {
+            const unsigned iA = g[c].bins0 & 511u;
+            if ((g[c].bins1 & WON_CD) && v_cd[c] != 0.0) unsafeAtomicAdd(&acc[iA ^ 1u], -v_cd[c]);
+            if ((g[c].bins1 & WON_EF) && v_ef[c] != 0.0) unsafeAtomicAdd(&acc[iA ^ 2u], -v_ef[c]);
         }
     }
     __syncthreads();
     // S1 (value |dc|) and S9 (value |dth|): elect in sX, add into the accumulator
 #pragma unroll
     for (int stmt = 0; stmt < 2; ++stmt) {
-        for (int b = lane; b < 352; b += 64) sX[b] = 0;
+        for (int b = lane; b < 176; b += 64) reinterpret_cast<ulonglong2 *>(sX)[b] = make_ulonglong2(0ull, 0ull);
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -982,7 +1007,7 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
                                                     int64_t m, shot_consts K, double *__restrict__ lrf,
                                                     int normalize, int64_t min_nb, double *__restrict__ out)
 {
-    __shared__ unsigned long long slot[704];
+    __shared__ __attribute__((aligned(16))) unsigned long long slot[704];
     const int64_t q = sf_xcd_block();
     if (q >= m) return;
     // The kernel is instantiated for the LONGEST list of the launch (a 1M-point uniform cloud at 110 neighbours on average
