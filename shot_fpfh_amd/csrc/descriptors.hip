@@ -784,6 +784,18 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
     vA = (((1.0 - adc) + cur) + curv) + (1.0 - adth);
 }
 
+// The waves of a K5 workgroup are independent (one keypoint and one LDS region each): what orders a wave's LDS phases is
+// the in-order execution of its own LDS instructions, so the "barrier" is a compiler fence, never an s_barrier.
+#define SF_SHOT_SYNC()                                                                                               \
+    do {                                                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                      \
+    } while (0)
+#ifndef SF_SHOT_WPB
+#define SF_SHOT_WPB 2 // waves (= keypoints) per workgroup: 1.61 / 1.54 / 1.55 / 1.80 ms at C3 for 1 / 2 / 4 / 8
+#endif
+
 template <int NCH, bool FUSED>
 __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
                                                  const double *__restrict__ qx, const double *__restrict__ qy,
@@ -802,7 +814,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // (unused by doubles below 2.0): the S3/S4 pair of a winner has a single non-zero member, selected by
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
     unsigned long long *const sA = slot;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int64_t s = offset[q];
     const int k = cnt[q];
     const int64_t row = qrow ? qrow[q] : q;
@@ -874,7 +886,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
         return;
     }
-    __syncthreads();
+    SF_SHOT_SYNC();
     // Election and accumulation.  sA (352 slots) first elects the writers of S2+S5+S8+S10 by rho, then becomes the
     // ACCUMULATOR of the row: its winners store their (negated) value, and every other statement's winner adds its own
     // (negated) value to the bin it feeds with an LDS float64 atomic add -- the LDS pipe does the additions, the bins are
@@ -882,9 +894,9 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // the order of the additions into a bin -- hence every bit of the row -- is the same in every run.
     // S3/S4 and S6/S7 need no election of their own: their writer is the farthest neighbour of a cell (cosine, azimuth,
     // half-space) over BOTH radial shells, resp. of a cell (cosine, azimuth, shell) over both half-spaces -- i.e. the
-    // farther of the two S2 winners of bins base ^ 1, resp. base ^ 2.  The four S2 keys of the aligned group of bins
-    // {base & ~3 ..} are read back after the election (two 16-byte reads) and compared: that replaces two 64-bit LDS
-    // atomic maxima and two compare-and-swaps per neighbour (the LDS pipe was 77 % busy, more than half of it bank
+    // farther of the two S2 winners of bins base ^ 1, resp. base ^ 2.  Those two keys are read back after the election,
+    // next to the bin's own, and compared: three plain reads replace two 64-bit LDS atomic maxima and two
+    // compare-and-swaps per neighbour (the LDS pipe was 77 % busy, more than half of it bank
     // conflicts of the random 8-byte atomics -- tools/pmc_k5.sh).  sX (352 slots) serves S1 (B), then S9 (G).
     unsigned long long *const sX = slot + 352;
     double *const acc = reinterpret_cast<double *>(slot);
@@ -900,19 +912,15 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
             atomicMax(&sA[g[c].bins0 & 511u], key);
         }
     }
-    __syncthreads();
+    SF_SHOT_SYNC();
     // who writes what (all reads of the keys come before the first winner replaces its key by a value)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (g[c].bins1 >> 31) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             const unsigned iA = g[c].bins0 & 511u;
-            const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(&sA[iA & ~3u]);
-            const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(&sA[(iA & ~3u) + 2u]);
             const bool up = iA & 2u, odd = iA & 1u; // (bit 1: z > 0, bit 0: outer shell)
-            const unsigned long long own = up ? (odd ? hi.y : hi.x) : (odd ? lo.y : lo.x);
-            const unsigned long long other_shell = up ? (odd ? hi.x : hi.y) : (odd ? lo.x : lo.y); // bin base ^ 1
-            const unsigned long long other_half = up ? (odd ? lo.y : lo.x) : (odd ? hi.y : hi.x);  // bin base ^ 2
+            const unsigned long long own = sA[iA], other_shell = sA[iA ^ 1u], other_half = sA[iA ^ 2u];
             unsigned f = 0u;
             if (own == key) {
                 f = WON_A;
@@ -942,7 +950,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
             if ((g[c].bins1 & WON_A) && atomicCAS(&sA[iA], key, tag_value(vA)) != key) g[c].bins1 &= ~(WON_A | WON_CD | WON_EF);
         }
     }
-    __syncthreads();
+    SF_SHOT_SYNC();
     // S3/S4 and S6/S7: the writer adds into the bin with the OTHER radial / elevation bit than its own
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -952,12 +960,12 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
             if ((g[c].bins1 & WON_EF) && v_ef[c] != 0.0) unsafeAtomicAdd(&acc[iA ^ 2u], -v_ef[c]);
         }
     }
-    __syncthreads();
+    SF_SHOT_SYNC();
     // S1 (value |dc|) and S9 (value |dth|): elect in sX, add into the accumulator
 #pragma unroll
     for (int stmt = 0; stmt < 2; ++stmt) {
         for (int b = lane; b < 176; b += 64) reinterpret_cast<ulonglong2 *>(sX)[b] = make_ulonglong2(0ull, 0ull);
-        __syncthreads();
+        SF_SHOT_SYNC();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (g[c].bins1 >> 31) {
@@ -965,7 +973,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
                 atomicMax(&sX[(g[c].bins0 >> (stmt ? 18 : 9)) & 511u], key);
             }
         }
-        __syncthreads();
+        SF_SHOT_SYNC();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (g[c].bins1 >> 31) {
@@ -975,7 +983,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
                 if (atomicCAS(&sX[iW], key, SHOT_CLAIMED) == key && val != 0.0) unsafeAtomicAdd(&acc[iW], -val);
             }
         }
-        __syncthreads();
+        SF_SHOT_SYNC();
     }
     // every slot of the accumulator is +0 (nothing written) or minus the bin's value
     double vals[6];
@@ -999,7 +1007,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
 
 
 template <int NCH, bool FUSED>
-__global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ rec,
+__global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *__restrict__ rec,
                                                     const double *__restrict__ qx, const double *__restrict__ qy,
                                                     const double *__restrict__ qz, const int64_t *__restrict__ offset,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
@@ -1007,8 +1015,10 @@ __global__ __launch_bounds__(64) void k_shot_cached(const double *__restrict__ r
                                                     int64_t m, shot_consts K, double *__restrict__ lrf,
                                                     int normalize, int64_t min_nb, double *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long slot[704];
-    const int64_t q = sf_xcd_block();
+    __shared__ __attribute__((aligned(16))) unsigned long long slots[SF_SHOT_WPB][704];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long *const slot = slots[wave];
+    const int64_t q = sf_xcd_block() * SF_SHOT_WPB + wave;
     if (q >= m) return;
     // The kernel is instantiated for the LONGEST list of the launch (a 1M-point uniform cloud at 110 neighbours on average
     // has one of 160+), but nearly every keypoint fits one chunk less: a wave-uniform branch picks the body that
@@ -1131,7 +1141,7 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
 {
     const int64_t m = nb->m;
     if (!m) return SF_OK;
-    const dim3 grid(sf_xcd_grid(m)), block(64);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), grid_streaming(sf_xcd_grid(m)), block(64 * SF_SHOT_WPB), block_streaming(64);
 #define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m
     const double r_ = nb->radius;
     const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2)}; // the reference's own expressions (shot.py:95-117, 235)
@@ -1145,7 +1155,7 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     else if (chunks == 4) { SF_SHOT_CASE(4) }
     else {
         if (fused) { sf_set_error("internal: fused SHOT needs neighbourhoods of at most 256 points"); return SF_ERR_STATE; }
-        SF_LAUNCH(ctx, "k5_shot", k_shot, grid, block, SF_SHOT_ARGS, r_, (const double *)dlrf, normalize, min_nb, dout); // streaming
+        SF_LAUNCH(ctx, "k5_shot", k_shot, grid_streaming, block_streaming, SF_SHOT_ARGS, r_, (const double *)dlrf, normalize, min_nb, dout);
     }
 #undef SF_SHOT_CASE
 #undef SF_SHOT_ARGS
