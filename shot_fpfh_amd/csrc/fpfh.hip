@@ -73,8 +73,12 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
 // NB: the bin count as a compile-time constant (1..8, one instantiation each): the edge comparisons unroll to exactly
 // NB - 1 per feature and only the edges in use occupy SGPRs.  With a run-time count every slot of the 4 x 9 edge
 // table stays live and the compiler spills SGPRs into VGPR lanes (a v_readlane per comparison: +40 % time).
+#ifndef SF_SPFH_WPB
+#define SF_SPFH_WPB 2 // waves (= points) per workgroup (0.655 / 0.643 / 0.645 ms at C3 for 4 / 2 / 1)
+#endif
+
 template <typename CT, int NCH, int NB>
-__global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
+__global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
@@ -82,9 +86,9 @@ __global__ __launch_bounds__(256) void k_spfh(const double *__restrict__ rec,
                                               double *__restrict__ p4, double mom_radius, double *__restrict__ cov)
 {
     const int nb = NB > 0 ? NB : nb_rt;
-    __shared__ unsigned int hist[4][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
+    __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = sf_uniform64(sf_xcd_block() * 4 + wave);
+    const int64_t q = sf_uniform64(sf_xcd_block() * SF_SPFH_WPB + wave);
     if (q >= m) return; // whole wave exits together; no block-wide barrier below
     unsigned int *h = hist[wave];
     for (int b = lane; b < nb3; b += 64) h[b] = 0;
@@ -598,7 +602,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     }
     const int64_t m = nb->m;
     if (!m) return SF_OK;
-    const dim3 grid(sf_xcd_grid(sf_div_up(m, 4))), block(256);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SPFH_WPB))), block(64 * SF_SPFH_WPB);
     int chunks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \

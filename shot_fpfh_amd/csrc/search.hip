@@ -68,8 +68,12 @@ struct __attribute__((aligned(8))) sf_dbl2 {
 // MODE 2: optimistic single pass -- query q owns the fixed slot [q*cap, (q+1)*cap) of idx; hits beyond cap
 //         are counted but not stored, and the host falls back to the exact two-pass scheme if any list
 //         overflowed (HBM is plentiful: slots cost cap*4 B per query).
+#ifndef SF_K2_WPB
+#define SF_K2_WPB 8 // waves per workgroup, four queries each (0.521 / 0.516 / 0.498 / 0.489 ms at C3 for 1 / 2 / 4 / 8)
+#endif
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *__restrict__ cell_start,
+__global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const int32_t *__restrict__ cell_start,
                                                 const double *__restrict__ xs, const double *__restrict__ ys,
                                                 const double *__restrict__ zs, const double *__restrict__ qx,
                                                 const double *__restrict__ qy, const double *__restrict__ qz,
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
     // 40 % of the kernel's (issue-bound) vector instructions.  The candidate sweeps then run query after query with the
     // whole wave, as before.
     const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
-    const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 4);
+    const int64_t q0 = sf_uniform64((sf_xcd_block() * SF_K2_WPB + (threadIdx.x >> 6)) * 4);
     if (q0 >= m) return;
     const int nq = (int)(m - q0 < 4 ? m - q0 : 4);
     const int64_t qm = q0 + (rw < nq ? rw : 0);
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void k_radius(sf_grid_desc g, const int32_t *_
     // end in units of candidate PAIRS (a pair = one even-aligned 16-byte load) and every step of a sweep takes the next
     // 64 pairs, whichever runs they fall in.  Everything a lane needs to find its pair is vector work -- a DPP scan
     // gives the runs' first pair slots, the table goes to LDS -- because the scalar unit is shared by the whole CU.
-    __shared__ int4 runs[4][4][12];
+    __shared__ int4 runs[SF_K2_WPB][4][12];
     int4(*const tabs)[12] = runs[threadIdx.x >> 6];
     int first_slot = 0; // lane r < 9 of a row: first pair slot of run r; lane 9: the total
     {
@@ -418,7 +422,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     SF_HIP(hipMemsetAsync(nb->count, 0, (size_t)(m + 1) * sizeof(int32_t), ctx->stream));
     SF_HIP(hipMemsetAsync(nb->offset, 0, (size_t)(m + 1) * sizeof(int64_t), ctx->stream));
     sf_grid_desc g = sf_make_grid_desc(c);
-    const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 16))), block(256); // 4 waves x 4 queries
+    const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4 * SF_K2_WPB))), block(64 * SF_K2_WPB); // waves x 4 queries
     if (!m) {
         SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)8));
         return SF_OK;
