@@ -38,6 +38,18 @@ typedef int v2i_t __attribute__((ext_vector_type(2)));
 #define SF_MC_WPB 4 // waves (= keypoints in flight) per workgroup: 4.6 KB of LDS each
 #endif
 
+typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
+template <int W>
+__device__ __forceinline__ void sf_lane_swap(double &a, double &b)
+{
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    const sf_u2 lo = W == 32 ? __builtin_amdgcn_permlane32_swap(alo, blo, false, false) : __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const sf_u2 hi = W == 32 ? __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false) : __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
 template <int NKS>
 __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
@@ -194,22 +206,33 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     // sum over the four limb groups g = kb, transposing as we go: after the exchange with lane ^ 32 a lane keeps only
     // the blocks bb = 4 (kb >> 1) + {0..3}, after the one with lane ^ 16 only bb = 4 (kb >> 1) + 2 (kb & 1) + {0, 1}
     // -- the two bins it writes
-    const bool up = (kb >> 1) != 0, odd = (kb & 1) != 0;
+    // gfx950's lane-swap instructions do the exchange AND the selection in one go, without the LDS: v_permlane32_swap(a, b)
+    // leaves a = {a[0..31], b[0..31]}, b = {a[32..63], b[32..63]}, so a + b is "my half's block plus the partner's" in both
+    // halves; v_permlane16_swap does the same between the 16-lane rows 0/1 and 2/3 (tools/ubench/permlane_swap.hip).
     double keep[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const double mine = up ? part[4 + u] : part[u], send = up ? part[u] : part[4 + u];
-        keep[u] = mine + __shfl_xor(send, 32);
+        double a_ = part[u], b_ = part[4 + u];
+        sf_lane_swap<32>(a_, b_);
+        keep[u] = a_ + b_;
     }
-    const double vsel0 = (odd ? keep[2] : keep[0]) + __shfl_xor(odd ? keep[0] : keep[2], 16);
-    const double vsel1 = (odd ? keep[3] : keep[1]) + __shfl_xor(odd ? keep[1] : keep[3], 16);
+    double a0 = keep[0], b0_ = keep[2], a1 = keep[1], b1_ = keep[3];
+    sf_lane_swap<16>(a0, b0_);
+    sf_lane_swap<16>(a1, b1_);
+    const double vsel0 = a0 + b0_, vsel1 = a1 + b1_;
     {
         const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
         const int b0 = 16 * bb0 + a, b1 = b0 + 16;
         const uint8_t *own = counts + i * 128;
         double *o = out + q * (int64_t)nb3;
-        if (b0 < nb3) o[b0] = (double)((unsigned)own[b0] ^ 128u) / kd + vsel0 * inv_k;
-        if (b1 < nb3) o[b1] = (double)((unsigned)own[b1] ^ 128u) / kd + vsel1 * inv_k;
+        // count / k (the keypoint's own SPFH term, fpfh.py:88-90) through the reciprocal already at hand and one residual
+        // step -- the closing step of a division: correctly rounded for these small integers at a tenth of the instructions
+        const double c0 = (double)((unsigned)own[b0] ^ 128u), c1 = (double)((unsigned)own[b1] ^ 128u);
+        double s0 = c0 * inv_k, s1 = c1 * inv_k;
+        s0 = __builtin_fma(__builtin_fma(-s0, kd, c0), inv_k, s0);
+        s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
+        if (b0 < nb3) o[b0] = s0 + vsel0 * inv_k;
+        if (b1 < nb3) o[b1] = s1 + vsel1 * inv_k;
     }
 }
 
