@@ -86,9 +86,11 @@ __global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_de
 
 // positions: SoA (for the candidate sweeps of K2) + slots 0..2 of the AoS records (for gathers) + inv_perm
 // (positions [base, base + n): the whole cloud, or the slab a block build populates)
-__global__ void k_gather_sorted(const double *__restrict__ xyz, const int32_t *__restrict__ perm, int64_t base, int64_t n,
-                                double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ zs,
-                                double *__restrict__ rec, int32_t *__restrict__ inv_perm)
+// nrm != NULL: the cloud has normals already -- they travel in the same pass (one read of perm, whole 48-byte records
+// written) instead of waiting for sf_cloud_ensure_sorted_normals' own gather
+__global__ void k_gather_sorted(const double *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ perm,
+                                int64_t base, int64_t n, double *__restrict__ xs, double *__restrict__ ys,
+                                double *__restrict__ zs, double *__restrict__ rec, int32_t *__restrict__ inv_perm)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -97,6 +99,11 @@ __global__ void k_gather_sorted(const double *__restrict__ xyz, const int32_t *_
     const double x = xyz[3 * o + 0], y = xyz[3 * o + 1], z = xyz[3 * o + 2];
     xs[i] = x; ys[i] = y; zs[i] = z;
     rec[6 * i + 0] = x; rec[6 * i + 1] = y; rec[6 * i + 2] = z;
+    if (nrm) {
+        rec[6 * i + 3] = nrm[3 * o + 0];
+        rec[6 * i + 4] = nrm[3 * o + 1];
+        rec[6 * i + 5] = nrm[3 * o + 2];
+    }
     inv_perm[o] = (int32_t)i;
 }
 
@@ -416,9 +423,12 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
                                              ctx->stream));
         }
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,
-                  c->perm, base, ns, c->xs, c->ys, c->zs, c->rec, c->inv_perm);
+                  (const double *)c->nrm_orig, c->perm, base, ns, c->xs, c->ys, c->zs, c->rec, c->inv_perm);
         sf_pool_release(ctx, tmp);
     }
+    // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
+    // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
+    c->normals_sorted = c->nrm_orig != nullptr;
     SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, base, ns,
               ncell, c->cell_start);
     if (cid_sel) sf_pool_release(ctx, cid_sel);
