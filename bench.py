@@ -199,6 +199,8 @@ def main() -> int:
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-to-host drop-in timing (N = 1)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="diagnostic: time the steps without the per-kernel HIP events (no roofline / kernels_ms_per_step then)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="FUNCTIONAL TEST ONLY: allow more ranks than GPUs; the exchange is then staged through host memory "
                          "and gloo (RCCL refuses two ranks on one device) and no timing is a scaling result")
@@ -318,29 +320,71 @@ def main() -> int:
         return float(t.item())
 
     # ---- timed region: K descriptor passes ---------------------------------------------------------------------------
-    for _ in range(args.warmup):
+    # Two HIP event records per launch cost the step 1.6 % (4.55 against 4.48 ms), so the timed region brackets the roofline
+    # kernel only -- roofline.achieved is measured live over the timed launches, as the contract asks; which kernel that is
+    # comes from the warm-up steps (every launch bracketed; the first step, which grows the pools, left out when there are
+    # two or more), and the breakdown of the other kernels from a few untimed steps after the timed ones.
+    warm_rep, warm_steps = {}, 0
+    for w in range(args.warmup):
+        if w == min(1, args.warmup - 1):
+            eng.sync()
+            eng.profile_reset()
+            eng.profile(True)
         job.step()
+        warm_steps += 1 if w >= min(1, args.warmup - 1) else 0
+    if args.warmup:
+        eng.sync()
+        eng.profile(False)
+        warm_rep = eng.profile_report()
+    timed_only = None
+    if warm_rep and not args.no_kernel_timers:
+        cand = [k for k, v in warm_rep.items() if k in ALG_BYTES and v[0] > 0 and v[1] > 0]
+        if cand:
+            timed_only = max(cand, key=lambda k: warm_rep[k][1])
     barrier()
     eng.profile_reset()
-    eng.profile(True)
+    eng.profile_only(timed_only)
+    eng.profile(not args.no_kernel_timers)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
     barrier()
     elapsed = time.perf_counter() - t0
     eng.profile(False)
+    eng.profile_only(None)
     elapsed = max_over_ranks(elapsed)
     rep = eng.profile_report()
+    if timed_only is not None:
+        # the breakdown of the other kernels: a few more steps, untimed, every launch bracketed, with the clocks where the
+        # timed steps left them (the warm-up steps run 5-10 % slow and only chose the roofline kernel)
+        warm_steps = min(args.steps, 5)
+        eng.profile_reset()
+        eng.profile(True)
+        for _ in range(warm_steps):
+            job.step()
+        eng.sync()
+        eng.profile(False)
+        warm_rep = eng.profile_report()
+        barrier()
 
     kinds = (1 if job.do_fpfh else 0) + (1 if job.do_shot else 0)
     n_desc = kinds * n_total
     ms_per_step = 1000.0 * elapsed / args.steps
     value = n_desc / (elapsed / args.steps)
 
+    if args.no_kernel_timers:
+        if lead:
+            os.write(json_fd, (json.dumps({"diagnostic": "steps timed without per-kernel HIP events", "ms_per_step": ms_per_step,
+                                           "value": value, "n_gpus": world, "steps": args.steps}) + "\n").encode())
+        return 0
     out = {}
     if lead:
         kern = {k: (v[0], v[1] / max(v[0], 1)) for k, v in rep.items() if v[0] > 0 and v[1] > 0}
         per_step_ms = {k: rep[k][1] / args.steps for k in kern}
+        if timed_only is not None:  # the other kernels: from the instrumented warm-up steps
+            for k, v in warm_rep.items():
+                if k not in per_step_ms and v[0] > 0 and v[1] > 0:
+                    per_step_ms[k] = v[1] / max(warm_steps, 1)
         dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: rep[k][1])
         launches, avg_ms = kern[dom]
         units = job.m  # descriptors of this rank's block per launch (halo SPFH rows are extra work, not counted)
@@ -377,6 +421,9 @@ def main() -> int:
                 "exchange": exchange,
             },
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step_ms.items())},
+            "kernels_ms_per_step_source": "HIP events around every launch of the timed steps" if timed_only is None else
+            f"{timed_only}: HIP events around its launches in the timed steps; the others: {warm_steps} more, untimed steps with every "
+            "launch bracketed (two event records per launch cost the step 1.6 %, so the timed steps bracket the roofline kernel only)",
             "roofline": {
                 "kernel": dom,
                 "bound": "hbm",

@@ -274,6 +274,9 @@ int sf_comm_destroy(sf_ctx *ctx);
 /* ---- per-kernel timing with HIP events on the ctx stream -------------------------------- */
 int sf_profile_enable(sf_ctx *ctx, int on);
 int sf_profile_reset(sf_ctx *ctx);
+/* time launches of this kernel name only (NULL or "" = all): two event records per launch cost a few microseconds, which a
+ * caller timing whole passes may not want on every kernel */
+int sf_profile_only(sf_ctx *ctx, const char *name);
 /* writes "name launches total_ms\n" lines; returns bytes needed (call with buf == NULL to size) */
 int64_t sf_profile_report(sf_ctx *ctx, char *buf, int64_t cap);
 

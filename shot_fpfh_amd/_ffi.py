@@ -94,6 +94,7 @@ SIGNATURES = {
     "sf_comm_destroy": (_int, [_vp]),
     "sf_profile_enable": (_int, [_vp, _int]),
     "sf_profile_reset": (_int, [_vp]),
+    "sf_profile_only": (_int, [_vp, C.c_char_p]),
     "sf_profile_report": (_i64, [_vp, _vp, _i64]),
 }
 

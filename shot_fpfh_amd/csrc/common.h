@@ -52,6 +52,7 @@ struct sf_ctx {
     hipStream_t streams[2] = {nullptr, nullptr};
     hipEvent_t join_event = nullptr;
     bool profiling = false;
+    std::string prof_only; // sf_profile_only: time launches of this name only ("" = all)
     std::map<std::string, sf_prof_entry> prof;
     std::vector<hipEvent_t> event_pool;
     void *comm = nullptr; // ncclComm_t
@@ -119,9 +120,11 @@ struct sf_launch_timer {
     sf_ctx *ctx;
     const char *name;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    sf_launch_timer(sf_ctx *c, const char *n) : ctx(c), name(n)
+    bool active;
+    sf_launch_timer(sf_ctx *c, const char *n)
+        : ctx(c), name(n), active(c->profiling && (c->prof_only.empty() || c->prof_only == n))
     {
-        if (ctx->profiling) {
+        if (active) {
             e0 = sf_ctx_event(ctx);
             e1 = sf_ctx_event(ctx);
             (void)hipEventRecord(e0, ctx->stream);
@@ -129,7 +132,7 @@ struct sf_launch_timer {
     }
     ~sf_launch_timer()
     {
-        if (ctx->profiling) {
+        if (active) {
             (void)hipEventRecord(e1, ctx->stream);
             sf_prof_entry &p = ctx->prof[name];
             p.launches++;

@@ -290,6 +290,13 @@ extern "C" int sf_profile_enable(sf_ctx *ctx, int on)
     return SF_OK;
 }
 
+extern "C" int sf_profile_only(sf_ctx *ctx, const char *name)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    ctx->prof_only = name ? name : "";
+    return SF_OK;
+}
+
 extern "C" int sf_profile_reset(sf_ctx *ctx)
 {
     if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }

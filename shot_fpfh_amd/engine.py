@@ -335,6 +335,10 @@ class Engine:
     def profile(self, on: bool) -> None:
         _ffi.check(self.lib.sf_profile_enable(self.h, int(on)), "sf_profile_enable")
 
+    def profile_only(self, name: Optional[str]) -> None:
+        """Time launches of this kernel name only (None = all)."""
+        _ffi.check(self.lib.sf_profile_only(self.h, None if name is None else name.encode()), "sf_profile_only")
+
     def profile_reset(self) -> None:
         _ffi.check(self.lib.sf_profile_reset(self.h), "sf_profile_reset")
 
