@@ -55,9 +55,11 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
 #pragma unroll
         for (int i = 1; i < SF_FAST_FPFH_BINS; ++i)
             if (i < nb) {
-                const double tb = ed.tan_t[i] * b;
-                bin += a >= tb ? 1 : 0;
-                gap = fmin(gap, fabs(a - tb));
+                // a - tan(e_i) b with ONE rounding: its sign is that of the exact difference, and whenever that differs
+                // from the rounded product's verdict the gap is within an ulp, far inside the band the fallback owns
+                const double di = __builtin_fma(-ed.tan_t[i], b, a);
+                bin += di >= 0.0 ? 1 : 0;
+                gap = fmin(gap, fabs(di));
             }
         // one (conservative) test for all edges: |tan(e_i) b| <= |tan(e_1)| b, the outermost interior edge
         if (gap > band * (aa + fabs(ed.tan_t[1]) * b)) return bin;
@@ -126,8 +128,10 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
         const double w = mom_radius - sf_sqrt_fast((cx * cx + cy * cy) + cz * cz);
         ws += w;
         const double wx = cx * w, wy = cy * w, wz = cz * w;
-        a11 += cx * wx; a21 += cy * wx; a31 += cz * wx;
-        a22 += cy * wy; a32 += cz * wy; a33 += cz * wz;
+        // (multiply-adds: these sums feed an eigen-decomposition, not a bin decision, and the reference forms them in an FMA
+        // BLAS -- `(w * centred.T) @ centred`, shot.py:33)
+        a11 = __builtin_fma(cx, wx, a11); a21 = __builtin_fma(cy, wx, a21); a31 = __builtin_fma(cz, wx, a31);
+        a22 = __builtin_fma(cy, wy, a22); a32 = __builtin_fma(cz, wy, a32); a33 = __builtin_fma(cz, wz, a33);
     };
     if (NCH > 0) {
         constexpr int NC = NCH > 0 ? NCH : 1;
