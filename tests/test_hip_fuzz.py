@@ -259,3 +259,56 @@ def test_degenerate_families_golden(eng, name):
         with ShotMultiprocessor(normalize=True, min_neighborhood_size=5, verbose=False) as sm:
             d = sm.compute_descriptor_single_scale(p, nr, kq, r)
         assert np.abs(d - g[f"{name}_shot"])[framed].max() < 1e-9
+
+
+# ---- the drop-in calls with the argument FORMS NumPy code hands them -------------------------------------------------
+def test_drop_in_calls_accept_numpy_argument_forms(eng):
+    """float32 / Fortran-ordered / strided / list inputs, index arrays of any integer type, NumPy scalars for radius and
+    bin count: the reference's NumPy / sklearn code takes all of them; results must equal the canonical float64 C-order call."""
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+    from shot_fpfh_amd.matching import basic_matching
+
+    rng = np.random.default_rng(77)
+    p = rng.random((3000, 3), dtype=np.float32).astype(np.float64)  # float32-representable, so the float32 form is lossless
+    nr = _unit(rng.standard_normal((3000, 3))).astype(np.float32).astype(np.float64)
+    kp = np.sort(rng.choice(3000, 200, replace=False))
+    r = 0.12
+    base_f = s.compute_fpfh_descriptor(kp, p, nr, r, 5)
+    base_n = s.compute_normals(p[kp], p, k=20)
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+        base_s = sm.compute_descriptor_single_scale(p, nr, p[kp], r)
+
+    wide = np.zeros((3000, 7))
+    wide[:, 1:4] = p
+    forms = {
+        "float32": (p.astype(np.float32), nr.astype(np.float32)),
+        "fortran": (np.asfortranarray(p), np.asfortranarray(nr)),
+        "strided view": (wide[:, 1:4], nr[::1]),
+        "lists": (p.tolist(), nr.tolist()),
+    }
+    for name, (pp, nn) in forms.items():
+        got = s.compute_fpfh_descriptor(kp, pp, nn, r, 5)
+        assert got.dtype == np.float64 and np.array_equal(got, base_f), name
+        assert np.array_equal(s.compute_normals(np.asarray(pp)[kp], pp, k=20), base_n), name
+        with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+            assert np.array_equal(sm.compute_descriptor_single_scale(pp, nn, np.asarray(pp)[kp], r), base_s), name
+    for kk in (kp.astype(np.int32), kp.astype(np.uint16), kp.tolist(), kp[::-1][::-1]):
+        assert np.array_equal(s.compute_fpfh_descriptor(kk, p, nr, r, 5), base_f)
+    assert np.array_equal(s.compute_fpfh_descriptor(kp, p, nr, np.float32(r).astype(np.float64), np.int64(5)),
+                          s.compute_fpfh_descriptor(kp, p, nr, float(np.float32(r)), 5))
+    # matching on float32 / non-contiguous descriptor matrices
+    a, b = base_s[:150], base_s[50:]
+    want = basic_matching(a, b)
+    for aa, bb in ((np.asfortranarray(a), np.asfortranarray(b)), (base_s[:150:1], base_s[50::1])):
+        got = basic_matching(aa, bb)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # repeated and unsorted keypoint indices (fancy indexing semantics: one row per entry, in the order given)
+    idx = np.array([5, 5, 1999, 0, 5, 42])
+    rows = s.compute_fpfh_descriptor(idx, p, nr, r, 5)
+    full = s.compute_fpfh_descriptor(np.arange(3000), p, nr, r, 5)
+    assert np.array_equal(rows, full[idx])
+    # empty keypoint set
+    assert s.compute_fpfh_descriptor(np.zeros(0, dtype=np.int64), p, nr, r, 5).shape == (0, 125)
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+        assert sm.compute_descriptor_single_scale(p, nr, np.zeros((0, 3)), r).shape == (0, 352)
