@@ -128,6 +128,9 @@ __global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t bas
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c > ncell) return;
     int64_t lo = 0, hi = n;
+    // (a rank's slab populates an eighth of the cells of an 8-rank cloud: the others need no search)
+    if (n > 0 && c <= (int64_t)sorted_cid[0]) hi = 0;
+    else if (n > 0 && c > (int64_t)sorted_cid[n - 1]) lo = n;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
         if ((int64_t)sorted_cid[mid] < c) lo = mid + 1; else hi = mid;
