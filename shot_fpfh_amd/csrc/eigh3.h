@@ -129,8 +129,8 @@ struct tri3 {
     }
 };
 
-// dsteqr(compz='I') specialised to n = 3.  Control flow mirrors the LAPACK routine (labels in
-// comments) because the rotation sequence determines the eigenvector signs.
+// dsteqr(compz='I') specialised to n = 3.  The sequence of floating-point operations per matrix is LAPACK's (labels in
+// comments) because the rotation sequence determines the eigenvector signs; its QL and QR loops share one body (below).
 __device__ inline void steqr3(tri3 &T)
 {
     const double eps = 1.1102230246251565e-16, eps2 = eps * eps, safmin = 2.2250738585072014e-308;
@@ -165,107 +165,89 @@ __device__ inline void steqr3(tri3 &T)
             for (int i = l; i <= lend - 1; ++i) T.setE(i, T.E(i) / anorm * ssfmin);
         }
         if (fabs(T.D(lend)) < fabs(T.D(l))) { lend = lsv; l = lendsv; }
-        if (lend > l) {
-            // ---- QL iteration ----
-            for (;;) { // label 40
-                m = lend;
-                if (l != lend)
-                    for (int mm = l; mm <= lend - 1; ++mm) {
-                        double a = fabs(T.E(mm));
-                        if (a * a <= (eps2 * fabs(T.D(mm))) * fabs(T.D(mm + 1)) + safmin) { m = mm; break; }
-                    }
-                if (m < lend) T.setE(m, 0.0);
-                double p = T.D(l);
-                if (m == l) { // label 80
-                    l = l + 1;
-                    if (l <= lend) continue;
+        // ---- QL (lend > l) and QR (lend < l) iteration in ONE loop body, on a mirrored copy ----
+        // LAPACK writes the two as separate loops that are mirror images of each other -- the same expressions with the
+        // index walking the other way and the saved rotation's sine negated.  A lane runs one or the other, so with two
+        // copies of the code a wave pays for both.  Here the tridiagonal is copied into (A1, A2, A3 | B1, B2) read from
+        // l's side -- node i' = i for QL, 4 - i for QR; pair p' (between nodes p' and p' + 1) = pair p resp. 3 - p -- and
+        // every lane walks upwards through the same instructions with compile-time indices (the run-time-indexed
+        // accessors, two or three selects per access, were two thirds of the old loop).  What is NOT mirror-symmetric in
+        // dsteqr is kept as it is there: dlaev2 always takes (lower index, off-diagonal, upper index) of the ORIGINAL
+        // numbering, and the rotations go to the original column pairs.
+        {
+            const bool fw = lend > l;
+            int lm = fw ? l : 4 - l;            // l in the mirrored numbering: moves up
+            const int lendm = fw ? lend : 4 - lend;
+            double A1 = fw ? T.d1 : T.d3, A2 = T.d2, A3 = fw ? T.d3 : T.d1;
+            double B1 = fw ? T.e1 : T.e2, B2 = fw ? T.e2 : T.e1;
+            for (;;) {
+                // look for a small off-diagonal between l and lend, starting at l (labels 40 / 90)
+                int mm_ = lendm;
+                if (lm == 1 && lendm >= 2 && fabs(B1) * fabs(B1) <= (eps2 * fabs(A1)) * fabs(A2) + safmin) mm_ = 1;
+                else if (lm <= 2 && lendm == 3 && fabs(B2) * fabs(B2) <= (eps2 * fabs(A2)) * fabs(A3) + safmin) mm_ = 2;
+                if (mm_ < lendm) { // E(m) := 0
+                    B1 = mm_ == 1 ? 0.0 : B1;
+                    B2 = mm_ == 2 ? 0.0 : B2;
+                }
+                if (mm_ == lm) { // an eigenvalue has converged (labels 80 / 130)
+                    lm += 1;
+                    if (lm <= lendm) continue;
                     break;
                 }
-                if (m == l + 1) {
+                if (mm_ == lm + 1) { // a 2 x 2 block between mirrored nodes lm, lm + 1 (lm is 1 or 2)
+                    const bool low = lm == 1;
+                    const double an = low ? A1 : A2, af = low ? A2 : A3, bb = low ? B1 : B2; // node lm, node lm + 1, their pair
                     double rt1, rt2, c, s;
-                    sym2x2(T.D(l), T.E(l), T.D(l + 1), rt1, rt2, c, s);
-                    T.rot(l, c, s);
-                    T.setD(l, rt1); T.setD(l + 1, rt2); T.setE(l, 0.0);
-                    l = l + 2;
-                    if (l <= lend) continue;
+                    // dlaev2(d(lo), e(lo), d(lo + 1)) with lo the lower ORIGINAL index: node lm for QL, node lm + 1 for QR
+                    sym2x2(fw ? an : af, bb, fw ? af : an, rt1, rt2, c, s);
+                    T.rot(fw ? lm : 3 - lm, c, s); // original pair index
+                    const double nn = fw ? rt1 : rt2, nf = fw ? rt2 : rt1; // d(lo) = rt1, d(lo + 1) = rt2
+                    A1 = low ? nn : A1;
+                    A2 = low ? nf : nn;
+                    A3 = low ? A3 : nf;
+                    B1 = low ? 0.0 : B1;
+                    B2 = low ? B2 : 0.0;
+                    lm += 2;
+                    if (lm <= lendm) continue;
                     break;
                 }
                 if (jtot == nmaxit) break;
                 ++jtot;
-                double g = (T.D(l + 1) - p) / (2.0 * T.E(l));
+                // The step proper: here lm = 1 and the small-off-diagonal search came back with m = 3, the whole matrix.
+                // Same operations in the same order as dsteqr's loops at labels 70 / 120.
+                double p = A1;
+                double g = (A2 - p) / (2.0 * B1); // Wilkinson shift from the pair next to l
                 double r = pythag(g, 1.0);
-                g = T.D(m) - p + (T.E(l) / (g + fsign(r, g)));
+                g = A3 - p + (B1 / (g + fsign(r, g)));
                 double s = 1.0, c = 1.0;
                 p = 0.0;
-                // here m - l == 2 (n = 3): i runs m-1 = l+1, then l; rotations saved as (c, -s)
-                double c_hi = 1.0, s_hi = 0.0, c_lo = 1.0, s_lo = 0.0;
-                for (int i = m - 1; i >= l; --i) {
-                    double f = s * T.E(i), b = c * T.E(i);
-                    givens(g, f, c, s, r);
-                    if (i != m - 1) T.setE(i + 1, r);
-                    g = T.D(i + 1) - p;
-                    r = (T.D(i) - g) * s + 2.0 * c * b;
-                    p = s * r;
-                    T.setD(i + 1, g + p);
-                    g = c * r - b;
-                    if (i == l) { c_lo = c; s_lo = -s; } else { c_hi = c; s_hi = -s; }
-                }
-                // dlasr('R','V','B') over columns l..m: j = m-1 first, then down to l
-                if (m - l == 2) { T.rot(l + 1, c_hi, s_hi); T.rot(l, c_lo, s_lo); }
-                else T.rot(l, c_lo, s_lo);
-                T.setD(l, T.D(l) - p);
-                T.setE(l, g);
+                // first rotation: the pair next to m
+                double f = s * B2, b = c * B2;
+                givens(g, f, c, s, r);
+                g = A3 - p;
+                r = (A2 - g) * s + 2.0 * c * b;
+                p = s * r;
+                A3 = g + p;
+                g = c * r - b;
+                const double c_k0 = c, s_k0 = fw ? -s : s;
+                // second rotation: the pair next to l
+                f = s * B1; b = c * B1;
+                givens(g, f, c, s, r);
+                B2 = r;
+                g = A2 - p;
+                r = (A1 - g) * s + 2.0 * c * b;
+                p = s * r;
+                A2 = g + p;
+                g = c * r - b;
+                const double c_k1 = c, s_k1 = fw ? -s : s;
+                // the eigenvector columns, in the order the rotations were made (dlasr 'B' for QL, 'F' for QR)
+                T.rot(fw ? 2 : 1, c_k0, s_k0);
+                T.rot(fw ? 1 : 2, c_k1, s_k1);
+                A1 = A1 - p;
+                B1 = g;
             }
-        } else {
-            // ---- QR iteration ----
-            for (;;) { // label 90
-                m = lend;
-                if (l != lend)
-                    for (int mm = l; mm >= lend + 1; --mm) {
-                        double a = fabs(T.E(mm - 1));
-                        if (a * a <= (eps2 * fabs(T.D(mm))) * fabs(T.D(mm - 1)) + safmin) { m = mm; break; }
-                    }
-                if (m > lend) T.setE(m - 1, 0.0);
-                double p = T.D(l);
-                if (m == l) { // label 130
-                    l = l - 1;
-                    if (l >= lend) continue;
-                    break;
-                }
-                if (m == l - 1) {
-                    double rt1, rt2, c, s;
-                    sym2x2(T.D(l - 1), T.E(l - 1), T.D(l), rt1, rt2, c, s);
-                    T.rot(l - 1, c, s);
-                    T.setD(l - 1, rt1); T.setD(l, rt2); T.setE(l - 1, 0.0);
-                    l = l - 2;
-                    if (l >= lend) continue;
-                    break;
-                }
-                if (jtot == nmaxit) break;
-                ++jtot;
-                double g = (T.D(l - 1) - p) / (2.0 * T.E(l - 1));
-                double r = pythag(g, 1.0);
-                g = T.D(m) - p + (T.E(l - 1) / (g + fsign(r, g)));
-                double s = 1.0, c = 1.0;
-                p = 0.0;
-                double c_lo = 1.0, s_lo = 0.0, c_hi = 1.0, s_hi = 0.0;
-                for (int i = m; i <= l - 1; ++i) {
-                    double f = s * T.E(i), b = c * T.E(i);
-                    givens(g, f, c, s, r);
-                    if (i != m) T.setE(i - 1, r);
-                    g = T.D(i) - p;
-                    r = (T.D(i + 1) - g) * s + 2.0 * c * b;
-                    p = s * r;
-                    T.setD(i, g + p);
-                    g = c * r - b;
-                    if (i == m) { c_lo = c; s_lo = s; } else { c_hi = c; s_hi = s; }
-                }
-                // dlasr('R','V','F') over columns m..l: j = m first, then up
-                T.rot(m, c_lo, s_lo);
-                if (l - m == 2) T.rot(m + 1, c_hi, s_hi);
-                T.setD(l, T.D(l) - p);
-                T.setE(l - 1, g);
-            }
+            T.d1 = fw ? A1 : A3; T.d2 = A2; T.d3 = fw ? A3 : A1;
+            T.e1 = fw ? B1 : B2; T.e2 = fw ? B2 : B1;
         }
         if (iscale == 1) {
             for (int i = lsv; i <= lendsv; ++i) T.setD(i, T.D(i) / ssfmax * anorm);
