@@ -140,19 +140,29 @@ __device__ inline void steqr3(tri3 &T)
     const int n = 3, nmaxit = 90;
     int jtot = 0, l1 = 1;
     while (l1 <= n) { // label 10
-        if (l1 > 1) T.setE(l1 - 1, 0.0);
+        // (written out for n = 3: compile-time indices instead of the run-time-indexed accessors)
+        if (l1 == 2) T.e1 = 0.0;
+        if (l1 == 3) T.e2 = 0.0;
         int m = n;
-        for (int mm = l1; mm <= n - 1; ++mm) {
-            double tst = fabs(T.E(mm));
-            if (tst == 0.0) { m = mm; break; }
-            if (tst <= (sqrt(fabs(T.D(mm))) * sqrt(fabs(T.D(mm + 1)))) * eps) { T.setE(mm, 0.0); m = mm; break; }
+        if (l1 == 1) { // mm = 1
+            const double tst = fabs(T.e1);
+            if (tst == 0.0) m = 1;
+            else if (tst <= (sqrt(fabs(T.d1)) * sqrt(fabs(T.d2))) * eps) { T.e1 = 0.0; m = 1; }
+        }
+        if (m == n && l1 <= 2) { // mm = 2
+            const double tst = fabs(T.e2);
+            if (tst == 0.0) m = 2;
+            else if (tst <= (sqrt(fabs(T.d2)) * sqrt(fabs(T.d3))) * eps) { T.e2 = 0.0; m = 2; }
         }
         int l = l1, lsv = l, lend = m, lendsv = lend;
         l1 = m + 1;
         if (lend == l) continue;
-        double anorm = 0.0;
-        for (int i = l; i <= lend; ++i) anorm = fmax(anorm, fabs(T.D(i)));
-        for (int i = l; i <= lend - 1; ++i) anorm = fmax(anorm, fabs(T.E(i)));
+        double anorm = 0.0; // max |d(l..lend)|, |e(l..lend-1)| in dsteqr's order
+        if (l <= 1 && lend >= 1) anorm = fmax(anorm, fabs(T.d1));
+        if (l <= 2 && lend >= 2) anorm = fmax(anorm, fabs(T.d2));
+        if (lend >= 3) anorm = fmax(anorm, fabs(T.d3));
+        if (l <= 1 && lend >= 2) anorm = fmax(anorm, fabs(T.e1));
+        if (l <= 2 && lend >= 3) anorm = fmax(anorm, fabs(T.e2));
         int iscale = 0;
         if (anorm == 0.0) continue;
         if (anorm > ssfmax) {
@@ -258,16 +268,24 @@ __device__ inline void steqr3(tri3 &T)
         }
         if (jtot >= nmaxit) break;
     }
-    // ascending selection sort with column swaps (label 160)
-    for (int ii = 2; ii <= n; ++ii) {
-        int i = ii - 1, k = i;
-        double p = T.D(i);
-        for (int j = ii; j <= n; ++j)
-            if (T.D(j) < p) { k = j; p = T.D(j); }
-        if (k != i) {
-            T.setD(k, T.D(i));
-            T.setD(i, p);
-            T.swap_cols(i, k);
+    // ascending selection sort with column swaps (label 160), written out for n = 3: position 1 takes the first strict
+    // minimum of (d1, d2, d3), then position 2 the smaller of what is left (ties keep their order, as in dsteqr)
+    {
+        int k = 1;
+        double p = T.d1;
+        if (T.d2 < p) { k = 2; p = T.d2; }
+        if (T.d3 < p) { k = 3; p = T.d3; }
+        if (k != 1) {
+            T.d2 = k == 2 ? T.d1 : T.d2;
+            T.d3 = k == 3 ? T.d1 : T.d3;
+            T.d1 = p;
+            T.swap_cols(1, k);
+        }
+        if (T.d3 < T.d2) {
+            const double t = T.d2;
+            T.d2 = T.d3;
+            T.d3 = t;
+            T.swap_cols(2, 3);
         }
     }
 }
