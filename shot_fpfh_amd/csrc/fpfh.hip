@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
                                               CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias,
-                                              double *__restrict__ p4, double mom_radius, double *__restrict__ cov)
+                                              double *__restrict__ p4, double mom_radius, double *__restrict__ cov,
+                                              unsigned *__restrict__ live)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
@@ -180,7 +181,23 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     CT *row = counts + i * (int64_t)stride;
-    for (int b = lane; b < stride; b += 64) row[b] = (CT)((b < nb3 ? h[b] : 0u) ^ bias); // (padding bins: count 0)
+    if (live) { // uint8 table: 128 bins, two per lane; which 16-bin blocks of this row hold a count goes into the table-wide mask
+        const unsigned v0 = lane < nb3 ? h[lane] : 0u, v1 = lane + 64 < nb3 ? h[lane + 64] : 0u; // (padding bins: count 0)
+        row[lane] = (CT)(v0 ^ bias);
+        row[lane + 64] = (CT)(v1 ^ bias);
+        const unsigned long long n0 = __ballot(v0 != 0u), n1 = __ballot(v1 != 0u);
+        unsigned mask = 0u;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            mask |= ((n0 >> (16 * kq)) & 0xffffull) ? 1u << kq : 0u;
+            mask |= ((n1 >> (16 * kq)) & 0xffffull) ? 16u << kq : 0u;
+        }
+        // (one plain, cacheable read per wave -- a stale value only costs a redundant atomic; the atomic itself only while
+        // the table-wide mask is still growing)
+        if (lane == 0 && (mask & ~*live)) atomicOr(live, mask);
+    } else {
+        for (int b = lane; b < stride; b += 64) row[b] = (CT)((b < nb3 ? h[b] : 0u) ^ bias); // (padding bins: count 0)
+    }
     if (lane == 0) {
         kout[i] = k;
         if (p4) { // the per-neighbour record of the matrix-core K7
@@ -379,13 +396,26 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
-                                                 const double *__restrict__ p4, double *__restrict__ out)
+                                                 const double *__restrict__ p4, const unsigned *__restrict__ live,
+                                                 double *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // 32 rows of 128 B
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
     const int wv_id = threadIdx.x >> 6;
     const int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
     if (q >= m) return;
+    // which 16-bin blocks of the table hold anything at all (K6's OR over every row): with at most two of the eight --
+    // the reference's un-normalised v keeps alpha in ONE of its bins whenever the radius is well below that bin's width,
+    // so 100 of the 125 bins are structurally empty -- only those blocks are streamed and multiplied
+    const unsigned mask = sf_uniform(*live) & 0xffu;
+    if (__popc(mask) <= 2) {
+        const int b0 = mask ? __ffs(mask) - 1 : 0;
+        const unsigned rest = mask & (mask - 1u);
+        const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7; // (a lone live block is paired with an empty one)
+        fpfh_mc_body_sparse<NKS>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, b0, b1,
+                                 rowbuf_all[wv_id], abuf_all[wv_id]);
+        return;
+    }
     fpfh_mc_body<NKS>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
                       abuf_all[wv_id]);
 }
@@ -547,7 +577,10 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     }
     if (hipMalloc(&sp->counts, nn * sp->stride * sp->elem_bytes) != hipSuccess ||
         hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess ||
-        (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess)) {
+        (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess) ||
+        (sp->elem_bytes == 1 && (hipMalloc(&sp->live, sizeof(unsigned)) != hipSuccess ||
+                                 // SF_FPFH_DENSE=1: every block counts as live from the start (K7 always takes its full form)
+                                 hipMemset(sp->live, getenv("SF_FPFH_DENSE") ? 0xff : 0, sizeof(unsigned)) != hipSuccess))) {
         sf_set_error("sf_spfh_create: out of device memory");
         sf_spfh_free(ctx, sp);
         return nullptr;
@@ -562,6 +595,7 @@ extern "C" void sf_spfh_free(sf_ctx *ctx, sf_spfh *sp)
     if (sp->counts) (void)hipFree(sp->counts);
     if (sp->k) (void)hipFree(sp->k);
     if (sp->p4) (void)hipFree(sp->p4);
+    if (sp->live) (void)hipFree(sp->live);
     delete sp;
 }
 
@@ -611,7 +645,8 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
-              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov)
+              nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov, \
+              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
@@ -678,6 +713,8 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
         char *pb = (char *)sp->p4;
         SF_CHECK(sf_comm_allgather(ctx, pb + (size_t)ctx->rank * rows_per_rank * 32, pb, (size_t)rows_per_rank * 32));
     }
+    // the gathered rows come from other ranks' K6: every block of the table counts as live from here on
+    if (sp->live) SF_HIP(hipMemsetAsync(sp->live, 0xff, sizeof(unsigned), ctx->stream));
     return SF_OK;
 }
 
@@ -764,7 +801,7 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     const int nks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
 #define SF_MC_LAUNCH(NKS)                                                                                            \
     SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc<NKS>, grid, block, c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, \
-              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, (const double *)sp->p4, dout)
+              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, dout)
     if (nks <= 1) { SF_MC_LAUNCH(1); }
     else if (nks == 2) { SF_MC_LAUNCH(2); }
     else if (nks == 3) { SF_MC_LAUNCH(3); }

@@ -237,3 +237,174 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
 }
 
 #undef SF_MC_DMA
+
+// --------------------------------------------------------------------------------------------------
+// The same contraction when at most TWO of the table's eight 16-bin blocks hold any count (blocks b0, b1; K6 keeps the OR
+// of the non-empty blocks of every row it writes).  Per step of 32 neighbours ONE LDS-DMA instruction fetches the two live
+// 16-byte chunks of each row (lane l: row l >> 1 ... see the mapping below) instead of four instructions for the whole
+// rows, two transposing reads + two MFMAs replace eight, and the padding column that removes the -128 bias is an MFMA
+// against a constant operand (every byte 0x80) instead of a column read from the table.  Results are those of the full
+// kernel bit for bit: the integer sums of the live bins are the same sums, and a dead bin's sum is exactly its bias.
+// --------------------------------------------------------------------------------------------------
+template <int NKS>
+__device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                                    const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                    int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                                    const uint8_t *__restrict__ counts, unsigned table_bytes,
+                                                    const double *__restrict__ p4, double *__restrict__ out, int64_t q,
+                                                    int b0, int b1, unsigned *rowbuf /* 1 KB used */,
+                                                    unsigned char *abuf /* 576 B */)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
+    const int64_t slot = i - nbrs_begin;
+    const int64_t s = offset[slot];
+    const int k = cnt[slot];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
+    const int a = lane & 15, kb = lane >> 4;
+    // LDS image of a step: 64 pieces of 16 bytes, piece P = 32 (kb >> 1) + 16 u + 8 (kb & 1) + q holds chunk b_u of row
+    // 8 kb + q -- the DMA writes its lanes' pieces back to back, so lane P fetches exactly that; the 32 pieces a
+    // transposing read of block u touches per half-wave then lie in 32 different 8-byte bank pairs.
+    const int d_u = (lane >> 4) & 1, d_row = 16 * (lane >> 5) + (lane & 15); // = 8 (2 (P >> 5) + ((P >> 3) & 1)) + (P & 7)
+    const unsigned dma_chunk16 = 16u * (unsigned)(d_u ? b1 : b0);
+    const int rd_piece = 32 * (kb >> 1) + 8 * (kb & 1) + (a >> 1); // + 16 u ; bytes 8 (a & 1) .. of the piece
+    const int rd0 = 16 * rd_piece + 8 * (a & 1), rd1 = rd0 + 256;
+    const unsigned lds_rows = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)rowbuf);
+#define SF_MCS_DMA(ST)                                                                                              \
+    {                                                                                                               \
+        const int jr0 = __shfl(jv[(ST) >> 1], 32 * ((ST) & 1) + d_row);                                             \
+        const int jr = jr0 < 0 ? 0 : jr0; /* idle slots of the last step fetch row 0 */                             \
+        const unsigned voff = (unsigned)jr * 128u + dma_chunk16;                                                    \
+        unsigned keep_;                                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                         \
+                     "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"                                  \
+                     : "=&s"(keep_)                                                                                 \
+                     : "v"(voff), "s"(rsrc), "s"(lds_rows)                                                          \
+                     : "memory");                                                                                   \
+    }
+    // ---- weights of all neighbours, exactly as in fpfh_mc_body ----
+    int jv[NKS];
+    double wv[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const int t = c * 64 + lane;
+        jv[c] = -1;
+        if (c == 0 || c * 64 < k) jv[c] = t < k ? idx[s + t] : -1;
+    }
+    SF_MCS_DMA(0) // in flight while the weights are computed
+    double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        gx[c] = gy[c] = gz[c] = gk[c] = 0.0;
+        if (c == 0 || c * 64 < k) {
+            const int j = jv[c] < 0 ? 0 : jv[c];
+            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j);
+            const double2 u0 = pp[0], u1 = pp[1];
+            gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
+        }
+    }
+    double wmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        wv[c] = 0.0;
+        if (c == 0 || c * 64 < k) {
+            const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
+            const double d2 = (cx * cx + cy * cy) + cz * cz;
+            const double kd = gk[c], xx = d2 * (kd * kd);
+            const double y0 = __builtin_amdgcn_rsq(xx);
+            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+            wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0;
+            wmax = fmax(wmax, wv[c]);
+        }
+        jv[c] = jv[c] < 0 ? 0 : jv[c];
+    }
+    wmax = sf_wave_max_nonneg(wmax);
+    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
+    const int S = 62 - e2;
+
+    v4i acc0 = v4i{0, 0, 0, 0}, acc1 = v4i{0, 0, 0, 0}, accp = v4i{0, 0, 0, 0}; // blocks b0, b1, and the padding column
+    const long Bpad = (long)0x8080808080808080ull; // eight neighbours' padding bin: -128 each
+
+#pragma unroll
+    for (int st = 0; st < 2 * NKS; ++st) {
+        if (st * 32 < k) { // wave-uniform
+            if (st > 0) SF_MCS_DMA(st)
+            if ((st & 1) == 0) { // this lane's weight as nine 7-bit limbs: abuf[limb][lane]
+                const int ks = st >> 1;
+                const double x = ldexp(wv[ks], S - 32); // < 2^31
+                const unsigned hi = (unsigned)x;
+                const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
+                const int pos = lane;
+                abuf[0 * 64 + pos] = (unsigned char)(lo & 127u);
+                abuf[1 * 64 + pos] = (unsigned char)((lo >> 7) & 127u);
+                abuf[2 * 64 + pos] = (unsigned char)((lo >> 14) & 127u);
+                abuf[3 * 64 + pos] = (unsigned char)((lo >> 21) & 127u);
+                abuf[4 * 64 + pos] = (unsigned char)(((lo >> 28) | (hi << 4)) & 127u);
+                abuf[5 * 64 + pos] = (unsigned char)((hi >> 3) & 127u);
+                abuf[6 * 64 + pos] = (unsigned char)((hi >> 10) & 127u);
+                abuf[7 * 64 + pos] = (unsigned char)((hi >> 17) & 127u);
+                abuf[8 * 64 + pos] = (unsigned char)((hi >> 24) & 127u);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
+            __builtin_amdgcn_wave_barrier();
+            long A = 0;
+            if (a < 9) A = *reinterpret_cast<const long *>(&abuf[a * 64 + 32 * (st & 1) + 8 * kb]); // row a = limb a
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
+            const v2i_t t0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd0));
+            const v2i_t t1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd1));
+            accp = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bpad, accp, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)(((unsigned long long)(unsigned)t0[1] << 32) | (unsigned)t0[0]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)(((unsigned long long)(unsigned)t1[1] << 32) | (unsigned)t1[0]), acc1, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next step's DMA overwrites the pieces
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- recombination: lane (a, g) holds limbs 4g .. 4g + 3 of bin 16 b_u + a in acc_u, and of the padding column in accp
+    //      (every column of accp is the same sum) ----
+    const int pad01 = (accp[1] << 7) + accp[0], pad23 = (accp[3] << 7) + accp[2];
+    const double p0 = ldexp(1.0, 28 * kb - S); // 2^(7 (4 g) - S)
+    const double f0 = p0, f2 = p0 * 16384.0;
+    const double kd = (double)k;
+    double inv_k = __builtin_amdgcn_rcp(kd);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    double part0, part1;
+    {
+        const int e01 = ((acc0[1] << 7) + acc0[0]) - pad01, e23 = ((acc0[3] << 7) + acc0[2]) - pad23;
+        part0 = __builtin_fma((double)e23, f2, (double)e01 * f0);
+        const int g01 = ((acc1[1] << 7) + acc1[0]) - pad01, g23 = ((acc1[3] << 7) + acc1[2]) - pad23;
+        part1 = __builtin_fma((double)g23, f2, (double)g01 * f0);
+    }
+    // Sum over the four limb groups in the SAME order as the full kernel -- (g + (g ^ 2)) first, then the two halves of that
+    // -- so that the rounding, hence every bit of the row, is the full kernel's: after the 32-swap the lower half of the
+    // wave holds block b0's pair sums and the upper half block b1's, after the 16-swap both rows of a half hold the total.
+    sf_lane_swap<32>(part0, part1);
+    double v = part0 + part1;     // lanes 0..31: block b0, groups (g, g + 2) ; lanes 32..63: block b1
+    double w = v;
+    sf_lane_swap<16>(v, w);
+    const double tot = v + w;     // all four groups; lanes 0..31: bin 16 b0 + a, lanes 32..63: bin 16 b1 + a
+    // every lane needs both totals for the row it helps write: the other half's through one more 32-swap
+    double mine = tot, other = tot;
+    sf_lane_swap<32>(mine, other); // lower half: mine = own (b0), other = b1's ; upper half: mine = b0's, other = own (b1)
+    const double tot0 = mine, tot1 = other; // (after the swap `mine` is block b0's total in both halves, `other` b1's)
+    {
+        const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
+        const int o0 = 16 * bb0 + a, o1 = o0 + 16; // the two bins this lane writes, as in the full kernel
+        const uint8_t *own = counts + i * 128;
+        double *o = out + q * (int64_t)nb3;
+        const double c0 = (double)((unsigned)own[o0] ^ 128u), c1 = (double)((unsigned)own[o1] ^ 128u);
+        double s0 = c0 * inv_k, s1 = c1 * inv_k;
+        s0 = __builtin_fma(__builtin_fma(-s0, kd, c0), inv_k, s0);
+        s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
+        const double v0 = bb0 == b0 ? tot0 : (bb0 == b1 ? tot1 : 0.0);
+        const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
+        if (o0 < nb3) o[o0] = s0 + v0 * inv_k;
+        if (o1 < nb3) o[o1] = s1 + v1 * inv_k;
+    }
+}
+
+#undef SF_MCS_DMA
+
