@@ -210,9 +210,12 @@ struct sf_spfh {
     int32_t *k = nullptr;   // n, neighbourhood size (self included), by sorted position
     double *p4 = nullptr;   // uint8 table only: n x {x, y, z, (double)k} -- all the matrix-core K7 gathers per neighbour
                             // besides the table row, in ONE 32-byte record (one cache line per lane instead of three)
-    unsigned *live = nullptr; // uint8 table only: bit b set <=> some row computed so far has a non-zero count among bins
-                              // 16 b .. 16 b + 15 (OR-accumulated by K6, never cleared: a superset is always safe).  The
-                              // matrix-core K7 streams and multiplies only the live 16-bin blocks of the rows.
+    unsigned *live = nullptr; // uint8 table only, two words.  [0]: bit b set <=> some row computed so far has a non-zero
+                              // count among bins 16 b .. 16 b + 15 (OR-accumulated by K6, never cleared: a superset is always
+                              // safe); the matrix-core K7 streams and multiplies only the live 16-bin blocks of the rows.
+                              // [1]: the mask under which EVERY row of `packed` was last written (~0: not valid).
+    uint8_t *packed = nullptr; // uint8 table only: n x 32 bytes, the (at most) two live blocks of each row side by side --
+                               // four rows per cache line instead of one for K7's gather
 };
 
 static inline int64_t sf_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const double *__restrict__ p4, const unsigned *__restrict__ live,
+                                                 const uint8_t *__restrict__ packed, unsigned packed_bytes,
                                                  double *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // 32 rows of 128 B
@@ -412,14 +413,47 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
         const int b0 = mask ? __ffs(mask) - 1 : 0;
         const unsigned rest = mask & (mask - 1u);
         const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7; // (a lone live block is paired with an empty one)
-        fpfh_mc_body_sparse<NKS>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, b0, b1,
-                                 rowbuf_all[wv_id], abuf_all[wv_id]);
+        // ... from the packed copy (32 bytes per row: four rows per cache line) when every row of it was written under this
+        // very mask, else from the table itself
+        if (sf_uniform(live[1]) == mask) {
+            fpfh_mc_body_sparse<NKS, true>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q,
+                                           b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
+        } else {
+            fpfh_mc_body_sparse<NKS, false>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q,
+                                            b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
+        }
         return;
     }
     fpfh_mc_body<NKS>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
                       abuf_all[wv_id]);
 }
 
+
+// After K6 on the uint8 table: when at most two of the eight 16-bin blocks are live, their two 16-byte chunks of every
+// row are copied side by side into `packed` (32 bytes per row).  Rows [begin, end) were just (re)computed; the others are
+// re-packed too if the mask they were packed under (live[1]) is not the current one -- the mask only ever grows, and a
+// row packed under an older mask may hold a different pair of blocks.  k_spfh_pack_done then records the mask.
+__global__ __launch_bounds__(256) void k_spfh_pack(const uint8_t *__restrict__ counts, int64_t n, int64_t begin, int64_t end,
+                                                   const unsigned *__restrict__ live, uint8_t *__restrict__ packed)
+{
+    const unsigned mask = live[0] & 0xffu, sig = live[1];
+    if (__popc(mask) > 2) return;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n || (sig == mask && (row < begin || row >= end))) return;
+    const int b0 = mask ? __ffs(mask) - 1 : 0;
+    const unsigned rest = mask & (mask - 1u);
+    const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7;
+    const uint4 *src = reinterpret_cast<const uint4 *>(counts + row * 128);
+    uint4 *dst = reinterpret_cast<uint4 *>(packed + row * 32);
+    dst[0] = src[b0];
+    dst[1] = src[b1];
+}
+
+__global__ void k_spfh_pack_done(unsigned *__restrict__ live)
+{
+    const unsigned mask = live[0] & 0xffu;
+    live[1] = __popc(mask) <= 2 ? mask : ~0u;
+}
 
 template <typename CT>
 __global__ void k_spfh_export(const CT *__restrict__ counts, const int32_t *__restrict__ kk,
@@ -578,9 +612,11 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     if (hipMalloc(&sp->counts, nn * sp->stride * sp->elem_bytes) != hipSuccess ||
         hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess ||
         (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess) ||
-        (sp->elem_bytes == 1 && (hipMalloc(&sp->live, sizeof(unsigned)) != hipSuccess ||
+        (sp->elem_bytes == 1 && (hipMalloc(&sp->live, 2 * sizeof(unsigned)) != hipSuccess ||
+                                 hipMalloc(&sp->packed, nn * 32) != hipSuccess ||
                                  // SF_FPFH_DENSE=1: every block counts as live from the start (K7 always takes its full form)
-                                 hipMemset(sp->live, getenv("SF_FPFH_DENSE") ? 0xff : 0, sizeof(unsigned)) != hipSuccess))) {
+                                 hipMemset(sp->live, getenv("SF_FPFH_DENSE") ? 0xff : 0, sizeof(unsigned)) != hipSuccess ||
+                                 hipMemset(sp->live + 1, 0xff, sizeof(unsigned)) != hipSuccess))) {
         sf_set_error("sf_spfh_create: out of device memory");
         sf_spfh_free(ctx, sp);
         return nullptr;
@@ -596,6 +632,7 @@ extern "C" void sf_spfh_free(sf_ctx *ctx, sf_spfh *sp)
     if (sp->k) (void)hipFree(sp->k);
     if (sp->p4) (void)hipFree(sp->p4);
     if (sp->live) (void)hipFree(sp->live);
+    if (sp->packed) (void)hipFree(sp->packed);
     delete sp;
 }
 
@@ -668,6 +705,10 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     }
     if (sp->elem_bytes == 1) {
         SF_SPFH_DISPATCH(uint8_t)
+        // rows [self_begin, self_begin + m) are new: pack their live blocks (a no-op on the device when more than two are)
+        SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack, dim3((unsigned)sf_div_up(sp->n, 256)), dim3(256), (const uint8_t *)sp->counts,
+                  sp->n, nb->self_begin, nb->self_begin + m, (const unsigned *)sp->live, sp->packed);
+        SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack_done, dim3(1), dim3(1), sp->live);
     } else if (sp->elem_bytes == 2) {
         SF_SPFH_DISPATCH(uint16_t)
     } else {
@@ -714,7 +755,7 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
         SF_CHECK(sf_comm_allgather(ctx, pb + (size_t)ctx->rank * rows_per_rank * 32, pb, (size_t)rows_per_rank * 32));
     }
     // the gathered rows come from other ranks' K6: every block of the table counts as live from here on
-    if (sp->live) SF_HIP(hipMemsetAsync(sp->live, 0xff, sizeof(unsigned), ctx->stream));
+    if (sp->live) SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->stream));
     return SF_OK;
 }
 
@@ -801,7 +842,8 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     const int nks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
 #define SF_MC_LAUNCH(NKS)                                                                                            \
     SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc<NKS>, grid, block, c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, \
-              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, dout)
+              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, \
+              (const uint8_t *)sp->packed, (unsigned)((size_t)sp->rows_alloc * 32), dout)
     if (nks <= 1) { SF_MC_LAUNCH(1); }
     else if (nks == 2) { SF_MC_LAUNCH(2); }
     else if (nks == 3) { SF_MC_LAUNCH(3); }

@@ -246,14 +246,16 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
 // against a constant operand (every byte 0x80) instead of a column read from the table.  Results are those of the full
 // kernel bit for bit: the integer sums of the live bins are the same sums, and a dead bin's sum is exactly its bias.
 // --------------------------------------------------------------------------------------------------
-template <int NKS>
+// PACKED: the two chunks come from K6's packed copy of the table (`rows`: 32 bytes per row = {chunk b0, chunk b1}) instead
+// of the table itself (`rows` = counts, 128 bytes per row): four rows per cache line for the gather.
+template <int NKS, bool PACKED>
 __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                     int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
-                                                    const uint8_t *__restrict__ counts, unsigned table_bytes,
-                                                    const double *__restrict__ p4, double *__restrict__ out, int64_t q,
-                                                    int b0, int b1, unsigned *rowbuf /* 1 KB used */,
-                                                    unsigned char *abuf /* 576 B */)
+                                                    const uint8_t *__restrict__ counts, const uint8_t *__restrict__ rows,
+                                                    unsigned rows_bytes, const double *__restrict__ p4,
+                                                    double *__restrict__ out, int64_t q, int b0, int b1,
+                                                    unsigned *rowbuf /* 1 KB used */, unsigned char *abuf /* 576 B */)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
@@ -261,13 +263,14 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     const int64_t s = offset[slot];
     const int k = cnt[slot];
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(rows), 0, (int)rows_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
     // LDS image of a step: 64 pieces of 16 bytes, piece P = 32 (kb >> 1) + 16 u + 8 (kb & 1) + q holds chunk b_u of row
     // 8 kb + q -- the DMA writes its lanes' pieces back to back, so lane P fetches exactly that; the 32 pieces a
     // transposing read of block u touches per half-wave then lie in 32 different 8-byte bank pairs.
     const int d_u = (lane >> 4) & 1, d_row = 16 * (lane >> 5) + (lane & 15); // = 8 (2 (P >> 5) + ((P >> 3) & 1)) + (P & 7)
-    const unsigned dma_chunk16 = 16u * (unsigned)(d_u ? b1 : b0);
+    const unsigned dma_chunk16 = PACKED ? 16u * (unsigned)d_u : 16u * (unsigned)(d_u ? b1 : b0);
+    constexpr unsigned ROW_BYTES = PACKED ? 32u : 128u;
     const int rd_piece = 32 * (kb >> 1) + 8 * (kb & 1) + (a >> 1); // + 16 u ; bytes 8 (a & 1) .. of the piece
     const int rd0 = 16 * rd_piece + 8 * (a & 1), rd1 = rd0 + 256;
     const unsigned lds_rows = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -276,7 +279,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     {                                                                                                               \
         const int jr0 = __shfl(jv[(ST) >> 1], 32 * ((ST) & 1) + d_row);                                             \
         const int jr = jr0 < 0 ? 0 : jr0; /* idle slots of the last step fetch row 0 */                             \
-        const unsigned voff = (unsigned)jr * 128u + dma_chunk16;                                                    \
+        const unsigned voff = (unsigned)jr * ROW_BYTES + dma_chunk16;                                               \
         unsigned keep_;                                                                                             \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                         \
                      "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"                                  \
