@@ -277,14 +277,14 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
         (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)rowbuf);
 #define SF_MCS_DMA(ST)                                                                                              \
     {                                                                                                               \
-        const int jr0 = __shfl(jv[(ST) >> 1], 32 * ((ST) & 1) + d_row);                                             \
+        const int jr0 = __shfl(jv[((ST) >> 1) < NKS ? ((ST) >> 1) : 0], 32 * ((ST) & 1) + d_row);                   \
         const int jr = jr0 < 0 ? 0 : jr0; /* idle slots of the last step fetch row 0 */                             \
         const unsigned voff = (unsigned)jr * ROW_BYTES + dma_chunk16;                                               \
         unsigned keep_;                                                                                             \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                         \
                      "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"                                  \
                      : "=&s"(keep_)                                                                                 \
-                     : "v"(voff), "s"(rsrc), "s"(lds_rows)                                                          \
+                     : "v"(voff), "s"(rsrc), "s"(lds_rows + 1024u * (unsigned)((ST) & 3))                           \
                      : "memory");                                                                                   \
     }
     // ---- weights of all neighbours, exactly as in fpfh_mc_body ----
@@ -296,7 +296,13 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
         jv[c] = -1;
         if (c == 0 || c * 64 < k) jv[c] = t < k ? idx[s + t] : -1;
     }
-    SF_MCS_DMA(0) // in flight while the weights are computed
+    // The image of a step is 1 KB, so the 4 KB row buffer holds FOUR steps: the rows of the first two chunks (128
+    // neighbours -- the whole list for nine keypoints in ten) are all requested here, in flight while the weights are
+    // computed, and the step loop below never waits on memory again; only a third / fourth chunk re-uses the buffer.
+    SF_MCS_DMA(0)
+    if (32 < k) SF_MCS_DMA(1)
+    if (NKS >= 2 && 64 < k) SF_MCS_DMA(2)
+    if (NKS >= 2 && 96 < k) SF_MCS_DMA(3)
     double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
 #pragma unroll
     for (int c = 0; c < NKS; ++c) {
@@ -334,7 +340,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
 #pragma unroll
     for (int st = 0; st < 2 * NKS; ++st) {
         if (st * 32 < k) { // wave-uniform
-            if (st > 0) SF_MCS_DMA(st)
+            if (st >= 4) SF_MCS_DMA(st) // (steps 0 .. 3 were requested up front; by now their regions have been consumed)
             if ((st & 1) == 0) { // this lane's weight as nine 7-bit limbs: abuf[limb][lane]
                 const int ks = st >> 1;
                 const double x = ldexp(wv[ks], S - 32); // < 2^31
@@ -356,8 +362,8 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
             long A = 0;
             if (a < 9) A = *reinterpret_cast<const long *>(&abuf[a * 64 + 32 * (st & 1) + 8 * kb]); // row a = limb a
             const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
-            const v2i_t t0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd0));
-            const v2i_t t1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd1));
+            const v2i_t t0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd0 + 1024 * (st & 3)));
+            const v2i_t t1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd1 + 1024 * (st & 3)));
             accp = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bpad, accp, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)(((unsigned long long)(unsigned)t0[1] << 32) | (unsigned)t0[0]), acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)(((unsigned long long)(unsigned)t1[1] << 32) | (unsigned)t1[0]), acc1, 0, 0, 0);
