@@ -430,16 +430,12 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
 
 
 // After K6 on the uint8 table: when at most two of the eight 16-bin blocks are live, their two 16-byte chunks of every
-// row are copied side by side into `packed` (32 bytes per row).  Rows [begin, end) were just (re)computed; the others are
-// re-packed too if the mask they were packed under (live[1]) is not the current one -- the mask only ever grows, and a
-// row packed under an older mask may hold a different pair of blocks.  k_spfh_pack_done then records the mask.
-__global__ __launch_bounds__(256) void k_spfh_pack(const uint8_t *__restrict__ counts, int64_t n, int64_t begin, int64_t end,
-                                                   const unsigned *__restrict__ live, uint8_t *__restrict__ packed)
+// row are copied side by side into `packed` (32 bytes per row).  Rows [begin, end) were just (re)computed: k_spfh_pack.
+// The others are re-packed too if the mask they were packed under (live[1]) is not the current one -- the mask only ever
+// grows, and a row packed under an older mask may hold a different pair of blocks: k_spfh_repack, a small grid that
+// returns at once in the usual case.  k_spfh_pack_done then records the mask.
+__device__ inline void spfh_pack_row(const uint8_t *__restrict__ counts, uint8_t *__restrict__ packed, int64_t row, unsigned mask)
 {
-    const unsigned mask = live[0] & 0xffu, sig = live[1];
-    if (__popc(mask) > 2) return;
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n || (sig == mask && (row < begin || row >= end))) return;
     const int b0 = mask ? __ffs(mask) - 1 : 0;
     const unsigned rest = mask & (mask - 1u);
     const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7;
@@ -447,6 +443,24 @@ __global__ __launch_bounds__(256) void k_spfh_pack(const uint8_t *__restrict__ c
     uint4 *dst = reinterpret_cast<uint4 *>(packed + row * 32);
     dst[0] = src[b0];
     dst[1] = src[b1];
+}
+
+__global__ __launch_bounds__(256) void k_spfh_pack(const uint8_t *__restrict__ counts, int64_t begin, int64_t end,
+                                                   const unsigned *__restrict__ live, uint8_t *__restrict__ packed)
+{
+    const unsigned mask = live[0] & 0xffu;
+    if (__popc(mask) > 2) return;
+    const int64_t row = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < end) spfh_pack_row(counts, packed, row, mask);
+}
+
+__global__ __launch_bounds__(256) void k_spfh_repack(const uint8_t *__restrict__ counts, int64_t n, int64_t begin, int64_t end,
+                                                     const unsigned *__restrict__ live, uint8_t *__restrict__ packed)
+{
+    const unsigned mask = live[0] & 0xffu, sig = live[1];
+    if (__popc(mask) > 2 || sig == mask) return;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x)
+        if (row < begin || row >= end) spfh_pack_row(counts, packed, row, mask);
 }
 
 __global__ void k_spfh_pack_done(unsigned *__restrict__ live)
@@ -706,8 +720,10 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     if (sp->elem_bytes == 1) {
         SF_SPFH_DISPATCH(uint8_t)
         // rows [self_begin, self_begin + m) are new: pack their live blocks (a no-op on the device when more than two are)
-        SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack, dim3((unsigned)sf_div_up(sp->n, 256)), dim3(256), (const uint8_t *)sp->counts,
-                  sp->n, nb->self_begin, nb->self_begin + m, (const unsigned *)sp->live, sp->packed);
+        SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack, dim3((unsigned)sf_div_up(m, 256)), dim3(256), (const uint8_t *)sp->counts,
+                  nb->self_begin, nb->self_begin + m, (const unsigned *)sp->live, sp->packed);
+        SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_repack, dim3(2048), dim3(256), (const uint8_t *)sp->counts, sp->n, nb->self_begin,
+                  nb->self_begin + m, (const unsigned *)sp->live, sp->packed);
         SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack_done, dim3(1), dim3(1), sp->live);
     } else if (sp->elem_bytes == 2) {
         SF_SPFH_DISPATCH(uint16_t)

@@ -423,3 +423,41 @@ def test_knn_with_more_than_448_neighbours(eng, n, m, k):
     with pytest.raises(s.ShotFpfhError):
         cloud.knn_search(q, 1985) if n >= 1985 else cloud.knn_search(q[:0], 1985)
     cloud.free()
+
+
+# ---- K7's sparse-block form and the packed copy of the SPFH table --------------------------------------------------
+def test_fpfh_live_block_mask_grows_between_computes(eng, O):
+    """One SPFH table filled by TWO computes whose rows have different non-empty 16-bin blocks: a plane with normals along
+    its own (phi = 0 for every pair: one block of the 27-bin table) sorts before a blob (both blocks).  After the first
+    compute the matrix-core K7 runs its one-block form on the packed copy; the second compute grows the table-wide mask,
+    so the plane's rows have to be re-packed under the new pair of blocks.  Every stage against the oracle."""
+    rng = np.random.default_rng(4)
+    plane = np.column_stack([rng.random((6000, 2)), np.zeros(6000)])
+    blob = rng.random((6000, 3)) * np.array([1.0, 1.0, 0.3]) + np.array([0.0, 0.0, 2.0])
+    p = np.ascontiguousarray(np.vstack([plane, blob]).astype(np.float32).astype(np.float64))
+    nr = np.vstack([np.tile([0.0, 0.0, 1.0], (6000, 1)), rng.standard_normal((6000, 3))])
+    nr[6000:] /= np.linalg.norm(nr[6000:], axis=1)[:, None]
+    r, nb = 0.06, 3
+    want = O.compute_fpfh_descriptor(np.arange(12000), p, nr, r, nb)
+    cloud = eng.cloud(p, nr)
+    cloud.build_grid(r)
+    perm = cloud.perm()
+    assert set(perm[:6000].tolist()) == set(range(6000))  # z-major cell order: the plane's points come first
+    full = cloud.radius_search_self(r)
+    lo, hi = cloud.radius_search_self(r, 0, 6000), cloud.radius_search_self(r, 6000, 12000)
+    sp = eng.spfh(cloud, nb, full.max_count)
+    sp.compute(lo)
+    got_lo = sp.fpfh(lo)
+    assert np.abs(got_lo - want[perm[:6000]]).max() < 1e-9
+    assert not got_lo[:, 16:].any() and got_lo[:, 12:15].any()  # only bins 12..14 (alpha, phi central): block 0
+    sp.compute(hi)
+    got = sp.fpfh(full)
+    assert np.abs(got - want[perm]).max() < 1e-9
+    assert got[6000:, 16:].any()  # the blob does reach the second block
+    # ... and the same table computed in one go, and again (steady state), gives the same bits
+    sp2 = eng.spfh(cloud, nb, full.max_count)
+    for _ in range(2):
+        sp2.compute(full)
+        assert np.array_equal(sp2.fpfh(full), got)
+    kp = rng.choice(12000, 500, replace=False)
+    assert np.array_equal(sp.fpfh(full, kp), got[np.argsort(perm)][kp])
