@@ -17,7 +17,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHORT = [
     ("k_rows_gather", "k8_rows_gather"), ("k_rows_nonzero", "k8_rows_nonzero"), ("k_icp_", "i1_icp"), ("k_transform", "i0_transform"),
-    ("k_voxel", "v_voxel"), ("k_azimuth", "k5_azimuth_idx"), ("k_spfh_generic", "k6_spfh_generic"), ("k_fpfh_generic", "k7_fpfh_generic"),
+    ("k_voxel", "v_voxel"), ("k_azimuth", "k5_azimuth_idx"), ("k_spfh_generic", "k6_spfh_generic"), ("k_spfh_pack", "k6_spfh_pack"), ("k_spfh_repack", "k6_spfh_pack"), ("k_fpfh_generic", "k7_fpfh_generic"),
     ("k_lrf_from_cov", "k4_lrf_from_cov"), ("k_shot_lrf", "k4_shot_lrf"), ("k_lrf_", "k4_shot_lrf"), ("k_shot", "k5_shot"), ("k_fpfh", "k7_fpfh"), ("k_spfh_export", "k6_spfh_export"),
     ("k_spfh", "k6_spfh"), ("k_radius<2>", "k2_radius_slots"), ("k_radius<1>", "k2_radius_fill"), ("k_radius<0>", "k2_radius_count"),
     ("k_radius<true>", "k2_radius_fill"), ("k_radius<false>", "k2_radius_count"), ("k_export_lists", "k2_export_lists"),
