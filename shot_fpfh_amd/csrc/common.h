@@ -178,6 +178,7 @@ struct sf_cloud {
     // costs 16 cycles per wave instruction whatever the width, so 3 wide loads beat 6 narrow ones)
     double *rec = nullptr;
     bool normals_sorted = false;
+    double nrm_max2 = -1.0;         // largest squared norm among the normals (< 0: not computed yet; sf_cloud_normals_max2)
     // cell-sorted positions that are actually populated: [0, n) after sf_cloud_build_grid, the slab a block needs
     // after sf_cloud_build_grid_block (positions keep their GLOBAL numbering either way)
     int64_t pop_begin = 0, pop_end = 0;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
                                               CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias,
                                               double *__restrict__ p4, double mom_radius, double *__restrict__ cov,
-                                              unsigned *__restrict__ live)
+                                              unsigned *__restrict__ live, int alpha_bin)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
         if (d2 > 0.0) { // dist > 0 (fpfh.py:50-57)
             const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
             const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
-            const double alpha = (vx * njx + vy * njy) + vz * njz;
+
             // phi = (c . u) / sqrt(d2) only picks a bin.  One Newton step on v_rsq_f64 gives it to ~1e-15; the
             // reference's own expression (sqrt, then the division: 34 instructions) is evaluated only when that
             // value lies within 1e-9 bin widths of an edge, so the bin is the reference's in every case.
@@ -118,7 +118,12 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
             const double pos = (phi - ed.p[0]) * p_inv_width;
             if (fabs(pos - rint(pos)) <= 1e-9) phi = num / sqrt(d2);
             const int bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, (njx * ux + njy * uy) + njz * uz);
-            const int ba = hist_bin(ed.a, nb, alpha), bp = hist_bin(ed.p, nb, phi);
+            // alpha = v . n_j with v = c x u NOT normalised (fpfh.py:60): |alpha| <= |c| |u| |n_j| <= radius when no normal
+            // is longer than 1, so with the radius below the smallest |edge| of the alpha histogram every sample is in the
+            // bin around 0 -- the host passes that bin (alpha_bin >= 0, wave-uniform) and alpha is never formed
+            int ba = alpha_bin;
+            if (alpha_bin < 0) ba = hist_bin(ed.a, nb, (vx * njx + vy * njy) + vz * njz);
+            const int bp = hist_bin(ed.p, nb, phi);
             if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt], 1u);
         }
     };
@@ -691,13 +696,27 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     }
     const int64_t m = nb->m;
     if (!m) return SF_OK;
+    // alpha's bin is known beforehand when every |alpha| <= radius * max|n|^2 stays clear of the histogram's edges (see
+    // k_spfh): the bin that holds 0, if 0 is strictly inside one
+    int alpha_bin = -1;
+    {
+        double n2 = 0.0;
+        SF_CHECK(sf_cloud_normals_max2(ctx, c, &n2));
+        const double reach = nb->radius * n2 * (1.0 + 1e-9); // |u| |n_j| <= max |n|^2
+        double nearest = INFINITY;
+        for (int i = 0; i <= nbn; ++i) nearest = std::min(nearest, std::fabs(ed.a[i]));
+        if (std::isfinite(reach) && reach < nearest)
+            for (int i = 0; i < nbn; ++i)
+                if (ed.a[i] < 0.0 && 0.0 < ed.a[i + 1]) alpha_bin = i;
+        if (getenv("SF_FPFH_NO_ALPHA_SHORTCUT")) alpha_bin = -1;
+    }
     const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SPFH_WPB))), block(64 * SF_SPFH_WPB);
     int chunks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
     if (chunks > 4) chunks = 0; // streaming kernel
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
               nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov, \
-              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr)
+              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <cstring>
+
 #include "common.h"
 #include "device_util.h"
 
@@ -222,6 +224,47 @@ extern "C" int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *c, const double *norm
     if (c->n) SF_HIP(hipMemcpyAsync(c->nrm_orig, normals, (size_t)c->n * 24, kind, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
     c->normals_sorted = false;
+    c->nrm_max2 = -1.0;
+    return SF_OK;
+}
+
+namespace {
+// max over the normals of |n|^2 (non-finite components count as +inf): non-negative doubles order like their bit patterns
+__global__ void k_normals_max2(const double *__restrict__ nrm, int64_t n, unsigned long long *__restrict__ out)
+{
+    double mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = nrm[3 * i], b = nrm[3 * i + 1], c = nrm[3 * i + 2];
+        const double v = (a * a + b * b) + c * c;
+        mx = v <= 1.7976931348623157e308 ? fmax(mx, v) : INFINITY; // NaN / inf -> inf
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
+}
+} // namespace
+
+// Largest squared norm among the cloud's normals, computed once per set of normals (one small kernel + read-back).
+// K6 uses it: with unit normals |alpha| <= |p_j - p_i| <= radius, which pins alpha's bin when the radius is small.
+int sf_cloud_normals_max2(sf_ctx *ctx, sf_cloud *c, double *out)
+{
+    if (!c->nrm_orig) { sf_set_error("this operation needs normals, but the cloud has none"); return SF_ERR_STATE; }
+    if (c->nrm_max2 < 0.0) {
+        unsigned long long *d = nullptr;
+        void *pin = nullptr;
+        SF_CHECK(sf_palloc(ctx, &d, (size_t)1));
+        SF_CHECK(sf_ctx_pinned(ctx, &pin));
+        SF_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+        if (c->n) SF_LAUNCH(ctx, "k1_normals_max", k_normals_max2, dim3(512), dim3(256), (const double *)c->nrm_orig, c->n, d);
+        SF_HIP(hipMemcpyAsync(pin, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        sf_pool_release(ctx, d);
+        long long bits = *(const long long *)pin;
+        double v;
+        static_assert(sizeof(v) == sizeof(bits), "");
+        memcpy(&v, &bits, sizeof(v));
+        c->nrm_max2 = v;
+    }
+    *out = c->nrm_max2;
     return SF_OK;
 }
 

@@ -461,3 +461,25 @@ def test_fpfh_live_block_mask_grows_between_computes(eng, O):
         assert np.array_equal(sp2.fpfh(full), got)
     kp = rng.choice(12000, 500, replace=False)
     assert np.array_equal(sp.fpfh(full, kp), got[np.argsort(perm)][kp])
+
+
+def test_spfh_alpha_bin_shortcut_only_with_short_normals(eng, O):
+    """K6 skips alpha when |alpha| <= radius * max|n|^2 cannot reach an edge of its histogram.  Unit normals and a small
+    radius take the shortcut; the same cloud with normals ten times too long (alpha up to 100 x larger: other bins, and
+    samples beyond +-1 that the reference drops) must not -- both against the oracle, on the integer SPFH table itself."""
+    import shot_fpfh_amd as s
+
+    p, nr, rng = synth_cloud(20000, 123)
+    kp = np.arange(20000)
+    r = 0.05
+    for scale in (1.0, 10.0, 0.5):
+        nn = nr * scale
+        got = s.compute_fpfh_descriptor(kp, p, nn, r, 5)
+        want = O.compute_fpfh_descriptor(kp, p, nn, r, 5)
+        assert np.abs(got - want).max() < 1e-9, scale
+        live_alpha = sorted(set((np.flatnonzero(want.any(axis=0)) // 25).tolist()))
+        assert (live_alpha == [2]) == (scale <= 1.0), (scale, live_alpha)
+    # even bin count: 0 is an edge of the alpha histogram, no shortcut possible; radius above the inner edge neither
+    for nb, rr in ((4, 0.05), (5, 0.25)):
+        got = s.compute_fpfh_descriptor(kp[:3000], p, nr, rr, nb)
+        assert np.abs(got - O.compute_fpfh_descriptor(kp[:3000], p, nr, rr, nb)).max() < 1e-9
