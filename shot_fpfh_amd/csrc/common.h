@@ -217,6 +217,8 @@ struct sf_spfh {
                               // [1]: the mask under which EVERY row of `packed` was last written (~0: not valid).
     uint8_t *packed = nullptr; // uint8 table only: n x 32 bytes, the (at most) two live blocks of each row side by side --
                                // four rows per cache line instead of one for K7's gather
+    unsigned host_live[2] = {0xffu, ~0u}; // the two words of `live` as last read back ...
+    bool host_live_valid = false;         // ... valid until the next K6 on this table (sf_fpfh reads them back once)
 };
 
 static inline int64_t sf_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }

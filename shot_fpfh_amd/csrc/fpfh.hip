@@ -18,6 +18,7 @@
 // read + 1000 FPFH write = 3048 B per descriptor when every point is a keypoint.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "common.h"
 #include "device_util.h"
@@ -410,27 +411,43 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     const int wv_id = threadIdx.x >> 6;
     const int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
     if (q >= m) return;
-    // which 16-bin blocks of the table hold anything at all (K6's OR over every row): with at most two of the eight --
-    // the reference's un-normalised v keeps alpha in ONE of its bins whenever the radius is well below that bin's width,
-    // so 100 of the 125 bins are structurally empty -- only those blocks are streamed and multiplied
-    const unsigned mask = sf_uniform(*live) & 0xffu;
-    if (__popc(mask) <= 2) {
-        const int b0 = mask ? __ffs(mask) - 1 : 0;
-        const unsigned rest = mask & (mask - 1u);
-        const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7; // (a lone live block is paired with an empty one)
-        // ... from the packed copy (32 bytes per row: four rows per cache line) when every row of it was written under this
-        // very mask, else from the table itself
-        if (sf_uniform(live[1]) == mask) {
-            fpfh_mc_body_sparse<NKS, true>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q,
-                                           b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
-        } else {
-            fpfh_mc_body_sparse<NKS, false>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q,
-                                            b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
-        }
-        return;
-    }
+    // (the full and the sparse-block form are two kernels -- in ONE the full form's register allocation suffered, 1.45
+    // instead of 1.29 ms on a table with all eight blocks live -- and the host launches the one the table-wide block mask
+    // asks for; the check here only guards against a stale host copy)
+    if (__popc(sf_uniform(*live) & 0xffu) <= 2) return;
     fpfh_mc_body<NKS>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
                       abuf_all[wv_id]);
+}
+
+// K7 when at most two of the table's eight 16-bin blocks hold anything at all (K6's OR over every row): the reference's
+// un-normalised v keeps alpha in ONE of its bins whenever the radius is well below that bin's width, so 100 of the 125
+// bins are structurally empty -- only those blocks are streamed and multiplied (fpfh_mc_body_sparse)
+template <int NKS>
+__global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fpfh_mc_sparse(
+    const double *__restrict__ rec, const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ idx, int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m, int nb3,
+    const uint8_t *__restrict__ counts, unsigned table_bytes, const double *__restrict__ p4, const unsigned *__restrict__ live,
+    const uint8_t *__restrict__ packed, unsigned packed_bytes, double *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // four steps of 32 rows x 32 B
+    __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
+    const int wv_id = threadIdx.x >> 6;
+    const int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
+    if (q >= m) return;
+    const unsigned mask = sf_uniform(*live) & 0xffu;
+    if (__popc(mask) > 2) return; // the full kernel's case
+    const int b0 = mask ? __ffs(mask) - 1 : 0;
+    const unsigned rest = mask & (mask - 1u);
+    const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7; // (a lone live block is paired with an empty one)
+    // ... from the packed copy (32 bytes per row: four rows per cache line) when every row of it was written under this
+    // very mask, else from the table itself
+    if (sf_uniform(live[1]) == mask) {
+        fpfh_mc_body_sparse<NKS, true>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q,
+                                       b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
+    } else {
+        fpfh_mc_body_sparse<NKS, false>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q,
+                                        b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
+    }
 }
 
 
@@ -744,6 +761,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
         SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_repack, dim3(2048), dim3(256), (const uint8_t *)sp->counts, sp->n, nb->self_begin,
                   nb->self_begin + m, (const unsigned *)sp->live, sp->packed);
         SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack_done, dim3(1), dim3(1), sp->live);
+        sp->host_live_valid = false;
     } else if (sp->elem_bytes == 2) {
         SF_SPFH_DISPATCH(uint16_t)
     } else {
@@ -791,6 +809,7 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
     }
     // the gathered rows come from other ranks' K6: every block of the table counts as live from here on
     if (sp->live) SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->stream));
+    sp->host_live_valid = false;
     return SF_OK;
 }
 
@@ -875,15 +894,30 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
         return SF_ERR_UNSUPPORTED;
     }
     const int nks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+#define SF_MC_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, sp->nb3, (const uint8_t *)sp->counts,       \
+                   (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, (const uint8_t *)sp->packed,                \
+                   (unsigned)((size_t)sp->rows_alloc * 32), dout
+    // Which form runs is decided here, on the table-wide block mask -- read back once per K6 (8 bytes; the one host
+    // round trip of sf_fpfh: it waits for K6, so a caller that wants it hidden queues independent work first, as
+    // DescriptorJob does with the frame eigen-solves on the side stream).  Both kernels re-check the mask on the device.
+    if (!sp->host_live_valid) {
+        void *pin = nullptr;
+        SF_CHECK(sf_ctx_pinned(ctx, &pin));
+        SF_HIP(hipMemcpyAsync(pin, sp->live, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(sp->host_live, pin, 2 * sizeof(unsigned));
+        sp->host_live_valid = true;
+    }
+    const bool sparse = __builtin_popcount(sp->host_live[0] & 0xffu) <= 2;
 #define SF_MC_LAUNCH(NKS)                                                                                            \
-    SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc<NKS>, grid, block, c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, \
-              sp->nb3, (const uint8_t *)sp->counts, (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, \
-              (const uint8_t *)sp->packed, (unsigned)((size_t)sp->rows_alloc * 32), dout)
+    if (sparse) { SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc_sparse<NKS>, grid, block, SF_MC_ARGS); }                       \
+    else { SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc<NKS>, grid, block, SF_MC_ARGS); }
     if (nks <= 1) { SF_MC_LAUNCH(1); }
     else if (nks == 2) { SF_MC_LAUNCH(2); }
     else if (nks == 3) { SF_MC_LAUNCH(3); }
     else { SF_MC_LAUNCH(4); }
 #undef SF_MC_LAUNCH
+#undef SF_MC_ARGS
     return SF_OK;
 }
 

@@ -50,6 +50,78 @@ __device__ __forceinline__ void sf_lane_swap(double &a, double &b)
     b = __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
+// ---- pieces shared by the full and the sparse-block form ---------------------------------------------------------
+// the lane's entries of the keypoint's neighbour list, chunk by chunk (lane t of chunk c <-> neighbour 64 c + t; -1 past the
+// end).  The kernel is instantiated for the longest list of the launch; the chunks past THIS keypoint's list -- the last
+// one for nine keypoints in ten -- are skipped wave-uniformly: no index load, no gather, no weight.
+template <int NKS>
+__device__ __forceinline__ void fpfh_mc_list(const int32_t *__restrict__ idx, int64_t s, int k, int lane, int (&jv)[NKS])
+{
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        const int t = c * 64 + lane;
+        jv[c] = -1;
+        if (c == 0 || c * 64 < k) jv[c] = t < k ? idx[s + t] : -1;
+    }
+}
+
+// weights 1 / (k_j d_j) of all neighbours from their 32-byte records {x, y, z, k} (one rsqrt + two Newton steps each; d == 0
+// is masked out, fpfh.py:110-114), the fixed-point exponent S = 62 - floor(log2 of the largest), and jv clamped to valid
+// rows for the gathers that follow
+template <int NKS>
+__device__ __forceinline__ int fpfh_mc_weights(const double *__restrict__ p4, double px, double py, double pz, int k,
+                                               int (&jv)[NKS], double (&wv)[NKS])
+{
+    double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        gx[c] = gy[c] = gz[c] = gk[c] = 0.0;
+        if (c == 0 || c * 64 < k) {
+            const int j = jv[c] < 0 ? 0 : jv[c];
+            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j); // {x, y}, {z, k}: one 32-byte record
+            const double2 u0 = pp[0], u1 = pp[1];
+            gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
+        }
+    }
+    double wmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        wv[c] = 0.0;
+        if (c == 0 || c * 64 < k) {
+            const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
+            const double d2 = (cx * cx + cy * cy) + cz * cz;
+            const double kd = gk[c], xx = d2 * (kd * kd);
+            const double y0 = __builtin_amdgcn_rsq(xx);
+            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+            wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0;
+            wmax = fmax(wmax, wv[c]);
+        }
+        jv[c] = jv[c] < 0 ? 0 : jv[c];
+    }
+    wmax = sf_wave_max_nonneg(wmax);
+    // fixed point: W = floor(w 2^S) < 2^63 with S = 62 - floor(log2 wmax)
+    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
+    return 62 - e2;
+}
+
+// this lane's weight as nine 7-bit limbs, written where the A operands' lanes will read them: abuf[limb][lane]
+__device__ __forceinline__ void fpfh_mc_limbs(unsigned char *abuf, int lane, double w, int S)
+{
+    const double x = ldexp(w, S - 32); // < 2^31
+    const unsigned hi = (unsigned)x;
+    const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
+    abuf[0 * 64 + lane] = (unsigned char)(lo & 127u);
+    abuf[1 * 64 + lane] = (unsigned char)((lo >> 7) & 127u);
+    abuf[2 * 64 + lane] = (unsigned char)((lo >> 14) & 127u);
+    abuf[3 * 64 + lane] = (unsigned char)((lo >> 21) & 127u);
+    abuf[4 * 64 + lane] = (unsigned char)(((lo >> 28) | (hi << 4)) & 127u);
+    abuf[5 * 64 + lane] = (unsigned char)((hi >> 3) & 127u);
+    abuf[6 * 64 + lane] = (unsigned char)((hi >> 10) & 127u);
+    abuf[7 * 64 + lane] = (unsigned char)((hi >> 17) & 127u);
+    abuf[8 * 64 + lane] = (unsigned char)((hi >> 24) & 127u);
+}
+
 template <int NKS>
 __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
@@ -94,49 +166,11 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
                          : "memory");                                                                               \
         }                                                                                                           \
     }
-    // ---- weights of all neighbours (lane t of step ks <-> neighbour 64 ks + t), as in the vector kernel ----
     int jv[NKS];
     double wv[NKS];
-#pragma unroll
-    // (the kernel is instantiated for the longest list of the launch; the chunks past THIS keypoint's list -- the last one
-    // for nine keypoints in ten -- are skipped wave-uniformly: no index load, no gather, no weight)
-    for (int c = 0; c < NKS; ++c) {
-        const int t = c * 64 + lane;
-        jv[c] = -1;
-        if (c == 0 || c * 64 < k) jv[c] = t < k ? idx[s + t] : -1;
-    }
+    fpfh_mc_list<NKS>(idx, s, k, lane, jv);
     SF_MC_DMA(0) // in flight while the weights are computed
-    double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
-#pragma unroll
-    for (int c = 0; c < NKS; ++c) {
-        gx[c] = gy[c] = gz[c] = gk[c] = 0.0;
-        if (c == 0 || c * 64 < k) {
-            const int j = jv[c] < 0 ? 0 : jv[c];
-            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j); // {x, y}, {z, k}: one 32-byte record
-            const double2 u0 = pp[0], u1 = pp[1];
-            gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
-        }
-    }
-    double wmax = 0.0;
-#pragma unroll
-    for (int c = 0; c < NKS; ++c) {
-        wv[c] = 0.0;
-        if (c == 0 || c * 64 < k) {
-            const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
-            const double d2 = (cx * cx + cy * cy) + cz * cz;
-            const double kd = gk[c], xx = d2 * (kd * kd);
-            const double y0 = __builtin_amdgcn_rsq(xx);
-            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
-            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
-            wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0; // 1 / (k_j d_j); d == 0 is masked out (fpfh.py:110-114)
-            wmax = fmax(wmax, wv[c]);
-        }
-        jv[c] = jv[c] < 0 ? 0 : jv[c];
-    }
-    wmax = sf_wave_max_nonneg(wmax);
-    // fixed point: W = floor(w 2^S) < 2^63 with S = 62 - floor(log2 wmax)
-    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
-    const int S = 62 - e2;
+    const int S = fpfh_mc_weights<NKS>(p4, px, py, pz, k, jv, wv);
 
     v4i acc[8]; // acc[bb]: column a = bin 16 bb + a, rows = limbs 4 kb .. 4 kb + 3
 #pragma unroll
@@ -146,24 +180,7 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     for (int st = 0; st < 2 * NKS; ++st) {
         if (st * 32 < k) { // wave-uniform
             if (st > 0) SF_MC_DMA(st) // (step 0 was issued before the weights were computed)
-            if ((st & 1) == 0) {
-                // ---- this lane's weight as nine 7-bit limbs, written where the A operands' lanes will read them:
-                //      abuf[limb][lane]; the two steps of a chunk use the lower / upper 32 columns ----
-                const int ks = st >> 1;
-                const double x = ldexp(wv[ks], S - 32); // < 2^31
-                const unsigned hi = (unsigned)x;
-                const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
-                const int pos = lane;
-                abuf[0 * 64 + pos] = (unsigned char)(lo & 127u);
-                abuf[1 * 64 + pos] = (unsigned char)((lo >> 7) & 127u);
-                abuf[2 * 64 + pos] = (unsigned char)((lo >> 14) & 127u);
-                abuf[3 * 64 + pos] = (unsigned char)((lo >> 21) & 127u);
-                abuf[4 * 64 + pos] = (unsigned char)(((lo >> 28) | (hi << 4)) & 127u);
-                abuf[5 * 64 + pos] = (unsigned char)((hi >> 3) & 127u);
-                abuf[6 * 64 + pos] = (unsigned char)((hi >> 10) & 127u);
-                abuf[7 * 64 + pos] = (unsigned char)((hi >> 17) & 127u);
-                abuf[8 * 64 + pos] = (unsigned char)((hi >> 24) & 127u);
-            }
+            if ((st & 1) == 0) fpfh_mc_limbs(abuf, lane, wv[st >> 1], S); // the two steps of a chunk use the lower / upper 32 columns
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
             __builtin_amdgcn_wave_barrier(); // both buffers are private to the wave; LDS operations of a wave stay in order
             long A = 0;
@@ -255,7 +272,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
                                                     const uint8_t *__restrict__ counts, const uint8_t *__restrict__ rows,
                                                     unsigned rows_bytes, const double *__restrict__ p4,
                                                     double *__restrict__ out, int64_t q, int b0, int b1,
-                                                    unsigned *rowbuf /* 1 KB used */, unsigned char *abuf /* 576 B */)
+                                                    unsigned *rowbuf /* 4 KB: four steps of 1 KB */, unsigned char *abuf /* 576 B */)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
@@ -287,15 +304,9 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
                      : "v"(voff), "s"(rsrc), "s"(lds_rows + 1024u * (unsigned)((ST) & 3))                           \
                      : "memory");                                                                                   \
     }
-    // ---- weights of all neighbours, exactly as in fpfh_mc_body ----
     int jv[NKS];
     double wv[NKS];
-#pragma unroll
-    for (int c = 0; c < NKS; ++c) {
-        const int t = c * 64 + lane;
-        jv[c] = -1;
-        if (c == 0 || c * 64 < k) jv[c] = t < k ? idx[s + t] : -1;
-    }
+    fpfh_mc_list<NKS>(idx, s, k, lane, jv);
     // The image of a step is 1 KB, so the 4 KB row buffer holds FOUR steps: the rows of the first two chunks (128
     // neighbours -- the whole list for nine keypoints in ten) are all requested here, in flight while the weights are
     // computed, and the step loop below never waits on memory again; only a third / fourth chunk re-uses the buffer.
@@ -303,36 +314,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     if (32 < k) SF_MCS_DMA(1)
     if (NKS >= 2 && 64 < k) SF_MCS_DMA(2)
     if (NKS >= 2 && 96 < k) SF_MCS_DMA(3)
-    double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
-#pragma unroll
-    for (int c = 0; c < NKS; ++c) {
-        gx[c] = gy[c] = gz[c] = gk[c] = 0.0;
-        if (c == 0 || c * 64 < k) {
-            const int j = jv[c] < 0 ? 0 : jv[c];
-            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j);
-            const double2 u0 = pp[0], u1 = pp[1];
-            gx[c] = u0.x; gy[c] = u0.y; gz[c] = u1.x; gk[c] = u1.y;
-        }
-    }
-    double wmax = 0.0;
-#pragma unroll
-    for (int c = 0; c < NKS; ++c) {
-        wv[c] = 0.0;
-        if (c == 0 || c * 64 < k) {
-            const double cx = gx[c] - px, cy = gy[c] - py, cz = gz[c] - pz;
-            const double d2 = (cx * cx + cy * cy) + cz * cz;
-            const double kd = gk[c], xx = d2 * (kd * kd);
-            const double y0 = __builtin_amdgcn_rsq(xx);
-            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
-            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
-            wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0;
-            wmax = fmax(wmax, wv[c]);
-        }
-        jv[c] = jv[c] < 0 ? 0 : jv[c];
-    }
-    wmax = sf_wave_max_nonneg(wmax);
-    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
-    const int S = 62 - e2;
+    const int S = fpfh_mc_weights<NKS>(p4, px, py, pz, k, jv, wv);
 
     v4i acc0 = v4i{0, 0, 0, 0}, acc1 = v4i{0, 0, 0, 0}, accp = v4i{0, 0, 0, 0}; // blocks b0, b1, and the padding column
     const long Bpad = (long)0x8080808080808080ull; // eight neighbours' padding bin: -128 each
@@ -341,22 +323,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     for (int st = 0; st < 2 * NKS; ++st) {
         if (st * 32 < k) { // wave-uniform
             if (st >= 4) SF_MCS_DMA(st) // (steps 0 .. 3 were requested up front; by now their regions have been consumed)
-            if ((st & 1) == 0) { // this lane's weight as nine 7-bit limbs: abuf[limb][lane]
-                const int ks = st >> 1;
-                const double x = ldexp(wv[ks], S - 32); // < 2^31
-                const unsigned hi = (unsigned)x;
-                const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
-                const int pos = lane;
-                abuf[0 * 64 + pos] = (unsigned char)(lo & 127u);
-                abuf[1 * 64 + pos] = (unsigned char)((lo >> 7) & 127u);
-                abuf[2 * 64 + pos] = (unsigned char)((lo >> 14) & 127u);
-                abuf[3 * 64 + pos] = (unsigned char)((lo >> 21) & 127u);
-                abuf[4 * 64 + pos] = (unsigned char)(((lo >> 28) | (hi << 4)) & 127u);
-                abuf[5 * 64 + pos] = (unsigned char)((hi >> 3) & 127u);
-                abuf[6 * 64 + pos] = (unsigned char)((hi >> 10) & 127u);
-                abuf[7 * 64 + pos] = (unsigned char)((hi >> 17) & 127u);
-                abuf[8 * 64 + pos] = (unsigned char)((hi >> 24) & 127u);
-            }
+            if ((st & 1) == 0) fpfh_mc_limbs(abuf, lane, wv[st >> 1], S);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
             __builtin_amdgcn_wave_barrier();
             long A = 0;
