@@ -181,7 +181,10 @@ int sf_shot_serial(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int64_t min_neig
  * sf_nbrs_slice view this is how a shard reduces only its own block).
  * sf_spfh_export writes the float64 SPFH table (n x n_bins^3, original numbering).
  * max_count (the largest neighbourhood the table will see, sf_nbrs_max_count) picks the storage of the integer
- * bin counts: bytes up to 255 points (and n_bins <= 5), 16 bits up to 65535, 32 bits beyond. */
+ * bin counts: bytes up to 255 points (and n_bins <= 5), 16 bits up to 65535, 32 bits beyond.
+ * On the byte table sf_spfh_compute also records which 16-bin blocks of the rows hold any count; sf_fpfh reads that
+ * mask back (8 bytes, once per sf_spfh_compute: it waits for K6 on the context's stream) and, when at most two of the
+ * eight blocks do, multiplies only those -- same results, bit for bit. */
 sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_count);
 int sf_spfh_compute(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const double *edges);
 /* Extension for callers that want FPFH and SHOT from the SAME self-search lists (both descriptors of config 3 / 5):
