@@ -483,3 +483,23 @@ def test_spfh_alpha_bin_shortcut_only_with_short_normals(eng, O):
     for nb, rr in ((4, 0.05), (5, 0.25)):
         got = s.compute_fpfh_descriptor(kp[:3000], p, nr, rr, nb)
         assert np.abs(got - O.compute_fpfh_descriptor(kp[:3000], p, nr, rr, nb)).max() < 1e-9
+
+
+def test_fpfh_sparse_block_form_equals_full_form_bit_for_bit(monkeypatch):
+    """SF_FPFH_DENSE=1 marks every 16-bin block of a new SPFH table live, which forces K7's full form; without it tables
+    with one or two live blocks (small radius, any bin count) take the sparse-block form on the packed copy.  Same bits."""
+    import shot_fpfh_amd as s
+
+    rng = np.random.default_rng(5)
+    for n, r, scale in ((60000, 0.04, 1.0), (20000, 0.45, 1.0), (40000, 40.0, 1000.0)):
+        p = rng.random((n, 3), dtype=np.float32).astype(np.float64) * scale
+        nr = rng.standard_normal((n, 3))
+        nr /= np.linalg.norm(nr, axis=1)[:, None]
+        kp = np.sort(rng.choice(n, 5000, replace=False))
+        for nb in (5, 4, 3, 2):
+            monkeypatch.delenv("SF_FPFH_DENSE", raising=False)
+            a = s.compute_fpfh_descriptor(kp, p, nr, r, nb)
+            monkeypatch.setenv("SF_FPFH_DENSE", "1")
+            b = s.compute_fpfh_descriptor(kp, p, nr, r, nb)
+            assert np.array_equal(a, b), (n, r, nb)
+    monkeypatch.delenv("SF_FPFH_DENSE", raising=False)
