@@ -11,6 +11,8 @@ What is compared, and how strictly:
     (last-writer-wins on an unstable argsort, shot.py:218) and without supports so flat that the frame's third axis is
     rounding noise.  Lattices and exact planes therefore check neighbour search, normals, FPFH and PCA only.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -44,7 +46,9 @@ def _radius_for(p, rng, target):
     return float((target * vol / (n * unit_ball)) ** (1.0 / d) * rng.uniform(0.8, 1.3))
 
 
-SEEDS = [0, 1, 2]
+# three seeds by default; SF_FUZZ_SEEDS="a:b" runs seeds a .. b-1 (a long sweep on an idle GPU: tools/fuzz_sweep.sh)
+_sweep = os.environ.get("SF_FUZZ_SEEDS")
+SEEDS = list(range(*(int(v) for v in _sweep.split(":")))) if _sweep else [0, 1, 2]
 
 
 @pytest.mark.parametrize("seed", SEEDS)
