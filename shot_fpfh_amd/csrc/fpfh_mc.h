@@ -12,13 +12,13 @@
 //
 // fpfh[q][b] - spfh[q][b] = (1/k_q) sum_j w_j c_jb is, per keypoint, the product of a 1 x k row of weights with
 // the k x 128 matrix of its neighbours' integer bin counts.  Done on the vector ALU it costs three instructions
-// per count (extract, convert, FMA).  Here the weights are turned into 63-bit fixed point (scaled by the
-// keypoint's largest weight) and cut into nine 7-bit limbs, and  R[limb][bin] = sum_j limb_j * (c_jb - 128)  is
+// per count (extract, convert, FMA).  Here the weights are turned into 62-bit fixed point (scaled by the
+// keypoint's largest weight) and cut into eight signed-byte limbs, and  R[limb][bin] = sum_j limb_j * (c_jb - 128)  is
 // accumulated EXACTLY in int32 by v_mfma_i32_16x16x64_i8: A = limbs x 64 neighbours, B = 64 neighbours x 16 bins,
 // the counts going from the table to the matrix unit as the bytes they are (the table stores count ^ 128, which
 // read as int8 is count - 128; a padding bin holds -128, so its column is -128 * sum_j limb_j and cancels the bias).
-// The sums are recombined in float64 once per keypoint:  sum_j w_j c_jb = 2^-S sum_i 2^(7i) (R[i][b] - R[i][pad]).
-// The only rounding is in the fixed-point weights (2^-62 of the largest one) and in that final recombination.
+// The sums are recombined in float64 once per keypoint:  sum_j w_j c_jb = 2^-S sum_i 2^(8i) (R[i][b] - R[i][pad]).
+// The only rounding is in the fixed-point weights (2^-61 of the largest one) and in that final recombination.
 //
 // One wave per keypoint, 32 neighbours per step (v_mfma_i32_16x16x32_i8).  Layouts (tools/ubench: probed on the
 // device): operand lane l holds row / column l % 16 and the 8 consecutive k of block l / 16, one per byte; the result
@@ -66,7 +66,7 @@ __device__ __forceinline__ void fpfh_mc_list(const int32_t *__restrict__ idx, in
 }
 
 // weights 1 / (k_j d_j) of all neighbours from their 32-byte records {x, y, z, k} (one rsqrt + two Newton steps each; d == 0
-// is masked out, fpfh.py:110-114), the fixed-point exponent S = 62 - floor(log2 of the largest), and jv clamped to valid
+// is masked out, fpfh.py:110-114), the fixed-point exponent S = 61 - floor(log2 of the largest), and jv clamped to valid
 // rows for the gathers that follow
 template <int NKS>
 __device__ __forceinline__ int fpfh_mc_weights(const double *__restrict__ p4, double px, double py, double pz, int k,
@@ -100,26 +100,35 @@ __device__ __forceinline__ int fpfh_mc_weights(const double *__restrict__ p4, do
         jv[c] = jv[c] < 0 ? 0 : jv[c];
     }
     wmax = sf_wave_max_nonneg(wmax);
-    // fixed point: W = floor(w 2^S) < 2^63 with S = 62 - floor(log2 wmax)
+    // fixed point: W = floor(w 2^S) < 2^62 with S = 61 - floor(log2 wmax)
     const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
-    return 62 - e2;
+    return 61 - e2;
 }
 
-// this lane's weight as nine 7-bit limbs, written where the A operands' lanes will read them: abuf[limb][lane]
+// This lane's weight as EIGHT signed-byte limbs: W = floor(w 2^S) < 2^62 is written in the signed-digit form
+// W = sum_i d_i 256^i, d_i in [-128, 127] -- add 0x80 to every byte of W with carries, then flip every byte's top bit --
+// which is what an int8 MFMA operand wants, 8 bits per limb instead of 7.  The limbs of neighbour t are the 8 bytes at
+// abuf + 8 t: one ds_write_b64 per lane; the A operand (row = limb, k = neighbour) comes back through the same
+// transposing read as the B operand (fpfh_mc_a_operand).
 __device__ __forceinline__ void fpfh_mc_limbs(unsigned char *abuf, int lane, double w, int S)
 {
-    const double x = ldexp(w, S - 32); // < 2^31
+    const double x = ldexp(w, S - 32); // < 2^30
     const unsigned hi = (unsigned)x;
     const unsigned lo = (unsigned)ldexp(x - (double)hi, 32);
-    abuf[0 * 64 + lane] = (unsigned char)(lo & 127u);
-    abuf[1 * 64 + lane] = (unsigned char)((lo >> 7) & 127u);
-    abuf[2 * 64 + lane] = (unsigned char)((lo >> 14) & 127u);
-    abuf[3 * 64 + lane] = (unsigned char)((lo >> 21) & 127u);
-    abuf[4 * 64 + lane] = (unsigned char)(((lo >> 28) | (hi << 4)) & 127u);
-    abuf[5 * 64 + lane] = (unsigned char)((hi >> 3) & 127u);
-    abuf[6 * 64 + lane] = (unsigned char)((hi >> 10) & 127u);
-    abuf[7 * 64 + lane] = (unsigned char)((hi >> 17) & 127u);
-    abuf[8 * 64 + lane] = (unsigned char)((hi >> 24) & 127u);
+    const unsigned long long W = ((unsigned long long)hi << 32) | lo;
+    const unsigned long long D = (W + 0x8080808080808080ull) ^ 0x8080808080808080ull; // (hi < 2^30: no carry out)
+    *reinterpret_cast<unsigned long long *>(abuf + 8 * lane) = D;
+}
+
+// A operand of a step (32 neighbours: 32 (st & 1) .. of the chunk whose limbs are in abuf): lane (a, kb) wants limb a of
+// neighbours 8 kb .. 8 kb + 7, one per byte.  In its 16-lane group lane 2 q + p supplies the address of "row" q = one
+// neighbour's 8 limb bytes for p = 0 and of 8 zero bytes (abuf + 512) for p = 1 -- limbs 8 .. 15 do not exist -- and
+// receives column a of those eight 16-byte rows.
+__device__ __forceinline__ long fpfh_mc_a_operand(const unsigned char *abuf, int a, int kb, int st)
+{
+    const unsigned char *ap = (a & 1) ? abuf + 512 : abuf + 8 * (32 * (st & 1) + 8 * kb + (a >> 1));
+    const v2i_t t = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)ap);
+    return (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
 }
 
 template <int NKS>
@@ -138,6 +147,7 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
+    if (lane == 0) *reinterpret_cast<unsigned long long *>(abuf + 512) = 0ull; // the "limbs 8 .. 15" every A operand reads
     // A step covers 32 neighbours (v_mfma_i32_16x16x32_i8: 8 k per 16-lane group).  Transposing reads: in its group
     // (k block kb) lane 2 q + p supplies the address of row 8 kb + q, bytes 8 p .. + 7 of chunk bb (slot bb ^ f(row),
     // f(row) = (row >> 1) & 7), and receives bin 16 bb + a of those eight rows -- exactly its B operand.
@@ -183,8 +193,7 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
             if ((st & 1) == 0) fpfh_mc_limbs(abuf, lane, wv[st >> 1], S); // the two steps of a chunk use the lower / upper 32 columns
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
             __builtin_amdgcn_wave_barrier(); // both buffers are private to the wave; LDS operations of a wave stay in order
-            long A = 0;
-            if (a < 9) A = *reinterpret_cast<const long *>(&abuf[a * 64 + 32 * (st & 1) + 8 * kb]); // row a = limb a
+            const long A = fpfh_mc_a_operand(abuf, a, kb, st); // row a = limb a (rows 8 .. 15: zero)
             const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb) {
@@ -201,13 +210,14 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     int rpad[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of bb = 7: bin 127
-    // A lane's four limb rows are combined in INTEGER arithmetic first: |R| <= 127 * 128 * 255 < 2^22, so
-    // (R[r+1] << 7) + R[r] and the same combination of the padding column stay below 2^30 and their difference fits an
-    // int32 exactly -- two shift-adds and a subtraction per pair of limbs instead of a subtraction, a conversion and a
-    // float64 FMA per limb.
-    const int pad01 = (rpad[1] << 7) + rpad[0], pad23 = (rpad[3] << 7) + rpad[2];
-    const double p0 = ldexp(1.0, 28 * kb - S); // 2^(7 (4 g) - S)
-    const double f0 = p0, f2 = p0 * 16384.0;
+    // A lane's four limb rows are combined in INTEGER arithmetic first: |R| <= 128 * 128 * 255 < 2^22, so
+    // (R[r+1] << 8) + R[r] and the same combination of the padding column stay below 2^30.01, and their difference --
+    // (sum_j d_j c_jb of limb r + 1) 2^8 + (that of limb r), each at most 128 * 255 * 255 -- is below 2^31: it fits an
+    // int32 exactly (two's-complement wrap-around of an intermediate is harmless).  Two shift-adds and a subtraction per
+    // pair of limbs instead of a subtraction, a conversion and a float64 FMA per limb.
+    const int pad01 = (rpad[1] << 8) + rpad[0], pad23 = (rpad[3] << 8) + rpad[2];
+    const double p0 = ldexp(1.0, 32 * kb - S); // 2^(8 (4 g) - S)
+    const double f0 = p0, f2 = p0 * 65536.0;
     const double kd = (double)k;
     double inv_k = __builtin_amdgcn_rcp(kd);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
@@ -216,8 +226,8 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     double part[8];
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) {
-        const int e01 = ((acc[bb][1] << 7) + acc[bb][0]) - pad01;
-        const int e23 = ((acc[bb][3] << 7) + acc[bb][2]) - pad23;
+        const int e01 = ((acc[bb][1] << 8) + acc[bb][0]) - pad01;
+        const int e23 = ((acc[bb][3] << 8) + acc[bb][2]) - pad23;
         part[bb] = __builtin_fma((double)e23, f2, (double)e01 * f0);
     }
     // sum over the four limb groups g = kb, transposing as we go: after the exchange with lane ^ 32 a lane keeps only
@@ -282,6 +292,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(rows), 0, (int)rows_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
+    if (lane == 0) *reinterpret_cast<unsigned long long *>(abuf + 512) = 0ull; // the "limbs 8 .. 15" every A operand reads
     // LDS image of a step: 64 pieces of 16 bytes, piece P = 32 (kb >> 1) + 16 u + 8 (kb & 1) + q holds chunk b_u of row
     // 8 kb + q -- the DMA writes its lanes' pieces back to back, so lane P fetches exactly that; the 32 pieces a
     // transposing read of block u touches per half-wave then lie in 32 different 8-byte bank pairs.
@@ -326,8 +337,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
             if ((st & 1) == 0) fpfh_mc_limbs(abuf, lane, wv[st >> 1], S);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA pieces have landed
             __builtin_amdgcn_wave_barrier();
-            long A = 0;
-            if (a < 9) A = *reinterpret_cast<const long *>(&abuf[a * 64 + 32 * (st & 1) + 8 * kb]); // row a = limb a
+            const long A = fpfh_mc_a_operand(abuf, a, kb, st); // row a = limb a (rows 8 .. 15: zero)
             const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
             const v2i_t t0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd0 + 1024 * (st & 3)));
             const v2i_t t1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd1 + 1024 * (st & 3)));
@@ -340,18 +350,18 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     }
     // ---- recombination: lane (a, g) holds limbs 4g .. 4g + 3 of bin 16 b_u + a in acc_u, and of the padding column in accp
     //      (every column of accp is the same sum) ----
-    const int pad01 = (accp[1] << 7) + accp[0], pad23 = (accp[3] << 7) + accp[2];
-    const double p0 = ldexp(1.0, 28 * kb - S); // 2^(7 (4 g) - S)
-    const double f0 = p0, f2 = p0 * 16384.0;
+    const int pad01 = (accp[1] << 8) + accp[0], pad23 = (accp[3] << 8) + accp[2];
+    const double p0 = ldexp(1.0, 32 * kb - S); // 2^(8 (4 g) - S)
+    const double f0 = p0, f2 = p0 * 65536.0;
     const double kd = (double)k;
     double inv_k = __builtin_amdgcn_rcp(kd);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
     double part0, part1;
     {
-        const int e01 = ((acc0[1] << 7) + acc0[0]) - pad01, e23 = ((acc0[3] << 7) + acc0[2]) - pad23;
+        const int e01 = ((acc0[1] << 8) + acc0[0]) - pad01, e23 = ((acc0[3] << 8) + acc0[2]) - pad23;
         part0 = __builtin_fma((double)e23, f2, (double)e01 * f0);
-        const int g01 = ((acc1[1] << 7) + acc1[0]) - pad01, g23 = ((acc1[3] << 7) + acc1[2]) - pad23;
+        const int g01 = ((acc1[1] << 8) + acc1[0]) - pad01, g23 = ((acc1[3] << 8) + acc1[2]) - pad23;
         part1 = __builtin_fma((double)g23, f2, (double)g01 * f0);
     }
     // Sum over the four limb groups in the SAME order as the full kernel -- (g + (g ^ 2)) first, then the two halves of that
