@@ -646,12 +646,12 @@ __device__ inline double sf_atan_octant_fraction(double t)
     return t * p;
 }
 
-// acos(z) / (pi/2) for -1 <= z <= 1 (result in [0, 2]): sf_acos with 2/pi folded into the coefficients -- the elevation
-// weights are linear in phi / (pi/2).  z = 0 gives exactly 1, z = +-1 exactly 0 / 2.
-__device__ inline double sf_acos_quadrants(double z)
+// acos(|z|) / (pi/2) for |z| <= 1 (result in [0, 1]; |z| = 0 gives exactly 1, |z| = 1 exactly 0): the asin-form minimax
+// polynomial with 2/pi folded into its coefficients.  The elevation weights are linear in phi / (pi/2) and symmetric about
+// the equator -- acos(-z) = pi - acos(z) -- so the angle of |z| is all they need (shot_weights).
+__device__ inline double sf_acos_abs_quadrants(double az)
 {
     constexpr double K = 0.6366197723675814; // 2 / pi
-    const double az = fabs(z);
     const bool big = az > 0.5;
     const double xb = __builtin_fma(-0.5, az, 0.5), xs = az * az; // (1 - |z|) / 2 is exact
     const double rb = sf_sqrt_small(fmin(xb, 0.25));
@@ -671,11 +671,8 @@ __device__ inline double sf_acos_quadrants(double z)
     SF_HORNER(p, x, 0.1666666666666665 * K);
     SF_HORNER(p, x, K);
     const double as = r * p; // asin(r) / (pi/2)
-    // |z| <= 1/2: 1 -+ as ;  z > 1/2: 2 as ;  z < -1/2: 2 - 2 as
-    const bool neg = z < 0.0;
-    const double a = big ? (neg ? 2.0 : 0.0) : 1.0;
-    const double b = big ? (neg ? -2.0 : 2.0) : (neg ? 1.0 : -1.0);
-    return __builtin_fma(b, as, a);
+    // |z| <= 1/2: 1 - as ;  |z| > 1/2: 2 as
+    return big ? as + as : 1.0 - as;
 }
 
 __device__ inline double sf_dot3(double a0, double a1, double a2, double b0, double b1, double b2)
@@ -771,16 +768,18 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
     const double cur = off_half ? 1.0 - fabs(dr) * k.inv_hr : 0.0;
     const double toward = ri ? -dr : dr; // (3r/4 - rho) in the outer shell, (rho - r/4) in the inner one
     v_cd = off_half ? fmax(toward, 0.0) * k.inv_hr : 0.0;
-    // elevation (interpolate_vertical_volumes), u = phi / (pi/2) in [0, 2]
-    const double u = sf_acos_quadrants(fmin(fmax(g.lzr, -1.0), 1.0));
-    const bool below = u < 1.0;                                  // phi < pi/2
-    const bool near_eq = fabs(u - 1.0) < 1e-10 * 0.6366197723675814; // |phi - pi/2| < 1e-10
-    const double curv = 1.0 - fabs(u - (below ? 0.5 : 1.5));
-    // upper = [(phi > pi/2 or (near and z <= 0)) and phi <= 3pi/4] (3pi/4 - phi)/(pi/2), counted for z <= 0 writers;
-    // lower = [(phi < pi/2 and (not near or z > 0)) and phi >= pi/4] (phi - pi/4)/(pi/2), counted for z > 0 writers
-    const double e = z_pos ? u - 0.5 : 1.5 - u;
-    const bool side = z_pos ? below : ((u > 1.0) | near_eq);
-    v_ef = side ? fmax(e, 0.0) : 0.0;
+    // elevation (interpolate_vertical_volumes).  With u = phi / (pi/2) the reference's terms are
+    //   current = 1 - |u - 1/2| for phi < pi/2, 1 - |u - 3/2| for phi >= pi/2;
+    //   lower  = [phi < pi/2 and (not near or z > 0) and phi >= pi/4] (u - 1/2), counted for z > 0 writers;
+    //   upper  = [(phi > pi/2 or (near and z <= 0)) and phi <= 3pi/4] (3/2 - u), counted for z <= 0 writers
+    // (near: |phi - pi/2| < 1e-10).  phi = acos(z) is symmetric about the equator, u(-z) = 2 - u(z), so in terms of
+    // t = acos(|z|) / (pi/2) in [0, 1] all three are ONE expression per neighbour whatever the sign of z:
+    //   current = 1 - |t - 1/2| ;  lower resp. upper = max(t - 1/2, 0), with the single exception the masks leave:
+    //   a writer with z > 0 whose phi ROUNDS to pi/2 (t = 1 exactly) fails "phi < pi/2" and gets 0.
+    const double t = sf_acos_abs_quadrants(fmin(fabs(g.lzr), 1.0));
+    const double curv = 1.0 - fabs(t - 0.5);
+    const bool side = !z_pos | (t < 1.0);
+    v_ef = side ? fmax(t - 0.5, 0.0) : 0.0;
     vA = (((1.0 - adc) + cur) + curv) + (1.0 - adth);
 }
 
