@@ -753,7 +753,7 @@ struct shot_consts {
 __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, double &vA, double &v_cd, double &v_ef, double &adth)
 {
     const unsigned base = g.bins0 & 511u;
-    const bool ri = base & 1u, z_pos = base & 2u; // rho > r/2 ; lz > 0 -- both decided in shot_geometry
+    const bool z_pos = base & 2u; // lz > 0, decided in shot_geometry
     const double rho = g.rho;
     const double adc = fabs(g.dc);
     // |dth|: angle off the octant's centre ray as a fraction of the octant, clipped to 1/2.  lx = ly = 0 has dot = 0:
@@ -763,11 +763,12 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
     const double at = fmin(sf_atan_octant_fraction(tq), 0.5);
     adth = fwd ? at : 0.5;
     // radial shells (interpolate_on_adjacent_husks): rho == r/2 belongs to neither and gets all three terms zero
+    // The two shells mirror each other about rho = r/2: with s = |rho - r/2| the distance to the current shell's centre
+    // is |s - r/4| and the distance "towards the other shell" (3r/4 - rho outside, rho - r/4 inside) is r/4 - s, in both.
     const bool off_half = rho != k.half_r;
-    const double dr = rho - (ri ? k.q3 : k.q1);
-    const double cur = off_half ? 1.0 - fabs(dr) * k.inv_hr : 0.0;
-    const double toward = ri ? -dr : dr; // (3r/4 - rho) in the outer shell, (rho - r/4) in the inner one
-    v_cd = off_half ? fmax(toward, 0.0) * k.inv_hr : 0.0;
+    const double ds = fabs(rho - k.half_r) - k.q1;
+    const double cur = off_half ? 1.0 - fabs(ds) * k.inv_hr : 0.0;
+    v_cd = off_half ? fmax(-ds, 0.0) * k.inv_hr : 0.0;
     // elevation (interpolate_vertical_volumes).  With u = phi / (pi/2) the reference's terms are
     //   current = 1 - |u - 1/2| for phi < pi/2, 1 - |u - 3/2| for phi >= pi/2;
     //   lower  = [phi < pi/2 and (not near or z > 0) and phi >= pi/4] (u - 1/2), counted for z > 0 writers;
