@@ -70,6 +70,32 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
     return hist_bin(ed.t, nb, atan2(a, b));
 }
 
+// The same decision from a CHEAPER form of a.  a = n_j . (u x (c x u)) = (n_j . c) |u|^2 - (n_j . u)(c . u) exactly (the
+// triple-product expansion), which needs one dot product and three operations where the two cross products need 23; evaluated
+// in floating point it differs from the reference's cross-product evaluation by at most E (the caller's bound on both
+// rounding errors together).  Every test of theta_bin is made with that margin added on the safe side, so an answer given
+// here is the answer theta_bin gives on the reference's a; -2 = undecided at this precision, the caller evaluates the
+// reference's expression and asks theta_bin.
+__device__ inline int theta_bin_fast(const fpfh_edges &ed, int nb, double a, double b, double E)
+{
+    const double band = 1e-13;
+    const double aa = fabs(a) + E; // >= |a_ref|
+    if (b > band * aa) {
+        int bin = 0;
+        double gap = 1.0e300;
+#pragma unroll
+        for (int i = 1; i < SF_FAST_FPFH_BINS; ++i)
+            if (i < nb) {
+                const double di = __builtin_fma(-ed.tan_t[i], b, a);
+                bin += di >= 0.0 ? 1 : 0;
+                gap = fmin(gap, fabs(di));
+            }
+        // gap - E <= the reference's gap; beyond its band with E to spare every sign above is the reference's sign
+        return gap > band * (aa + fabs(ed.tan_t[1]) * b) + E ? bin : -2;
+    }
+    return b < -band * aa ? -1 : -2;
+}
+
 // NCH > 0: neighbourhoods of at most 64*NCH points -- every chunk's indices, then every chunk's
 // coordinates / normals, are requested before any is used, so a wave pays ONE index round trip and ONE
 // gather round trip instead of one per chunk.  NCH == 0: streaming loop for any size.
@@ -81,13 +107,13 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
 #endif
 
 template <typename CT, int NCH, int NB>
-__global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restrict__ rec,
+__global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_eu(6))) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
                                               CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias,
                                               double *__restrict__ p4, double mom_radius, double *__restrict__ cov,
-                                              unsigned *__restrict__ live, int alpha_bin)
+                                              unsigned *__restrict__ live, int alpha_bin, double nrm_max)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
@@ -103,12 +129,13 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
     const double ux = rec[6 * i + 3], uy = rec[6 * i + 4], uz = rec[6 * i + 5];
     __builtin_amdgcn_wave_barrier();
     const double p_inv_width = (double)nb / (ed.p[nb] - ed.p[0]); // np.linspace edges: equal widths up to rounding
+    // theta_bin_fast's margin: |a_fast - a_reference| <= ~24 eps |n_j| |u|^2 |c| (a dozen roundings on either side, each
+    // relative to a product of those norms); 64 eps max|n| |u|^2 per unit of |c| is the bound used
+    const double uu = (ux * ux + uy * uy) + uz * uz;
+    const double e_per_dist = 1.5e-14 * nrm_max * uu;
     auto pair = [&](double cx, double cy, double cz, double njx, double njy, double njz) {
         const double d2 = (cx * cx + cy * cy) + cz * cz;
         if (d2 > 0.0) { // dist > 0 (fpfh.py:50-57)
-            const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
-            const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
-
             // phi = (c . u) / sqrt(d2) only picks a bin.  One Newton step on v_rsq_f64 gives it to ~1e-15; the
             // reference's own expression (sqrt, then the division: 34 instructions) is evaluated only when that
             // value lies within 1e-9 bin widths of an edge, so the bin is the reference's in every case.
@@ -118,12 +145,22 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) void k_spfh(const double *__restr
             double phi = num * y1;
             const double pos = (phi - ed.p[0]) * p_inv_width;
             if (fabs(pos - rint(pos)) <= 1e-9) phi = num / sqrt(d2);
-            const int bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, (njx * ux + njy * uy) + njz * uz);
+            const double b = (njx * ux + njy * uy) + njz * uz;
             // alpha = v . n_j with v = c x u NOT normalised (fpfh.py:60): |alpha| <= |c| |u| |n_j| <= radius when no normal
             // is longer than 1, so with the radius below the smallest |edge| of the alpha histogram every sample is in the
-            // bin around 0 -- the host passes that bin (alpha_bin >= 0, wave-uniform) and alpha is never formed
-            int ba = alpha_bin;
-            if (alpha_bin < 0) ba = hist_bin(ed.a, nb, (vx * njx + vy * njy) + vz * njz);
+            // bin around 0 -- the host passes that bin (alpha_bin >= 0, wave-uniform) and alpha is never formed.  Then v and
+            // w = u x v are not needed either unless theta's cheap form cannot decide (theta_bin_fast).
+            int ba = alpha_bin, bt = -2;
+            if (alpha_bin >= 0) {
+                const double nc = (njx * cx + njy * cy) + njz * cz;
+                bt = theta_bin_fast(ed, nb, nc * uu - b * num, b, e_per_dist * (d2 * y1) * 1.01);
+            }
+            if (bt == -2) { // the reference's own expressions (fpfh.py:58-66)
+                const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
+                const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
+                bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, b);
+                if (alpha_bin < 0) ba = hist_bin(ed.a, nb, (vx * njx + vy * njy) + vz * njz);
+            }
             const int bp = hist_bin(ed.p, nb, phi);
             if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt], 1u);
         }
@@ -716,9 +753,11 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     // alpha's bin is known beforehand when every |alpha| <= radius * max|n|^2 stays clear of the histogram's edges (see
     // k_spfh): the bin that holds 0, if 0 is strictly inside one
     int alpha_bin = -1;
+    double nrm_max = 1.0;
     {
         double n2 = 0.0;
         SF_CHECK(sf_cloud_normals_max2(ctx, c, &n2));
+        nrm_max = std::sqrt(n2) * (1.0 + 1e-12);
         const double reach = nb->radius * n2 * (1.0 + 1e-9); // |u| |n_j| <= max |n|^2
         double nearest = INFINITY;
         for (int i = 0; i <= nbn; ++i) nearest = std::min(nearest, std::fabs(ed.a[i]));
@@ -733,7 +772,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
               nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov, \
-              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin)
+              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
