@@ -181,7 +181,10 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
             total += __popcll(m0) + __popcll(m1);
         }
         if (lane == 0) {
-            if (MODE != 1) count[q] = total;
+            if (MODE != 1) {
+                count[q] = total;
+                if (q == m - 1) count[m] = 0; // (the one element past the last query: no memset of the arrays needed)
+            }
             if (MODE == 2) {
                 offset[q] = out;
                 if (q == m - 1) offset[m] = out + cap;
@@ -419,8 +422,12 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     const double r2 = nb->radius * nb->radius;
     SF_CHECK(sf_palloc(ctx, &nb->count, (size_t)(m + 1)));
     SF_CHECK(sf_palloc(ctx, &nb->offset, (size_t)(m + 1)));
-    SF_HIP(hipMemsetAsync(nb->count, 0, (size_t)(m + 1) * sizeof(int32_t), ctx->stream));
-    SF_HIP(hipMemsetAsync(nb->offset, 0, (size_t)(m + 1) * sizeof(int64_t), ctx->stream));
+    // (every element of count / offset is written by the kernels below -- count[m] by the last query's wave, offset by the
+    // slots kernel or the scan -- so neither array is cleared first; only the empty query set needs its single element)
+    if (!m) {
+        SF_HIP(hipMemsetAsync(nb->count, 0, sizeof(int32_t), ctx->stream));
+        SF_HIP(hipMemsetAsync(nb->offset, 0, sizeof(int64_t), ctx->stream));
+    }
     sf_grid_desc g = sf_make_grid_desc(c);
     const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4 * SF_K2_WPB))), block(64 * SF_K2_WPB); // waves x 4 queries
     if (!m) {
