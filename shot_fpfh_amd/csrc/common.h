@@ -170,7 +170,8 @@ struct sf_cloud {
     int64_t ncell = 0;
     int32_t *cell_start = nullptr;  // ncell + 1
     int32_t *perm = nullptr;        // sorted position -> original index
-    int32_t *inv_perm = nullptr;    // original index -> sorted position
+    int32_t *inv_perm = nullptr;    // original index -> sorted position (filled on demand: sf_cloud_ensure_inv_perm)
+    bool inv_perm_valid = false;
     // cell-sorted SoA
     double *xs = nullptr, *ys = nullptr, *zs = nullptr;
     // cell-sorted AoS records {x, y, z, nx, ny, nz} (48 B, 16-byte aligned): what the list-driven kernels

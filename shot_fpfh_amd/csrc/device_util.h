@@ -209,4 +209,5 @@ static inline unsigned sf_xcd_grid(long long blocks) { return (unsigned)(((block
 
 sf_grid_desc sf_make_grid_desc(const sf_cloud *c);
 int sf_cloud_ensure_sorted_normals(struct sf_ctx *ctx, sf_cloud *c);
+int sf_cloud_ensure_inv_perm(struct sf_ctx *ctx, sf_cloud *c);
 int sf_cloud_normals_max2(struct sf_ctx *ctx, sf_cloud *c, double *out); // max |n|^2 over the cloud's normals, cached

@@ -985,6 +985,7 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
         SF_CHECK(tmp.alloc(&pos, (size_t)m));
         SF_CHECK(tmp.alloc(&dbad, 1));
         SF_HIP(hipMemsetAsync(dbad, 0, sizeof(int), ctx->stream));
+        SF_CHECK(sf_cloud_ensure_inv_perm(ctx, c));
         SF_LAUNCH(ctx, "k7_map_positions", k_map_positions, dim3((unsigned)sf_div_up(m, 256)), dim3(256), src,
                   c->inv_perm, m, c->n, pos, dbad);
         int bad = 0;

@@ -92,7 +92,7 @@ __global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_de
 // written) instead of waiting for sf_cloud_ensure_sorted_normals' own gather
 __global__ void k_gather_sorted(const double *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ perm,
                                 int64_t base, int64_t n, double *__restrict__ xs, double *__restrict__ ys,
-                                double *__restrict__ zs, double *__restrict__ rec, int32_t *__restrict__ inv_perm)
+                                double *__restrict__ zs, double *__restrict__ rec)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -106,7 +106,16 @@ __global__ void k_gather_sorted(const double *__restrict__ xyz, const double *__
         rec[6 * i + 4] = nrm[3 * o + 1];
         rec[6 * i + 5] = nrm[3 * o + 2];
     }
-    inv_perm[o] = (int32_t)i;
+}
+
+// inv_perm[perm[i]] = i: a scattered 4-byte write per point (a 64-byte sector each), so only made when somebody asks for
+// positions by original index (keypoint subsets, k-NN lists): sf_cloud_ensure_inv_perm
+__global__ void k_inv_perm(const int32_t *__restrict__ perm, int64_t base, int64_t n, int32_t *__restrict__ inv_perm)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    i += base;
+    inv_perm[perm[i]] = (int32_t)i;
 }
 
 // normals: slots 3..5 of the AoS records
@@ -177,6 +186,7 @@ static void cloud_release_grid(sf_ctx *ctx, sf_cloud *c)
             if (ctx) sf_pool_release(ctx, p); else (void)hipFree(p);
         }
     c->cell_start = c->perm = c->inv_perm = nullptr;
+    c->inv_perm_valid = false;
     c->xs = c->ys = c->zs = c->rec = nullptr;
     c->normals_sorted = false;
     c->cell = 0.0;
@@ -265,6 +275,19 @@ int sf_cloud_normals_max2(sf_ctx *ctx, sf_cloud *c, double *out)
         c->nrm_max2 = v;
     }
     *out = c->nrm_max2;
+    return SF_OK;
+}
+
+// inv_perm on first use after a grid build (see k_inv_perm)
+int sf_cloud_ensure_inv_perm(sf_ctx *ctx, sf_cloud *c)
+{
+    if (c->inv_perm_valid) return SF_OK;
+    if (!c->perm || !c->inv_perm) { sf_set_error("grid not built"); return SF_ERR_STATE; }
+    const int64_t np = c->pop_end - c->pop_begin;
+    if (np > 0)
+        SF_LAUNCH(ctx, "k1_inv_perm", k_inv_perm, dim3((unsigned)sf_div_up(np, 256)), dim3(256), (const int32_t *)c->perm,
+                  c->pop_begin, np, c->inv_perm);
+    c->inv_perm_valid = true;
     return SF_OK;
 }
 
@@ -469,7 +492,7 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
                                              ctx->stream));
         }
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,
-                  (const double *)c->nrm_orig, c->perm, base, ns, c->xs, c->ys, c->zs, c->rec, c->inv_perm);
+                  (const double *)c->nrm_orig, c->perm, base, ns, c->xs, c->ys, c->zs, c->rec);
         sf_pool_release(ctx, tmp);
     }
     // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything

@@ -689,6 +689,7 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         sf_set_error("sf_knn_search: internal error, %zu queries unresolved", pending.size());
         return fail();
     }
+    if (sf_cloud_ensure_inv_perm(ctx, c) != SF_OK) return fail();
     {
         sf_launch_timer t_(ctx, "k2_knn_to_positions");
         hipLaunchKernelGGL(k_knn_to_positions, dim3((unsigned)sf_div_up(nb->total, 256)), dim3(256), 0, ctx->stream, nb->total,
