@@ -436,7 +436,7 @@ def main() -> int:
                 f"NOT measured in this run: per-launch HBM bytes from separate rocprofv3 --pmc passes of this command, {traffic_src}",
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": ("the kernel is float64-VALU-issue bound, not HBM bound: 846 vector instructions per keypoint at ~95 % "
+                "note": ("the kernel is float64-VALU-issue bound, not HBM bound: 783 vector instructions per keypoint at ~95 % "
                          "issue (SQ counters, profiles/r02_k5.md); the HBM fraction is reported because the contract asks for it")
                 if dom == "k5_shot" else None,
             },
