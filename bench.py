@@ -186,7 +186,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--radius", type=float, default=0.03)
-    ap.add_argument("--spfh-exchange", choices=["halo", "allgather"], default="halo")
+    ap.add_argument("--spfh-exchange", choices=["neighbor", "halo", "allgather"], default="neighbor",
+                    help="N > 1: how a rank gets the SPFH rows of its block's halo (sharding.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="points of the reference-shaped CPU baseline's sample")
     ap.add_argument("--only", choices=["both", "fpfh", "shot"], default="both")
@@ -303,7 +304,7 @@ def main() -> int:
     points, normals = make_cloud(n_total, 3)
     job = DescriptorJob(eng, points, normals, radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world,
                         rank=rank, spfh_exchange=args.spfh_exchange, do_fpfh=args.only in ("both", "fpfh"),
-                        do_shot=args.only in ("both", "shot"), overlap_chains=args.overlap)
+                        do_shot=args.only in ("both", "shot"), overlap_chains=args.overlap, emulate_peers=emulated)
 
     def barrier():
         eng.sync()

@@ -108,6 +108,11 @@ int sf_cloud_perm(sf_ctx *ctx, sf_cloud *cloud, int32_t *perm);
  * orders cells z-slowest, so a block is a z-slab and its halo is one contiguous run on each side. */
 int sf_cloud_halo_range(sf_ctx *ctx, sf_cloud *cloud, int64_t begin, int64_t end, int64_t *halo_begin,
                         int64_t *halo_end);
+/* first[z] = first cell-sorted position of z-layer z of the grid's cells, z = 0 .. *n_layers (first[*n_layers] = n);
+ * `first` (host, nullable) has room for `cap` entries.  A block build keeps the table for the WHOLE replicated cloud
+ * (it comes out of its per-layer histogram), so every rank can work out every rank's block, halo and the rows two
+ * ranks exchange (shot_fpfh_amd/sharding.py) without talking to anybody. */
+int sf_cloud_layer_table(sf_ctx *ctx, sf_cloud *cloud, int64_t *first, int64_t cap, int64_t *n_layers);
 
 /* ---- radius search: replaces KDTree.query_radius (kernels K2 count / fill) --------------
  * Inclusion rule of sklearn's euclidean KDTree: ((dx*dx + dy*dy) + dz*dz) <= r*r in float64,
@@ -130,6 +135,8 @@ sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nbrs, int64_t first, int64_t count)
 int64_t sf_nbrs_num_queries(const sf_nbrs *nbrs);
 int64_t sf_nbrs_total(const sf_nbrs *nbrs);
 int64_t sf_nbrs_max_count(const sf_nbrs *nbrs);
+/* the longest list over EVERY rank's searches when sf_comm_collective_stats is on (else = sf_nbrs_max_count) */
+int64_t sf_nbrs_max_count_all(const sf_nbrs *nbrs);
 int sf_nbrs_export(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int64_t *offsets /* m+1 */,
                    int32_t *idx /* total */, double *dist /* nullable, total */);
 void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nbrs);
@@ -203,6 +210,17 @@ int sf_lrf_raw_from_moments(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const d
 int sf_shot_from_raw_lrf(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, double *lrf_dev, int normalize,
                          int64_t min_neighborhood_size, double *out_dev);
 int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *spfh, int64_t rows_per_rank); /* RCCL, in place */
+/* Neighbour-to-neighbour exchange of SPFH rows in one RCCL send/recv group: operation i sends this rank's rows
+ * [send_begin[i], send_end[i]) to rank peer[i] and receives that rank's rows into [recv_begin[i], recv_end[i]) (cell-sorted
+ * positions; the two sides of an operation must name equally many rows).  Per row only what K7 reads per neighbour
+ * travels (64 B on the byte table with at most two live blocks).  See fpfh.hip. */
+int sf_spfh_exchange_rows(sf_ctx *ctx, sf_spfh *spfh, int n_ops, const int *peer, const int64_t *send_begin,
+                          const int64_t *send_end, const int64_t *recv_begin, const int64_t *recv_end);
+/* The same wire image of rows [begin, end) through HOST memory, for transports other than RCCL: write_back = 0 copies it
+ * out of the table into `host` (cap bytes of room), 1 copies it from `host` into the table's rows; *bytes (nullable)
+ * receives the image size, and host == NULL only queries it. */
+int sf_spfh_rows_image(sf_ctx *ctx, sf_spfh *spfh, int64_t begin, int64_t end, void *host, size_t cap, int write_back,
+                       size_t *bytes);
 int sf_spfh_export(sf_ctx *ctx, sf_cloud *cloud, sf_spfh *spfh, double *out /* n x nb^3 */, int flags);
 void sf_spfh_free(sf_ctx *ctx, sf_spfh *spfh);
 int sf_fpfh(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const int64_t *kp_idx, int64_t m,
@@ -272,6 +290,15 @@ int sf_transform_points(sf_ctx *ctx, double *pts_dev, int64_t n, const double *R
 int sf_comm_unique_id(char id[128]);
 int sf_comm_init(sf_ctx *ctx, const char id[128], int nranks, int rank);
 int sf_comm_allgather(sf_ctx *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+/* Grouped point-to-point exchange (ncclSend / ncclRecv in one group): operation i sends send_bytes[i] bytes to rank
+ * peer[i] and receives recv_bytes[i] bytes from it; a rank may name itself. */
+int sf_comm_exchange(sf_ctx *ctx, int n_ops, const int *peer, const void *const *send_dev, const size_t *send_bytes,
+                     void *const *recv_dev, const size_t *recv_bytes);
+/* element-wise minimum over the ranks of n unsigned 64-bit words (ncclAllReduce; in place allowed): the column arg-min of
+ * a sharded matching travels as packed (distance bits, index) keys */
+int sf_comm_allreduce_min_u64(sf_ctx *ctx, const void *send_dev, void *recv_dev, size_t n);
+/* on: every radius search of the context also folds its longest-list statistic over all ranks (collective call) */
+int sf_comm_collective_stats(sf_ctx *ctx, int on);
 int sf_comm_destroy(sf_ctx *ctx);
 
 /* ---- per-kernel timing with HIP events on the ctx stream -------------------------------- */

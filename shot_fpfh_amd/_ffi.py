@@ -50,6 +50,7 @@ SIGNATURES = {
     "sf_cloud_free": (None, [_vp, _vp]),
     "sf_cloud_perm": (_int, [_vp, _vp, _vp]),
     "sf_cloud_halo_range": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "sf_cloud_layer_table": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "sf_radius_search": (_vp, [_vp, _vp, _vp, _i64, _f64, _int]),
     "sf_radius_search_self": (_vp, [_vp, _vp, _f64, _i64, _i64]),
     "sf_knn_search": (_vp, [_vp, _vp, _vp, _i64, _int, _int]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "sf_nbrs_num_queries": (_i64, [_vp]),
     "sf_nbrs_total": (_i64, [_vp]),
     "sf_nbrs_max_count": (_i64, [_vp]),
+    "sf_nbrs_max_count_all": (_i64, [_vp]),
     "sf_nbrs_export": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sf_nbrs_free": (None, [_vp, _vp]),
     "sf_normals": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
@@ -73,6 +75,8 @@ SIGNATURES = {
     "sf_lrf_raw_from_moments": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "sf_shot_from_raw_lrf": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp]),
     "sf_spfh_allgather": (_int, [_vp, _vp, _i64]),
+    "sf_spfh_exchange_rows": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    "sf_spfh_rows_image": (_int, [_vp, _vp, _i64, _i64, _vp, _sz, _int, _vp]),
     "sf_spfh_export": (_int, [_vp, _vp, _vp, _vp, _int]),
     "sf_spfh_free": (None, [_vp, _vp]),
     "sf_fpfh": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _int]),
@@ -91,6 +95,9 @@ SIGNATURES = {
     "sf_comm_unique_id": (_int, [_vp]),
     "sf_comm_init": (_int, [_vp, _vp, _int, _int]),
     "sf_comm_allgather": (_int, [_vp, _vp, _vp, _sz]),
+    "sf_comm_exchange": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    "sf_comm_allreduce_min_u64": (_int, [_vp, _vp, _vp, _sz]),
+    "sf_comm_collective_stats": (_int, [_vp, _int]),
     "sf_comm_destroy": (_int, [_vp]),
     "sf_profile_enable": (_int, [_vp, _int]),
     "sf_profile_reset": (_int, [_vp]),

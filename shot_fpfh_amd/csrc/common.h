@@ -57,6 +57,7 @@ struct sf_ctx {
     std::vector<hipEvent_t> event_pool;
     void *comm = nullptr; // ncclComm_t
     int nranks = 1, rank = 0;
+    bool collective_stats = false; // sf_comm_collective_stats: radius searches all-reduce their list statistics
     // small reusable device scratch (bbox partials etc.)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -110,6 +111,7 @@ struct sf_pool_guard {
     }
 };
 
+int sf_comm_allreduce_max_i32(sf_ctx *ctx, const int *send, int *recv, size_t n); // comm.hip
 int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out);
 #define SF_PINNED_BYTES 4096
 int sf_ctx_pinned(sf_ctx *ctx, void **out);
@@ -183,6 +185,13 @@ struct sf_cloud {
     // cell-sorted positions that are actually populated: [0, n) after sf_cloud_build_grid, the slab a block needs
     // after sf_cloud_build_grid_block (positions keep their GLOBAL numbering either way)
     int64_t pop_begin = 0, pop_end = 0;
+    // z coordinates alone, in the uploaded order (made by the first block build and kept, like the bounding box): the two
+    // whole-cloud passes of a block build -- layer histogram, slab selection -- read 8 bytes per point instead of
+    // pulling the 24-byte AoS records through the fabric
+    double *z_orig = nullptr;
+    // first cell-sorted position of every z-layer of cells (dim[2] + 1 entries, host): written by the block build
+    // (which needs it anyway), fetched from cell_start on demand after a whole-cloud build (sf_cloud_layer_table)
+    std::vector<int64_t> layer_first;
 };
 
 struct sf_nbrs {
@@ -190,6 +199,7 @@ struct sf_nbrs {
     double radius = 0.0;
     int64_t total = 0;
     int64_t max_count = 0;
+    int64_t max_count_all = 0; // the same over every rank's lists when the context folds its statistics (else = max_count)
     bool view = false;       // non-owning slice of another sf_nbrs
     bool self = false;       // queries are cloud points
     int64_t self_begin = 0;  // first sorted position when self
@@ -212,14 +222,16 @@ struct sf_spfh {
     int32_t *k = nullptr;   // n, neighbourhood size (self included), by sorted position
     double *p4 = nullptr;   // uint8 table only: n x {x, y, z, (double)k} -- all the matrix-core K7 gathers per neighbour
                             // besides the table row, in ONE 32-byte record (one cache line per lane instead of three)
-    unsigned *live = nullptr; // uint8 table only, two words.  [0]: bit b set <=> some row computed so far has a non-zero
+    unsigned *live = nullptr; // uint8 table only, four words ([2]: raised by a K7 launched in the wrong form, [3]: unused).  [0]: bit b set <=> some row computed so far has a non-zero
                               // count among bins 16 b .. 16 b + 15 (OR-accumulated by K6, never cleared: a superset is always
                               // safe); the matrix-core K7 streams and multiplies only the live 16-bin blocks of the rows.
                               // [1]: the mask under which EVERY row of `packed` was last written (~0: not valid).
     uint8_t *packed = nullptr; // uint8 table only: n x 32 bytes, the (at most) two live blocks of each row side by side --
                                // four rows per cache line instead of one for K7's gather
     unsigned host_live[2] = {0xffu, ~0u}; // the two words of `live` as last read back ...
-    bool host_live_valid = false;         // ... valid until the next K6 on this table (sf_fpfh reads them back once)
+    bool host_live_valid = false;         // ... valid until the next K6 whose blocks the data decides (sf_fpfh reads them back once)
+    bool mask_known = false;              // every mask that ever went into live[0] was known on the host: host_live is exact
+                                          // and a function of the calls' parameters alone (the same on every rank)
 };
 
 static inline int64_t sf_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -430,6 +430,16 @@ __global__ __launch_bounds__(256) void k_fpfh(const double *__restrict__ rec, co
 
 #include "fpfh_mc.h"
 
+// The two matrix-core forms of K7 are separate kernels and the host picks one from its copy of the table-wide block mask.
+// Should that copy ever disagree with the device's, the keypoint's row is filled with NaN and word 2 of `live` raised
+// (sf_fpfh reports it at its next synchronisation) -- a wrong launch is loud, never an unwritten row.
+__device__ inline void fpfh_mc_wrong_form(const unsigned *__restrict__ live, double *__restrict__ out, int64_t q, int nb3)
+{
+    const int lane = threadIdx.x & 63;
+    for (int b = lane; b < nb3; b += 64) out[q * nb3 + b] = __builtin_nan("");
+    if (lane == 0) atomicOr(const_cast<unsigned *>(live) + 2, 1u);
+}
+
 // waves_per_eu(8, 8): left to itself the allocator gives the 3-chunk instantiation 74 registers (6 waves per SIMD); asked
 // for eight waves it fits 64 without spilling (the 4-chunk form spills five dwords), and the kernel -- which lives on the
 // number of waves that cover its LDS-DMA round trips -- runs 11 % faster at C3 (1.48 -> 1.31 ms).  LDS (4.6 KB per wave)
@@ -451,7 +461,10 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     // (the full and the sparse-block form are two kernels -- in ONE the full form's register allocation suffered, 1.45
     // instead of 1.29 ms on a table with all eight blocks live -- and the host launches the one the table-wide block mask
     // asks for; the check here only guards against a stale host copy)
-    if (__popc(sf_uniform(*live) & 0xffu) <= 2) return;
+    if (__popc(sf_uniform(*live) & 0xffu) <= 2) { // the host launched the wrong form: never leave the row unwritten
+        fpfh_mc_wrong_form(live, out, q, nb3);
+        return;
+    }
     fpfh_mc_body<NKS>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
                       abuf_all[wv_id]);
 }
@@ -472,7 +485,10 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     const int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
     if (q >= m) return;
     const unsigned mask = sf_uniform(*live) & 0xffu;
-    if (__popc(mask) > 2) return; // the full kernel's case
+    if (__popc(mask) > 2) { // the full kernel's case
+        fpfh_mc_wrong_form(live, out, q, nb3);
+        return;
+    }
     const int b0 = mask ? __ffs(mask) - 1 : 0;
     const unsigned rest = mask & (mask - 1u);
     const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7; // (a lone live block is paired with an empty one)
@@ -521,6 +537,11 @@ __global__ __launch_bounds__(256) void k_spfh_repack(const uint8_t *__restrict__
     for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x)
         if (row < begin || row >= end) spfh_pack_row(counts, packed, row, mask);
 }
+
+// det != 0: the blocks K6 can possibly touch are known on the host (alpha's bin is pinned, see spfh_compute); they are
+// marked live BEFORE K6 runs, so the mask after K6 is a function of the call's parameters alone -- the same on every
+// rank of a sharded job, and known to the host without a read-back.
+__global__ void k_spfh_live_or(unsigned *__restrict__ live, unsigned det) { live[0] |= det; }
 
 __global__ void k_spfh_pack_done(unsigned *__restrict__ live)
 {
@@ -685,8 +706,9 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     if (hipMalloc(&sp->counts, nn * sp->stride * sp->elem_bytes) != hipSuccess ||
         hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess ||
         (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess) ||
-        (sp->elem_bytes == 1 && (hipMalloc(&sp->live, 2 * sizeof(unsigned)) != hipSuccess ||
+        (sp->elem_bytes == 1 && (hipMalloc(&sp->live, 4 * sizeof(unsigned)) != hipSuccess ||
                                  hipMalloc(&sp->packed, nn * 32) != hipSuccess ||
+                                 hipMemset(sp->live, 0, 4 * sizeof(unsigned)) != hipSuccess ||
                                  // SF_FPFH_DENSE=1: every block counts as live from the start (K7 always takes its full form)
                                  hipMemset(sp->live, getenv("SF_FPFH_DENSE") ? 0xff : 0, sizeof(unsigned)) != hipSuccess ||
                                  hipMemset(sp->live + 1, 0xff, sizeof(unsigned)) != hipSuccess))) {
@@ -694,6 +716,10 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
         sf_spfh_free(ctx, sp);
         return nullptr;
     }
+    // the host's mirror of live[0..1]: exact as long as every mask that went in was known here (mask_known)
+    sp->host_live[0] = getenv("SF_FPFH_DENSE") ? ~0u : 0u;
+    sp->host_live[1] = ~0u;
+    sp->host_live_valid = sp->mask_known = sp->elem_bytes == 1;
     return sp;
 }
 
@@ -793,6 +819,11 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     default: { SF_SPFH_LAUNCH(CT, 0); } break;                   \
     }
     if (sp->elem_bytes == 1) {
+        // alpha pinned to one bin => only the 16-bin blocks that hold that bin's n_bins^2 slots can receive a count
+        unsigned det = 0u;
+        if (alpha_bin >= 0)
+            for (int blk = (alpha_bin * nbn * nbn) / 16; blk <= ((alpha_bin + 1) * nbn * nbn - 1) / 16; ++blk) det |= 1u << blk;
+        if (det) SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_live_or, dim3(1), dim3(1), sp->live, det);
         SF_SPFH_DISPATCH(uint8_t)
         // rows [self_begin, self_begin + m) are new: pack their live blocks (a no-op on the device when more than two are)
         SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack, dim3((unsigned)sf_div_up(m, 256)), dim3(256), (const uint8_t *)sp->counts,
@@ -800,7 +831,15 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
         SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_repack, dim3(2048), dim3(256), (const uint8_t *)sp->counts, sp->n, nb->self_begin,
                   nb->self_begin + m, (const unsigned *)sp->live, sp->packed);
         SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack_done, dim3(1), dim3(1), sp->live);
-        sp->host_live_valid = false;
+        if (det && sp->mask_known) { // the device's mask words, without asking the device
+            sp->host_live[0] |= det;
+            const unsigned m8 = sp->host_live[0] & 0xffu;
+            sp->host_live[1] = __builtin_popcount(m8) <= 2 ? m8 : ~0u;
+            sp->host_live_valid = true;
+        } else { // data decides which blocks are live: sf_fpfh reads the mask back
+            sp->mask_known = false;
+            sp->host_live_valid = false;
+        }
     } else if (sp->elem_bytes == 2) {
         SF_SPFH_DISPATCH(uint16_t)
     } else {
@@ -847,9 +886,100 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
         SF_CHECK(sf_comm_allgather(ctx, pb + (size_t)ctx->rank * rows_per_rank * 32, pb, (size_t)rows_per_rank * 32));
     }
     // the gathered rows come from other ranks' K6: every block of the table counts as live from here on
-    if (sp->live) SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->stream));
-    sp->host_live_valid = false;
+    if (sp->live) {
+        SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->stream));
+        sp->host_live[0] = sp->host_live[1] = ~0u;
+        sp->host_live_valid = sp->mask_known = true; // (every block: nothing left for the data to decide)
+    }
     return SF_OK;
+}
+
+// The two arrays that make up the wire image of a table row (see sf_spfh_exchange_rows), decided from the table's storage and
+// the HOST-known block mask alone.  A byte table whose mask the data decided is switched to "every block live" first.
+struct spfh_part { char *base; size_t row; };
+static int spfh_wire_parts(sf_ctx *ctx, sf_spfh *sp, spfh_part parts[2])
+{
+    if (sp->elem_bytes == 1) {
+        const unsigned m8 = sp->host_live[0] & 0xffu;
+        const bool sparse = sp->mask_known && sp->host_live_valid && __builtin_popcount(m8) <= 2 && sp->host_live[1] == m8;
+        if (!sparse) { // rows from other ranks' K6 under masks this rank cannot know: every block counts as live
+            SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->stream));
+            sp->host_live[0] = sp->host_live[1] = ~0u;
+            sp->host_live_valid = sp->mask_known = true;
+        }
+        parts[0] = sparse ? spfh_part{(char *)sp->packed, 32} : spfh_part{(char *)sp->counts, 128};
+        parts[1] = spfh_part{(char *)sp->p4, 32};
+    } else {
+        parts[0] = spfh_part{(char *)sp->counts, (size_t)sp->stride * sp->elem_bytes};
+        parts[1] = spfh_part{(char *)sp->k, sizeof(int32_t)};
+    }
+    return SF_OK;
+}
+
+// The wire image of rows [begin, end) in host memory -- for transports other than RCCL (and for tests): write_back = 0
+// copies the image out of the table, 1 copies it into the table's rows.  *bytes (nullable) = size of the image.
+extern "C" int sf_spfh_rows_image(sf_ctx *ctx, sf_spfh *sp, int64_t begin, int64_t end, void *host, size_t cap, int write_back,
+                                  size_t *bytes)
+{
+    if (!ctx || !sp || begin < 0 || begin > end || end > sp->n) { sf_set_error("sf_spfh_rows_image: bad argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    spfh_part parts[2];
+    SF_CHECK(spfh_wire_parts(ctx, sp, parts));
+    const size_t rows = (size_t)(end - begin), need = rows * (parts[0].row + parts[1].row);
+    if (bytes) *bytes = need;
+    if (!host) return SF_OK; // size query
+    if (cap < need) { sf_set_error("sf_spfh_rows_image: %zu bytes needed, %zu given", need, cap); return SF_ERR_ARG; }
+    char *h = (char *)host;
+    for (const spfh_part &pt : parts) {
+        char *d = pt.base + (size_t)begin * pt.row;
+        if (rows) {
+            if (write_back) SF_HIP(hipMemcpyAsync(d, h, rows * pt.row, hipMemcpyHostToDevice, ctx->stream));
+            else SF_HIP(hipMemcpyAsync(h, d, rows * pt.row, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        h += rows * pt.row;
+    }
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+// Neighbour-to-neighbour exchange of SPFH rows (collective C1 without the all-gather): for operation i this
+// rank sends its rows [send_begin[i], send_end[i]) to rank peer[i] and receives that rank's rows into
+// [recv_begin[i], recv_end[i]) -- cell-sorted positions, which number the replicated cloud identically on every rank, so
+// a rank's z-slab block borrows exactly the one-layer halo its FPFH reduction reads (sharding.py plans the ranges).
+// What travels per row is what K7 reads per neighbour, no more: on the byte table with at most two live 16-bin blocks
+// the 32-byte packed row + the 32-byte {x, y, z, k} record (64 B instead of the 1000 B of the float64 row); with more
+// live blocks the 128-byte row + the record; on the wider tables the row + k.  The choice is a function of the table's
+// storage and of the HOST-known block mask only, so every rank makes the same one (the ranks size their tables by
+// sf_nbrs_max_count_all).  One RCCL group: all sends and receives of a rank are in flight together.
+extern "C" int sf_spfh_exchange_rows(sf_ctx *ctx, sf_spfh *sp, int n_ops, const int *peer, const int64_t *send_begin,
+                                     const int64_t *send_end, const int64_t *recv_begin, const int64_t *recv_end)
+{
+    if (!ctx || !sp || n_ops < 0 || (n_ops && (!peer || !send_begin || !send_end || !recv_begin || !recv_end))) {
+        sf_set_error("sf_spfh_exchange_rows: bad argument");
+        return SF_ERR_ARG;
+    }
+    for (int i = 0; i < n_ops; ++i)
+        if (send_begin[i] < 0 || send_begin[i] > send_end[i] || send_end[i] > sp->n || recv_begin[i] < 0 ||
+            recv_begin[i] > recv_end[i] || recv_end[i] > sp->n) {
+            sf_set_error("sf_spfh_exchange_rows: operation %d names rows outside the table of %lld", i, (long long)sp->n);
+            return SF_ERR_ARG;
+        }
+    SF_HIP(hipSetDevice(ctx->device));
+    spfh_part parts[2];
+    SF_CHECK(spfh_wire_parts(ctx, sp, parts));
+    std::vector<int> peers;
+    std::vector<const void *> sends;
+    std::vector<void *> recvs;
+    std::vector<size_t> sbytes, rbytes;
+    for (int i = 0; i < n_ops; ++i)
+        for (const spfh_part &pt : parts) {
+            peers.push_back(peer[i]);
+            sends.push_back(pt.base + (size_t)send_begin[i] * pt.row);
+            sbytes.push_back((size_t)(send_end[i] - send_begin[i]) * pt.row);
+            recvs.push_back(pt.base + (size_t)recv_begin[i] * pt.row);
+            rbytes.push_back((size_t)(recv_end[i] - recv_begin[i]) * pt.row);
+        }
+    return sf_comm_exchange(ctx, (int)peers.size(), peers.data(), sends.data(), sbytes.data(), recvs.data(), rbytes.data());
 }
 
 extern "C" int sf_spfh_export(sf_ctx *ctx, sf_cloud *c, sf_spfh *sp, double *out, int flags)
@@ -942,10 +1072,14 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     if (!sp->host_live_valid) {
         void *pin = nullptr;
         SF_CHECK(sf_ctx_pinned(ctx, &pin));
-        SF_HIP(hipMemcpyAsync(pin, sp->live, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipMemcpyAsync(pin, sp->live, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
         memcpy(sp->host_live, pin, 2 * sizeof(unsigned));
         sp->host_live_valid = true;
+        if (((const unsigned *)pin)[2]) {
+            sf_set_error("sf_fpfh: an earlier launch took the wrong matrix-core form for this table (host copy of the block mask was stale); its rows are NaN");
+            return SF_ERR_STATE;
+        }
     }
     const bool sparse = __builtin_popcount(sp->host_live[0] & 0xffu) <= 2;
 #define SF_MC_LAUNCH(NKS)                                                                                            \

@@ -150,31 +150,65 @@ __global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t bas
 }
 
 #define SF_MAX_LAYERS 4096
-// points per z-layer of cells (block build: where do the cell-sorted positions of a layer start?)
-__global__ void k_layer_hist(const int32_t *__restrict__ cid, int64_t n, int layer_cells, int nlayers,
-                             unsigned int *__restrict__ hist)
+// ---- block build (one rank of a sharded job) ------------------------------------------------------------------
+// The replicated cloud is in no particular order, so a rank has to look at every point to find the ones of its slab;
+// both whole-cloud passes read the 8-byte z coordinate only (sf_cloud::z_orig).
+__global__ void k_extract_z(const double *__restrict__ xyz, int64_t n, double *__restrict__ z)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = xyz[3 * i + 2];
+}
+
+// pass A: points per z-layer of cells (the first cell-sorted position of a layer is the number of points below it)
+__global__ __launch_bounds__(256) void k_layer_hist_z(const double *__restrict__ z, int64_t n, double lo, double inv_cell,
+                                                      int nlayers, unsigned int *__restrict__ hist)
 {
     __shared__ unsigned int sh[SF_MAX_LAYERS];
     for (int b = threadIdx.x; b < nlayers; b += blockDim.x) sh[b] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&sh[cid[i] / layer_cells], 1u);
+    const int64_t npair = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    const double2 *z2 = reinterpret_cast<const double2 *>(z);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npair; i += stride) {
+        const double2 v = z2[i];
+        atomicAdd(&sh[sf_cell_coord(v.x, lo, inv_cell, nlayers)], 1u);
+        atomicAdd(&sh[sf_cell_coord(v.y, lo, inv_cell, nlayers)], 1u);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sh[sf_cell_coord(z[n - 1], lo, inv_cell, nlayers)], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nlayers; b += blockDim.x)
         if (sh[b]) atomicAdd(&hist[b], sh[b]);
 }
 
-__global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__restrict__ sel, int64_t n,
-                             int32_t *__restrict__ dst)
+// pass B's predicate: is this z inside the layers [zlo, zhi] the block needs?
+struct z_in_layers {
+    double lo, inv_cell;
+    int dim, zlo, zhi;
+    __host__ __device__ bool operator()(double z) const
+    {
+        const int cz = sf_cell_coord(z, lo, inv_cell, dim);
+        return cz >= zlo && cz <= zhi;
+    }
+};
+
+// cell ids of the kept points only (ascending original index, as the selection left them)
+__global__ void k_cell_ids_sel(const double *__restrict__ xyz, const int32_t *__restrict__ sel, int64_t ns, sf_grid_desc g,
+                               int32_t *__restrict__ cid)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[sel[i]];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const int64_t o = sel[i];
+    const int cx = sf_cell_coord(xyz[3 * o + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
+    const int cy = sf_cell_coord(xyz[3 * o + 1], g.lo[1], g.inv_cell, g.dim[1]);
+    const int cz = sf_cell_coord(xyz[3 * o + 2], g.lo[2], g.inv_cell, g.dim[2]);
+    cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
 }
 
-struct cid_in_range {
-    int32_t lo, hi;
-    __host__ __device__ bool operator()(int32_t c) const { return c >= lo && c < hi; }
-};
+// first cell-sorted position of every z-layer, read off the cell table (after a whole-cloud build)
+__global__ void k_layer_first(const int32_t *__restrict__ cell_start, int64_t layer_cells, int nl, int64_t *__restrict__ out)
+{
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z <= nl) out[z] = cell_start[(int64_t)z * layer_cells];
+}
 
 } // namespace
 
@@ -191,6 +225,7 @@ static void cloud_release_grid(sf_ctx *ctx, sf_cloud *c)
     c->normals_sorted = false;
     c->cell = 0.0;
     c->pop_begin = c->pop_end = 0;
+    c->layer_first.clear();
 }
 
 extern "C" sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const double *normals, int64_t n, int flags)
@@ -408,28 +443,33 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         return SF_OK;
     }
     // ---- cell ids, stable radix sort (ties keep ascending original index), SoA gather ---------
-    int32_t *cid = nullptr, *cid_sorted = nullptr, *val = nullptr;
-    SF_CHECK(sf_palloc(ctx, &cid, nn));
-    SF_CHECK(sf_palloc(ctx, &cid_sorted, nn));
-    SF_CHECK(sf_palloc(ctx, &val, nn));
+    sf_pool_guard tmp(ctx);
+    int32_t *cid_sorted = nullptr;
+    SF_CHECK(tmp.alloc(&cid_sorted, nn));
     sf_grid_desc g = sf_make_grid_desc(c);
-    SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, g, cid,
-              val);
     int bits = 1;
     while (((int64_t)1 << bits) < ncell) ++bits;
 
     int64_t base = 0, ns = n;                  // populated slice [base, base + ns) of the global order
-    int32_t *key_in = cid, *val_in = val;      // what gets sorted
-    int32_t *cid_sel = nullptr, *val_sel = nullptr;
+    int32_t *key_in = nullptr, *val_in = nullptr; // what gets sorted
     const bool whole = block_end < 0 || c->dim[2] > SF_MAX_LAYERS; // (the layer histogram lives in LDS)
-    if (!whole) {
-        // ---- which z-layers does the block need? ------------------------------------------------
+    if (whole) {
+        SF_CHECK(tmp.alloc(&key_in, nn));
+        SF_CHECK(tmp.alloc(&val_in, nn));
+        SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, g, key_in,
+                  val_in);
+    } else {
+        // ---- pass A: which z-layers does the block need? ------------------------------------------
+        if (!c->z_orig) {
+            SF_HIP(hipMalloc(&c->z_orig, (nn + 2) * sizeof(double)));
+            SF_LAUNCH(ctx, "k1_extract_z", k_extract_z, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, c->z_orig);
+        }
         const int nl = c->dim[2];
-        const int layer_cells = c->dim[0] * c->dim[1];
         unsigned int *dhist = nullptr;
-        SF_CHECK(sf_palloc(ctx, &dhist, (size_t)nl));
+        SF_CHECK(tmp.alloc(&dhist, (size_t)nl));
         SF_HIP(hipMemsetAsync(dhist, 0, (size_t)nl * sizeof(unsigned int), ctx->stream));
-        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist, dim3(1024), dim3(256), cid, n, layer_cells, nl, dhist);
+        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_z, dim3(2048), dim3(256), (const double *)c->z_orig, n, c->lo[2], c->inv_cell,
+                  nl, dhist);
         std::vector<unsigned int> hist((size_t)nl);
         void *pin = nullptr;
         SF_CHECK(sf_ctx_pinned(ctx, &pin));
@@ -437,8 +477,8 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         SF_HIP(hipMemcpyAsync(dst, dhist, (size_t)nl * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
         if (dst != hist.data()) std::copy(dst, dst + nl, hist.begin());
-        sf_pool_release(ctx, dhist);
-        std::vector<int64_t> first((size_t)nl + 1, 0); // global position of each layer's first point
+        std::vector<int64_t> &first = c->layer_first; // global position of each layer's first point
+        first.assign((size_t)nl + 1, 0);
         for (int z = 0; z < nl; ++z) first[(size_t)z + 1] = first[(size_t)z] + hist[(size_t)z];
         int zb = 0, ze = nl - 1;
         if (block_begin < block_end) {
@@ -451,31 +491,25 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         const int zlo = std::max(zb - reach, 0), zhi = block_begin < block_end ? std::min(ze + reach, nl - 1) : -1;
         base = zhi >= zlo ? first[(size_t)zlo] : 0;
         ns = zhi >= zlo ? first[(size_t)zhi + 1] - base : 0;
-        // ---- stable selection of the points of those layers ----------------------------------------
-        if (ns > 0 && ns < n) {
-            SF_CHECK(sf_palloc(ctx, &cid_sel, (size_t)ns + 1));
-            SF_CHECK(sf_palloc(ctx, &val_sel, (size_t)ns + 1));
+        // ---- pass B: stable selection of the points of those layers, then their cell ids ----------------
+        if (ns > 0) {
+            SF_CHECK(tmp.alloc(&key_in, (size_t)ns + 1));
+            SF_CHECK(tmp.alloc(&val_in, (size_t)ns + 1));
             size_t *dcount = nullptr;
-            SF_CHECK(sf_palloc(ctx, &dcount, 2));
-            const cid_in_range pred{(int32_t)((int64_t)zlo * layer_cells), (int32_t)std::min<int64_t>((int64_t)(zhi + 1) * layer_cells, 2147483647LL)};
-            auto flags = rocprim::make_transform_iterator(cid, pred);
-            size_t sel_bytes = 0;
-            // ONE pass over the n cell ids: the (ascending) indices of the points kept; their cell ids are then a
-            // gather over the ~n/N kept points
+            SF_CHECK(tmp.alloc(&dcount, 2));
+            const z_in_layers pred{c->lo[2], c->inv_cell, nl, zlo, zhi};
+            auto flags = rocprim::make_transform_iterator((const double *)c->z_orig, pred);
             auto ids = rocprim::make_counting_iterator<int32_t>(0);
-            SF_HIP(rocprim::select(nullptr, sel_bytes, ids, flags, val_sel, dcount, (size_t)n, ctx->stream));
-            void *sel_tmp = nullptr;
-            SF_CHECK(sf_pool_alloc(ctx, sel_bytes ? sel_bytes : 8, &sel_tmp));
+            size_t sel_bytes = 0;
+            SF_HIP(rocprim::select(nullptr, sel_bytes, ids, flags, val_in, dcount, (size_t)n, ctx->stream));
+            char *sel_tmp = nullptr;
+            SF_CHECK(tmp.alloc(&sel_tmp, sel_bytes ? sel_bytes : 8));
             {
                 sf_launch_timer t_(ctx, "k1_select_slab");
-                SF_HIP(rocprim::select(sel_tmp, sel_bytes, ids, flags, val_sel, dcount, (size_t)n, ctx->stream));
+                SF_HIP(rocprim::select(sel_tmp, sel_bytes, ids, flags, val_in, dcount, (size_t)n, ctx->stream));
             }
-            SF_LAUNCH(ctx, "k1_select_slab", k_gather_i32, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), (const int32_t *)cid,
-                      (const int32_t *)val_sel, ns, cid_sel);
-            sf_pool_release(ctx, sel_tmp);
-            sf_pool_release(ctx, dcount);
-            key_in = cid_sel;
-            val_in = val_sel;
+            SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids_sel, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), (const double *)c->xyz_orig,
+                      (const int32_t *)val_in, ns, g, key_in);
         }
     }
     c->pop_begin = base;
@@ -484,27 +518,51 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         size_t tmp_bytes = 0;
         SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
                                          ctx->stream));
-        void *tmp = nullptr;
-        SF_CHECK(sf_pool_alloc(ctx, tmp_bytes ? tmp_bytes : 8, &tmp));
+        char *stmp = nullptr;
+        SF_CHECK(tmp.alloc(&stmp, tmp_bytes ? tmp_bytes : 8));
         {
             sf_launch_timer t_(ctx, "k1_radix_sort");
-            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(tmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
+            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(stmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
                                              ctx->stream));
         }
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,
                   (const double *)c->nrm_orig, c->perm, base, ns, c->xs, c->ys, c->zs, c->rec);
-        sf_pool_release(ctx, tmp);
     }
     // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
     // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
     c->normals_sorted = c->nrm_orig != nullptr;
     SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, base, ns,
               ncell, c->cell_start);
-    if (cid_sel) sf_pool_release(ctx, cid_sel);
-    if (val_sel) sf_pool_release(ctx, val_sel);
-    sf_pool_release(ctx, cid);
-    sf_pool_release(ctx, cid_sorted);
-    sf_pool_release(ctx, val);
+    return SF_OK;
+}
+
+// First cell-sorted position of every z-layer of cells, dim[2] + 1 entries: kept by the block build, read off the cell
+// table (one small kernel + copy) after a whole-cloud build.
+static int cloud_layer_first(sf_ctx *ctx, sf_cloud *c)
+{
+    if (!c->cell_start) { sf_set_error("grid not built"); return SF_ERR_STATE; }
+    const int nl = c->dim[2];
+    if ((int64_t)c->layer_first.size() == (int64_t)nl + 1) return SF_OK;
+    sf_pool_guard tmp(ctx);
+    int64_t *d = nullptr;
+    SF_CHECK(tmp.alloc(&d, (size_t)nl + 1));
+    SF_LAUNCH(ctx, "k1_layer_first", k_layer_first, dim3((unsigned)sf_div_up(nl + 1, 256)), dim3(256), (const int32_t *)c->cell_start,
+              (int64_t)c->dim[0] * c->dim[1], nl, d);
+    c->layer_first.assign((size_t)nl + 1, 0);
+    SF_HIP(hipMemcpyAsync(c->layer_first.data(), d, ((size_t)nl + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_cloud_layer_table(sf_ctx *ctx, sf_cloud *c, int64_t *first, int64_t cap, int64_t *n_layers)
+{
+    if (!ctx || !c || !n_layers) { sf_set_error("sf_cloud_layer_table: null argument"); return SF_ERR_ARG; }
+    SF_CHECK(cloud_layer_first(ctx, c));
+    *n_layers = c->dim[2];
+    if (first) {
+        if (cap < (int64_t)c->layer_first.size()) { sf_set_error("sf_cloud_layer_table: room for %lld entries, %zu needed", (long long)cap, c->layer_first.size()); return SF_ERR_ARG; }
+        std::copy(c->layer_first.begin(), c->layer_first.end(), first);
+    }
     return SF_OK;
 }
 
@@ -548,22 +606,16 @@ extern "C" int sf_cloud_halo_range(sf_ctx *ctx, sf_cloud *c, int64_t begin, int6
     }
     if (!c->cell_start) { sf_set_error("sf_cloud_halo_range: grid not built"); return SF_ERR_STATE; }
     if (begin == end) { *hb = begin; *he = end; return SF_OK; }
-    // z coordinates of the first and last point of the block give its z-layers of cells
-    double zz[2];
-    SF_HIP(hipMemcpyAsync(&zz[0], c->zs + begin, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipMemcpyAsync(&zz[1], c->zs + (end - 1), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipStreamSynchronize(ctx->stream));
-    const int z0 = sf_cell_coord(zz[0], c->lo[2], c->inv_cell, c->dim[2]);
-    const int z1 = sf_cell_coord(zz[1], c->lo[2], c->inv_cell, c->dim[2]);
-    const int64_t layer = (int64_t)c->dim[0] * c->dim[1];
-    const int64_t c0 = (int64_t)std::max(z0 - 1, 0) * layer;
-    const int64_t c1 = (int64_t)std::min(z1 + 2, c->dim[2]) * layer;
-    int32_t v[2];
-    SF_HIP(hipMemcpyAsync(&v[0], c->cell_start + c0, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipMemcpyAsync(&v[1], c->cell_start + c1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipStreamSynchronize(ctx->stream));
-    *hb = std::min<int64_t>(v[0], begin);
-    *he = std::max<int64_t>(v[1], end);
+    // the z-layers of cells holding the block's first and last position, one more layer on either side
+    SF_CHECK(cloud_layer_first(ctx, c));
+    const std::vector<int64_t> &first = c->layer_first;
+    const int nl = c->dim[2];
+    int zb = 0;
+    while (zb + 1 < nl && first[(size_t)zb + 1] <= begin) ++zb;
+    int ze = zb;
+    while (ze + 1 < nl && first[(size_t)ze + 1] <= end - 1) ++ze;
+    *hb = std::min<int64_t>(first[(size_t)std::max(zb - 1, 0)], begin);
+    *he = std::max<int64_t>(first[(size_t)std::min(ze + 2, nl)], end);
     return SF_OK;
 }
 
@@ -576,5 +628,6 @@ extern "C" void sf_cloud_free(sf_ctx *ctx, sf_cloud *c)
     cloud_release_grid(ctx, c);
     if (c->xyz_orig) (void)hipFree(c->xyz_orig);
     if (c->nrm_orig) (void)hipFree(c->nrm_orig);
+    if (c->z_orig) (void)hipFree(c->z_orig);
     delete c;
 }

@@ -396,23 +396,29 @@ __global__ __launch_bounds__(256) void k_count_stats(const int32_t *__restrict__
 static int count_stats(sf_ctx *ctx, sf_nbrs *nb, int64_t *total, int32_t *mx)
 {
     const int64_t m = nb->m;
-    void *tmp = nullptr, *pin = nullptr;
-    const size_t bytes = SF_STATS_BLOCKS * (sizeof(long long) + sizeof(int));
-    SF_CHECK(sf_pool_alloc(ctx, bytes, &tmp));
+    const size_t bytes = SF_STATS_BLOCKS * (sizeof(long long) + 2 * sizeof(int));
+    static_assert(SF_STATS_BLOCKS * (sizeof(long long) + 2 * sizeof(int)) <= SF_PINNED_BYTES, "statistics exceed the pinned words");
+    sf_pool_guard tmp(ctx);
+    char *dev = nullptr;
+    void *pin = nullptr;
+    SF_CHECK(tmp.alloc(&dev, bytes));
     SF_CHECK(sf_ctx_pinned(ctx, &pin));
-    long long *psum = (long long *)tmp;
-    int *pmax = (int *)(psum + SF_STATS_BLOCKS);
+    long long *psum = (long long *)dev;
+    int *pmax = (int *)(psum + SF_STATS_BLOCKS), *gmax = pmax + SF_STATS_BLOCKS;
     SF_LAUNCH(ctx, "k2_reduce", k_count_stats, dim3(SF_STATS_BLOCKS), dim3(256), (const int32_t *)nb->count, m, psum, pmax);
-    SF_HIP(hipMemcpyAsync(pin, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // sf_comm_collective_stats: the longest list over every rank (the ranks size their SPFH tables by it)
+    const bool fold = ctx->collective_stats && ctx->comm;
+    if (fold) SF_CHECK(sf_comm_allreduce_max_i32(ctx, pmax, gmax, SF_STATS_BLOCKS));
+    SF_HIP(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    sf_pool_release(ctx, tmp);
     const long long *hs = (const long long *)pin;
-    const int *hm = (const int *)(hs + SF_STATS_BLOCKS);
+    const int *hm = (const int *)(hs + SF_STATS_BLOCKS), *hg = hm + SF_STATS_BLOCKS;
     int64_t t = 0;
-    int32_t mm = 0;
-    for (int b = 0; b < SF_STATS_BLOCKS; ++b) { t += hs[b]; mm = std::max<int32_t>(mm, hm[b]); }
+    int32_t mm = 0, ga = 0;
+    for (int b = 0; b < SF_STATS_BLOCKS; ++b) { t += hs[b]; mm = std::max<int32_t>(mm, hm[b]); ga = std::max<int32_t>(ga, hg[b]); }
     *total = t;
     *mx = mm;
+    nb->max_count_all = fold ? std::max(ga, mm) : mm;
     return SF_OK;
 }
 
@@ -718,6 +724,7 @@ extern "C" sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nb, int64_t first, int64
     v->offset = nb->offset + first; // offsets stay absolute into idx
     v->idx = nb->idx;
     v->max_count = nb->max_count;
+    v->max_count_all = nb->max_count_all;
     v->total = -1; // unknown without a device read; views are for compute, not export
     return v;
 }
@@ -725,6 +732,7 @@ extern "C" sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nb, int64_t first, int64
 extern "C" int64_t sf_nbrs_num_queries(const sf_nbrs *nb) { return nb ? nb->m : -1; }
 extern "C" int64_t sf_nbrs_total(const sf_nbrs *nb) { return nb ? nb->total : -1; }
 extern "C" int64_t sf_nbrs_max_count(const sf_nbrs *nb) { return nb ? nb->max_count : -1; }
+extern "C" int64_t sf_nbrs_max_count_all(const sf_nbrs *nb) { return nb ? std::max(nb->max_count_all, nb->max_count) : -1; }
 
 extern "C" int sf_nbrs_export(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t *offsets, int32_t *idx, double *dist)
 {

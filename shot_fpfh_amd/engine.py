@@ -331,6 +331,30 @@ class Engine:
             "sf_comm_allgather",
         )
 
+    def exchange(self, ops) -> None:
+        """Grouped point-to-point exchange (ncclSend / ncclRecv in ONE group).  ops: iterable of
+        (peer, send DeviceArray | None, send_byte_offset, send_bytes, recv DeviceArray | None, recv_byte_offset, recv_bytes)."""
+        ops = list(ops)
+        n = len(ops)
+        peers = (C.c_int * max(n, 1))(*[int(o[0]) for o in ops])
+        sp = (C.c_void_p * max(n, 1))(*[None if o[1] is None else o[1].ptr + int(o[2]) for o in ops])
+        sb = (C.c_size_t * max(n, 1))(*[int(o[3]) for o in ops])
+        rp = (C.c_void_p * max(n, 1))(*[None if o[4] is None else o[4].ptr + int(o[5]) for o in ops])
+        rb = (C.c_size_t * max(n, 1))(*[int(o[6]) for o in ops])
+        _ffi.check(self.lib.sf_comm_exchange(self.h, n, peers, sp, sb, rp, rb), "sf_comm_exchange")
+
+    def allreduce_min_u64(self, buf: DeviceArray, n: Optional[int] = None) -> None:
+        """In-place element-wise minimum over the ranks of a uint64 device array (packed (distance, index) keys)."""
+        if buf.dtype != np.uint64:
+            raise ValueError("allreduce_min_u64 needs a uint64 array")
+        count = int(np.prod(buf.shape)) if n is None else int(n)
+        _ffi.check(self.lib.sf_comm_allreduce_min_u64(self.h, buf.ptr, buf.ptr, count), "sf_comm_allreduce_min_u64")
+
+    def collective_stats(self, on: bool) -> None:
+        """While on, radius searches fold their longest-list statistic over all ranks (Neighbors.max_count_all): every
+        rank must then run the same searches in the same order."""
+        _ffi.check(self.lib.sf_comm_collective_stats(self.h, int(bool(on))), "sf_comm_collective_stats")
+
     # ---- profiling ----------------------------------------------------------------------------------
     def profile(self, on: bool) -> None:
         _ffi.check(self.lib.sf_profile_enable(self.h, int(on)), "sf_profile_enable")
@@ -395,6 +419,16 @@ class Cloud:
         _ffi.check(self.engine.lib.sf_cloud_perm(self.engine.h, self.h, _ptr(out)), "sf_cloud_perm")
         return out
 
+    def layer_table(self) -> np.ndarray:
+        """first[z] = first cell-sorted position of z-layer z of the grid (len = layers + 1, last entry = n): what the
+        sharding plan needs to know every rank's halo (valid after a grid build)."""
+        nl = C.c_int64(0)
+        _ffi.check(self.engine.lib.sf_cloud_layer_table(self.engine.h, self.h, None, 0, C.byref(nl)), "sf_cloud_layer_table")
+        first = np.zeros(nl.value + 1, dtype=np.int64)
+        _ffi.check(self.engine.lib.sf_cloud_layer_table(self.engine.h, self.h, _ptr(first), first.size, C.byref(nl)),
+                   "sf_cloud_layer_table")
+        return first
+
     def halo_range(self, begin: int, end: int) -> tuple[int, int]:
         """Range of cell-sorted positions holding every point within one grid cell of block [begin, end)."""
         hb, he = C.c_int64(0), C.c_int64(0)
@@ -450,6 +484,7 @@ class Neighbors:
         self.m = lib.sf_nbrs_num_queries(handle)
         self.total = lib.sf_nbrs_total(handle)
         self.max_count = lib.sf_nbrs_max_count(handle)
+        self.max_count_all = lib.sf_nbrs_max_count_all(handle)  # over every rank, when Engine.collective_stats is on
 
     def slice(self, first: int, count: int) -> "Neighbors":
         """Non-owning view of queries [first, first+count); keep the parent alive while it is used."""
@@ -621,12 +656,37 @@ class Spfh:
     def allgather(self, rows_per_rank: int) -> None:
         _ffi.check(self.engine.lib.sf_spfh_allgather(self.engine.h, self.h, int(rows_per_rank)), "sf_spfh_allgather")
 
+    def exchange_rows(self, ops) -> None:
+        """Neighbour-to-neighbour exchange of table rows.  ops: iterable of (peer, send_begin, send_end, recv_begin,
+        recv_end) in cell-sorted positions (sharding.exchange_plan)."""
+        ops = list(ops)
+        n = len(ops)
+        peers = (C.c_int * max(n, 1))(*[int(o[0]) for o in ops])
+        cols = [(C.c_int64 * max(n, 1))(*[int(o[j]) for o in ops]) for j in (1, 2, 3, 4)]
+        _ffi.check(self.engine.lib.sf_spfh_exchange_rows(self.engine.h, self.h, n, peers, *cols), "sf_spfh_exchange_rows")
+
+    def rows_image(self, begin: int, end: int) -> np.ndarray:
+        """Wire image (bytes) of table rows [begin, end): what exchange_rows would send for them."""
+        need = C.c_size_t(0)
+        lib, eh = self.engine.lib, self.engine.h
+        _ffi.check(lib.sf_spfh_rows_image(eh, self.h, int(begin), int(end), None, 0, 0, C.byref(need)), "sf_spfh_rows_image")
+        img = np.zeros(need.value, dtype=np.uint8)
+        _ffi.check(lib.sf_spfh_rows_image(eh, self.h, int(begin), int(end), _ptr(img), img.size, 0, None), "sf_spfh_rows_image")
+        return img
+
+    def set_rows_image(self, begin: int, end: int, image: np.ndarray) -> None:
+        """Write a wire image (rows_image of the owning rank) into rows [begin, end): the host-staged exchange."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        _ffi.check(self.engine.lib.sf_spfh_rows_image(self.engine.h, self.h, int(begin), int(end), _ptr(img), img.size, 1, None),
+                   "sf_spfh_rows_image")
+
     def export(self) -> np.ndarray:
         out = np.zeros((self.cloud.n, self.n_bins**3))
         _ffi.check(self.engine.lib.sf_spfh_export(self.engine.h, self.cloud.h, self.h, _ptr(out), SF_HOST), "sf_spfh_export")
         return out
 
-    def fpfh(self, self_nbrs: Neighbors, keypoints_indices=None, out: Optional[DeviceArray] = None):
+    def fpfh(self, self_nbrs: Neighbors, keypoints_indices=None, out: Optional[DeviceArray] = None, out_row: int = 0):
+        """K7.  out (device): rows [out_row, out_row + m) receive the descriptors."""
         nb3 = self.n_bins**3
         if keypoints_indices is None:
             m, kp = self_nbrs.m, None
@@ -634,8 +694,11 @@ class Spfh:
             kp = np.ascontiguousarray(keypoints_indices, dtype=np.int64)
             m = kp.shape[0]
         if out is not None:
+            if out_row < 0 or out_row + m > out.shape[0]:
+                raise ValueError("fpfh: output rows outside the array")
             _ffi.check(
-                self.engine.lib.sf_fpfh(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(kp), m, out.ptr, SF_OUT_DEVICE),
+                self.engine.lib.sf_fpfh(self.engine.h, self.cloud.h, self_nbrs.h, self.h, _ptr(kp), m,
+                                        out.offset_ptr(out_row * nb3 * 8), SF_OUT_DEVICE),
                 "sf_fpfh",
             )
             return out

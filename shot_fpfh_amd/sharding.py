@@ -8,8 +8,13 @@ orders cells z-slowest, so rank g's contiguous block of cell-sorted positions is
 * SHOT, normals and SPFH of a block need only read access to the cloud: no exchange.
 * FPFH of a block needs the SPFH rows of the block's neighbours, some of which belong to the two
   adjacent slabs.  Two ways to get them (`spfh_exchange`):
+    "neighbor"   compute only the block and borrow the halo rows from the ranks that own them: one grouped
+                 ncclSend / ncclRecv with (normally) the two adjacent slabs, 64 bytes per row -- what K7 reads per
+                 neighbour -- issued on the side stream under the FPFH reduction of the block's INTERIOR keypoints
+                 (which need no foreign row); only the boundary layers wait for it;
     "halo"       recompute SPFH for the one-cell-thick halo on each side of the block -- a
-                 contiguous run of positions -- so the descriptor pass has NO data-path collective;
+                 contiguous run of positions -- so the descriptor pass has NO data-path collective
+                 (24 % more K2 / K6 rows per interior rank of eight);
     "allgather"  compute only the block and all-gather the integer SPFH table over RCCL/xGMI.
 * Matching needs every reference descriptor on every rank: one RCCL all-gather of descriptor rows
   (`gather_rows`) before K8, whose row arg-min is then local to each rank's scan block.
@@ -26,7 +31,7 @@ import numpy as np
 
 from .engine import Cloud, DeviceArray, Engine, Neighbors, Spfh
 
-__all__ = ["ShardPlan", "DescriptorJob", "MatchJob", "SubsetMatchJob"]
+__all__ = ["ShardPlan", "ExchangePlan", "exchange_plan", "DescriptorJob", "MatchJob", "SubsetMatchJob"]
 
 
 @dataclass(frozen=True)
@@ -59,6 +64,63 @@ class ShardPlan:
         return self.block()[1]
 
 
+@dataclass(frozen=True)
+class ExchangePlan:
+    """What one rank's FPFH pass borrows and lends (cell-sorted positions, identical numbering on every rank)."""
+
+    halo: tuple[int, int]        # [hb, he): the block plus every row its keypoints' neighbours can be
+    interior: tuple[int, int]    # [i0, i1): keypoints of the block all of whose neighbours the block itself holds
+    ops: tuple                   # (peer, send_begin, send_end, recv_begin, recv_end), one per peer with anything to move
+
+
+def _layer_of(first: np.ndarray, pos: int) -> int:
+    """z-layer holding cell-sorted position `pos` (first[z] <= pos < first[z + 1]; empty layers are skipped)."""
+    return int(np.searchsorted(first, pos, side="right")) - 1
+
+
+def exchange_plan(layer_first, n: int, world: int, rank: int) -> ExchangePlan:
+    """Halo, interior and the rows to exchange for `rank`, from the grid's layer table (Cloud.layer_table) alone.
+
+    A keypoint in z-layer L reads rows of layers L - 1 .. L + 1 (the grid's cells are at least one radius thick), i.e.
+    positions [first[L - 1], first[L + 2]).  Rank r therefore needs [first[zb - 1], first[ze + 2]) with zb / ze the layers
+    of its first / last position; what of that lies in rank p's block is what p sends to r.  Blocks need not be aligned
+    to layers, need not be a layer thick (a halo may then reach beyond the adjacent rank) and may be empty."""
+    first = np.asarray(layer_first, dtype=np.int64)
+    nl = first.size - 1
+    if nl < 1 or first[0] != 0 or first[-1] != n:
+        raise ValueError("layer table does not describe a cloud of this size")
+
+    def halo_of(r: int):
+        b, e = ShardPlan(n, world, r).block()
+        if b == e:
+            return b, e, b, e
+        zb, ze = _layer_of(first, b), _layer_of(first, e - 1)
+        return b, e, min(int(first[max(zb - 1, 0)]), b), max(int(first[min(ze + 2, nl)]), e)
+
+    b, e, hb, he = halo_of(rank)
+    # interior layers: the whole 3-layer reach inside [b, e)
+    i0 = i1 = b
+    if b < e:
+        zb, ze = _layer_of(first, b), _layer_of(first, e - 1)
+        ok = [z for z in range(zb, ze + 1) if first[max(z - 1, 0)] >= b and first[min(z + 2, nl)] <= e]
+        if ok:
+            i0, i1 = max(int(first[ok[0]]), b), min(int(first[ok[-1] + 1]), e)
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        pb, pe, phb, phe = halo_of(p)
+        # what I receive: my halo outside my block, inside p's block (p is entirely below or entirely above me)
+        rb, re = (max(hb, pb), min(b, pe)) if p < rank else (max(e, pb), min(he, pe))
+        # what I send: p's halo outside p's block, inside my block
+        sb, se = (max(phb, b), min(pb, e)) if rank < p else (max(pe, b), min(phe, e))
+        rb, re = (rb, re) if re > rb else (0, 0)
+        sb, se = (sb, se) if se > sb else (0, 0)
+        if re > rb or se > sb:
+            ops.append((p, sb, se, rb, re))
+    return ExchangePlan((hb, he), (i0, i1), tuple(ops))
+
+
 class DescriptorJob:
     """FPFH + SHOT for this rank's block of a resident cloud, outputs kept in HBM.
 
@@ -70,10 +132,15 @@ class DescriptorJob:
     """
 
     def __init__(self, engine: Engine, points, normals, radius: float, n_bins: int = 5, normalize: bool = True,
-                 min_neighborhood_size: int = 10, world: int = 1, rank: int = 0, spfh_exchange: str = "halo",
-                 do_fpfh: bool = True, do_shot: bool = True, overlap_chains: bool = False, share_sweep: bool = True):
-        if spfh_exchange not in ("halo", "allgather"):
-            raise ValueError("spfh_exchange must be 'halo' or 'allgather'")
+                 min_neighborhood_size: int = 10, world: int = 1, rank: int = 0, spfh_exchange: str = "neighbor",
+                 do_fpfh: bool = True, do_shot: bool = True, overlap_chains: bool = False, share_sweep: bool = True,
+                 emulate_peers: bool = False):
+        if spfh_exchange not in ("neighbor", "halo", "allgather"):
+            raise ValueError("spfh_exchange must be 'neighbor', 'halo' or 'allgather'")
+        # emulate_peers: ONE process stands in for rank `rank` of `world` (bench.py --emulate-rank): the rows the peers would
+        # send are computed here once, before the first pass, and the passes themselves skip the exchange call
+        self.emulate_peers = bool(emulate_peers)
+        self._halo_filled = False
         self.engine, self.radius, self.n_bins = engine, float(radius), int(n_bins)
         self.normalize, self.min_nb = bool(normalize), int(min_neighborhood_size)
         self.exchange, self.do_fpfh, self.do_shot = spfh_exchange, do_fpfh, do_shot
@@ -102,8 +169,90 @@ class DescriptorJob:
             self._spfh_wide = wide
         return self.spfh
 
+    # ---- world > 1, spfh_exchange="neighbor" -----------------------------------------------------------------------
+    def _prefill_halo(self, hb: int, he: int) -> None:
+        """emulate_peers: the SPFH rows of the halo, as the adjacent ranks would have sent them."""
+        cloud, (b, e) = self.cloud, self.plan.block()
+        cloud.build_grid(self.radius, block=(b, e), reach=2)
+        nb = cloud.radius_search_self(self.radius, hb, he)
+        try:
+            self._spfh_table(nb.max_count).compute(nb)
+        finally:
+            nb.free()
+        self._halo_filled = True
+
+    def _step_neighbor(self) -> None:
+        eng, cloud, (b, e) = self.engine, self.cloud, self.plan.block()
+        cloud.build_grid(self.radius, block=(b, e), reach=1)  # the block's own neighbours: one cell
+        xp = exchange_plan(cloud.layer_table(), cloud.n, self.plan.world, self.plan.rank) if self.do_fpfh else None
+        if self.do_fpfh and self.emulate_peers and not self._halo_filled:
+            self._prefill_halo(*xp.halo)
+            cloud.build_grid(self.radius, block=(b, e), reach=1)
+        fold = self.do_fpfh and not self.emulate_peers
+        if fold:
+            eng.collective_stats(True)  # every rank sizes its table by the longest list of ANY rank (same row format)
+        try:
+            nb: Neighbors = cloud.radius_search_self(self.radius, b, e)
+        finally:
+            if fold:
+                eng.collective_stats(False)
+        try:
+            self.last_pairs = nb.total
+            if not self.do_fpfh:
+                nb.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
+                return
+            kind = self._spfh_wide
+            spfh = self._spfh_table(max(nb.max_count_all, nb.max_count))
+            if self.emulate_peers and self._spfh_wide != kind and kind != -1:
+                raise RuntimeError("emulate_peers: the table changed its storage after the halo rows were filled")
+            shared = self.share_sweep and nb.max_count <= 256
+            if shared:
+                if self.moments is None or self.moments.shape[0] < nb.m:
+                    if self.moments is not None:
+                        self.moments.free()
+                    self.moments = eng.empty((nb.m, 6))
+                spfh.compute(nb, moments_out=self.moments)
+            else:
+                spfh.compute(nb)
+            i0, i1 = xp.interior
+            pieces = [(i0, i1), (b, i0), (i1, e)]  # interior first: it is what the exchange hides under
+            views = [(lo, nb.slice(lo - b, hi - lo)) if (lo, hi) != (b, e) else (lo, nb) for lo, hi in pieces if hi > lo]
+            forked = False
+            try:
+                eng.fork()  # side stream: the exchange, then the frame eigen-solves
+                forked = True
+                if not self.emulate_peers:
+                    spfh.exchange_rows(xp.ops)
+                if shared:
+                    nb.lrf_raw_from_moments(self.moments, 0, self.lrf_out)
+                eng.switch(0)
+                first_piece = True
+                for lo, view in views:
+                    if not (first_piece and (lo, lo + view.m) == (i0, i1)) and forked:
+                        eng.join()  # boundary keypoints read the borrowed rows
+                        forked = False
+                    spfh.fpfh(view, None, out=self.fpfh_out, out_row=lo - b)
+                    first_piece = False
+                if forked:
+                    eng.join()
+                    forked = False
+                if shared:
+                    nb.shot_from_raw_lrf(self.lrf_out, self.normalize, self.min_nb, self.shot_out)
+                elif self.do_shot:
+                    nb.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
+            finally:
+                if forked:
+                    eng.join()
+                for _, view in views:
+                    if view is not nb:
+                        view.free()
+        finally:
+            nb.free()
+
     def step(self) -> None:
         cloud, (b, e) = self.cloud, self.plan.block()
+        if self.plan.world > 1 and self.exchange == "neighbor":
+            return self._step_neighbor()
         if self.plan.world > 1:
             # only this rank's slab of the replicated cloud is sorted: the block's queries reach one cell, the SPFH
             # rows of the block's halo (recomputed here) one more

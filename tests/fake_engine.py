@@ -44,6 +44,7 @@ class FakeNbrs:
         self.m = len(off) - 1
         self.total = int(off[-1] - off[0])
         self.max_count = int(np.diff(off).max()) if self.m else 0
+        self.max_count_all = self.max_count
 
     def slice(self, first, count):
         return FakeNbrs(self.cloud, self.radius, self.begin + first, self.off[first:first + count + 1], self.idx)
@@ -112,7 +113,26 @@ class FakeSpfh:
         full = torch.cat(parts).numpy()[: self.cloud.n]
         self.table = np.where(full == -7.0, np.nan, full)
 
-    def fpfh(self, blk, kp, out=None):
+    def exchange_rows(self, ops):
+        """The neighbour-to-neighbour exchange over gloo point-to-point messages."""
+        import torch
+        import torch.distributed as dist
+
+        reqs, landing = [], []
+        for peer, sb, se, rb, re in ops:
+            if se > sb:
+                assert not np.isnan(self.table[sb:se]).any()  # a rank only lends rows it computed
+                reqs.append(dist.isend(torch.from_numpy(self.table[sb:se].copy()), peer))
+            if re > rb:
+                buf = torch.zeros((re - rb, self.table.shape[1]), dtype=torch.float64)
+                reqs.append(dist.irecv(buf, peer))
+                landing.append((rb, re, buf))
+        for r in reqs:
+            r.wait()
+        for rb, re, buf in landing:
+            self.table[rb:re] = buf.numpy()
+
+    def fpfh(self, blk, kp, out=None, out_row=0):
         ps = self.cloud.ps
         for q in range(blk.m):
             i = blk.begin + q
@@ -120,7 +140,7 @@ class FakeSpfh:
             d = np.sqrt(((ps[js] - ps[i]) ** 2).sum(axis=1))
             keep = d > 0
             acc = (self.table[js[keep]] / d[keep, None]).sum(axis=0) if keep.any() else 0.0
-            out.a[q] = self.table[i] + acc / len(js)
+            out.a[out_row + q] = self.table[i] + acc / len(js)
         return out
 
     def free(self):
@@ -142,6 +162,9 @@ class FakeCloud:
         self._perm = np.argsort(cid, kind="stable")
         self.ps, self.ns = np.ascontiguousarray(self.p[self._perm]), np.ascontiguousarray(self.nr[self._perm])
         self.cz = c[self._perm, 2]
+
+    def layer_table(self):
+        return np.searchsorted(self.cz, np.arange(int(self.dim[2]) + 1), side="left").astype(np.int64)
 
     def perm(self):
         return self._perm.astype(np.int32)
@@ -191,6 +214,9 @@ class FakeEngine:
         flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
 
     def sync(self):
+        pass
+
+    def collective_stats(self, on):
         pass
 
     def rows_gather_device(self, rows, sel, out):

@@ -310,7 +310,7 @@ def test_sharded_blocks_bit_identical_to_single(eng, O, world):
         f, s = np.zeros((20000, 125)), np.zeros((20000, 352))
         seen = np.zeros(20000, dtype=int)
         for rank in range(w):
-            job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=w, rank=rank)
+            job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=w, rank=rank, spfh_exchange="halo")
             job.step()
             rows = job.block_original_indices()
             f[rows], s[rows] = job.fpfh_out.to_host(), job.shot_out.to_host()
@@ -793,7 +793,7 @@ def test_config_c3_full_size_properties(eng, O):
     full = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10)
     full.step()
     world, rank = 50, 17
-    part = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=rank)
+    part = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=rank, spfh_exchange="halo")
     part.step()
     b, e = part.plan.block()
     assert e - b == n // world
@@ -954,7 +954,7 @@ def test_shared_sweep_frames_equal_the_two_kernel_form(eng, O):
     so = O.shot_single_scale(p, nr, p[rows[pick]], r, normalize=True, min_neighborhood_size=10)
     assert close(s1[pick], so).all()
     # a shard (block view of the lists, moments offset by the halo) gives the same rows as the full run, bit for bit
-    part = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=3, rank=1)
+    part = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=3, rank=1, spfh_exchange="halo")
     part.step()
     b, e = part.plan.block()
     assert np.array_equal(part.shot_out.to_host(), s1[b:e]) and np.array_equal(part.fpfh_out.to_host(), f1[b:e])

@@ -140,29 +140,7 @@ def test_config_c3_fpfh_and_shot_rows_vs_oracle_at_full_size(eng, O):
     job.close()
 
 
-@pytest.mark.parametrize("rank", [3])
-def test_config_c5_rank_block_of_the_8m_cloud_vs_oracle(eng, O, rank):
-    """BASELINE config 5's descriptor pass as ONE of its 8 ranks executes it: the 8M-point cloud (seed 5, r = 0.015)
-    replicated, rank `rank`'s block of 1M cell-sorted positions, block grid build with halo SPFH recompute.
-    A sample of FPFH and SHOT rows against the oracle (which searches the whole 8M cloud), and the block's row -> point
-    map must be a slice of a permutation."""
-    from shot_fpfh_amd.sharding import DescriptorJob
-
-    n, r, world = 8_000_000, 0.015, 8
-    p, nr, rng = synth_cloud(n, 5)
-    job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=rank)
-    job.step()
-    assert job.m == n // world
-    orig = job.block_original_indices()
-    assert np.unique(orig).size == job.m and orig.min() >= 0 and orig.max() < n
-    pick = np.sort(rng.choice(job.m, 200, replace=False))
-    f = np.stack([job.fpfh_out.rows_to_host(int(i), 1)[0] for i in pick])
-    fo = O.compute_fpfh_descriptor_sample(orig[pick], p, nr, r, 5)
-    assert close(f, fo).all() and np.abs(f - fo).max() < 1e-9, np.abs(f - fo).max()
-    d = np.stack([job.shot_out.rows_to_host(int(i), 1)[0] for i in pick])
-    do = O.shot_single_scale(p, nr, p[orig[pick]], r, True, 10)
-    assert close(d, do).all() and np.abs(d - do).max() < 1e-9
-    job.close()
+# (config C5 at full size: tests/test_hip_round3.py, ranks 0, 3 and 7, both SPFH exchange modes)
 
 
 # ---- C4 at full size ---------------------------------------------------------------------------------------------------------
@@ -400,7 +378,7 @@ def test_fpfh_generic_bins_through_the_sharded_job(eng, O):
     fo = O.compute_fpfh_descriptor(np.arange(4000), p, nr, 0.1, 10)
     got = np.full((4000, 1000), np.nan)
     for rank in range(2):
-        job = DescriptorJob(eng, p, nr, 0.1, n_bins=10, min_neighborhood_size=5, world=2, rank=rank)
+        job = DescriptorJob(eng, p, nr, 0.1, n_bins=10, min_neighborhood_size=5, world=2, rank=rank, spfh_exchange="halo")
         job.step()
         got[job.block_original_indices()] = job.fpfh_out.to_host()
         job.close()

@@ -1,0 +1,271 @@
+"""GPU parity tests added in round 3 (all through the C ABI):
+
+  * the neighbour-to-neighbour SPFH exchange: ncclSend / ncclRecv really executed (one-rank communicator, self exchange)
+    on raw buffers and on table rows in all three wire formats; a sharded pass with borrowed halo rows against the
+    unsharded one, bit for bit; two ranks on one device exchanging through the host-staged wire image;
+  * the block grid build (z-only passes over the replicated cloud) against the whole-cloud build;
+  * BASELINE config 5's descriptor pass as ranks 0, 3 and 7 of 8 execute it, against the oracle.
+"""
+import numpy as np
+import pytest
+
+from conftest import synth_cloud
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL):
+    return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import shot_fpfh_amd as s
+
+    return s.default_engine()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def comm_engine():
+    """A second context on GPU 0 with a ONE-rank RCCL communicator: collectives and send/recv go through RCCL."""
+    import shot_fpfh_amd as s
+
+    e = s.Engine(0)
+    e.comm_init(e.comm_unique_id(), 1, 0)
+    yield e
+    e.close()
+
+
+# ---- the exchange primitives -------------------------------------------------------------------------------------------
+def test_nccl_send_recv_group_moves_raw_buffers_on_a_one_rank_communicator(comm_engine):
+    e = comm_engine
+    rng = np.random.default_rng(3)
+    a = e.empty((1 << 16,), np.float64).from_host(rng.random(1 << 16))
+    b = e.empty((1 << 16,), np.float64).from_host(np.zeros(1 << 16))
+    e.profile_reset()
+    # two operations in ONE group, different sizes and offsets, both to "the peer" (this rank)
+    e.exchange([(0, a, 0, 8 * 1000, b, 8 * 5000, 8 * 1000), (0, a, 8 * 40000, 8 * 20000, b, 8 * 10000, 8 * 20000)])
+    e.sync()
+    ha, hb = a.to_host(), b.to_host()
+    assert np.array_equal(hb[5000:6000], ha[:1000]) and np.array_equal(hb[10000:30000], ha[40000:60000])
+    assert not hb[:5000].any() and not hb[6000:10000].any() and not hb[30000:].any()
+    assert e.profile_report()["c_exchange"][0] == 1  # one RCCL group was launched
+    with pytest.raises(Exception):
+        e.exchange([(1, a, 0, 8, b, 0, 8)])  # no such peer
+    with pytest.raises(Exception):
+        e.exchange([(0, a, 0, 16, b, 0, 8)])  # a self exchange must send what it receives
+    a.free()
+    b.free()
+
+
+def test_allreduce_min_u64_on_a_one_rank_communicator(comm_engine):
+    e = comm_engine
+    v = np.random.default_rng(1).integers(0, 2**63, 4096, dtype=np.uint64)
+    d = e.empty((4096,), np.uint64).from_host(v)
+    e.allreduce_min_u64(d)
+    e.sync()
+    assert np.array_equal(d.to_host(), v)
+    d.free()
+
+
+@pytest.mark.parametrize("n_bins,expect_row_bytes", [(5, 64), (4, 160), (7, 1028)])
+def test_spfh_rows_travel_in_the_format_k7_reads(comm_engine, n_bins, expect_row_bytes):
+    """sf_spfh_exchange_rows through ncclSend / ncclRecv (self exchange): the image of the receiving rows afterwards is
+    the image of the sent rows before.  5 bins: alpha is pinned, two live blocks, packed rows (64 B); 4 bins: an edge at
+    alpha = 0, every block live (160 B); 7 bins: 343 bins per row, the 16-bit table (1024 B + k)."""
+    e = comm_engine
+    p, nr, _ = synth_cloud(6000, 12)
+    cloud = e.cloud(p, nr)
+    cloud.build_grid(0.1)
+    nb = cloud.radius_search_self(0.1)
+    sp = e.spfh(cloud, n_bins, nb.max_count)
+    sp.compute(nb)
+    before = sp.rows_image(100, 1300)
+    assert before.size == 1200 * expect_row_bytes
+    untouched = sp.rows_image(0, 100)
+    e.profile_reset()
+    sp.exchange_rows([(0, 100, 1300, 3000, 4200)])
+    e.sync()
+    assert e.profile_report()["c_exchange"][0] == 1
+    assert np.array_equal(sp.rows_image(3000, 4200), before)
+    assert np.array_equal(sp.rows_image(100, 1300), before) and np.array_equal(sp.rows_image(0, 100), untouched)
+    # the host-staged path writes the same image
+    sp.set_rows_image(4500, 5700, before)
+    assert np.array_equal(sp.rows_image(4500, 5700), before)
+    with pytest.raises(Exception):
+        sp.exchange_rows([(0, 0, 10, 5995, 6005)])
+    for obj in (sp, nb, cloud):
+        obj.free()
+
+
+# ---- block build + borrowed halo rows ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3, 7])
+@pytest.mark.parametrize("n,radius,n_bins", [(30000, 0.06, 5), (9000, 0.1, 4)])
+def test_neighbor_mode_blocks_equal_the_unsharded_pass_bit_for_bit(eng, world, n, radius, n_bins):
+    """Every rank's pass in spfh_exchange="neighbor" (block build with reach 1, K2 / K6 on the block only, K7 split into
+    interior and boundary keypoints), the peers' rows standing in the table as they would after the exchange
+    (emulate_peers), stitched together == the one-rank pass, bit for bit, for FPFH, SHOT and the frames."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    p, nr, _ = synth_cloud(n, 77)
+    one = DescriptorJob(eng, p, nr, radius, n_bins=n_bins, min_neighborhood_size=5)
+    one.step()
+    f1, s1, l1, rows1 = one.fpfh_out.to_host(), one.shot_out.to_host(), one.lrf_out.to_host(), one.block_original_indices()
+    one.close()
+    seen = np.zeros(n, int)
+    for rank in range(world):
+        job = DescriptorJob(eng, p, nr, radius, n_bins=n_bins, min_neighborhood_size=5, world=world, rank=rank,
+                            spfh_exchange="neighbor", emulate_peers=True)
+        for _ in range(2):  # (the second pass reuses the table and the halo rows)
+            job.step()
+        b, e = job.plan.block()
+        assert np.array_equal(job.block_original_indices(), rows1[b:e])
+        assert np.array_equal(job.fpfh_out.to_host(), f1[b:e])
+        assert np.array_equal(job.shot_out.to_host(), s1[b:e])
+        assert np.array_equal(job.lrf_out.to_host(), l1[b:e])
+        seen[rows1[b:e]] += 1
+        job.close()
+    assert (seen == 1).all()
+
+
+def test_two_ranks_on_one_device_exchange_through_the_wire_image(eng):
+    """Ranks 0 and 1 of 2 as two jobs on one device: each computes its block's SPFH rows only, the rows of the
+    exchange plan travel as wire images through host memory (sf_spfh_rows_image), then each reduces its block.  Equal to
+    the one-rank pass bit for bit -- and a missing exchange is noticed (the borrowed rows are poisoned first)."""
+    from shot_fpfh_amd.sharding import DescriptorJob, exchange_plan
+
+    n, radius = 20000, 0.07
+    p, nr, _ = synth_cloud(n, 5)
+    one = DescriptorJob(eng, p, nr, radius, min_neighborhood_size=5)
+    one.step()
+    f1 = one.fpfh_out.to_host()
+    one.close()
+    jobs = [DescriptorJob(eng, p, nr, radius, min_neighborhood_size=5, world=2, rank=r, spfh_exchange="neighbor") for r in (0, 1)]
+    mail = {}
+
+    class Staged:
+        """Stand-in for Spfh.exchange_rows: post first, deliver when both ranks have posted."""
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def __call__(self, spfh, ops):
+            for peer, sb, se, rb, re in ops:
+                mail[(self.rank, peer)] = (spfh.rows_image(sb, se), (rb, re), spfh)
+
+    got = {}
+    for r, job in enumerate(jobs):
+        # run the pass up to and including K6 by hand (the job's own step would need both ranks in flight at once)
+        b, e = job.plan.block()
+        job.cloud.build_grid(radius, block=(b, e), reach=1)
+        xp = exchange_plan(job.cloud.layer_table(), n, 2, r)
+        nb = job.cloud.radius_search_self(radius, b, e)
+        sp = job._spfh_table(nb.max_count)
+        sp.compute(nb)
+        Staged(r)(sp, xp.ops)
+        got[r] = (nb, sp, xp)
+    for (src, dst), (img, _, _) in mail.items():
+        _, (rb, re), _ = mail[(dst, src)]
+        sp_dst = got[dst][1]
+        poison = np.full_like(sp_dst.rows_image(rb, re), 0xEE)
+        sp_dst.set_rows_image(rb, re, poison)
+    for r, job in enumerate(jobs):  # without the borrowed rows the boundary keypoints come out wrong ...
+        nb, sp, xp = got[r]
+        b, e = job.plan.block()
+        sp.fpfh(nb, None, out=job.fpfh_out)
+        wrong = job.fpfh_out.to_host()
+        i0, i1 = xp.interior
+        assert np.array_equal(wrong[i0 - b:i1 - b], f1[i0:i1])  # interior keypoints never read a borrowed row
+        assert not np.array_equal(wrong, f1[b:e])
+    for (src, dst), (img, _, _) in mail.items():  # ... and right once the images have been delivered
+        _, (rb, re), _ = mail[(dst, src)]
+        got[dst][1].set_rows_image(rb, re, img)
+    for r, job in enumerate(jobs):
+        nb, sp, xp = got[r]
+        b, e = job.plan.block()
+        sp.fpfh(nb, None, out=job.fpfh_out)
+        assert np.array_equal(job.fpfh_out.to_host(), f1[b:e])
+        nb.free()
+        job.close()
+
+
+def test_block_grid_build_keeps_global_numbering_and_layer_table(eng):
+    """sf_cloud_build_grid_block (z-only histogram + selection passes) vs the whole-cloud build: same layer table, same
+    perm inside the populated slab, same neighbour lists for the block's queries."""
+    p, nr, _ = synth_cloud(40000, 9)
+    whole = eng.cloud(p, nr)
+    whole.build_grid(0.05)
+    first = whole.layer_table()
+    perm = whole.perm()
+    assert first[0] == 0 and first[-1] == 40000 and (np.diff(first) >= 0).all()
+    blk = eng.cloud(p, nr)
+    for (b, e) in [(0, 5000), (13000, 21111), (35000, 40000), (7, 7)]:
+        for reach in (1, 2):
+            pb, pe = blk.build_grid(0.05, block=(b, e), reach=reach)
+            assert np.array_equal(blk.layer_table(), first)
+            if b == e:
+                assert pb == pe
+                continue
+            assert pb <= b and e <= pe and pb in first and pe in first
+            assert np.array_equal(blk.perm()[pb:pe], perm[pb:pe])
+            hb, he = blk.halo_range(b, e)
+            assert (hb, he) == whole.halo_range(b, e)
+            if reach == 2:
+                assert pb <= hb and he <= pe
+            nb_b, nb_w = blk.radius_search_self(0.05, b, e), whole.radius_search_self(0.05, b, e)
+            ob, ib = nb_b.export()
+            ow, iw = nb_w.export()
+            assert np.array_equal(ob, ow) and np.array_equal(ib, iw)
+            nb_b.free()
+            nb_w.free()
+    blk.free()
+    whole.free()
+
+
+# ---- config C5: ranks 0, 3 and 7 of 8 at full size ----------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cloud_8m():
+    return synth_cloud(8_000_000, 5)
+
+
+@pytest.mark.parametrize("rank,mode", [(0, "neighbor"), (3, "neighbor"), (7, "neighbor"), (3, "halo")])
+def test_config_c5_rank_blocks_of_the_8m_cloud_vs_oracle(eng, O, cloud_8m, rank, mode):
+    """BASELINE config 5's descriptor pass as ONE of its 8 ranks executes it: the 8M-point cloud (seed 5, r = 0.015)
+    replicated, rank `rank`'s block of 1M cell-sorted positions -- an edge rank (one halo) at either end and an interior
+    one; in "neighbor" mode the halo rows stand in the table as the adjacent ranks would have sent them.  A sample of
+    FPFH and SHOT rows against the oracle (which searches the whole 8M cloud), weighted towards the block's boundary
+    layers, whose FPFH rows read the borrowed SPFH rows."""
+    from shot_fpfh_amd.sharding import DescriptorJob, exchange_plan
+
+    p, nr, _ = cloud_8m
+    n, r, world = p.shape[0], 0.015, 8
+    rng = np.random.default_rng(100 + rank)
+    job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=rank,
+                        spfh_exchange=mode, emulate_peers=mode == "neighbor")
+    job.step()
+    assert job.m == n // world
+    b, e = job.plan.block()
+    orig = job.block_original_indices()
+    assert np.unique(orig).size == job.m and orig.min() >= 0 and orig.max() < n
+    xp = exchange_plan(job.cloud.layer_table(), n, world, rank)
+    i0, i1 = xp.interior
+    assert b <= i0 < i1 <= e and (i0 > b or rank == 0) and (i1 < e or rank == world - 1)
+    assert {o[0] for o in xp.ops} == {q for q in (rank - 1, rank + 1) if 0 <= q < world}
+    edge_rows = np.concatenate([np.arange(b, i0), np.arange(i1, e)]) - b
+    pick = np.sort(np.concatenate([rng.choice(edge_rows, 120, replace=False), rng.choice(np.arange(i0, i1) - b, 80, replace=False)]))
+    f = np.stack([job.fpfh_out.rows_to_host(int(i), 1)[0] for i in pick])
+    fo = O.compute_fpfh_descriptor_sample(orig[pick], p, nr, r, 5)
+    assert close(f, fo).all() and np.abs(f - fo).max() < 1e-9, np.abs(f - fo).max()
+    d = np.stack([job.shot_out.rows_to_host(int(i), 1)[0] for i in pick])
+    do = O.shot_single_scale(p, nr, p[orig[pick]], r, True, 10)
+    assert close(d, do).all() and np.abs(d - do).max() < 1e-9
+    job.close()

@@ -21,8 +21,8 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("mode", ["halo", "allgather"])
-def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("neighbor", 2), ("neighbor", 3), ("halo", 2), ("allgather", 2)])
+def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode, world):
     from fake_engine import FakeEngine
     from oracle import oracle as O
     from shot_fpfh_amd.sharding import DescriptorJob
@@ -30,8 +30,8 @@ def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode):
     out = str(tmp_path / "stitched.npz")
     port = free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):  # (three ranks: the middle one borrows from and lends to both sides)
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, mode], env=env))
     for p in procs:
@@ -51,6 +51,54 @@ def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode):
     fo = O.compute_fpfh_descriptor(np.arange(1500), p, nr, 0.15, 5)
     so = O.shot_single_scale(p, nr, p, 0.15, True, 5)
     assert np.abs(got["fpfh"] - fo).max() < 1e-9 and np.abs(got["shot"] - so).max() < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+def test_exchange_plan_covers_every_halo_and_pairs_up(world):
+    """sharding.exchange_plan from a layer table alone: for every rank, block + received rows = its halo exactly; what
+    r sends to p is what p receives from r; interior keypoints reach no foreign row.  Unaligned blocks, blocks thinner
+    than a layer, empty layers and empty blocks included."""
+    from shot_fpfh_amd.sharding import ShardPlan, exchange_plan
+
+    rng = np.random.default_rng(world)
+    for case in range(40):
+        nl = int(rng.integers(1, 30))
+        pop = rng.integers(0, 50, nl) * (rng.random(nl) < 0.8)
+        if case % 7 == 0:
+            pop[:] = 0
+            pop[rng.integers(0, nl)] = rng.integers(1, 9)  # almost every block empty
+        if pop.sum() == 0:
+            pop[0] = 1
+        first = np.concatenate([[0], np.cumsum(pop)]).astype(np.int64)
+        n = int(first[-1])
+        layer = np.repeat(np.arange(nl), pop)  # layer of every position
+        plans = [exchange_plan(first, n, world, r) for r in range(world)]
+        for r, xp in enumerate(plans):
+            b, e = ShardPlan(n, world, r).block()
+            need = np.zeros(n, bool)
+            for q in range(b, e):
+                need |= np.abs(layer - layer[q]) <= 1
+            hb, he = xp.halo
+            assert need[hb:he].all() and not need[:hb].any() and not need[he:].any() or b == e
+            have = np.zeros(n, bool)
+            have[b:e] = True
+            for p, sb, se, rb, re in xp.ops:
+                assert p != r and not have[rb:re].any()
+                have[rb:re] = True
+                pb, pe = ShardPlan(n, world, p).block()
+                assert pb <= rb and re <= pe and b <= sb and se <= e
+                back = [o for o in plans[p].ops if o[0] == r]
+                assert len(back) == 1 and back[0][1:3] == (rb, re) and back[0][3:5] == (sb, se)
+            assert np.array_equal(have, need | have) and (have[hb:he].all() if b < e else True)
+            i0, i1 = xp.interior
+            assert b <= i0 <= i1 <= e
+            for q in range(i0, i1):
+                reach = np.flatnonzero(np.abs(layer - layer[q]) <= 1)
+                assert reach[0] >= b and reach[-1] < e
+            # the interior is maximal: the keypoints just outside it do reach a foreign row (or are outside the block)
+            for q in ([i0 - 1] if i0 > b and i1 > i0 else []) + ([i1] if i1 < e and i1 > i0 else []):
+                reach = np.flatnonzero(np.abs(layer - layer[q]) <= 1)
+                assert reach[0] < b or reach[-1] >= e
 
 
 def test_two_rank_gloo_sharded_matching_equals_basic_matching(tmp_path):
