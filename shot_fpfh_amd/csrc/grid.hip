@@ -10,8 +10,6 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_select.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
@@ -159,48 +157,90 @@ __global__ void k_extract_z(const double *__restrict__ xyz, int64_t n, double *_
     if (i < n) z[i] = xyz[3 * i + 2];
 }
 
-// pass A: points per z-layer of cells (the first cell-sorted position of a layer is the number of points below it)
-__global__ __launch_bounds__(256) void k_layer_hist_z(const double *__restrict__ z, int64_t n, double lo, double inv_cell,
-                                                      int nlayers, unsigned int *__restrict__ hist)
+// Both passes cut the cloud into `gridDim.x` contiguous chunks of `chunk` points (an even number), one per workgroup.
+// pass A: points per z-layer of cells, per chunk: row b of `mat` (nblocks x nlayers).  The column sums give every layer's
+// first cell-sorted position; the rows tell pass B where each chunk's kept points start in the (index-ordered) selection,
+// so that pass needs no scan of its own.
+__global__ __launch_bounds__(256) void k_layer_hist_z(const double *__restrict__ z, int64_t n, int64_t chunk, double lo,
+                                                      double inv_cell, int nlayers, unsigned int *__restrict__ mat)
 {
     __shared__ unsigned int sh[SF_MAX_LAYERS];
     for (int b = threadIdx.x; b < nlayers; b += blockDim.x) sh[b] = 0;
     __syncthreads();
-    const int64_t npair = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t c0 = (int64_t)blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
     const double2 *z2 = reinterpret_cast<const double2 *>(z);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npair; i += stride) {
-        const double2 v = z2[i];
+    for (int64_t i = c0 + 2 * (int64_t)threadIdx.x; i < c1; i += 2 * (int64_t)blockDim.x) {
+        const double2 v = z2[i >> 1]; // (c0 and the stride are even; the array has two doubles of padding)
         atomicAdd(&sh[sf_cell_coord(v.x, lo, inv_cell, nlayers)], 1u);
-        atomicAdd(&sh[sf_cell_coord(v.y, lo, inv_cell, nlayers)], 1u);
+        if (i + 1 < c1) atomicAdd(&sh[sf_cell_coord(v.y, lo, inv_cell, nlayers)], 1u);
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sh[sf_cell_coord(z[n - 1], lo, inv_cell, nlayers)], 1u);
     __syncthreads();
-    for (int b = threadIdx.x; b < nlayers; b += blockDim.x)
-        if (sh[b]) atomicAdd(&hist[b], sh[b]);
+    for (int b = threadIdx.x; b < nlayers; b += blockDim.x) mat[(int64_t)blockIdx.x * nlayers + b] = sh[b];
 }
 
-// pass B's predicate: is this z inside the layers [zlo, zhi] the block needs?
-struct z_in_layers {
-    double lo, inv_cell;
-    int dim, zlo, zhi;
-    __host__ __device__ bool operator()(double z) const
-    {
-        const int cz = sf_cell_coord(z, lo, inv_cell, dim);
-        return cz >= zlo && cz <= zhi;
-    }
-};
-
-// cell ids of the kept points only (ascending original index, as the selection left them)
-__global__ void k_cell_ids_sel(const double *__restrict__ xyz, const int32_t *__restrict__ sel, int64_t ns, sf_grid_desc g,
-                               int32_t *__restrict__ cid)
+__global__ __launch_bounds__(256) void k_layer_hist_fold(const unsigned int *__restrict__ mat, int nblocks, int nlayers,
+                                                         unsigned int *__restrict__ hist)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
-    const int64_t o = sel[i];
-    const int cx = sf_cell_coord(xyz[3 * o + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
-    const int cy = sf_cell_coord(xyz[3 * o + 1], g.lo[1], g.inv_cell, g.dim[1]);
-    const int cz = sf_cell_coord(xyz[3 * o + 2], g.lo[2], g.inv_cell, g.dim[2]);
-    cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlayers) return;
+    unsigned int s = 0;
+    for (int b = 0; b < nblocks; ++b) s += mat[(int64_t)b * nlayers + l];
+    hist[l] = s;
+}
+
+// pass B: the points of layers [zlo, zhi], in ascending original index (the stable sort that follows keeps that order
+// inside a cell), with their cell ids.  A chunk's first output slot is the number of kept points in the chunks before
+// it -- a sum over rows of pass A's matrix -- and inside the chunk the order comes from ballots and a running count.
+__global__ __launch_bounds__(256) void k_select_slab(const double *__restrict__ z, const double *__restrict__ xyz, int64_t n,
+                                                     int64_t chunk, sf_grid_desc g, int zlo, int zhi,
+                                                     const unsigned int *__restrict__ mat, int32_t *__restrict__ sel,
+                                                     int32_t *__restrict__ cid)
+{
+    __shared__ unsigned long long red[4];
+    __shared__ unsigned int wave_tot[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nl = g.dim[2];
+    unsigned long long before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += blockDim.x)
+        for (int l = zlo; l <= zhi; ++l) before += mat[(int64_t)b * nl + l];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if (lane == 0) red[wave] = before;
+    __syncthreads();
+    int64_t pos = (int64_t)(red[0] + red[1] + red[2] + red[3]); // next output slot of this chunk
+    const int64_t c0 = (int64_t)blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
+    const double2 *z2 = reinterpret_cast<const double2 *>(z);
+    for (int64_t t0 = c0; t0 < c1; t0 += 2 * (int64_t)blockDim.x) { // (block-uniform trip count)
+        const int64_t i = t0 + 2 * (int64_t)threadIdx.x;
+        bool k0 = false, k1 = false;
+        if (i < c1) {
+            const double2 v = z2[i >> 1];
+            const int a = sf_cell_coord(v.x, g.lo[2], g.inv_cell, nl);
+            k0 = a >= zlo && a <= zhi;
+            if (i + 1 < c1) {
+                const int b = sf_cell_coord(v.y, g.lo[2], g.inv_cell, nl);
+                k1 = b >= zlo && b <= zhi;
+            }
+        }
+        const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+        const int mine = sf_prefix_count(b0) + sf_prefix_count(b1); // kept points of the lanes below
+        __syncthreads(); // (the previous tile's wave_tot has been read by everybody)
+        if (lane == 0) wave_tot[wave] = (unsigned)(__popcll(b0) + __popcll(b1));
+        __syncthreads();
+        int64_t at = pos + mine;
+        for (int w = 0; w < wave; ++w) at += wave_tot[w];
+        pos += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (h == 0 ? k0 : k1) {
+                const int64_t o = i + h;
+                const int cx = sf_cell_coord(xyz[3 * o + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
+                const int cy = sf_cell_coord(xyz[3 * o + 1], g.lo[1], g.inv_cell, g.dim[1]);
+                const int cz = sf_cell_coord(xyz[3 * o + 2], g.lo[2], g.inv_cell, g.dim[2]);
+                sel[at] = (int32_t)o;
+                cid[at] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+                ++at;
+            }
+    }
 }
 
 // first cell-sorted position of every z-layer, read off the cell table (after a whole-cloud build)
@@ -465,11 +505,16 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
             SF_LAUNCH(ctx, "k1_extract_z", k_extract_z, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, c->z_orig);
         }
         const int nl = c->dim[2];
-        unsigned int *dhist = nullptr;
+        // chunks: as many workgroups as keep the per-chunk histogram matrix within a megaword (1024 up to 1024 layers)
+        const int nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(64, ((int64_t)1 << 20) / nl));
+        const int64_t chunk = 2 * sf_div_up(sf_div_up(n, 2), nblocks);
+        unsigned int *dmat = nullptr, *dhist = nullptr;
+        SF_CHECK(tmp.alloc(&dmat, (size_t)nblocks * nl));
         SF_CHECK(tmp.alloc(&dhist, (size_t)nl));
-        SF_HIP(hipMemsetAsync(dhist, 0, (size_t)nl * sizeof(unsigned int), ctx->stream));
-        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_z, dim3(2048), dim3(256), (const double *)c->z_orig, n, c->lo[2], c->inv_cell,
-                  nl, dhist);
+        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_z, dim3(nblocks), dim3(256), (const double *)c->z_orig, n, chunk, c->lo[2],
+                  c->inv_cell, nl, dmat);
+        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_fold, dim3((unsigned)sf_div_up(nl, 256)), dim3(256), (const unsigned int *)dmat,
+                  nblocks, nl, dhist);
         std::vector<unsigned int> hist((size_t)nl);
         void *pin = nullptr;
         SF_CHECK(sf_ctx_pinned(ctx, &pin));
@@ -491,25 +536,12 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         const int zlo = std::max(zb - reach, 0), zhi = block_begin < block_end ? std::min(ze + reach, nl - 1) : -1;
         base = zhi >= zlo ? first[(size_t)zlo] : 0;
         ns = zhi >= zlo ? first[(size_t)zhi + 1] - base : 0;
-        // ---- pass B: stable selection of the points of those layers, then their cell ids ----------------
+        // ---- pass B: the points of those layers in index order, with their cell ids ----------------------
         if (ns > 0) {
             SF_CHECK(tmp.alloc(&key_in, (size_t)ns + 1));
             SF_CHECK(tmp.alloc(&val_in, (size_t)ns + 1));
-            size_t *dcount = nullptr;
-            SF_CHECK(tmp.alloc(&dcount, 2));
-            const z_in_layers pred{c->lo[2], c->inv_cell, nl, zlo, zhi};
-            auto flags = rocprim::make_transform_iterator((const double *)c->z_orig, pred);
-            auto ids = rocprim::make_counting_iterator<int32_t>(0);
-            size_t sel_bytes = 0;
-            SF_HIP(rocprim::select(nullptr, sel_bytes, ids, flags, val_in, dcount, (size_t)n, ctx->stream));
-            char *sel_tmp = nullptr;
-            SF_CHECK(tmp.alloc(&sel_tmp, sel_bytes ? sel_bytes : 8));
-            {
-                sf_launch_timer t_(ctx, "k1_select_slab");
-                SF_HIP(rocprim::select(sel_tmp, sel_bytes, ids, flags, val_in, dcount, (size_t)n, ctx->stream));
-            }
-            SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids_sel, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), (const double *)c->xyz_orig,
-                      (const int32_t *)val_in, ns, g, key_in);
+            SF_LAUNCH(ctx, "k1_select_slab", k_select_slab, dim3(nblocks), dim3(256), (const double *)c->z_orig,
+                      (const double *)c->xyz_orig, n, chunk, g, zlo, zhi, (const unsigned int *)dmat, val_in, key_in);
         }
     }
     c->pop_begin = base;

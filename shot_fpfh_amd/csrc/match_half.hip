@@ -142,14 +142,33 @@ __device__ __forceinline__ float dpp_f32(float v)
 // chunk slots (PC = chunks per row rounded up to 16; 768-byte rows for d <= 352).  The bank spread comes from the
 // SOURCE side instead: slot p of column col holds chunk p ^ (col & 15), so the 16 lanes of a fragment read
 // (same chunk, 16 consecutive columns, pitch = 0 mod 64 banks) hit 16 different slots = all 64 banks once.
+// Work order (XCD-aware).  A workgroup is (row block, column split); the reference columns are cut into splits of at
+// most ~2 MB of FP16 rows, so that the split an XCD is working on stays in its own 4 MB L2 while all of that XCD's
+// workgroups -- consecutive row blocks -- stream it again and again.  Workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8), so XCD x takes the splits x, x + 8, ... one after the other, every row block of one split before the
+// next split starts: each tile of `bh` crosses the fabric about once per launch instead of once per row block (round 2:
+// one split, the 256 resident workgroups drifted apart along the 184 MB panel and 72 % of their tile reads missed L2).
+// A row's threshold is shared between the splits through `thr_best` (racy reads, atomic minimum at the end): any
+// threshold that some column has reached is a valid start value, so later splits start warm and append next to nothing;
+// the final result does not depend on who saw what when (k_half_final decides in float64 among a superset).
+__device__ inline void atomic_min_f32(float *addr, float v)
+{
+    if (v >= 0.0f) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned *>(addr), (unsigned)__float_as_int(v));
+}
+
 template <int KS>
 __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restrict__ ah, int64_t m1,
                                                         const _Float16 *__restrict__ bh, int64_t m2_pad,
                                                         const float *__restrict__ nbs, const float *__restrict__ win,
-                                                        int64_t tiles_per_split, int64_t m1_pad,
+                                                        int64_t tiles_per_split, int64_t m1_pad, int64_t row_blocks,
+                                                        int64_t nsplit, float *__restrict__ thr_best,
                                                         int *__restrict__ cnt, int32_t *__restrict__ cand_j,
                                                         float *__restrict__ cand_k, float *__restrict__ thr_out)
 {
+    const int64_t wq = (int64_t)(blockIdx.x >> 3), wls = wq / row_blocks;
+    const int64_t rb = wq - wls * row_blocks, split = wls * 8 + (int64_t)(blockIdx.x & 7u);
+    if (split >= nsplit) return;
     constexpr int DP = 16 * KS;
     constexpr int CPR = 2 * KS;                  // 16-byte chunks per row
     constexpr int PC = (CPR + 15) / 16 * 16;     // chunk slots per row in LDS
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * HM + 32 * wave;
+    const int64_t row0 = rb * HM + 32 * wave;
 
     h8 af[KS];
     {
@@ -173,8 +192,17 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
     // thresholds of the 16 rows this lane sees in an accumulator: row (r & 3) + 8 (r >> 2) + 4 h
     f16v T;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) T[r] = (row0 + (r & 3) + 8 * (r >> 2) + 4 * h) < m1 ? INFINITY : -INFINITY;
-    bool cold = row0 < m1; // wave-uniform: some real row still has T = +inf
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        T[r] = row < m1 ? (thr_best ? __builtin_nontemporal_load(thr_best + row) : INFINITY) : -INFINITY;
+    }
+    bool cold; // wave-uniform: some real row still has T = +inf
+    {
+        bool c = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c |= T[r] == INFINITY;
+        cold = __ballot(c) != 0;
+    }
     f16v zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
@@ -197,12 +225,12 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
 
     // column split blockIdx.y scans its own range of tiles with its own thresholds and candidate lists (used when
     // there are too few 256-row blocks to fill the chip); k_half_final merges the splits
-    const int64_t jt0 = (int64_t)blockIdx.y * tiles_per_split;
+    const int64_t jt0 = split * tiles_per_split;
     const int64_t ntiles = (m2_pad / HN < jt0 + tiles_per_split) ? m2_pad / HN : jt0 + tiles_per_split; // end tile
-    cnt += (int64_t)blockIdx.y * m1_pad;
-    cand_j += (int64_t)blockIdx.y * m1_pad * HCAP;
-    cand_k += (int64_t)blockIdx.y * m1_pad * HCAP;
-    thr_out += (int64_t)blockIdx.y * m1_pad;
+    cnt += split * m1_pad;
+    cand_j += split * m1_pad * HCAP;
+    cand_k += split * m1_pad * HCAP;
+    thr_out += split * m1_pad;
     const unsigned char *bbytes = reinterpret_cast<const unsigned char *>(bh);
     // The DMA is issued from inline assembly: the compiler then does not know about it and puts no vmcnt(0) in
     // front of the fragment reads of the OTHER buffer (it cannot tell the two halves of Bs apart); completion is
@@ -282,9 +310,9 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
             if (cold || __ballot(mx >= nbv)) {
                 const bool was_cold = cold;
                 // rare path: keep its address arithmetic out of the loop-invariant registers of the MFMA loop
-                int rowb = (int)(row0 - (int64_t)blockIdx.x * HM) + 4 * h;
+                int rowb = (int)(row0 - rb * HM) + 4 * h;
                 asm volatile("" : "+v"(rowb));
-                const int64_t rowbase = (int64_t)blockIdx.x * HM + rowb;
+                const int64_t rowbase = rb * HM + rowb;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float dot = was_cold ? acc[cb][r] : acc[cb][r] - T[r];
@@ -325,7 +353,11 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
     }
     if (r31 == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) thr_out[row0 + (r & 3) + 8 * (r >> 2) + 4 * h] = T[r];
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            thr_out[row] = T[r];
+            if (thr_best && row < m1 && T[r] < INFINITY) atomic_min_f32(thr_best + row, T[r]);
+        }
     }
 #undef SF_H_DMA
 #undef SF_H_DMA16
@@ -496,35 +528,49 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
         if (rc != SF_OK) return rc;
     }
     if (!std::isfinite(ebmax) || !std::isfinite(qbmax)) return SF_OK;
-    // column splits: enough workgroups for two per CU's worth of the chip, each with at least 32 tiles to scan
-    const int64_t row_blocks = m1p / HM, col_tiles = m2p / HN;
-    int64_t nsplit = 1;
-    if (row_blocks < 512) nsplit = std::max<int64_t>(1, std::min<int64_t>(sf_div_up(512, row_blocks), col_tiles / 32));
+    // column splits: (1) each split's FP16 rows fit an XCD's L2 next to everything else that passes through it (2 MB of
+    // the 4; SF_MATCH_HALF_CHUNK_KB overrides) -- see the work-order note above k_match_half; (2) with few row blocks,
+    // enough workgroups for two per CU's worth of the chip, each with at least 32 tiles to scan
+    const int64_t col_tiles = m2p / HN;
+    static const int64_t chunk_kb = [] { const char *e = getenv("SF_MATCH_HALF_CHUNK_KB"); const long long v = e ? atoll(e) : 2048; return (int64_t)(v > 0 ? v : 2048); }();
+    const int64_t tiles_in_l2 = std::max<int64_t>(8, chunk_kb * 1024 / ((int64_t)HN * dp * 2));
+    int64_t nsplit = sf_div_up(col_tiles, tiles_in_l2);
+    if ((m1p / HM) * nsplit < 512) nsplit = std::max<int64_t>(nsplit, std::min<int64_t>(sf_div_up(512, m1p / HM), std::max<int64_t>(col_tiles / 32, 1)));
     if (const char *e = getenv("SF_MATCH_HALF_SPLITS")) nsplit = std::max<int64_t>(1, std::min<int64_t>(atoll(e), col_tiles));
     const int64_t tiles_per_split = sf_div_up(col_tiles, nsplit);
     nsplit = sf_div_up(col_tiles, tiles_per_split);
-    SF_HALLOC(win, m1p); SF_HALLOC(thr, nsplit * m1p); SF_HALLOC(cnt, nsplit * m1p);
-    SF_HALLOC(candj, nsplit * m1p * HCAP); SF_HALLOC(candk, nsplit * m1p * HCAP);
+    static const bool seed = [] { const char *e = getenv("SF_MATCH_HALF_SEED"); return !(e && e[0] == '0'); }();
+    // scan rows go through in slabs: every (row, split) pair owns HCAP candidate slots, and 1M rows x 344 splits of them
+    // would be 90 GB -- a slab keeps the lists within ~8 GB (at least 64 row blocks, so a slab still fills the chip)
+    const int64_t slab_rows = std::min<int64_t>(m1p, HM * std::max<int64_t>(64, ((int64_t)8 << 30) / (nsplit * HCAP * 8 * HM)));
+    float *tbest = nullptr;
+    SF_HALLOC(win, slab_rows); SF_HALLOC(thr, nsplit * slab_rows); SF_HALLOC(cnt, nsplit * slab_rows); SF_HALLOC(tbest, slab_rows);
+    SF_HALLOC(candj, nsplit * slab_rows * HCAP); SF_HALLOC(candk, nsplit * slab_rows * HCAP);
     SF_HALLOC(flag, m1); SF_HALLOC(nflag, 1);
     const double gamma = (double)(dp + 32) * 2.384185791015625e-07; // 2^-22
-    SF_LAUNCH(ctx, "k8_half_window", k_half_window, dim3((unsigned)sf_div_up(m1p, 256)), dim3(256), (const double *)ea,
-              (const double *)qa, (const double *)na2, m1, m1p, std::sqrt(nbmax), ebmax, qbmax, nbmax, gamma, unit, win);
-    SF_HIP(hipMemsetAsync(cnt, 0, (size_t)(nsplit * m1p) * sizeof(int), ctx->stream));
     SF_HIP(hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream));
-    if (ks == 8) {
-        SF_LAUNCH(ctx, name, k_match_half<8>, dim3((unsigned)row_blocks, (unsigned)nsplit), dim3(512), (const _Float16 *)ah,
-                  m1, (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, tiles_per_split, m1p, cnt, candj,
-                  candk, thr);
-    } else {
-        SF_LAUNCH(ctx, name, k_match_half<22>, dim3((unsigned)row_blocks, (unsigned)nsplit), dim3(512), (const _Float16 *)ah,
-                  m1, (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, tiles_per_split, m1p, cnt, candj,
-                  candk, thr);
+    for (int64_t r0 = 0; r0 < m1; r0 += slab_rows) {
+        const int64_t ms = std::min(m1 - r0, slab_rows), msp = sf_div_up(ms, HM) * HM, row_blocks = msp / HM;
+        SF_LAUNCH(ctx, "k8_half_window", k_half_window, dim3((unsigned)sf_div_up(msp, 256)), dim3(256), (const double *)(ea + r0),
+                  (const double *)(qa + r0), (const double *)(na2 + r0), ms, msp, std::sqrt(nbmax), ebmax, qbmax, nbmax, gamma, unit, win);
+        SF_HIP(hipMemsetAsync(cnt, 0, (size_t)(nsplit * msp) * sizeof(int), ctx->stream));
+        SF_HIP(hipMemsetD32Async((hipDeviceptr_t)tbest, 0x7f800000, (size_t)msp, ctx->stream)); // +inf
+        const int64_t wgs = 8 * sf_div_up(nsplit, 8) * row_blocks; // XCD x: splits x, x + 8, ...; every row block of one, then the next
+        if (wgs > 0x7fffffffLL) { sf_set_error("sf_match_half: %lld workgroups exceed a launch", (long long)wgs); return SF_ERR_UNSUPPORTED; }
+        if (ks == 8) {
+            SF_LAUNCH(ctx, name, k_match_half<8>, dim3((unsigned)wgs), dim3(512), (const _Float16 *)(ah + r0 * dp),
+                      ms, (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, tiles_per_split, msp, row_blocks, nsplit,
+                      seed ? tbest : (float *)nullptr, cnt, candj, candk, thr);
+        } else {
+            SF_LAUNCH(ctx, name, k_match_half<22>, dim3((unsigned)wgs), dim3(512), (const _Float16 *)(ah + r0 * dp),
+                      ms, (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, tiles_per_split, msp, row_blocks, nsplit,
+                      seed ? tbest : (float *)nullptr, cnt, candj, candk, thr);
+        }
+        SF_LAUNCH(ctx, "k8_half_final", k_half_final, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), da + r0 * d, ms, db, d,
+                  a_ok ? a_ok + r0 : a_ok, (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr,
+                  (const float *)win, (const double *)(na2 + r0), unit, (int)nsplit, msp, didx + r0, ddist ? ddist + r0 : ddist,
+                  flag + r0, nflag);
     }
-    SF_LAUNCH(ctx, "k8_half_final", k_half_final, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), da, m1, db, d, a_ok,
-              (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, (const float *)win,
-              (const double *)na2, unit, (int)nsplit,
-              m1p, didx, ddist,
-              flag, nflag);
     int nf = 0;
     SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));

@@ -181,10 +181,18 @@ class DescriptorJob:
             nb.free()
         self._halo_filled = True
 
+    def _exchange_plan(self) -> ExchangePlan:
+        """(the plan is a function of the layer table, which a resident cloud reproduces pass after pass: planned once)"""
+        first = self.cloud.layer_table()
+        key = first.tobytes()
+        if getattr(self, "_xp_key", None) != key:
+            self._xp_key, self._xp = key, exchange_plan(first, self.cloud.n, self.plan.world, self.plan.rank)
+        return self._xp
+
     def _step_neighbor(self) -> None:
         eng, cloud, (b, e) = self.engine, self.cloud, self.plan.block()
         cloud.build_grid(self.radius, block=(b, e), reach=1)  # the block's own neighbours: one cell
-        xp = exchange_plan(cloud.layer_table(), cloud.n, self.plan.world, self.plan.rank) if self.do_fpfh else None
+        xp = self._exchange_plan() if self.do_fpfh else None
         if self.do_fpfh and self.emulate_peers and not self._halo_filled:
             self._prefill_halo(*xp.halo)
             cloud.build_grid(self.radius, block=(b, e), reach=1)
