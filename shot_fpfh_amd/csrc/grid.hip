@@ -178,14 +178,18 @@ __global__ __launch_bounds__(256) void k_layer_hist_z(const double *__restrict__
     for (int b = threadIdx.x; b < nlayers; b += blockDim.x) mat[(int64_t)blockIdx.x * nlayers + b] = sh[b];
 }
 
+// column sums of pass A's matrix: one workgroup per layer
 __global__ __launch_bounds__(256) void k_layer_hist_fold(const unsigned int *__restrict__ mat, int nblocks, int nlayers,
                                                          unsigned int *__restrict__ hist)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= nlayers) return;
+    __shared__ unsigned int part[4];
+    const int l = blockIdx.x;
     unsigned int s = 0;
-    for (int b = 0; b < nblocks; ++b) s += mat[(int64_t)b * nlayers + l];
-    hist[l] = s;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += mat[(int64_t)b * nlayers + l];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) hist[l] = part[0] + part[1] + part[2] + part[3];
 }
 
 // pass B: the points of layers [zlo, zhi], in ascending original index (the stable sort that follows keeps that order
@@ -513,8 +517,8 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         SF_CHECK(tmp.alloc(&dhist, (size_t)nl));
         SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_z, dim3(nblocks), dim3(256), (const double *)c->z_orig, n, chunk, c->lo[2],
                   c->inv_cell, nl, dmat);
-        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_fold, dim3((unsigned)sf_div_up(nl, 256)), dim3(256), (const unsigned int *)dmat,
-                  nblocks, nl, dhist);
+        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_fold, dim3((unsigned)nl), dim3(256), (const unsigned int *)dmat, nblocks, nl,
+                  dhist);
         std::vector<unsigned int> hist((size_t)nl);
         void *pin = nullptr;
         SF_CHECK(sf_ctx_pinned(ctx, &pin));

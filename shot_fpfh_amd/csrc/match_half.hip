@@ -145,8 +145,8 @@ __device__ __forceinline__ float dpp_f32(float v)
 // Work order (XCD-aware).  A workgroup is (row block, column split); the reference columns are cut into splits of at
 // most ~2 MB of FP16 rows, so that the split an XCD is working on stays in its own 4 MB L2 while all of that XCD's
 // workgroups -- consecutive row blocks -- stream it again and again.  Workgroups are dealt round-robin over the 8 XCDs
-// (blockIdx % 8), so XCD x takes the splits x, x + 8, ... one after the other, every row block of one split before the
-// next split starts: each tile of `bh` crosses the fabric about once per launch instead of once per row block (round 2:
+// (blockIdx % 8) and XCD x takes a contiguous eighth of the splits, one after the other, every row block of one split before
+// the next split starts (with fewer than eight splits several XCDs share one, each with its own range of row blocks): each tile of `bh` crosses the fabric about once per launch instead of once per row block (round 2:
 // one split, the 256 resident workgroups drifted apart along the 184 MB panel and 72 % of their tile reads missed L2).
 // A row's threshold is shared between the splits through `thr_best` (racy reads, atomic minimum at the end): any
 // threshold that some column has reached is a valid start value, so later splits start warm and append next to nothing;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
                                                         int *__restrict__ cnt, int32_t *__restrict__ cand_j,
                                                         float *__restrict__ cand_k, float *__restrict__ thr_out)
 {
-    const int64_t wq = (int64_t)(blockIdx.x >> 3), wls = wq / row_blocks;
-    const int64_t rb = wq - wls * row_blocks, split = wls * 8 + (int64_t)(blockIdx.x & 7u);
+    // XCD x (= blockIdx % 8) walks its own contiguous eighth of the split-major list of (split, row block) pairs
+    const int64_t wv = sf_xcd_block(), split = wv / row_blocks, rb = wv - split * row_blocks;
     if (split >= nsplit) return;
     constexpr int DP = 16 * KS;
     constexpr int CPR = 2 * KS;                  // 16-byte chunks per row
@@ -528,11 +528,11 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
         if (rc != SF_OK) return rc;
     }
     if (!std::isfinite(ebmax) || !std::isfinite(qbmax)) return SF_OK;
-    // column splits: (1) each split's FP16 rows fit an XCD's L2 next to everything else that passes through it (2 MB of
-    // the 4; SF_MATCH_HALF_CHUNK_KB overrides) -- see the work-order note above k_match_half; (2) with few row blocks,
+    // column splits: (1) each split is short enough for an XCD's workgroups to share its tiles through their L2 (8 MB: hit rate
+    // 0.83, profiles/r03_match_summary.md; SF_MATCH_HALF_CHUNK_KB overrides) -- see the note above k_match_half; (2) with few row blocks,
     // enough workgroups for two per CU's worth of the chip, each with at least 32 tiles to scan
     const int64_t col_tiles = m2p / HN;
-    static const int64_t chunk_kb = [] { const char *e = getenv("SF_MATCH_HALF_CHUNK_KB"); const long long v = e ? atoll(e) : 2048; return (int64_t)(v > 0 ? v : 2048); }();
+    static const int64_t chunk_kb = [] { const char *e = getenv("SF_MATCH_HALF_CHUNK_KB"); const long long v = e ? atoll(e) : 8192; return (int64_t)(v > 0 ? v : 8192); }();
     const int64_t tiles_in_l2 = std::max<int64_t>(8, chunk_kb * 1024 / ((int64_t)HN * dp * 2));
     int64_t nsplit = sf_div_up(col_tiles, tiles_in_l2);
     if ((m1p / HM) * nsplit < 512) nsplit = std::max<int64_t>(nsplit, std::min<int64_t>(sf_div_up(512, m1p / HM), std::max<int64_t>(col_tiles / 32, 1)));
@@ -555,7 +555,7 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
                   (const double *)(qa + r0), (const double *)(na2 + r0), ms, msp, std::sqrt(nbmax), ebmax, qbmax, nbmax, gamma, unit, win);
         SF_HIP(hipMemsetAsync(cnt, 0, (size_t)(nsplit * msp) * sizeof(int), ctx->stream));
         SF_HIP(hipMemsetD32Async((hipDeviceptr_t)tbest, 0x7f800000, (size_t)msp, ctx->stream)); // +inf
-        const int64_t wgs = 8 * sf_div_up(nsplit, 8) * row_blocks; // XCD x: splits x, x + 8, ...; every row block of one, then the next
+        const int64_t wgs = sf_xcd_grid(nsplit * row_blocks); // XCD x: the x-th eighth of the split-major (split, row block) list
         if (wgs > 0x7fffffffLL) { sf_set_error("sf_match_half: %lld workgroups exceed a launch", (long long)wgs); return SF_ERR_UNSUPPORTED; }
         if (ks == 8) {
             SF_LAUNCH(ctx, name, k_match_half<8>, dim3((unsigned)wgs), dim3(512), (const _Float16 *)(ah + r0 * dp),

@@ -918,7 +918,7 @@ def test_match_large_permutation_property(eng, O):
     eng.match_argmin_device(da, db, idx, dist)
     eng.sync()
     eng.profile(False)
-    assert eng.profile_report().get("k8_match_half", (0, 0))[0] == 1, "this size was expected to take the FP16 pre-filter"
+    assert eng.profile_report().get("k8_match_half", (0, 0))[0] >= 1, "this size was expected to take the FP16 pre-filter"
     i_h, d_h = idx.to_host(), dist.to_host()
     assert np.array_equal(i_h, inv)
     pick = rng.choice(m, 2000, replace=False)
