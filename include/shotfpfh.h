@@ -248,6 +248,14 @@ int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, in
                                int64_t d, const unsigned char *a_ok, const unsigned char *b_ok, double max_val,
                                int64_t *idx, double *dist, int flags);
 
+/* Reciprocity test of match_descriptors (matching.py:62-74) when the scan rows are sharded over ranks: with each rank's
+ * column arg-min over its own scan block (sf_match_argmin_multiscale, operands swapped) and the all-reduced column minimum
+ * (sf_comm_allreduce_min_u64 on the distances' bit patterns), cand[j] = row_offset + local_idx[j] where this rank attains
+ * the global minimum of column j, ~0 elsewhere; a second all-reduce(min) of `cand` leaves distance_matrix.argmin(axis=0),
+ * first minimum included.  All pointers device memory. */
+int sf_match_col_candidates(sf_ctx *ctx, const double *local_dist_dev, const double *global_dist_dev,
+                            const int64_t *local_idx_dev, int64_t row_offset, int64_t m, void *cand_dev);
+
 /* ---- RANSAC scoring: inlier count of ransac.py:60-67, K9 ----------------------------------
  * a, b: m x 3 matched points; Rt: n_draws x 12 (row-major R, then t); counts ||a R^T + t - b|| <= thr. */
 int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, int64_t m, const double *Rt, int64_t n_draws,

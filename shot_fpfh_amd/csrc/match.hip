@@ -337,6 +337,40 @@ extern "C" int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, const int64_t
     return SF_OK;
 }
 
+namespace {
+// second half of a sharded column arg-min (see sf_match_col_candidates)
+__global__ void k_col_candidates(const double *__restrict__ local_dist, const double *__restrict__ global_dist,
+                                 const int64_t *__restrict__ local_idx, int64_t row_offset, int64_t m,
+                                 unsigned long long *__restrict__ cand)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double l = local_dist[j];
+    // (+inf: no scan row of this rank reaches the column at all -- a masked or empty block must not claim it)
+    cand[j] = (l == global_dist[j] && l < INFINITY) ? (unsigned long long)(row_offset + local_idx[j]) : ~0ull;
+}
+} // namespace
+
+// Reciprocity over sharded scan rows (matching.py:63-65: distance_matrix.argmin(axis=0) over ALL scan rows).  Every rank
+// has the arg-min of each reference column over its own scan block (local_idx, local_dist: sf_match_argmin_multiscale with
+// the operands swapped).  The column minimum over all ranks is an all-reduce(min) of the distances -- non-negative
+// doubles order like their bit patterns, sf_comm_allreduce_min_u64 -- and the winner is the LOWEST scan row that
+// attains it: this call turns (local, global) distances into candidates `row_offset + local_idx` where the rank attains
+// the global minimum and ~0 where it does not, and a second all-reduce(min) picks the first minimum, as NumPy does.
+extern "C" int sf_match_col_candidates(sf_ctx *ctx, const double *local_dist_dev, const double *global_dist_dev,
+                                       const int64_t *local_idx_dev, int64_t row_offset, int64_t m, void *cand_dev)
+{
+    if (!ctx || !local_dist_dev || !global_dist_dev || !local_idx_dev || !cand_dev || m < 0 || row_offset < 0) {
+        sf_set_error("sf_match_col_candidates: bad argument");
+        return SF_ERR_ARG;
+    }
+    SF_HIP(hipSetDevice(ctx->device));
+    if (m)
+        SF_LAUNCH(ctx, "k8_col_candidates", k_col_candidates, dim3((unsigned)sf_div_up(m, 256)), dim3(256), local_dist_dev,
+                  global_dist_dev, local_idx_dev, row_offset, m, (unsigned long long *)cand_dev);
+    return SF_OK;
+}
+
 extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1,
                                           int64_t m2, int64_t d, const unsigned char *a_ok, const unsigned char *b_ok,
                                           double max_val, int64_t *idx, double *dist, int flags)

@@ -301,6 +301,16 @@ class Engine:
             "sf_match_argmin_multiscale",
         )
 
+    def col_candidates_device(self, local_dist: DeviceArray, global_dist: DeviceArray, local_idx: DeviceArray, row_offset: int,
+                              out: DeviceArray, m: Optional[int] = None) -> DeviceArray:
+        """out[j] = row_offset + local_idx[j] where local_dist[j] equals the (all-reduced) global_dist[j], else 2^64 - 1."""
+        m = local_dist.shape[0] if m is None else m
+        if out.dtype != np.uint64:
+            raise ValueError("col_candidates_device writes uint64 candidates")
+        _ffi.check(self.lib.sf_match_col_candidates(self.h, local_dist.ptr, global_dist.ptr, local_idx.ptr, int(row_offset), int(m),
+                                                    out.ptr), "sf_match_col_candidates")
+        return out
+
     def ransac_score(self, a, b, rt, thr: float) -> np.ndarray:
         a, b = _f64(a, 3), _f64(b, 3)
         rt = _f64(rt).reshape(-1, 12)

@@ -371,19 +371,98 @@ class MatchJob:
         # communicator -- of ONE rank too -- this is ncclAllGather)
         eng.allgather(self.ref_all, plan.rows_per_rank * row_bytes)
         eng.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=plan.n)
+        self._scan_block = scan_block
         if self.m:
             eng.rows_nonzero_device(scan_block, self.scan_ok, n_rows=self.m)
             eng.match_masked_device(scan_block, self.scan_ok, self.ref_all, self.ref_ok, self.idx, self.dist,
                                     a_rows=self.m, b_rows=plan.n)
 
-    def matches(self) -> tuple[np.ndarray, np.ndarray]:
-        """(local scan rows that are non-empty, their matched reference rows) -- both in cell-sorted numbering."""
-        if not self.m:
+    # ---- the rest of match_descriptors (matching.py:54-74) on sharded rows ------------------------------------------------
+    def _all_ranks(self, mine: np.ndarray, fill) -> np.ndarray:
+        """A per-scan-row vector of this rank's block -> the vector over ALL scan rows, in global row order (one small
+        all-gather of equal, padded blocks)."""
+        eng, plan = self.engine, self.scan_plan
+        rpr = max(plan.rows_per_rank, 1)
+        buf = eng.empty((rpr * plan.world,), mine.dtype)
+        try:
+            block = np.full(rpr, fill, dtype=mine.dtype)
+            block[: mine.shape[0]] = mine
+            host = np.full(rpr * plan.world, fill, dtype=mine.dtype)
+            host[plan.rank * rpr:(plan.rank + 1) * rpr] = block
+            buf.from_host(host)
+            eng.allgather(buf, rpr * mine.dtype.itemsize)
+            flat = buf.to_host()
+        finally:
+            buf.free()
+        return np.concatenate([flat[r * rpr: r * rpr + (plan.block(r)[1] - plan.block(r)[0])] for r in range(plan.world)])
+
+    def _sum_over_ranks(self, value: int) -> int:
+        eng, plan = self.engine, self.scan_plan
+        if plan.world == 1:
+            return value
+        buf = eng.empty((plan.world,), np.int64)
+        try:
+            host = np.zeros(plan.world, dtype=np.int64)
+            host[plan.rank] = value
+            buf.from_host(host)
+            eng.allgather(buf, 8)
+            return int(buf.to_host().sum())
+        finally:
+            buf.free()
+
+    def column_argmin(self) -> np.ndarray:
+        """distance_matrix.argmin(axis=0) of matching.py:63 over ALL scan rows, for every reference row (global scan row
+        numbers; 2^64 - 1 where no non-empty scan row exists): local column arg-min over this rank's block, all-reduce(min)
+        of the column minima, then all-reduce(min) of the rows that attain them -- the first minimum, as NumPy takes it."""
+        eng, n_ref = self.engine, self.ref_plan.n
+        rows = max(self.ref_all.shape[0], 1)
+        cd, ci = eng.empty((rows,), np.float64), eng.empty((rows,), np.int64)
+        gd, cand = eng.empty((rows,), np.uint64), eng.empty((rows,), np.uint64)
+        try:
+            if self.m:
+                eng.match_masked_device(self.ref_all, self.ref_ok, self._scan_block, self.scan_ok, ci, cd, a_rows=n_ref, b_rows=self.m)
+            else:  # an empty block reaches no column
+                cd.from_host(np.full(rows, np.inf))
+                ci.from_host(np.zeros(rows, np.int64))
+            gd.copy_from_device(cd)
+            eng.allreduce_min_u64(gd, n_ref)       # non-negative doubles order like their bit patterns
+            eng.col_candidates_device(cd, gd, ci, self.scan_plan.begin, cand, m=n_ref)
+            eng.allreduce_min_u64(cand, n_ref)
+            return cand.to_host()[:n_ref]
+        finally:
+            for a in (cd, ci, gd, cand):
+                a.free()
+
+    def matches(self, filter_callback=None, filter_nonreciprocal: bool = False, n_min_matches: int = 100,
+                **kwargs) -> tuple[np.ndarray, np.ndarray]:
+        """(scan rows of this rank that are matched, their reference rows) -- both in the global, cell-sorted row numbering.
+
+        Without arguments: basic_matching, every non-empty scan row with its nearest non-empty reference row.  With a
+        `filter_callback` and / or `filter_nonreciprocal` it is match_descriptors' 2-D branch (matching.py:54-74) on the
+        sharded rows: the callback sees the winners' distances of ALL ranks' non-empty scan rows in global row order
+        (quantile / median filters need them all; one small all-gather), the reciprocity test uses the column arg-min over
+        all ranks (`column_argmin`), and "applied only if at least n_min_matches survive" counts survivors over all ranks.
+        Every rank must call it with the same arguments (it contains collectives)."""
+        if not self.m and filter_callback is None and not filter_nonreciprocal:
             return np.zeros(0, np.int64), np.zeros(0, np.int64)
-        ok = self.scan_ok.to_host()[: self.m].astype(bool)
-        idx = self.idx.to_host()[: self.m]
+        ok = self.scan_ok.to_host()[: self.m].astype(bool) if self.m else np.zeros(0, bool)
+        idx = self.idx.to_host()[: self.m] if self.m else np.zeros(0, np.int64)
         rows = np.flatnonzero(ok)
-        return rows + self.scan_plan.begin, idx[rows]
+        keep = np.ones(rows.shape[0], dtype=bool)
+        if filter_callback is not None:
+            dist = self.dist.to_host()[: self.m] if self.m else np.zeros(0)
+            ok_all = self._all_ranks(ok.astype(np.uint8), 0).astype(bool)
+            dist_all = self._all_ranks(dist, np.inf)
+            mask_all = np.asarray(filter_callback(dist_all[ok_all], **kwargs), dtype=bool)
+            before = int(ok_all[: self.scan_plan.begin].sum())  # non-empty scan rows of the ranks below this one
+            keep = mask_all[before: before + rows.shape[0]]
+        if filter_nonreciprocal:
+            col = self.column_argmin()
+            both = keep & (col[idx[rows]] == (rows + self.scan_plan.begin).astype(np.uint64))
+            survivors = self._sum_over_ranks(int(both.sum()))
+            if survivors >= n_min_matches:
+                keep = both
+        return rows[keep] + self.scan_plan.begin, idx[rows][keep]
 
     def close(self) -> None:
         for a in (self.ref_all, self.ref_ok, self.scan_ok, self.idx, self.dist):

@@ -37,6 +37,35 @@ def match_main(out_path, rank, world):
     dist.destroy_process_group()
 
 
+def reciprocal_main(out_path, rank, world):
+    """match_descriptors with filters and the reciprocity test on sharded rows: the reference's own golden inputs."""
+    from conftest import load_golden
+    from shot_fpfh_amd.matching.filters import quantile_filter, threshold_filter
+    from shot_fpfh_amd.sharding import MatchJob, ShardPlan
+
+    g = load_golden("match_300.npz")
+    a, b = g["scan"], g["ref"]
+    eng = FakeEngine()
+    job = MatchJob(eng, a.shape[1], a.shape[0], b.shape[0], world, rank)
+    sb, se = ShardPlan(a.shape[0], world, rank).block()
+    rb, re = ShardPlan(b.shape[0], world, rank).block()
+    job.run(eng.empty((se - sb, a.shape[1])).from_host(a[sb:se]), eng.empty((max(re - rb, 1), b.shape[1])).from_host(b[rb:re] if re > rb else 0.0))
+    res = {}
+    for name, kw in (("rec", dict(filter_nonreciprocal=True, n_min_matches=100)),
+                     ("recbig", dict(filter_nonreciprocal=True, n_min_matches=10**6)),
+                     ("thr", dict(filter_callback=threshold_filter, threshold_multiplier=10)),
+                     ("quant", dict(filter_callback=quantile_filter, quantiles=(0.2, 0.7))),
+                     ("quantrec", dict(filter_callback=quantile_filter, filter_nonreciprocal=True, n_min_matches=50, quantiles=(0.2, 0.7)))):
+        gathered = [None] * world
+        dist.all_gather_object(gathered, job.matches(**kw))
+        res[name + "_s"] = np.concatenate([x[0] for x in gathered])
+        res[name + "_r"] = np.concatenate([x[1] for x in gathered])
+    if rank == 0:
+        np.savez(out_path, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def subset_main(out_path, rank, world):
     """Config-5 tail on two ranks: every rank owns a block of scan and of reference descriptors; a keypoint subset
     (chosen by label) is gathered out of both, the reference part all-gathered with its labels, and matched."""
@@ -80,6 +109,8 @@ def main():
         return match_main(out_path, rank, world)
     if mode == "subset":
         return subset_main(out_path, rank, world)
+    if mode == "reciprocal":
+        return reciprocal_main(out_path, rank, world)
     p, nr, _ = synth_cloud(1500, 41)
     job = DescriptorJob(FakeEngine(), p, nr, 0.15, n_bins=5, normalize=True, min_neighborhood_size=5, world=world,
                         rank=rank, spfh_exchange=mode)

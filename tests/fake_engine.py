@@ -13,6 +13,7 @@ from oracle import oracle as O
 class FakeArray:
     def __init__(self, shape, dtype=np.float64):
         self.a = np.full(shape, np.nan) if np.dtype(dtype) == np.float64 else np.zeros(shape, dtype)
+        self.dtype_ = np.dtype(dtype)
         self.shape = self.a.shape
         self.nbytes = self.a.nbytes
 
@@ -215,6 +216,23 @@ class FakeEngine:
 
     def sync(self):
         pass
+
+    def allreduce_min_u64(self, buf, n=None):
+        import torch
+        import torch.distributed as dist
+
+        n = buf.a.size if n is None else n
+        # (gloo has no uint64: gather the words and fold them here)
+        mine = torch.from_numpy(buf.a.reshape(-1)[:n].view(np.int64).copy())
+        parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        buf.a.reshape(-1)[:n] = np.min(np.stack([p.numpy().view(np.uint64) for p in parts]), axis=0)
+
+    def col_candidates_device(self, local_dist, global_dist, local_idx, row_offset, out, m=None):
+        m = local_dist.a.shape[0] if m is None else m
+        l, g = local_dist.a[:m], global_dist.a[:m].view(np.float64)
+        out.a[:m] = np.where((l == g) & np.isfinite(l), (row_offset + local_idx.a[:m]).astype(np.uint64), np.uint64(2**64 - 1))
+        return out
 
     def collective_stats(self, on):
         pass

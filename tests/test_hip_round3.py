@@ -107,6 +107,38 @@ def test_spfh_rows_travel_in_the_format_k7_reads(comm_engine, n_bins, expect_row
         obj.free()
 
 
+def test_sharded_match_descriptors_reciprocity_on_a_one_rank_communicator(comm_engine):
+    """MatchJob.matches(filter_nonreciprocal=True, n_min_matches=...) -- local column arg-min, ncclAllReduce(min) of the
+    column minima, ncclAllReduce(min) of the rows attaining them -- against the reference's own match_descriptors outputs
+    (match_300.npz: 100 -> reciprocal matches kept, 10^6 -> fallback to all), bit for bit; with a distance filter too."""
+    from conftest import load_golden
+    from shot_fpfh_amd.matching.filters import threshold_filter
+    from shot_fpfh_amd.sharding import MatchJob
+
+    e = comm_engine
+    g = load_golden("match_300.npz")
+    a, b = g["scan"], g["ref"]
+    job = MatchJob(e, a.shape[1], a.shape[0], b.shape[0], 1, 0)
+    job.run(e.empty(a.shape).from_host(a), e.empty(b.shape).from_host(b))
+    s_, r_ = job.matches()
+    assert np.array_equal(s_, g["basic_s"]) and np.array_equal(r_, g["basic_r"])
+    e.profile_reset()
+    s_, r_ = job.matches(filter_nonreciprocal=True, n_min_matches=100)
+    assert np.array_equal(s_, g["rec_s"]) and np.array_equal(r_, g["rec_r"])
+    assert e.profile_report()["c_allreduce"][0] == 2
+    s_, r_ = job.matches(filter_nonreciprocal=True, n_min_matches=10**6)
+    assert np.array_equal(s_, g["recbig_s"]) and np.array_equal(r_, g["recbig_r"])
+    s_, r_ = job.matches(filter_callback=threshold_filter, threshold_multiplier=10)
+    assert np.array_equal(s_, g["thr_s"]) and np.array_equal(r_, g["thr_r"])
+    # the column arg-min itself against the product's own single-GPU call (first minimum on ties)
+    from shot_fpfh_amd.matching.match import _non_empty_rows
+
+    sr, rr = _non_empty_rows(a), _non_empty_rows(b)
+    _, _, col = e.match_argmin(a[sr], b[rr], want_col=True)
+    assert np.array_equal(job.column_argmin()[rr].astype(np.int64), sr[col])
+    job.close()
+
+
 # ---- block build + borrowed halo rows ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("world", [2, 3, 7])
 @pytest.mark.parametrize("n,radius,n_bins", [(30000, 0.06, 5), (9000, 0.1, 4)])

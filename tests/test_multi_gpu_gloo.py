@@ -144,3 +144,31 @@ def test_two_rank_gloo_subset_matching_by_label(tmp_path):
     have = dict(zip(got["s"].tolist(), got["r"].tolist()))
     assert have == want
     assert np.mean([k == v for k, v in have.items()]) > 0.9  # and the matches do recover the correspondence
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_match_descriptors_with_filters_and_reciprocity(tmp_path, world):
+    """MatchJob.matches(filter_callback, filter_nonreciprocal, n_min_matches) over gloo ranks on the reference's golden
+    inputs (match_300.npz): the union of the per-rank results, mapped back through the non-empty-row numbering, equals
+    the reference's match_descriptors outputs -- the reciprocity fallback (n_min_matches = 10^6) and a filter that needs
+    every rank's distances (quantile) included."""
+    from conftest import load_golden
+    from oracle import oracle as O
+    from shot_fpfh_amd.matching.filters import quantile_filter
+
+    out = str(tmp_path / "recip.npz")
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, "reciprocal"], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got, g = np.load(out), load_golden("match_300.npz")
+    for name in ("rec", "recbig", "thr"):  # the reference's own outputs
+        assert np.array_equal(got[name + "_s"], g[name + "_s"]) and np.array_equal(got[name + "_r"], g[name + "_r"]), name
+    s, r = O.match_descriptors(g["scan"], g["ref"], quantile_filter, quantiles=(0.2, 0.7))
+    assert np.array_equal(got["quant_s"], s) and np.array_equal(got["quant_r"], r)
+    s, r = O.match_descriptors(g["scan"], g["ref"], quantile_filter, filter_nonreciprocal=True, n_min_matches=50, quantiles=(0.2, 0.7))
+    assert np.array_equal(got["quantrec_s"], s) and np.array_equal(got["quantrec_r"], r)
