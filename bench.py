@@ -4,7 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 Run directly with N > 1 (no WORLD_SIZE in the environment) it starts N child processes itself, one per GPU, BEFORE
-touching the GPU; under a launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE set) it is one of the ranks.
+touching the GPU; under a launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE set) it is one of the ranks.  The ranks'
+control plane (rendezvous, barrier, max of the timings, the RCCL unique id) is a few lines of sockets + pickle on
+127.0.0.1 (class Control): the product has no PyTorch, and neither has its bench.
 
 Workload (BASELINE.json metric "descriptors/sec (SHOT+FPFH) on 1M-pt cloud"): a synthetic uniform cloud of 1M points
 PER GPU (seed 3, float32-grid coordinates, random unit normals), every point a keypoint, radius 0.03 at N = 1 (k ~ 110
@@ -17,6 +19,10 @@ eigen-solves, K5 SHOT (rows x 352 float64 out); outputs stay in HBM.  value = 2 
 (max over ranks).  Same definition at every N, so the driver's scaling efficiency compares like with like.
 
 After the timed region the SAME process measures the rest of the path north_star names and reports it under extra keys:
+  * `roofline_all`    -- every kernel of the step: algorithmic bytes, average launch time, fraction of the 8.0 TB/s spec
+    peak and of the 6.29 TB/s measured-copy peak; for K5 also the float64 issue ceiling its SQ counters give;
+  * `normals`         -- (N = 1) compute_normals(radius) on the same cloud: K2 + K3, resident and host to host;
+  * `strong_scaling`  -- (N > 1) the FIXED 1M-point cloud of the metric's name cut over the N ranks (`value` stays weak);
   * `exchange_match`  -- BASELINE config 5's tail: the C4 partner cloud's SHOT rows (one more descriptor pass), a
     keypoint subset of both descriptor sets gathered per rank, ONE RCCL all-gather of the reference subset rows over
     xGMI (ncclAllGather is executed at N = 1 too, on a one-rank communicator), the sharded K8 brute-force L2 matching,
@@ -44,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_COPY_GBS = 6290.0       # measured copy peak (ibid. :36) -- the ceiling a streaming kernel can actually reach
 FP16_MFMA_PEAK_TF = 2500.0  # dense FP16 matrix peak (ibid.)
 FP64_VALU_PEAK_TF = 78.6    # FP64 vector peak (ibid.)
 # algorithmic bytes per unit at float64 API widths (DESIGN.md "Measurement")
@@ -55,7 +62,12 @@ ALG_BYTES = {
     "k4_lrf_from_cov": 48 + 72,
     "k2_radius_count": 24 + 4,
     "k2_radius_fill": 24,  # + 4 B per pair, added below
+    "k2_radius_slots": 24,  # + 4 B per pair (the optimistic single pass), added below
+    "k3_normals": 24 + 24,  # query in, normal out
+    "k1_gather_sorted": 48 + 48 + 4,  # xyz + normal in, 48-byte record (+ SoA copy of xyz) out, perm
+    "k1_radix_sort": 16,  # (cell id, index) pairs in and out, per pass of the sort -- one pass counted
 }
+PER_PAIR = ("k2_radius_fill", "k2_radius_slots")
 C4_EULER, C4_T = (0.3, -0.2, 0.5), (0.1, -0.3, 0.2)  # SURVEY 8d, config C4's rigid motion
 
 
@@ -90,13 +102,141 @@ def spawn_ranks(n: int) -> int:
     port = free_port()
     procs = []
     for rank in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC, and without the variable RCCL's
+        # peer-to-peer set-up between processes fails (hipIpcGetMemHandle: invalid argument).  The image exports it already;
+        # whatever the caller has set is passed through untouched, "0" is only the default for a bare environment.
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), SF_BENCH_SELF_SPAWNED="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p in procs:
         rc = max(rc, abs(p.wait()))
     return rc
+
+
+class Control:
+    """The ranks' control plane: rank 0 listens on 127.0.0.1, the others connect; every operation is an all-gather of a
+    pickled object through rank 0 (barrier, max, broadcast are special cases).  A few small messages per run.
+
+    Port: MASTER_PORT when this script spawned the ranks itself; under torchrun that port belongs to the launcher's own
+    store, so the candidates are MASTER_PORT + 1 ... + 32 -- rank 0 takes the first it can bind and greets every
+    connection with a line naming MASTER_PORT and the world size, a client keeps trying the candidates until one answers
+    with that greeting."""
+
+    def __init__(self, rank: int, world: int, timeout: float = 180.0):
+        self.rank, self.world = rank, world
+        base = int(os.environ.get("MASTER_PORT", "29500"))
+        first = base if os.environ.get("SF_BENCH_SELF_SPAWNED") else base + 1
+        cands = [first + i for i in range(32)]
+        hello = f"SFBENCH {base} {world}\n".encode()
+        self.peers = []
+        if rank == 0:
+            srv = None
+            for port in cands:
+                try:
+                    srv = socket.socket()
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind(("127.0.0.1", port))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise SystemExit("bench control plane: no free port next to MASTER_PORT")
+            srv.listen(world)
+            srv.settimeout(timeout)
+            got = {}
+            while len(got) < world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                c.sendall(hello)
+                got[self._recv(c)] = c
+            srv.close()
+            self.peers = [got[r] for r in range(1, world)]
+        else:
+            deadline = time.time() + timeout
+            self.sock = None
+            while self.sock is None and time.time() < deadline:
+                for port in cands:
+                    try:
+                        c = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                        c.settimeout(2.0)
+                        if self._readline(c) == hello:
+                            c.settimeout(timeout)
+                            self.sock = c
+                            break
+                        c.close()
+                    except OSError:
+                        pass
+                else:
+                    time.sleep(0.2)
+            if self.sock is None:
+                raise SystemExit("bench control plane: rank 0 did not answer")
+            self._send(self.sock, rank)
+
+    @staticmethod
+    def _readline(c) -> bytes:
+        buf = b""
+        while not buf.endswith(b"\n") and len(buf) < 64:
+            chunk = c.recv(1)
+            if not chunk:
+                break
+            buf += chunk
+        return buf
+
+    @staticmethod
+    def _send(c, obj) -> None:
+        import pickle
+        import struct
+
+        data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+        c.sendall(struct.pack("<Q", len(data)) + data)
+
+    @staticmethod
+    def _recv(c):
+        import pickle
+        import struct
+
+        def exactly(n):
+            parts, left = [], n
+            while left:
+                chunk = c.recv(min(left, 1 << 20))
+                if not chunk:
+                    raise ConnectionError("bench control plane: peer closed")
+                parts.append(chunk)
+                left -= len(chunk)
+            return b"".join(parts)
+
+        (n,) = struct.unpack("<Q", exactly(8))
+        return pickle.loads(exactly(n))
+
+    def allgather(self, obj) -> list:
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj] + [self._recv(c) for c in self.peers]
+            for c in self.peers:
+                self._send(c, out)
+            return out
+        self._send(self.sock, obj)
+        return self._recv(self.sock)
+
+    def barrier(self) -> None:
+        self.allgather(None)
+
+    def max(self, x: float) -> float:
+        return max(self.allgather(float(x)))
+
+    def bcast(self, obj):
+        return self.allgather(obj)[0]
+
+    def close(self) -> None:
+        for c in self.peers + ([self.sock] if self.rank else []):
+            try:
+                c.close()
+            except OSError:
+                pass
 
 
 # ---- CPU baselines (N = 1 only) -----------------------------------------------------------------------------------
@@ -179,6 +319,96 @@ def parity_sample(job, points, normals, radius, rows: int = 300) -> dict:
     return out
 
 
+def rows_checksum(job) -> dict:
+    """A partition-independent fingerprint of the outputs a job left in HBM: per row a 64-bit hash of its bit pattern,
+    multiplied by an odd function of the row's ORIGINAL point index, summed modulo 2^64.  Equal for any number of ranks
+    exactly when every descriptor row is bit-identical (sum the per-rank values modulo 2^64)."""
+    orig = job.block_original_indices().astype(np.uint64)
+    key = 2 * orig + 1
+    out = {}
+    for name, arr in (("fpfh", job.fpfh_out), ("shot", job.shot_out)):
+        if arr is None:
+            continue
+        mult = np.random.default_rng(1234).integers(1, 2**63, arr.shape[1], dtype=np.uint64) | np.uint64(1)
+        total = np.uint64(0)
+        with np.errstate(over="ignore"):
+            for r0 in range(0, job.m, 65536):
+                rows = arr.rows_to_host(r0, min(65536, job.m - r0)).view(np.uint64)
+                h = (rows * mult[None, :]).sum(axis=1, dtype=np.uint64)
+                total = total + (h * key[r0:r0 + rows.shape[0]]).sum(dtype=np.uint64)
+        out[name] = int(total)
+    return out
+
+
+def fold_checksums(parts: list) -> dict:
+    return {k: format(sum(p[k] for p in parts) % 2**64, "016x") for k in parts[0]}
+
+
+def load_stamped(name: str, build: str):
+    """A measurement kept under profiles/ (HBM traffic per launch, SQ counters) -- but only if it was taken on the very
+    build that is loaded now (tools/parse_rocprof.py stamps the file with sf_version())."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        d = json.load(open(path))
+    except Exception:  # noqa: BLE001 -- absent or unreadable: nothing to quote
+        return None, f"profiles/{name} absent"
+    if d.get("_build") != build:
+        return None, f"profiles/{name} was measured on build {d.get('_build')!r}, this is {build!r}: not quoted"
+    return d, d.get("_source", f"profiles/{name}")
+
+
+def time_steps(job, eng, steps: int, warmup: int, barrier, max_over_ranks, with_timers: bool):
+    """W untimed steps, then exactly K steps between barrier + device sync on both sides; max over ranks.
+    Returns (seconds for the K steps, profile of the timed steps, profile of a few fully bracketed steps after them)."""
+    # Two HIP event records per launch cost the step 1.6 % (4.55 against 4.48 ms), so the timed region brackets the roofline
+    # kernel only -- roofline.achieved is measured live over the timed launches, as the contract asks; which kernel that is
+    # comes from the warm-up steps (every launch bracketed; the first step, which grows the pools, left out when there are
+    # two or more), and the breakdown of the other kernels from a few untimed steps after the timed ones.
+    warm_rep = {}
+    for w in range(warmup):
+        if w == min(1, warmup - 1):
+            eng.sync()
+            eng.profile_reset()
+            eng.profile(True)
+        job.step()
+    if warmup:
+        eng.sync()
+        eng.profile(False)
+        warm_rep = eng.profile_report()
+    timed_only = None
+    if warm_rep and with_timers:
+        cand = [k for k, v in warm_rep.items() if k in ALG_BYTES and k.startswith(("k5_", "k6_", "k7_", "k2_")) and v[0] > 0 and v[1] > 0]
+        if cand:
+            timed_only = max(cand, key=lambda k: warm_rep[k][1])
+    barrier()
+    eng.profile_reset()
+    eng.profile_only(timed_only)
+    eng.profile(with_timers)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    eng.profile_only(None)
+    elapsed = max_over_ranks(elapsed)
+    rep = eng.profile_report()
+    extra_rep, extra_steps = {}, 0
+    if timed_only is not None:
+        # the breakdown of the other kernels: a few more steps, untimed, every launch bracketed, with the clocks where the
+        # timed steps left them (the warm-up steps run 5-10 % slow and only chose the roofline kernel)
+        extra_steps = min(steps, 5)
+        eng.profile_reset()
+        eng.profile(True)
+        for _ in range(extra_steps):
+            job.step()
+        eng.sync()
+        eng.profile(False)
+        extra_rep = eng.profile_report()
+        barrier()
+    return elapsed, rep, timed_only, extra_rep, extra_steps
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,14 +429,21 @@ def main() -> int:
     ap.add_argument("--match-steps", type=int, default=2)
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-to-host drop-in timing (N = 1)")
+    ap.add_argument("--no-normals", action="store_true", help="skip the compute_normals line (N = 1)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling line (N > 1)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-rows", type=int, default=300)
+    ap.add_argument("--checksum", action="store_true",
+                    help="also report a partition-independent 64-bit fingerprint of the descriptor rows (N = 1: of the timed "
+                         "outputs; N > 1: of the strong-scaling outputs, the SAME cloud): equal values = bit-identical rows")
     ap.add_argument("--no-kernel-timers", action="store_true",
                     help="diagnostic: time the steps without the per-kernel HIP events (no roofline / kernels_ms_per_step then)")
     ap.add_argument("--oversubscribe", action="store_true",
-                    help="FUNCTIONAL TEST ONLY: allow more ranks than GPUs; the exchange is then staged through host memory "
-                         "and gloo (RCCL refuses two ranks on one device) and no timing is a scaling result")
+                    help="FUNCTIONAL TEST ONLY: allow more ranks than GPUs; every exchange is then staged through host memory "
+                         "and the control plane (RCCL refuses two ranks on one device) and no timing is a scaling result")
     ap.add_argument("--emulate-rank", type=int, default=None, metavar="R",
-                    help="single process, no rendezvous: run rank R's share of a --gpus N descriptor pass on this GPU")
+                    help="single process, no rendezvous: run rank R's share of a --gpus N descriptor pass on this GPU (the rows "
+                         "the adjacent ranks would send are computed once beforehand; the exchange call itself is skipped)")
     args = ap.parse_args()
 
     emulated = args.emulate_rank is not None
@@ -232,18 +469,16 @@ def main() -> int:
     if single and not args.no_cpu_baseline:  # (forks a Pool: must start before this process touches the GPU)
         shaped = finish_numpy_shaped_baseline(start_numpy_shaped_baseline(args.points_per_gpu, args.radius, args.cpu_sample))
 
-    dist = None
-    if world > 1 and not emulated:
-        import torch.distributed as dist  # control plane only: rendezvous, barrier, max-reduce of the timing
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctl = Control(rank, world) if world > 1 and not emulated else None
 
     import shot_fpfh_amd as s
     from shot_fpfh_amd import _ffi
+    from shot_fpfh_amd.engine import Spfh
     from shot_fpfh_amd.sharding import DescriptorJob, SubsetMatchJob
 
-    n_dev = max(_ffi.load().sf_device_count(), 1)
+    lib = _ffi.load()
+    build = lib.sf_version().decode()
+    n_dev = max(lib.sf_device_count(), 1)
     oversub = world > n_dev and not emulated
     if oversub and not args.oversubscribe:
         raise SystemExit(f"{world} ranks but {n_dev} GPU(s): one process per GPU is the only measured configuration "
@@ -252,51 +487,56 @@ def main() -> int:
     exchange = "none (descriptor pass only)"
     rccl_ranks = 0
 
-    def make_host_staged_allgather():
-        import torch
+    def stage_through_host(why: str) -> str:
+        """Every exchange through host memory and the control plane -- a functional stand-in, never a measurement."""
 
         def host_staged_allgather(buf, bytes_per_rank):
             flat = buf.to_host().reshape(-1).view(np.uint8)
-            mine = torch.from_numpy(flat[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy())
-            parts = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
+            parts = ctl.allgather(flat[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].tobytes())
+            flat[: world * bytes_per_rank] = np.frombuffer(b"".join(parts), dtype=np.uint8)
             buf.from_host(flat.view(buf.dtype).reshape(buf.shape))
 
-        return host_staged_allgather
+        def host_staged_rows(self, ops):
+            ops = list(ops)
+            mail = ctl.allgather({peer: self.rows_image(sb, se) for peer, sb, se, _, _ in ops if se > sb})
+            for peer, _, _, rb, re in ops:
+                if re > rb:
+                    self.set_rows_image(rb, re, mail[peer][rank])
+
+        def host_staged_min(buf, n=None):
+            flat = buf.to_host().reshape(-1)
+            n = flat.size if n is None else n
+            flat[:n] = np.min(np.stack(ctl.allgather(flat[:n].copy())), axis=0)
+            buf.from_host(flat.reshape(buf.shape))
+
+        eng.allgather = host_staged_allgather
+        eng.allreduce_min_u64 = host_staged_min
+        eng.collective_stats = lambda on: None  # (every rank sizes its table by its own lists: same storage on uniform clouds)
+        Spfh.exchange_rows = host_staged_rows
+        if args.spfh_exchange == "allgather":
+            raise SystemExit("the staged exchange supports the neighbor and halo SPFH modes only")
+        return f"control plane, staged through host memory -- {why}"
 
     if not emulated:
         if oversub:
-            exchange = "gloo, staged through host memory (oversubscribed functional test, NOT RCCL)"
-            eng.allgather = make_host_staged_allgather()
-            if args.spfh_exchange == "allgather":
-                raise SystemExit("--oversubscribe supports the halo SPFH exchange only")
+            exchange = stage_through_host("oversubscribed functional test, NOT RCCL")
         else:
-            # RCCL communicator -- one rank too, so that ncclAllGather really executes.  The descriptor pass (`value`)
-            # needs no collective; if the communicator cannot be built on this node the exchange phase still runs,
-            # staged through host memory, and the record says so instead of the whole bench dying.
+            # RCCL communicator -- one rank too, so that the collectives really execute.  If it cannot be built on this node
+            # the run still completes, staged through host memory, and the record says so instead of the whole bench dying.
             err = ""
             try:
-                ids = [eng.comm_unique_id() if rank == 0 else None]
-                if dist is not None:
-                    dist.broadcast_object_list(ids, src=0)
-                eng.comm_init(ids[0], world, rank)
+                uid = ctl.bcast(eng.comm_unique_id() if rank == 0 else None) if ctl else eng.comm_unique_id()
+                eng.comm_init(uid, world, rank)
             except Exception as exc:  # noqa: BLE001 -- reported in the record
                 err = f"{type(exc).__name__}: {exc}"
-            errs = [err]
-            if dist is not None:
-                errs = [None] * world
-                dist.all_gather_object(errs, err)
+            errs = ctl.allgather(err) if ctl else [err]
             if any(errs):
                 first = next(e for e in errs if e)
-                if dist is None:
+                if ctl is None:
                     raise SystemExit(f"RCCL communicator: {first}")
-                exchange = f"gloo, staged through host memory -- RCCL communicator failed ({first[:200]})"
-                eng.allgather = make_host_staged_allgather()
-                if args.spfh_exchange == "allgather":
-                    raise SystemExit("SPFH all-gather needs RCCL: " + first)
+                exchange = stage_through_host(f"RCCL communicator failed ({first[:200]})")
             else:
-                exchange = f"RCCL ncclAllGather over {world} rank(s)"
+                exchange = f"RCCL over {world} rank(s): ncclSend/ncclRecv (SPFH rows), ncclAllGather (descriptor rows)"
                 rccl_ranks = world
 
     n_total = args.points_per_gpu * world
@@ -308,66 +548,15 @@ def main() -> int:
 
     def barrier():
         eng.sync()
-        if dist is not None:
-            dist.barrier()
+        if ctl is not None:
+            ctl.barrier()
 
     def max_over_ranks(x: float) -> float:
-        if dist is None:
-            return x
-        import torch
-
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return x if ctl is None else ctl.max(x)
 
     # ---- timed region: K descriptor passes ---------------------------------------------------------------------------
-    # Two HIP event records per launch cost the step 1.6 % (4.55 against 4.48 ms), so the timed region brackets the roofline
-    # kernel only -- roofline.achieved is measured live over the timed launches, as the contract asks; which kernel that is
-    # comes from the warm-up steps (every launch bracketed; the first step, which grows the pools, left out when there are
-    # two or more), and the breakdown of the other kernels from a few untimed steps after the timed ones.
-    warm_rep, warm_steps = {}, 0
-    for w in range(args.warmup):
-        if w == min(1, args.warmup - 1):
-            eng.sync()
-            eng.profile_reset()
-            eng.profile(True)
-        job.step()
-        warm_steps += 1 if w >= min(1, args.warmup - 1) else 0
-    if args.warmup:
-        eng.sync()
-        eng.profile(False)
-        warm_rep = eng.profile_report()
-    timed_only = None
-    if warm_rep and not args.no_kernel_timers:
-        cand = [k for k, v in warm_rep.items() if k in ALG_BYTES and v[0] > 0 and v[1] > 0]
-        if cand:
-            timed_only = max(cand, key=lambda k: warm_rep[k][1])
-    barrier()
-    eng.profile_reset()
-    eng.profile_only(timed_only)
-    eng.profile(not args.no_kernel_timers)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    eng.profile(False)
-    eng.profile_only(None)
-    elapsed = max_over_ranks(elapsed)
-    rep = eng.profile_report()
-    if timed_only is not None:
-        # the breakdown of the other kernels: a few more steps, untimed, every launch bracketed, with the clocks where the
-        # timed steps left them (the warm-up steps run 5-10 % slow and only chose the roofline kernel)
-        warm_steps = min(args.steps, 5)
-        eng.profile_reset()
-        eng.profile(True)
-        for _ in range(warm_steps):
-            job.step()
-        eng.sync()
-        eng.profile(False)
-        warm_rep = eng.profile_report()
-        barrier()
-
+    elapsed, rep, timed_only, warm_rep, warm_steps = time_steps(job, eng, args.steps, args.warmup, barrier, max_over_ranks,
+                                                                not args.no_kernel_timers)
     kinds = (1 if job.do_fpfh else 0) + (1 if job.do_shot else 0)
     n_desc = kinds * n_total
     ms_per_step = 1000.0 * elapsed / args.steps
@@ -382,23 +571,43 @@ def main() -> int:
     if lead:
         kern = {k: (v[0], v[1] / max(v[0], 1)) for k, v in rep.items() if v[0] > 0 and v[1] > 0}
         per_step_ms = {k: rep[k][1] / args.steps for k in kern}
-        if timed_only is not None:  # the other kernels: from the instrumented warm-up steps
+        launches_per_step = {k: rep[k][0] / args.steps for k in kern}
+        if timed_only is not None:  # the other kernels: from the instrumented steps after the timed ones
             for k, v in warm_rep.items():
                 if k not in per_step_ms and v[0] > 0 and v[1] > 0:
                     per_step_ms[k] = v[1] / max(warm_steps, 1)
+                    launches_per_step[k] = v[0] / max(warm_steps, 1)
         dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: rep[k][1])
         launches, avg_ms = kern[dom]
         units = job.m  # descriptors of this rank's block per launch (halo SPFH rows are extra work, not counted)
-        alg_bytes = ALG_BYTES[dom] * units + (4 * job.last_pairs if dom == "k2_radius_fill" else 0)
+
+        def alg_bytes_of(k):
+            return ALG_BYTES[k] * units + (4 * job.last_pairs if k in PER_PAIR else 0)
+
+        alg_bytes = alg_bytes_of(dom)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic, traffic_src = tj.get(dom), tj.get("_source", "profiles/traffic.json")
-            except Exception:
-                traffic = None
+        tj, traffic_src = load_stamped("r03_traffic.json", build)
+        traffic = None if tj is None else tj.get(dom)
+        # ---- every kernel of the step against both HBM ceilings (per STEP: a kernel launched in pieces counts once) ------------
+        roof_all = {}
+        for k, ms in sorted(per_step_ms.items()):
+            if k not in ALG_BYTES or ms <= 0:
+                continue
+            gbs = alg_bytes_of(k) / (ms * 1e-3) / 1e9
+            roof_all[k] = {"algorithmic_bytes_per_step": alg_bytes_of(k), "ms_per_step": round(ms, 4),
+                           "launches_per_step": round(launches_per_step.get(k, 0), 2), "achieved_gbs": round(gbs, 1),
+                           "frac_of_8000": round(gbs / HBM_PEAK_GBS, 4), "frac_of_6290": round(gbs / HBM_COPY_GBS, 4),
+                           "hbm_bytes_measured": None if tj is None else tj.get(k)}
+        sq, sq_src = load_stamped("r03_k5_sq.json", build)
+        if sq is not None and "k5_shot" in roof_all:
+            # float64 issue ceiling: a wave's vector instructions occupy its SIMD for SQ_ACTIVE_INST_VALU quad-cycles (x 4
+            # cycles); one keypoint = one wave; 256 CUs x 4 SIMDs share the keypoints
+            cyc = sq["SQ_ACTIVE_INST_VALU_per_wave"] * 4.0
+            ceiling_ms = units * cyc / (256 * 4) / (sq["clock_mhz"] * 1e3)
+            roof_all["k5_shot"]["valu_issue"] = {
+                "vector_instructions_per_keypoint": sq["SQ_INSTS_VALU_per_wave"], "busy_cycles_per_keypoint": cyc,
+                "simds": 1024, "clock_mhz": sq["clock_mhz"], "ceiling_ms": round(ceiling_ms, 4),
+                "frac_of_ceiling": round(ceiling_ms / roof_all["k5_shot"]["ms_per_step"], 4), "source": sq_src}
         out = {
             "metric": "descriptors/sec (SHOT+FPFH) on 1M-pt cloud",
             "value": value,
@@ -417,9 +626,11 @@ def main() -> int:
                 f"keypoints, radius {radius:.5f}, {'FPFH(5 bins)' if job.do_fpfh else ''}"
                 f"{'+' if kinds == 2 else ''}{'SHOT(352, normalize, min_nb 10)' if job.do_shot else ''}, "
                 f"mean neighbourhood {job.last_pairs / max(job.plan.end - job.plan.begin, 1):.1f}",
-                "sharding": f"query blocks over {world} GPU(s), cloud replicated, SPFH {args.spfh_exchange}",
+                "sharding": f"query blocks over {world} GPU(s), cloud replicated, SPFH {args.spfh_exchange}"
+                + (f" -- EMULATED: rank {rank} of {world} alone on one GPU, the exchange call skipped (c_exchange not in the step)" if emulated else ""),
                 "points_per_gpu": args.points_per_gpu,
                 "exchange": exchange,
+                "library": build,
             },
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step_ms.items())},
             "kernels_ms_per_step_source": "HIP events around every launch of the timed steps" if timed_only is None else
@@ -432,15 +643,16 @@ def main() -> int:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
                 "traffic": traffic,
-                "traffic_source": None if traffic is None else
-                f"NOT measured in this run: per-launch HBM bytes from separate rocprofv3 --pmc passes of this command, {traffic_src}",
+                "traffic_source": traffic_src if traffic is None else
+                f"per-launch HBM bytes from separate rocprofv3 --pmc passes on THIS build ({build}), {traffic_src}",
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": ("the kernel is float64-VALU-issue bound, not HBM bound: 783 vector instructions per keypoint at ~95 % "
-                         "issue (SQ counters, profiles/r02_k5.md); the HBM fraction is reported because the contract asks for it")
-                if dom == "k5_shot" else None,
+                "note": ("the kernel is float64-VALU-issue bound, not HBM bound (roofline_all.k5_shot.valu_issue); the HBM fraction is "
+                         "reported because the contract asks for it") if dom == "k5_shot" else None,
             },
+            "roofline_all": roof_all,
             "whole_step_hbm": {"algorithmic_bytes": sum(ALG_BYTES[k] for k in ("k6_spfh", "k7_fpfh", "k5_shot")) * units,
                                "achieved_gbs": sum(ALG_BYTES[k] for k in ("k6_spfh", "k7_fpfh", "k5_shot")) * units / (ms_per_step * 1e-3) / 1e9}
             if kinds == 2 else None,
@@ -448,13 +660,39 @@ def main() -> int:
 
     # ---- parity of what the timed steps left in HBM ------------------------------------------------------------------
     if not args.no_parity:
-        par = parity_sample(job, points, normals, radius)
-        if dist is not None:
-            allp = [None] * world
-            dist.all_gather_object(allp, par)
+        par = parity_sample(job, points, normals, radius, args.parity_rows)
+        if ctl is not None:
+            allp = ctl.allgather(par)
             par = {"per_rank": allp, "ok": all(p["ok"] for p in allp)}
         if lead:
             out["parity"] = par
+    if args.checksum and single:
+        out["checksum"] = fold_checksums([rows_checksum(job)])
+
+    # ---- strong scaling: the metric's own 1M-point cloud cut over the N ranks (secondary; `value` stays weak) ---------------
+    if world > 1 and not args.no_strong and kinds == 2:
+        sp_pts, sp_nrm = make_cloud(args.points_per_gpu, 3)
+        sjob = DescriptorJob(eng, sp_pts, sp_nrm, args.radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world,
+                             rank=rank, spfh_exchange=args.spfh_exchange, emulate_peers=emulated)
+        s_elapsed, _, _, _, _ = time_steps(sjob, eng, args.steps, min(args.warmup, 3), barrier, max_over_ranks, False)
+        spar = None if args.no_parity else parity_sample(sjob, sp_pts, sp_nrm, args.radius, min(args.parity_rows, 100))
+        if ctl is not None and spar is not None:
+            spar = {"ok": all(p["ok"] for p in ctl.allgather(spar))}
+        ssum = None
+        if args.checksum and not emulated:
+            mine = rows_checksum(sjob)
+            ssum = fold_checksums(ctl.allgather(mine) if ctl is not None else [mine])
+        sjob.close()
+        if lead:
+            out["strong_scaling"] = {
+                "what": f"the {args.points_per_gpu}-point cloud of N = 1 (radius {args.radius}) cut into {world} blocks of "
+                        f"{-(-args.points_per_gpu // world)} keypoints: total work fixed",
+                "ms_per_step": 1000.0 * s_elapsed / args.steps,
+                "value": 2 * args.points_per_gpu / (s_elapsed / args.steps), "unit": "descriptors/s",
+                "speedup_vs_n1_needs": "the N = 1 line of the same build (ms_per_step there / ms_per_step here)",
+                "parity_ok": None if spar is None else spar["ok"],
+                "checksum": ssum,
+            }
 
     # ---- config 5's tail: partner cloud, subset, RCCL all-gather, sharded K8 ------------------------------------------
     if not args.no_match and job.do_shot and not emulated:
@@ -487,12 +725,8 @@ def main() -> int:
         mrep = eng.profile_report()
         s_lab, r_lab = sub.matches()
         stats = np.array([float((s_lab == r_lab).sum()), float(s_lab.size)])
-        if dist is not None:
-            import torch
-
-            tt = torch.from_numpy(stats)
-            dist.all_reduce(tt)
-            stats = tt.numpy()
+        if ctl is not None:
+            stats = np.sum(np.stack(ctl.allgather(stats)), axis=0)
         # the (scan, reference) pairs of every rank on every rank (one more small all-gather), then the registration
         # they are for: RANSAC over the WHOLE match set, scored on this rank's GPU (K9)
         t0 = time.perf_counter()
@@ -575,6 +809,65 @@ def main() -> int:
                 "translation_err": float(np.abs(tf.translation - np.asarray(C4_T)).max()),
             }
 
+    # ---- compute_normals(radius) on the same cloud (N = 1): K2 + K3, SURVEY 8d "timed as its own line" -------------------------
+    if single and not args.no_normals and not emulated:
+        from shot_fpfh_amd.descriptors import compute_normals
+
+        ncloud = eng.cloud(points)  # (no normals: that is what is being computed)
+        nout = eng.empty((n_total, 3))
+        reps = 5
+
+        def normals_pass():
+            ncloud.build_grid(radius)
+            nb = ncloud.radius_search_self(radius)
+            nb.normals(out=nout)
+            nb.free()
+
+        normals_pass()
+        eng.sync()
+        eng.profile_reset()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            normals_pass()
+        eng.sync()
+        t_n = (time.perf_counter() - t0) / reps
+        eng.profile(False)
+        nrep = {k: v[1] / reps for k, v in eng.profile_report().items() if v[1] > 0}
+        k3 = nrep.get("k3_normals", 0.0)
+        # parity of the resident result: a sample against the oracle, up to the sign LAPACK leaves open
+        from oracle import oracle as O
+
+        pick = np.sort(np.random.default_rng(6).choice(n_total, 200, replace=False))
+        # (rows are in cell-sorted order: map the sample through the inverse permutation)
+        perm = ncloud.perm().astype(np.int64)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(perm.size)
+        got = np.stack([nout.rows_to_host(int(i), 1)[0] for i in inv[pick]])
+        want = O.compute_normals(points[pick], points, radius=radius)
+        nerr = float(np.minimum(np.abs(got - want).max(axis=1), np.abs(got + want).max(axis=1)).max())
+        ncloud.free()
+        nout.free()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            compute_normals(points, points, radius=radius)
+            ts.append(time.perf_counter() - t0)
+        out["normals"] = {
+            "what": f"compute_normals(query_points = cloud_points = the {n_total}-point cloud, radius={radius}) "
+                    "(pca_based_descriptors.py:29-59): K1 + K2 + K3, result resident / host to host",
+            "resident_ms_per_pass": 1000.0 * t_n, "normals_per_s_resident": n_total / t_n,
+            "kernels_ms_per_pass": {k: round(v, 4) for k, v in sorted(nrep.items())},
+            "k3_roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": ALG_BYTES["k3_normals"] * n_total, "avg_launch_ms": k3,
+                            "achieved_gbs": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 if k3 > 0 else None,
+                            "frac_of_8000": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS if k3 > 0 else None,
+                            "frac_of_6290": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 / HBM_COPY_GBS if k3 > 0 else None,
+                            "note": "48 B per query are compulsory; the kernel gathers ~110 neighbours x 24 B per query through L2 and "
+                                    "solves a 3x3 eigenproblem per lane: latency / VALU bound (DESIGN kernel table)"},
+            "host_to_host_s": min(ts), "normals_per_s_host_to_host": n_total / min(ts),
+            "parity_max_abs_err_up_to_sign": nerr, "parity_rows": int(pick.size), "parity_ok": bool(nerr <= 1e-5),
+        }
+
     # ---- the drop-in calls, host to host (N = 1) ---------------------------------------------------------------------------
     if single and not args.no_dropin and not emulated:
         from shot_fpfh_amd.descriptors import ShotMultiprocessor, compute_fpfh_descriptor
@@ -615,9 +908,9 @@ def main() -> int:
             out["speedup_vs_c_port"] = value / out["cpu_baseline_c_port"]["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctl is not None:
+        ctl.barrier()
+        ctl.close()
     return 0
 
 

@@ -12,7 +12,10 @@ void sf_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *sf_last_error(void) { return g_err; }
-extern "C" const char *sf_version(void) { return "shotfpfh-gfx950 0.1"; }
+#ifndef SF_BUILD_ID
+#define SF_BUILD_ID "unknown"
+#endif
+extern "C" const char *sf_version(void) { return "shotfpfh-gfx950 0.3 build " SF_BUILD_ID; }
 
 extern "C" int sf_device_count(void)
 {

@@ -524,7 +524,13 @@ class Neighbors:
         return np.diff(off)
 
     # ---- descriptors on these lists ---------------------------------------------------------------
-    def normals(self, pre_computed_normals=None) -> np.ndarray:
+    def normals(self, pre_computed_normals=None, out: Optional[DeviceArray] = None):
+        """K3.  out ((m, 3) device array): the normals stay in HBM (no pre_computed_normals then)."""
+        if out is not None:
+            if pre_computed_normals is not None:
+                raise ValueError("device-resident output takes no pre_computed_normals")
+            _ffi.check(self.engine.lib.sf_normals(self.engine.h, self.cloud.h, self.h, None, out.ptr, SF_OUT_DEVICE), "sf_normals")
+            return out
         pre = None if pre_computed_normals is None else _f64(pre_computed_normals, 3)
         if pre is not None and pre.shape[0] != self.m:
             raise ValueError("pre_computed_normals must have one row per query point")

@@ -257,3 +257,54 @@ def test_pinned_output_pool_reuses_blocks_after_garbage_collection():
     del b, c
     gc.collect()
     assert sorted(lib.frees) == sorted(lib.allocs)  # after drain(), returning blocks are unpinned at once
+
+
+# ---- bench.py's control plane (sockets + pickle; no torch) ---------------------------------------------------------------
+_CTL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+c = bench.Control(rank, world, timeout=60)
+got = c.allgather({"rank": rank, "blob": bytes([rank]) * (300000 + rank)})
+assert [g["rank"] for g in got] == list(range(world)) and all(len(g["blob"]) == 300000 + r for r, g in enumerate(got))
+assert c.max(float(rank)) == world - 1
+assert c.bcast("id" if rank == 0 else None) == "id"
+c.barrier()
+c.close()
+"""
+
+
+@pytest.mark.parametrize("under_launcher", [False, True])
+def test_bench_control_plane_rendezvous_allgather_max_bcast(tmp_path, under_launcher):
+    """Three ranks over bench.Control.  under_launcher: MASTER_PORT is taken by somebody else's listener (torchrun's store
+    in real life) that never sends the greeting -- the ranks must meet on a neighbouring port."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    blocker = socket.socket()
+    blocker.bind(("127.0.0.1", 0))
+    port = blocker.getsockname()[1]
+    if under_launcher:
+        blocker.listen(8)
+    else:
+        blocker.close()
+    script = tmp_path / "w.py"
+    script.write_text(_CTL_WORKER)
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if not under_launcher:
+            env["SF_BENCH_SELF_SPAWNED"] = "1"
+        else:
+            env.pop("SF_BENCH_SELF_SPAWNED", None)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env))
+    try:
+        for p in procs:
+            assert p.wait(timeout=120) == 0
+    finally:
+        blocker.close()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile_gpu.sh run (rocprofv3 CSVs under gpurun_out/prof_<tag>/) into
-profiles/<tag>_summary.md and profiles/traffic.json (HBM bytes per launch of each hot kernel).
+profiles/<tag>_summary.md and profiles/r03_traffic.json (HBM bytes per launch of each hot kernel, stamped with the
+library's build id so that bench.py never quotes it for another build).
 
 HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are collected in SEPARATE --pmc passes, are reported in KiB, and on gfx950 FETCH_SIZE counts
@@ -26,7 +27,7 @@ SHORT = [
     ("k_half_window", "k8_half_window"), ("k_half_max", "k8_half_max"), ("k_match_gemm", "k8_match_gemm"),
     ("k_match_decide", "k8_match_decide"), ("k_row_sqnorm", "k8_row_sqnorm"),
     ("k_gather_sorted", "k1_gather_sorted"), ("k_gather_normals", "k1_gather_normals"), ("k_count_stats", "k2_reduce"),
-    ("k_layer_hist", "k1_layer_hist"), ("k_gather_i32", "k1_select_slab"), ("k_lrf_eigen", "k4_lrf_eigen"), ("k_pca", "k3_pca"), ("k_cell_ids", "k1_cell_ids"), ("k_cell_start", "k1_cell_start"),
+    ("k_layer_hist", "k1_layer_hist"), ("k_select_slab", "k1_select_slab"), ("k_extract_z", "k1_extract_z"), ("k_col_candidates", "k8_col_candidates"), ("k_lrf_eigen", "k4_lrf_eigen"), ("k_pca", "k3_pca"), ("k_cell_ids", "k1_cell_ids"), ("k_cell_start", "k1_cell_start"),
     ("k_bbox", "k1_bbox"), ("radix_sort", "rocprim_radix_sort"), ("merge_sort", "rocprim_radix_sort"),
     ("scan", "rocprim_scan"), ("reduce", "rocprim_reduce"), ("copyBuffer", "hip_copy"), ("fillBuffer", "hip_fill"),
 ]
@@ -87,8 +88,13 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     if bench_run:
+        # stamped with the build id of the library the counters were taken on: bench.py quotes the file for that build only
+        sys.path.insert(0, ROOT)
+        from shot_fpfh_amd import _ffi
+
+        traffic["_build"] = _ffi.load().sf_version().decode()
         traffic["_source"] = f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{cmd}`)"
-        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", "r03_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
