@@ -195,12 +195,14 @@ def test_config_c4_full_size_chain_with_cpu_checked_match_rows(eng, O):
     inv = np.empty(n, np.int64)
     inv[perm] = np.arange(n)
     correct = float((ri == inv[si]).mean())
-    assert correct > 0.85, correct
+    # the seeded, measured level (profiles/r02_config4.txt: 92.5 %; the REFERENCE itself recovers 93.9 % of a rigidly moved
+    # 6 000-point copy, tests/golden/c4_pair_6k.npz: frames whose sign votes tie keep LAPACK's sign, shot.py:40-45)
+    assert abs(correct - 0.925) <= 0.005, correct
     R.rng = np.random.default_rng(seed=72)
     ratio, tf = R.ransac_on_matches(si, ri, scan, ref, n_draws=10000, draw_size=4, distance_threshold=0.01,
                                     disable_progress_bar=True)
     assert abs(ratio - correct) < 0.02  # inliers are the correct matches (wrong ones land far away)
-    assert np.abs(tf.rotation - rot).max() < 5e-3 and np.abs(tf.translation - t).max() < 5e-3
+    assert np.abs(tf.rotation - rot).max() <= 1e-9 and np.abs(tf.translation - t).max() <= 1e-9
     # the winning draw's inlier count equals the NumPy expression of ransac.py:60-67 for that transform
     best_inl = (np.linalg.norm((scan[si] @ tf.rotation.T + tf.translation) - ref[ri], axis=1) <= 0.01).sum()
     assert abs(best_inl / si.size - ratio) < 1e-3
