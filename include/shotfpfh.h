@@ -46,7 +46,8 @@ extern "C" {
 
 #define SF_SHOT_LEN 352 /* 11 cosine x 8 azimuth x 2 elevation x 2 radial bins (shot.py:195) */
 #define SF_FAST_FPFH_BINS 8 /* n_bins up to here: LDS-histogram K6 and the matrix-core / streaming K7 */
-#define SF_MAX_FPFH_BINS 32 /* any n_bins up to here (the reference takes any, fpfh.py:16): generic K6 / K7, 32-bit counts */
+#define SF_MAX_FPFH_BINS 1290 /* n_bins^3 must fit an int; the reference takes any n_bins (fpfh.py:16).  What bounds n_bins in
+                                practice is the table of n x n_bins^3 32-bit counts in HBM (the reference holds twice that in host RAM) */
 
 typedef struct sf_ctx sf_ctx;     /* one GPU: device id, stream, scratch, optional RCCL comm  */
 typedef struct sf_cloud sf_cloud; /* resident point cloud + uniform grid (replaces KDTree(X))  */
@@ -128,7 +129,8 @@ sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, i
                           int flags);
 sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *cloud, double radius, int64_t begin, int64_t end);
 /* k nearest neighbours: replaces KDTree.query(Q, k=k, return_distance=False) (pca_based_descriptors.py:46).
- * Every list has exactly k entries, nearest first (ties: lower cell-sorted position).  1 <= k <= min(n, 1984). */
+ * Every list has exactly k entries, nearest first (ties: lower cell-sorted position).  1 <= k <= n (k <= 1984: the k best
+ * are kept in LDS during one sweep; beyond: count / fill / segmented sort through global memory). */
 sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, int k, int flags);
 /* non-owning view of queries [first, first+count) of `nbrs` (free it before the parent) */
 sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nbrs, int64_t first, int64_t count);
@@ -238,10 +240,12 @@ int sf_match_argmin(sf_ctx *ctx, const double *a, int64_t m1, const double *b, i
  * dist(i,j) = min over scales of (a_ok && b_ok ? euclidean distance : max_val); idx = first arg-min over j. */
 /* mask_dev[i] = 1 when row i of the device matrix rows_dev (m x d) has a non-zero entry (np.any(desc, axis=1)). */
 int sf_rows_nonzero(sf_ctx *ctx, const double *rows_dev, int64_t m, int64_t d, unsigned char *mask_dev);
-/* out_dev row i = rows_dev row sel_dev[i] (m x d, all device memory), or a zero row where sel_dev[i] < 0: selects a
+/* out_dev row i = row sel_dev[i] of rows_dev (n_rows x d; all device memory), or a zero row where sel_dev[i] < 0: selects a
  * keypoint subset of a resident descriptor matrix, padded to the equal per-rank block an all-gather needs (zero rows are
- * skipped by the matching, matching.py:162-163). */
-int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, const int64_t *sel_dev, int64_t m, int64_t d, double *out_dev);
+ * skipped by the matching, matching.py:162-163).  A selection >= n_rows is never dereferenced: its row comes out zero and
+ * the next synchronising call on the context (sf_sync, sf_d2h) returns SF_ERR_ARG. */
+int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, int64_t n_rows, const int64_t *sel_dev, int64_t m, int64_t d,
+                   double *out_dev);
 /* flags: SF_HOST, or SF_IN_DEVICE | SF_OUT_DEVICE with every pointer (masks included) on the device -- the form
  * the sharded matching uses with n_scales = 1 and max_val = +inf to skip all-zero descriptors in place. */
 int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1, int64_t m2,

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libshotfpfh.so")
 
 SF_HOST, SF_OUT_DEVICE, SF_IN_DEVICE = 0, 1, 2
 SHOT_LEN = 352
-MAX_FPFH_BINS = 32  # SF_MAX_FPFH_BINS (n_bins above 8 take the generic kernels)
+MAX_FPFH_BINS = 1290  # SF_MAX_FPFH_BINS: n_bins^3 fits an int (n_bins above 8 take the generic kernels; memory is the real bound)
 
 
 class ShotFpfhError(RuntimeError):
@@ -82,7 +82,7 @@ SIGNATURES = {
     "sf_fpfh": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _int]),
     "sf_match_argmin": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int]),
     "sf_rows_nonzero": (_int, [_vp, _vp, _i64, _i64, _vp]),
-    "sf_rows_gather": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "sf_rows_gather": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "sf_match_argmin_multiscale": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _f64, _vp, _vp, _int]),
     "sf_match_col_candidates": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "sf_ransac_score": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _int]),

@@ -64,6 +64,10 @@ struct sf_ctx {
     // page-locked host words for the few scalars a step reads back (bounding box, list statistics): a copy into
     // pageable memory is staged and costs tens of microseconds of idle GPU each time
     void *pinned = nullptr; // SF_PINNED_BYTES
+    // one page-locked, device-visible word that kernels set when an index array handed in by the caller (a row selection,
+    // a visiting order) holds a value out of range -- such an element is skipped, never dereferenced.  The host looks at
+    // the word after every synchronisation it makes anyway (sf_ctx_check_flag) and turns it into SF_ERR_ARG.
+    volatile int *dev_flag = nullptr;
     // stream-ordered caching allocator: freed blocks are reused by later launches on the SAME stream,
     // so neither hipMalloc nor the implicit device sync of hipFree sits inside a step of the path
     std::multimap<size_t, void *> pool_free;
@@ -113,6 +117,9 @@ struct sf_pool_guard {
 
 int sf_comm_allreduce_max_i32(sf_ctx *ctx, const int *send, int *recv, size_t n); // comm.hip
 int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out);
+#define SF_FLAG_ROWS_GATHER 1
+#define SF_FLAG_VOXEL_ORDER 2
+int sf_ctx_check_flag(sf_ctx *ctx); // after a stream synchronisation: SF_OK, or SF_ERR_ARG with the message of the raised bit(s)
 #define SF_PINNED_BYTES 4096
 int sf_ctx_pinned(sf_ctx *ctx, void **out);
 hipEvent_t sf_ctx_event(sf_ctx *ctx);

@@ -54,7 +54,26 @@ extern "C" sf_ctx *sf_create(int device)
         return nullptr;
     }
     ctx->stream = ctx->streams[0];
+    void *flag = nullptr;
+    if (hipHostMalloc(&flag, 64, hipHostMallocMapped) != hipSuccess) {
+        sf_set_error("hipHostMalloc failed");
+        delete ctx;
+        return nullptr;
+    }
+    memset(flag, 0, 64);
+    ctx->dev_flag = (volatile int *)flag;
     return ctx;
+}
+
+int sf_ctx_check_flag(sf_ctx *ctx)
+{
+    if (!ctx->dev_flag || !*ctx->dev_flag) return SF_OK;
+    const int bits = *ctx->dev_flag;
+    *ctx->dev_flag = 0;
+    sf_set_error("an index array passed to the library holds values out of range:%s%s (the offending elements were skipped)",
+                 bits & SF_FLAG_ROWS_GATHER ? " sf_rows_gather's row selection" : "",
+                 bits & SF_FLAG_VOXEL_ORDER ? " sf_voxels_select's visiting order" : "");
+    return SF_ERR_ARG;
 }
 
 extern "C" void sf_destroy(sf_ctx *ctx)
@@ -73,6 +92,7 @@ extern "C" void sf_destroy(sf_ctx *ctx)
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->dev_flag) (void)hipHostFree((void *)ctx->dev_flag);
     sf_pool_trim(ctx);
     for (auto &kv : ctx->pool_size) (void)hipFree(kv.first); // blocks still held by live handles
     (void)hipEventDestroy(ctx->join_event);
@@ -86,7 +106,7 @@ extern "C" int sf_sync(sf_ctx *ctx)
     if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
     SF_HIP(hipStreamSynchronize(ctx->streams[0]));
     SF_HIP(hipStreamSynchronize(ctx->streams[1]));
-    return SF_OK;
+    return sf_ctx_check_flag(ctx);
 }
 
 // Two streams per context let independent stages of the path (the FPFH chain K6 -> K7 and the SHOT chain
@@ -176,7 +196,7 @@ extern "C" int sf_d2h(sf_ctx *ctx, void *dst, const void *src, size_t bytes)
     if (!bytes) return SF_OK;
     SF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    return SF_OK;
+    return sf_ctx_check_flag(ctx);
 }
 
 extern "C" int sf_d2d(sf_ctx *ctx, void *dst, const void *src, size_t bytes)

@@ -890,8 +890,9 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // Election and accumulation.  sA (352 slots) first elects the writers of S2+S5+S8+S10 by rho, then becomes the
     // ACCUMULATOR of the row: its winners store their (negated) value, and every other statement's winner adds its own
     // (negated) value to the bin it feeds with an LDS float64 atomic add -- the LDS pipe does the additions, the bins are
-    // never assembled by the vector ALU.  A workgroup is ONE wave, whose LDS instructions execute in program order, so
-    // the order of the additions into a bin -- hence every bit of the row -- is the same in every run.
+    // never assembled by the vector ALU.  Every wave of the workgroup (SF_SHOT_WPB of them, one keypoint each) works in its
+    // OWN LDS region and never waits for another; a wave's LDS instructions execute in program order, so the order of the
+    // additions into a bin -- hence every bit of the row -- is the same in every run, whatever the workgroup size.
     // S3/S4 and S6/S7 need no election of their own: their writer is the farthest neighbour of a cell (cosine, azimuth,
     // half-space) over BOTH radial shells, resp. of a cell (cosine, azimuth, shell) over both half-spaces -- i.e. the
     // farther of the two S2 winners of bins base ^ 1, resp. base ^ 2.  Those two keys are read back after the election,

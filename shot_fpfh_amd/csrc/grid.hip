@@ -338,15 +338,15 @@ int sf_cloud_normals_max2(sf_ctx *ctx, sf_cloud *c, double *out)
 {
     if (!c->nrm_orig) { sf_set_error("this operation needs normals, but the cloud has none"); return SF_ERR_STATE; }
     if (c->nrm_max2 < 0.0) {
+        sf_pool_guard tmp(ctx); // (the block goes back to the pool on every exit)
         unsigned long long *d = nullptr;
         void *pin = nullptr;
-        SF_CHECK(sf_palloc(ctx, &d, (size_t)1));
+        SF_CHECK(tmp.alloc(&d, (size_t)1));
         SF_CHECK(sf_ctx_pinned(ctx, &pin));
         SF_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
         if (c->n) SF_LAUNCH(ctx, "k1_normals_max", k_normals_max2, dim3(512), dim3(256), (const double *)c->nrm_orig, c->n, d);
         SF_HIP(hipMemcpyAsync(pin, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
-        sf_pool_release(ctx, d);
         long long bits = *(const long long *)pin;
         double v;
         static_assert(sizeof(v) == sizeof(bits), "");

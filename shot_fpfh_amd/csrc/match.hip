@@ -142,13 +142,19 @@ __global__ __launch_bounds__(256) void k_rows_nonzero(const double *__restrict__
 
 // dst row i = src row sel[i], or a zero row when sel[i] < 0 (the padding of an equal-sized per-rank block): picks the
 // descriptors of a keypoint subset out of a resident descriptor matrix before the exchange that precedes K8
-__global__ __launch_bounds__(256) void k_rows_gather(const double *__restrict__ src, const int64_t *__restrict__ sel,
-                                                     int64_t m, int64_t d, double *__restrict__ dst)
+// (a selection >= n_rows is the caller's mistake: the row comes out zero and the context's flag is raised, see common.h)
+__global__ __launch_bounds__(256) void k_rows_gather(const double *__restrict__ src, int64_t n_rows,
+                                                     const int64_t *__restrict__ sel, int64_t m, int64_t d,
+                                                     double *__restrict__ dst, volatile int *__restrict__ flag)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= m) return;
-    const int64_t r = sel[i];
+    int64_t r = sel[i];
+    if (r >= n_rows) {
+        if (lane == 0) *flag = SF_FLAG_ROWS_GATHER;
+        r = -1;
+    }
     for (int64_t t = lane; t < d; t += 64) dst[i * d + t] = r < 0 ? 0.0 : src[r * d + t];
 }
 
@@ -325,14 +331,14 @@ extern "C" int sf_rows_nonzero(sf_ctx *ctx, const double *rows_dev, int64_t m, i
     return SF_OK;
 }
 
-extern "C" int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, const int64_t *sel_dev, int64_t m, int64_t d,
+extern "C" int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, int64_t n_rows, const int64_t *sel_dev, int64_t m, int64_t d,
                               double *out_dev)
 {
-    if (!ctx || !rows_dev || !sel_dev || !out_dev || m < 0 || d <= 0) { sf_set_error("sf_rows_gather: bad argument"); return SF_ERR_ARG; }
+    if (!ctx || !rows_dev || !sel_dev || !out_dev || m < 0 || d <= 0 || n_rows < 0) { sf_set_error("sf_rows_gather: bad argument"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
     if (m) {
-        SF_LAUNCH(ctx, "k8_rows_gather", k_rows_gather, dim3((unsigned)sf_div_up(m, 4)), dim3(256), rows_dev, sel_dev, m, d,
-                  out_dev);
+        SF_LAUNCH(ctx, "k8_rows_gather", k_rows_gather, dim3((unsigned)sf_div_up(m, 4)), dim3(256), rows_dev, n_rows, sel_dev, m, d,
+                  out_dev, ctx->dev_flag);
     }
     return SF_OK;
 }

@@ -10,6 +10,7 @@
 // Output: CSR in HBM -- int32 sorted positions, int64 offsets -- consumed by K3..K7.
 // Roofline: HBM/L2 bound integer+compare work; algorithmic bytes = 24 B per query in + 4 B per pair out.
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -111,19 +112,27 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
         // its x lies within w = sqrt(r^2 - dy^2 - dz^2) of the query's: only the FINE x cells (xsub per edge) that
         // [px - w, px + w] touches are swept, 12-14 edge-lengths of cells per query instead of 27.  The cell of a
         // coordinate is a monotone function of it, so every point with px - w <= x <= px + w lies in a cell between
-        // the cells of the two ends; the gaps shrink and w grows by 1e-9 relative, far above any rounding of the
-        // band edges, so the sweep can only be wider than necessary, never narrower.
-        const double slack = 1e-9 * g.cell;
-        const double by0 = g.lo[1] + (double)cy * g.cell, bz0 = g.lo[2] + (double)cz * g.cell;
-        const double dy = fmax(fmax(by0 - pyv, pyv - (by0 + g.cell)) - slack, 0.0);
-        const double dz = fmax(fmax(bz0 - pzv, pzv - (bz0 + g.cell)) - slack, 0.0);
+        // the cells of the two ends; the gaps shrink and w grows by a slack that is far above any rounding involved (next
+        // paragraph), so the sweep can only be wider than necessary, never narrower.
+        // All of it in GRID-RELATIVE coordinates (p - lo, what the cell assignment itself uses): the rounding of a relative
+        // coordinate, of a band edge c * cell and of fl(1 / cell) is a few ulps of the grid's EXTENT, whereas band edges
+        // and px +- w formed in absolute coordinates would round by ulps of |lo| and |p| -- for a cloud in UTM-like
+        // coordinates (1e6 .. 1e7 with a cell of 1e-2) far more than any fixed fraction of the cell.  `slack` covers both: 1e-9
+        // of the cell plus 1e-15 of the relative coordinates involved.
+        const double pxr = pxv - g.lo[0], pyr = pyv - g.lo[1], pzr = pzv - g.lo[2];
+        const double by0 = (double)cy * g.cell, bz0 = (double)cz * g.cell;
+        const double slack_y = 1e-9 * g.cell + 1e-15 * (fabs(pyr) + by0 + g.cell);
+        const double slack_z = 1e-9 * g.cell + 1e-15 * (fabs(pzr) + bz0 + g.cell);
+        const double dy = fmax(fmax(by0 - pyr, pyr - (by0 + g.cell)) - slack_y, 0.0);
+        const double dz = fmax(fmax(bz0 - pzr, pzr - (bz0 + g.cell)) - slack_z, 0.0);
         const double w2 = (r2 * (1.0 + 1e-9) - dy * dy) - dz * dz;
         ok = ok && w2 >= 0.0;
-        const double w = sf_sqrt_fast(fmax(w2, 0.0)) * (1.0 + 1e-9) + slack;
+        const double w = sf_sqrt_fast(fmax(w2, 0.0)) * (1.0 + 1e-9) + 1e-9 * g.cell +
+                         1e-15 * (fabs(pxr) + (double)g.dim[0] * (g.cell / (double)g.xsub));
         int s = 0, e = 0;
         if (sl < 9) {
-            s = cell_start[row + sf_cell_coord(pxv - w, g.lo[0], g.inv_cell_x, g.dim[0])];
-            e = cell_start[row + sf_cell_coord(pxv + w, g.lo[0], g.inv_cell_x, g.dim[0]) + 1];
+            s = cell_start[row + sf_cell_coord(pxr - w, 0.0, g.inv_cell_x, g.dim[0])];
+            e = cell_start[row + sf_cell_coord(pxr + w, 0.0, g.inv_cell_x, g.dim[0]) + 1];
         }
         if (!ok) { s = 0; e = 0; }
         const int base = s & ~1; // pairs start at an EVEN position: every 16-byte load is naturally aligned
@@ -357,6 +366,87 @@ __global__ void k_knn_fill_csr(int64_t m, int k, int32_t *__restrict__ count, in
     if (i > m) return;
     if (i < m) count[i] = k;
     offset[i] = i * (int64_t)k;
+}
+
+// ---- k above the LDS buffer of k_knn (k > 1984): count, fill, sort ------------------------------------------------------
+// Same stencil sweep.  k_knn_sweep<false> counts the points within R of each selected query; k_knn_sweep<true> writes
+// (d2, position) of those points to the query's segment of a global list -- in scan order, which IS ascending position
+// (rows of cells are visited in cell order).  A segmented radix sort on d2 and k_knn_take (ties on d2: lower position
+// first, whatever the sort did with them) then leave the k nearest, nearest first: KDTree.query's answer for any k <= n.
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_knn_sweep(sf_grid_desc g, const int32_t *__restrict__ cell_start,
+                                                  const double *__restrict__ xs, const double *__restrict__ ys,
+                                                  const double *__restrict__ zs, const double *__restrict__ qx,
+                                                  const double *__restrict__ qy, const double *__restrict__ qz,
+                                                  const int32_t *__restrict__ qsel, int64_t msel, double R2,
+                                                  int32_t *__restrict__ count, const int64_t *__restrict__ seg,
+                                                  double *__restrict__ d2_out, int32_t *__restrict__ pos_out)
+{
+    const int lane = threadIdx.x;
+    const int64_t slot = sf_xcd_block();
+    if (slot >= msel) return;
+    const int64_t q = qsel ? qsel[slot] : slot;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    int x0, x1, y0, y1, z0, z1;
+    stencil_bounds(px, g.lo[0], g.inv_cell, g.dim[0] / g.xsub, x0, x1);
+    x0 *= g.xsub;
+    x1 = x1 * g.xsub + (g.xsub - 1);
+    stencil_bounds(py, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
+    stencil_bounds(pz, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
+    x0 = sf_uniform(x0); x1 = sf_uniform(x1);
+    y0 = sf_uniform(y0); y1 = sf_uniform(y1);
+    z0 = sf_uniform(z0); z1 = sf_uniform(z1);
+    int64_t at = FILL ? seg[slot] : 0;
+    int within = 0;
+    for (int cz = z0; cz <= z1; ++cz)
+        for (int cy = y0; cy <= y1; ++cy) {
+            const int64_t row = ((int64_t)cz * g.dim[1] + cy) * g.dim[0];
+            const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+            for (int j0 = s; j0 < e; j0 += 64) {
+                const int j = j0 + lane;
+                bool cand = false;
+                double d2 = 0.0;
+                if (j < e) {
+                    const double dx = xs[j] - px, dy = ys[j] - py, dz = zs[j] - pz;
+                    d2 = (dx * dx + dy * dy) + dz * dz;
+                    cand = d2 <= R2;
+                }
+                const unsigned long long mask = __ballot(cand);
+                if (FILL && cand) {
+                    const int64_t o = at + sf_prefix_count(mask);
+                    d2_out[o] = d2;
+                    pos_out[o] = j;
+                }
+                const int c = __popcll(mask);
+                at += c;
+                within += c;
+            }
+        }
+    if (!FILL && lane == 0) count[slot] = within;
+}
+
+// sorted-by-d2 segment -> the k nearest in (d2, position) order, as ORIGINAL indices (see k_knn)
+__global__ __launch_bounds__(256) void k_knn_take(int64_t nres, int k, const int64_t *__restrict__ seg,
+                                                  const double *__restrict__ d2, const int32_t *__restrict__ pos,
+                                                  const int32_t *__restrict__ qres, const int32_t *__restrict__ perm,
+                                                  int32_t *__restrict__ idx_out)
+{
+    const int64_t r = blockIdx.x;
+    if (r >= nres) return;
+    const int64_t b = seg[r], e = seg[r + 1], q = qres[r];
+    // an element can only land among the first k if fewer than k precede it; everything at sorted index >= k + (length of
+    // the tie run that straddles k) is out, so looking at sorted indices below the end of that run is enough
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const double d = d2[i];
+        int64_t lo = i, hi = i + 1;
+        while (lo > b && d2[lo - 1] == d) --lo;
+        if (lo - b >= k) continue; // the whole run lies beyond the k-th place
+        while (hi < e && d2[hi] == d) ++hi;
+        int64_t rank = lo - b;
+        const int p = pos[i];
+        for (int64_t t = lo; t < hi; ++t) rank += pos[t] < p;
+        if (rank < k) idx_out[q * (int64_t)k + rank] = perm[p];
+    }
 }
 
 } // namespace
@@ -602,6 +692,69 @@ extern "C" sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *c, const double *que
 
 int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3]); // grid.hip
 
+// One round of the large-k path for the selected queries (sel == NULL: all m): count the points within R, and for the
+// queries that have at least k of them write, sort and take.  hstatus[q] = 0 answered / 1 retry with a larger R.
+// Queries are processed in batches whose candidate lists stay within ~1.5e8 entries (3 GB of scratch).
+static int knn_round_large(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const sf_grid_desc &g, const int32_t *sel, int64_t msel, int k,
+                           double R2, std::vector<int32_t> &hstatus, const std::vector<int32_t> *sel_host)
+{
+    sf_pool_guard tmp(ctx);
+    int32_t *dcount = nullptr;
+    SF_CHECK(tmp.alloc(&dcount, (size_t)msel));
+    SF_LAUNCH(ctx, "k2_knn", k_knn_sweep<false>, dim3(sf_xcd_grid(msel)), dim3(64), g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
+              nb->qy, nb->qz, sel, msel, R2, dcount, (const int64_t *)nullptr, (double *)nullptr, (int32_t *)nullptr);
+    std::vector<int32_t> hcount((size_t)msel);
+    SF_HIP(hipMemcpyAsync(hcount.data(), dcount, (size_t)msel * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t budget = 150000000;
+    int64_t s0 = 0;
+    while (s0 < msel) {
+        std::vector<int32_t> qres;
+        std::vector<int64_t> seg(1, 0);
+        int64_t s1 = s0;
+        for (; s1 < msel; ++s1) {
+            const int64_t q = sel_host ? (*sel_host)[(size_t)s1] : s1;
+            if (hcount[(size_t)s1] < k) { hstatus[(size_t)q] = 1; continue; }
+            if (!qres.empty() && seg.back() + hcount[(size_t)s1] > budget) break;
+            hstatus[(size_t)q] = 0;
+            qres.push_back((int32_t)q);
+            seg.push_back(seg.back() + hcount[(size_t)s1]);
+        }
+        s0 = s1;
+        const int64_t nres = (int64_t)qres.size(), total = seg.back();
+        if (!nres) continue;
+        if (total > 0xfffffff0LL) { sf_set_error("sf_knn_search: %lld candidates of one query exceed a sort", (long long)total); return SF_ERR_UNSUPPORTED; }
+        sf_pool_guard bt(ctx);
+        int32_t *dq = nullptr, *pin = nullptr, *pout = nullptr;
+        int64_t *dseg = nullptr;
+        double *din = nullptr, *dout = nullptr;
+        SF_CHECK(bt.alloc(&dq, (size_t)nres));
+        SF_CHECK(bt.alloc(&dseg, (size_t)nres + 1));
+        SF_CHECK(bt.alloc(&din, (size_t)total));
+        SF_CHECK(bt.alloc(&dout, (size_t)total));
+        SF_CHECK(bt.alloc(&pin, (size_t)total));
+        SF_CHECK(bt.alloc(&pout, (size_t)total));
+        SF_HIP(hipMemcpyAsync(dq, qres.data(), (size_t)nres * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        SF_HIP(hipMemcpyAsync(dseg, seg.data(), ((size_t)nres + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        SF_LAUNCH(ctx, "k2_knn", k_knn_sweep<true>, dim3(sf_xcd_grid(nres)), dim3(64), g, c->cell_start, c->xs, c->ys, c->zs, nb->qx,
+                  nb->qy, nb->qz, (const int32_t *)dq, nres, R2, (int32_t *)nullptr, (const int64_t *)dseg, din, pin);
+        size_t tb = 0;
+        SF_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, din, dout, pin, pout, (unsigned)total, (unsigned)nres, dseg, dseg + 1, 0,
+                                                   64, ctx->stream));
+        char *stmp = nullptr;
+        SF_CHECK(bt.alloc(&stmp, tb ? tb : 8));
+        {
+            sf_launch_timer t_(ctx, "k2_knn_sort");
+            SF_HIP(rocprim::segmented_radix_sort_pairs(stmp, tb, din, dout, pin, pout, (unsigned)total, (unsigned)nres, dseg, dseg + 1, 0,
+                                                       64, ctx->stream));
+        }
+        SF_LAUNCH(ctx, "k2_knn", k_knn_take, dim3((unsigned)nres), dim3(256), nres, k, (const int64_t *)dseg, (const double *)dout,
+                  (const int32_t *)pout, (const int32_t *)dq, (const int32_t *)c->perm, nb->idx);
+        SF_HIP(hipStreamSynchronize(ctx->stream)); // qres / seg are host buffers of the async copies
+    }
+    return SF_OK;
+}
+
 extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *queries, int64_t m, int k, int flags)
 {
     if (!ctx || !c || (!queries && m > 0) || m < 0 || m > 2147483000LL) {
@@ -612,7 +765,7 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         sf_set_error("sf_knn_search: k=%d must be in 1..%lld (the number of cloud points)", k, (long long)c->n);
         return nullptr;
     }
-    if (k > 1984) { sf_set_error("sf_knn_search: k=%d > 1984 exceeds the candidate buffer of the k-NN kernel", k); return nullptr; }
+    const bool large = k > 1984; // beyond the LDS buffer of k_knn: count / fill / segmented sort (k_knn_sweep, k_knn_take)
     if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
     double lo[3], hi[3];
     if (sf_cloud_bbox(ctx, c, lo, hi) != SF_OK) return nullptr;
@@ -642,8 +795,9 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
                            nb->offset);
     }
     if (!m) return nb;
+    sf_pool_guard ktmp(ctx); // status / qsel go back to the pool on every exit of this function
     int32_t *status = nullptr, *qsel = nullptr;
-    if (sf_palloc(ctx, &status, (size_t)m) != SF_OK || sf_palloc(ctx, &qsel, (size_t)m) != SF_OK) return fail();
+    if (ktmp.alloc(&status, (size_t)m) != SF_OK || ktmp.alloc(&qsel, (size_t)m) != SF_OK) return fail();
     std::vector<int32_t> hstatus((size_t)m), pending;
     int64_t msel = m;
     bool subset = false;
@@ -658,6 +812,11 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         const double R2 = one_cell ? INFINITY : R * R;
         const dim3 grid(sf_xcd_grid(msel)), block(64);
         const int32_t *sel = subset ? qsel : nullptr;
+        if (large) {
+            if (knn_round_large(ctx, c, nb, g, sel, msel, k, R2, hstatus, subset ? &pending : nullptr) != SF_OK) {
+                return fail();
+            }
+        } else {
         sf_launch_timer *tm = new sf_launch_timer(ctx, "k2_knn");
 #define SF_KNN_LAUNCH(EPL) hipLaunchKernelGGL(k_knn<EPL>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status)
         if (k <= 64) SF_KNN_LAUNCH(2);         // buffer of 64 * EPL candidates >= k + 64
@@ -671,8 +830,8 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
             hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             sf_set_error("sf_knn_search: launch failed");
-            sf_pool_release(ctx, status); sf_pool_release(ctx, qsel);
             return fail();
+        }
         }
         pending.clear();
         for (int64_t i = 0; i < m; ++i)
@@ -683,14 +842,11 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         if (sf_cloud_build_grid(ctx, c, R) != SF_OK ||
             hipMemcpyAsync(qsel, pending.data(), pending.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            sf_pool_release(ctx, status); sf_pool_release(ctx, qsel);
             return fail();
         }
         msel = (int64_t)pending.size();
         subset = true;
     }
-    sf_pool_release(ctx, status);
-    sf_pool_release(ctx, qsel);
     if (!resolved) { // never return lists with unwritten rows
         sf_set_error("sf_knn_search: internal error, %zu queries unresolved", pending.size());
         return fail();

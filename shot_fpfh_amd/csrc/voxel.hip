@@ -106,21 +106,38 @@ __global__ void k_voxel_inverse(const int32_t *__restrict__ perm, const int32_t 
     if (i < n) inverse[perm[i]] = rank[i];
 }
 
-// One thread per voxel.  order (nullable): a permutation of the points grouped by voxel in voxel order -- the elements
-// [start[v], start[v+1]) of it are voxel v's points in the caller's visiting order; null = this library's own (perm).
-__global__ void k_voxel_select(const double *__restrict__ xyz, const int32_t *__restrict__ start, int64_t nvox,
+// order (nullable): a permutation of the points grouped by voxel in voxel order -- the elements [start[v], start[v+1])
+// of it are voxel v's points in the caller's visiting order; null = this library's own (perm).  An element outside
+// [0, n) is never dereferenced: the voxel's answer becomes -1 and the context's flag is raised (common.h).
+// Small voxels (the usual case: a handful of points, millions of voxels): one THREAD per voxel, k_voxel_select.
+// Voxels of more than SF_VOXEL_WAVE points (a voxel size chosen large against the cloud's extent: a few voxels hold
+// everything): one WAVE per voxel, k_voxel_select_wave -- a lone thread walking 10^6 dependent, scattered loads twice takes
+// seconds.  The barycentre must still be the sequential row-by-row sum np.mean(axis=0) forms (subsampling.py:31): the
+// wave stages 64 points at a time in LDS with coalesced gathers and lanes 0..2 add the x / y / z columns in order; the
+// distances and the first minimum in visiting order are lane-parallel.
+#define SF_VOXEL_WAVE 32
+__global__ void k_voxel_select(const double *__restrict__ xyz, int64_t n, const int32_t *__restrict__ start, int64_t nvox,
                                const int32_t *__restrict__ perm, const int64_t *__restrict__ order,
-                               int64_t *__restrict__ selected, int64_t *__restrict__ counts)
+                               int64_t *__restrict__ selected, int64_t *__restrict__ counts, volatile int *__restrict__ flag)
 {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nvox) return;
     const int32_t s = start[v], e = start[v + 1];
+    if (counts) counts[v] = e - s;
+    if (e - s > SF_VOXEL_WAVE) return; // k_voxel_select_wave's
     double sx = 0.0, sy = 0.0, sz = 0.0;
+    bool bad = false;
     for (int32_t t = s; t < e; ++t) { // np.mean(axis=0): rows added one after the other (subsampling.py:31)
         const int64_t j = order ? order[t] : (int64_t)perm[t];
+        if (j < 0 || j >= n) { bad = true; continue; }
         sx += xyz[3 * j + 0];
         sy += xyz[3 * j + 1];
         sz += xyz[3 * j + 2];
+    }
+    if (bad) {
+        *flag = SF_FLAG_VOXEL_ORDER;
+        selected[v] = -1;
+        return;
     }
     const double k = (double)(e - s);
     const double mx = sx / k, my = sy / k, mz = sz / k;
@@ -133,7 +150,63 @@ __global__ void k_voxel_select(const double *__restrict__ xyz, const int32_t *__
         if (arg < 0 || d < best) { best = d; arg = j; } // argmin: the first minimum
     }
     selected[v] = arg;
-    if (counts) counts[v] = e - s;
+}
+
+__global__ __launch_bounds__(64) void k_voxel_select_wave(const double *__restrict__ xyz, int64_t n, const int32_t *__restrict__ start,
+                                                          int64_t nvox, const int32_t *__restrict__ perm,
+                                                          const int64_t *__restrict__ order, int64_t *__restrict__ selected,
+                                                          volatile int *__restrict__ flag)
+{
+    __shared__ double stage[3][64];
+    const int64_t v = blockIdx.x;
+    if (v >= nvox) return;
+    const int32_t s = start[v], e = start[v + 1];
+    if (e - s <= SF_VOXEL_WAVE) return; // k_voxel_select's
+    const int lane = threadIdx.x;
+    double acc = 0.0; // lanes 0, 1, 2: the running sums of x, y, z
+    bool bad = false;
+    for (int32_t t0 = s; t0 < e; t0 += 64) {
+        const int32_t t = t0 + lane;
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (t < e) {
+            const int64_t j = order ? order[t] : (int64_t)perm[t];
+            if (j < 0 || j >= n) bad = true;
+            else { x = xyz[3 * j + 0]; y = xyz[3 * j + 1]; z = xyz[3 * j + 2]; }
+        }
+        stage[0][lane] = x; stage[1][lane] = y; stage[2][lane] = z;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (lane < 3) {
+            const int cnt = e - t0 < 64 ? e - t0 : 64;
+            for (int u = 0; u < cnt; ++u) acc += stage[lane][u]; // one column, row after row
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    if (__ballot(bad)) {
+        if (lane == 0) { *flag = SF_FLAG_VOXEL_ORDER; selected[v] = -1; }
+        return;
+    }
+    const double k = (double)(e - s);
+    const double mx = __shfl(acc, 0) / k, my = __shfl(acc, 1) / k, mz = __shfl(acc, 2) / k;
+    double best = INFINITY;
+    int32_t best_t = 0x7fffffff; // visiting position of this lane's first minimum
+    for (int32_t t = s + lane; t < e; t += 64) {
+        const int64_t j = order ? order[t] : (int64_t)perm[t];
+        const double dx = xyz[3 * j + 0] - mx, dy = xyz[3 * j + 1] - my, dz = xyz[3 * j + 2] - mz;
+        const double d = sqrt((dx * dx + dy * dy) + dz * dz);
+        if (d < best) { best = d; best_t = t; } // (ascending t within a lane: the first of equal distances stays)
+    }
+    for (int off = 32; off > 0; off >>= 1) { // smallest distance, earliest visiting position among equals
+        const double od = __shfl_xor(best, off);
+        const int32_t ot = __shfl_xor(best_t, off);
+        if (od < best || (od == best && ot < best_t)) { best = od; best_t = ot; }
+    }
+    // (a voxel whose distances are all NaN: np.argmin returns the first NaN, i.e. the first visited point)
+    if (lane == 0) {
+        const int32_t t = best_t == 0x7fffffff ? s : best_t;
+        selected[v] = order ? order[t] : (int64_t)perm[t];
+    }
 }
 
 int bits_for(double cells) // bits needed to hold values 0 .. cells
@@ -264,10 +337,14 @@ extern "C" int sf_voxels_select(sf_ctx *ctx, sf_voxels *v, const int64_t *order,
     }
     SF_CHECK(tmp.alloc(&dsel, (size_t)v->nvox));
     if (counts) SF_CHECK(tmp.alloc(&dcnt, (size_t)v->nvox));
-    SF_LAUNCH(ctx, "v4_voxel_select", k_voxel_select, dim3((unsigned)sf_div_up(v->nvox, 128)), dim3(128), v->xyz, v->start, v->nvox,
-              v->perm, (const int64_t *)dorder, dsel, dcnt);
+    SF_LAUNCH(ctx, "v4_voxel_select", k_voxel_select, dim3((unsigned)sf_div_up(v->nvox, 128)), dim3(128), v->xyz, v->n, v->start,
+              v->nvox, v->perm, (const int64_t *)dorder, dsel, dcnt, ctx->dev_flag);
+    // (voxels above SF_VOXEL_WAVE points exist only when some voxel holds more than its share: skip the launch otherwise)
+    if (v->n > (int64_t)SF_VOXEL_WAVE)
+        SF_LAUNCH(ctx, "v4_voxel_select", k_voxel_select_wave, dim3((unsigned)v->nvox), dim3(64), v->xyz, v->n, v->start, v->nvox,
+                  v->perm, (const int64_t *)dorder, dsel, ctx->dev_flag);
     SF_HIP(hipMemcpyAsync(selected, dsel, (size_t)v->nvox * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     if (counts) SF_HIP(hipMemcpyAsync(counts, dcnt, (size_t)v->nvox * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    return SF_OK;
+    return sf_ctx_check_flag(ctx);
 }

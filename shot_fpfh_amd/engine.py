@@ -6,6 +6,7 @@ float64 at the boundary (the reference computes in float64 throughout)
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 import threading
@@ -103,24 +104,49 @@ class DeviceArray:
 
 
 class _PinnedPool:
-    """Page-locked host blocks (sf_host_alloc) behind the NumPy arrays `Engine.host_empty` hands out."""
+    """Page-locked host blocks (sf_host_alloc) behind the NumPy arrays `Engine.host_empty` hands out.
+
+    A block comes back through a weakref finalizer, which the garbage collector may run at ANY allocation point --
+    including inside `array()` of the same thread.  The finalizer therefore takes no lock at all: it appends to a deque
+    (atomic in CPython), and `array()` / `trim()` move the returned blocks into the free list under the lock."""
 
     THRESHOLD = 32 << 20      # smaller results use ordinary NumPy memory
-    KEEP_BYTES = 16 << 30     # cached (unused) blocks beyond this are unpinned at once
+    KEEP_BYTES = 4 << 30      # cached (unused) blocks beyond this are unpinned; Engine.trim_host_cache() drops them all
 
     def __init__(self, lib, ctx):
         self.lib, self.ctx = lib, ctx
         self.free: list[tuple[int, int]] = []  # (nbytes, address)
         self.cached = 0
         self.lock = threading.Lock()
+        self.returned: collections.deque = collections.deque()  # blocks handed back by finalizers, not yet sorted in
+
+    def _absorb(self) -> list:
+        """(under the lock) returned blocks -> free list; those beyond KEEP_BYTES are given to the caller to unpin."""
+        drop = []
+        while True:
+            try:
+                blk = self.returned.popleft()
+            except IndexError:
+                break
+            if self.ctx is not None and self.cached + blk[0] <= self.KEEP_BYTES:
+                self.free.append(blk)
+                self.cached += blk[0]
+            else:
+                drop.append(blk)
+        return drop
 
     def array(self, shape, dtype, count, nbytes) -> np.ndarray:
         with self.lock:
-            fit = [b for b in self.free if nbytes <= b[0] <= nbytes + nbytes // 2 + (1 << 20)]
-            blk = min(fit) if fit else None
+            drop = self._absorb()
+            blk = None
+            for b in self.free:  # (a plain loop: no allocation-heavy comprehension while the lock is held)
+                if nbytes <= b[0] <= nbytes + nbytes // 2 + (1 << 20) and (blk is None or b < blk):
+                    blk = b
             if blk is not None:
                 self.free.remove(blk)
                 self.cached -= blk[0]
+        for _, addr in drop:
+            self.lib.sf_host_free(None, addr)
         if blk is None:
             size = (nbytes + 4095) & ~4095
             addr = self.lib.sf_host_alloc(self.ctx, size)
@@ -132,16 +158,28 @@ class _PinnedPool:
         return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
     def _give_back(self, blk) -> None:
+        # no lock here (see the class note).  After drain() nobody sorts the deque in any more: unpin at once.
+        if self.ctx is None:
+            self.lib.sf_host_free(None, blk[1])
+        else:
+            self.returned.append(blk)
+
+    def trim(self, keep_bytes: int = 0) -> int:
+        """Unpin cached blocks until at most `keep_bytes` stay; returns the bytes released."""
         with self.lock:
-            if self.ctx is not None and self.cached + blk[0] <= self.KEEP_BYTES:
-                self.free.append(blk)
-                self.cached += blk[0]
-                return
-        self.lib.sf_host_free(None, blk[1])
+            drop = self._absorb()
+            self.free.sort()
+            while self.free and self.cached > keep_bytes:
+                blk = self.free.pop()
+                self.cached -= blk[0]
+                drop.append(blk)
+        for _, addr in drop:
+            self.lib.sf_host_free(None, addr)
+        return sum(b[0] for b in drop)
 
     def drain(self) -> None:
         with self.lock:
-            blocks, self.free, self.cached, self.ctx = self.free, [], 0, None
+            blocks, self.free, self.cached, self.ctx = self.free + self._absorb(), [], 0, None
         for _, addr in blocks:
             self.lib.sf_host_free(None, addr)
 
@@ -182,6 +220,11 @@ class Engine:
         if nbytes < _PinnedPool.THRESHOLD:
             return np.empty(shape, dtype=dtype)
         return self._pinned.array(shape, dtype, count, nbytes)
+
+    def trim_host_cache(self, keep_bytes: int = 0) -> int:
+        """Release the page-locked blocks the engine keeps for re-use by later results (at most 4 GiB are kept; results of
+        32 MiB and more live in such blocks for as long as the returned array or any view of it is alive)."""
+        return self._pinned.trim(keep_bytes)
 
     def __del__(self):
         try:
@@ -286,7 +329,7 @@ class Engine:
         m = sel.shape[0]
         if out.shape[0] < m or out.shape[1] != rows.shape[1] or sel.dtype != np.int64:
             raise ValueError("rows_gather_device: int64 selection and an (>= len(sel), d) output expected")
-        _ffi.check(self.lib.sf_rows_gather(self.h, rows.ptr, sel.ptr, m, rows.shape[1], out.ptr), "sf_rows_gather")
+        _ffi.check(self.lib.sf_rows_gather(self.h, rows.ptr, rows.shape[0], sel.ptr, m, rows.shape[1], out.ptr), "sf_rows_gather")
         return out
 
     def match_masked_device(self, a: DeviceArray, a_ok: DeviceArray, b: DeviceArray, b_ok: DeviceArray, idx: DeviceArray,

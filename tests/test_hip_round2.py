@@ -398,10 +398,6 @@ def test_knn_with_more_than_448_neighbours(eng, n, m, k):
     want = np.sort(np.argsort(d2, axis=1, kind="stable")[:, :k], axis=1)
     assert np.array_equal(np.sort(idx.reshape(m, k), axis=1), want)
     nb.free()
-    import shot_fpfh_amd as s
-
-    with pytest.raises(s.ShotFpfhError):
-        cloud.knn_search(q, 1985) if n >= 1985 else cloud.knn_search(q[:0], 1985)
     cloud.free()
 
 

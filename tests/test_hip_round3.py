@@ -324,3 +324,149 @@ def test_config_c5_rank_blocks_of_the_8m_cloud_vs_oracle(eng, O, cloud_8m, rank,
     do = O.shot_single_scale(p, nr, p[orig[pick]], r, True, 10)
     assert close(d, do).all() and np.abs(d - do).max() < 1e-9
     job.close()
+
+
+# ---- limits the reference does not have: lifted -----------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,k", [(6000, 40, 1985), (6000, 30, 4096), (4200, 12, 4200)])
+def test_knn_beyond_the_lds_buffer(eng, O, n, m, k):
+    """KDTree.query(k) for any k <= n (pca_based_descriptors.py:46): above 1984 the count / fill / segmented-sort path.
+    Sets AND order (nearest first, ties towards the lower index) against a stable NumPy sort of the exact d2; queries off
+    the cloud and on a cloud point; duplicated points force distance ties across the k-th place."""
+    p, _, rng = synth_cloud(n, k)
+    p[n - 300:] = p[:300]  # 300 duplicated points: exact ties
+    q = np.vstack([rng.random((m - 2, 3)), [[2.0, 2.0, 2.0]], p[:1]])
+    cloud = eng.cloud(p)
+    nb = cloud.knn_search(q, k)
+    off, idx = nb.export()  # (ascending index inside each list: the canonical form)
+    assert np.array_equal(off, np.arange(0, (m + 1) * k, k))
+    d = p[None, :, :] - q[:, None, :]
+    d2 = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
+    want = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx.reshape(m, k), np.sort(want, axis=1))
+    # normals from those lists == the oracle's k-NN normals
+    from shot_fpfh_amd.descriptors import compute_normals
+
+    nr = compute_normals(q[:8], p, k=k)
+    no = O.compute_normals(q[:8], p, k=k)
+    assert np.minimum(np.abs(nr - no).max(axis=1), np.abs(nr + no).max(axis=1)).max() < 1e-9
+    nb.free()
+    cloud.free()
+
+
+def test_fpfh_with_forty_bins_per_feature(O):
+    """compute_fpfh_descriptor(n_bins=40): 64 000 bins per point (fpfh.py:16 takes any n_bins; the table of 32-bit counts is
+    what bounds it here, 256 KB per point).  A keypoint sample against the oracle."""
+    import shot_fpfh_amd as s
+
+    p, nr, rng = synth_cloud(3000, 140)
+    kp = np.sort(rng.choice(3000, 24, replace=False))
+    f = s.compute_fpfh_descriptor(kp, p, nr, 0.12, 40, verbose=False)
+    fo = O.compute_fpfh_descriptor_sample(kp, p, nr, 0.12, 40)
+    assert f.shape == (24, 64000) and f.dtype == np.float64
+    assert close(f, fo).all() and np.abs(f - fo).max() < 1e-9
+    assert 0.5 < f.sum(axis=1).min()  # (rows are not empty)
+
+
+@pytest.mark.parametrize("offset", [(4.2e6, -3.1e6, 5.4e6), (6.7e7, 1.0e6, -2.5e7)])
+def test_neighbour_lists_of_a_cloud_in_utm_like_coordinates(eng, O, offset):
+    """A cloud millions of units from the origin with a cell of a few hundredths (survey coordinates): the search clips its
+    runs of cells to the reach of the ball, and the clip must be formed in grid-relative coordinates -- ulp(|p|) here is
+    1e-9 .. 1e-8, far more than any fixed fraction of the cell.  A lattice with spacing 1/16 (exact at these magnitudes)
+    searched with radii EXACTLY equal to lattice-shell distances puts neighbours on the ball's surface and on cell
+    boundaries; a uniform cloud covers the generic case.  Lists and distances bit for bit against the oracle."""
+    rng = np.random.default_rng(int(abs(offset[0])) % 1000)
+    off = np.asarray(offset)
+    g = np.arange(14) / 16.0
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + off
+    uniform = rng.random((4000, 3)) * 0.8 + off
+    for p, radii in ((lattice, [np.sqrt(3.0 / 256.0), np.sqrt(5.0 / 256.0), np.sqrt(9.0 / 256.0), 1.0 / 16.0]),
+                     (uniform, [0.03, 0.071])):
+        n = p.shape[0]
+        q = np.vstack([p[rng.choice(n, 300, replace=False)], p.min(0) + (p.max(0) - p.min(0)) * (rng.random((60, 3)) * 1.3 - 0.15)])
+        cloud = eng.cloud(p)
+        for r in radii:
+            r = float(r)
+            if p is lattice and r * r < round(r * r * 256.0) / 256.0:
+                r = float(np.nextafter(r, np.inf))  # (r * r must not round below the shell's exact d2)
+            nb = cloud.radius_search(q, r)
+            o, i, d = nb.export(return_distance=True)
+            oo, io, do = O.radius_search(p, q, r, return_distance=True)
+            assert np.array_equal(o, oo) and np.array_equal(i, io) and np.array_equal(d, do), (offset, r)
+            if p is lattice and r * r * 256.0 == round(r * r * 256.0):
+                assert (d == r).any()  # neighbours exactly ON the ball's surface were kept
+            nb.free()
+            ns = cloud.radius_search_self(r)
+            os_, is_ = ns.export()
+            ob, ib = O.radius_search(p, p, r)
+            perm = cloud.perm()
+            assert np.array_equal(np.diff(os_), np.diff(ob)[perm])
+            for pos in rng.choice(n, 150, replace=False):
+                j = int(perm[pos])
+                assert np.array_equal(is_[os_[pos]:os_[pos + 1]], ib[ob[j]:ob[j + 1]])
+            ns.free()
+        cloud.free()
+
+
+# ---- advisor's findings, round 2 ---------------------------------------------------------------------------------------------
+def test_grid_subsampling_with_a_voxel_size_that_swallows_the_cloud(eng):
+    """A voxel size large against the extent (the ICP default 0.2 on a unit cloud, or one voxel for everything): a few
+    voxels hold 10^5 points each.  One wave per such voxel -- the answer is still the reference's expression, the
+    sequential np.mean included -- and the call takes milliseconds, not seconds."""
+    import time
+
+    from shot_fpfh_amd.core.geometry import grid_subsampling
+
+    p, _, _ = synth_cloud(400_000, 21)
+    for vs in (0.5, 0.2, 3.0):
+        t0 = time.perf_counter()
+        got = grid_subsampling(p, vs, within_voxel_order="index")
+        dt = time.perf_counter() - t0
+        keys = ((p - p.min(axis=0)) // vs).astype(int)
+        _, inverse = np.unique(keys, axis=0, return_inverse=True)
+        inverse = inverse.reshape(-1)
+        want = []
+        for v in range(inverse.max() + 1):
+            idxs = np.flatnonzero(inverse == v)  # ascending index: the platform-independent visiting order
+            bary = np.mean(p[idxs], axis=0)
+            want.append(idxs[np.linalg.norm(p[idxs] - bary, axis=1).argmin()])
+        assert np.array_equal(got, np.array(want)), vs
+        assert dt < 0.5, f"voxel size {vs}: {dt:.2f} s"
+
+
+def test_out_of_range_index_arrays_are_refused_not_dereferenced(eng):
+    """sf_rows_gather with a selection beyond the matrix and sf_voxels_select with a visiting order beyond the cloud: the
+    offending elements are skipped on the device and the call (or the next synchronising one) fails with SF_ERR_ARG."""
+    import ctypes as C
+
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd import _ffi
+
+    rows = eng.empty((100, 8)).from_host(np.arange(800.0).reshape(100, 8))
+    out = eng.empty((4, 8))
+    sel = eng.empty((4,), np.int64).from_host(np.array([3, -1, 100, 99]))
+    eng.rows_gather_device(rows, sel, out)
+    with pytest.raises(s.ShotFpfhError, match="row selection"):
+        eng.sync()
+    eng.sync()  # (the flag is cleared once reported)
+    got = out.to_host()
+    assert np.array_equal(got[0], np.arange(24.0, 32.0)) and not got[1].any() and not got[2].any()
+    assert np.array_equal(got[3], np.arange(792.0, 800.0))
+    p, _, _ = synth_cloud(5000, 3)
+    lib = _ffi.load()
+    vox = _ffi.check_handle(lib.sf_voxels_build(eng.h, p.ctypes.data_as(C.c_void_p), 5000, 0.1, _ffi.SF_HOST), "sf_voxels_build")
+    nv = lib.sf_voxels_count(vox)
+    inv = np.zeros(5000, np.int64)
+    _ffi.check(lib.sf_voxels_inverse(eng.h, vox, inv.ctypes.data_as(C.c_void_p)))
+    order = np.argsort(inv, kind="stable").astype(np.int64)
+    sel_ok = np.zeros(nv, np.int64)
+    _ffi.check(lib.sf_voxels_select(eng.h, vox, order.ctypes.data_as(C.c_void_p), sel_ok.ctypes.data_as(C.c_void_p), None))
+    bad = order.copy()
+    bad[17] = 5000
+    bad[4000] = -3
+    sel_bad = np.zeros(nv, np.int64)
+    rc = lib.sf_voxels_select(eng.h, vox, bad.ctypes.data_as(C.c_void_p), sel_bad.ctypes.data_as(C.c_void_p), None)
+    assert rc == -1 and b"visiting order" in lib.sf_last_error()
+    assert (sel_bad == -1).sum() == 2 and np.array_equal(sel_bad[sel_bad >= 0], sel_ok[sel_bad >= 0])
+    lib.sf_voxels_free(eng.h, vox)
+    for a in (rows, out, sel):
+        a.free()

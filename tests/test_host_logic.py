@@ -248,7 +248,7 @@ def test_pinned_output_pool_reuses_blocks_after_garbage_collection():
     assert view[0, 0] == 3.0
     del view
     gc.collect()
-    assert len(pool.free) == 1 and len(lib.allocs) == 1
+    assert len(pool.free) + len(pool.returned) == 1 and len(lib.allocs) == 1  # (handed back, sorted in by the next request)
     b = pool.array((999, 352), np.dtype(np.float64), 999 * 352, 999 * 352 * 8)  # fits the cached block
     assert len(lib.allocs) == 1 and not pool.free
     c = pool.array((10, 352), np.dtype(np.float64), 3520, 3520 * 8)  # far smaller: its own block
@@ -308,3 +308,44 @@ def test_bench_control_plane_rendezvous_allgather_max_bcast(tmp_path, under_laun
             assert p.wait(timeout=120) == 0
     finally:
         blocker.close()
+
+
+def test_pinned_pool_finalizer_takes_no_lock_and_trim_releases():
+    """engine._PinnedPool: a block returns through a weakref finalizer that may run at any allocation point, also inside
+    array() while the pool's lock is held -- so the finalizer only appends to a deque.  Views keep a block alive; a
+    returned block is re-used for the next fitting request; trim() unpins what is cached."""
+    import ctypes
+    import gc
+
+    from shot_fpfh_amd.engine import _PinnedPool
+
+    class FakeLib:
+        def __init__(self):
+            self.live = {}
+
+        def sf_host_alloc(self, ctx, size):
+            b = ctypes.create_string_buffer(size)
+            self.live[ctypes.addressof(b)] = b
+            return ctypes.addressof(b)
+
+        def sf_host_free(self, ctx, addr):
+            del self.live[addr]
+
+    lib = FakeLib()
+    pool = _PinnedPool(lib, 1)
+    a = pool.array((1000,), np.float64, 1000, 8000)
+    view = a[10:20]
+    del a
+    gc.collect()
+    assert not pool.returned and len(lib.live) == 1  # the view keeps the block
+    del view
+    gc.collect()
+    assert len(pool.returned) == 1
+    with pool.lock:  # a finalizer firing while the lock is held must not block
+        c = pool.array.__self__.returned  # (the deque is what finalizers touch)
+        c.append(c.popleft())
+    b = pool.array((900,), np.float64, 900, 7200)  # fits the cached block
+    assert len(lib.live) == 1 and pool.cached == 0
+    del b
+    gc.collect()
+    assert pool.trim() == 8192 and not lib.live
