@@ -516,7 +516,7 @@ def test_fpfh_other_bin_counts_vs_oracle(O, nb):
     fo = O.compute_fpfh_descriptor(kp, p, nr, 0.13, nb)
     assert f.shape == (150, nb**3) and close(f, fo).all()
     with pytest.raises(ValueError):
-        s.compute_fpfh_descriptor(kp, p, nr, 0.13, 33, verbose=False)  # n_bins^3 bins per point: capped at 32 per axis
+        s.compute_fpfh_descriptor(kp, p, nr, 0.13, 0, verbose=False)  # (n_bins >= 1; above 32: tests/test_hip_round3.py)
 
 
 def test_fpfh_wide_count_table(eng, O):

@@ -202,7 +202,12 @@ def test_config_c4_full_size_chain_with_cpu_checked_match_rows(eng, O):
     ratio, tf = R.ransac_on_matches(si, ri, scan, ref, n_draws=10000, draw_size=4, distance_threshold=0.01,
                                     disable_progress_bar=True)
     assert abs(ratio - correct) < 0.02  # inliers are the correct matches (wrong ones land far away)
-    assert np.abs(tf.rotation - rot).max() <= 1e-9 and np.abs(tf.translation - t).max() <= 1e-9
+    # ransac_on_matches keeps the FIRST draw that reaches the best inlier count and does not refit (ransac.py:60-72): a draw
+    # of three true matches and one near miss moves every true match by less than the 0.01 threshold, scores as many
+    # inliers as an exact draw and wins if it comes first -- so the motion is recovered to the threshold's scale (1e-3
+    # here; 5e-16 with the bench's 2 000-draw sequence, where an all-true draw happens to come first), not to rounding
+    assert np.abs(tf.rotation - rot).max() < 5e-3 and np.abs(tf.translation - t).max() < 5e-3
+    assert ratio >= correct - 1e-12  # every true match is an inlier of the winning transform
     # the winning draw's inlier count equals the NumPy expression of ransac.py:60-67 for that transform
     best_inl = (np.linalg.norm((scan[si] @ tf.rotation.T + tf.translation) - ref[ri], axis=1) <= 0.01).sum()
     assert abs(best_inl / si.size - ratio) < 1e-3
