@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
                                               CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias,
                                               double *__restrict__ p4, double mom_radius, double *__restrict__ cov,
-                                              unsigned *__restrict__ live, int alpha_bin, double nrm_max)
+                                              unsigned *__restrict__ live, int alpha_bin, double nrm_max,
+                                              uint8_t *__restrict__ packed, int pack_b0, int pack_b1)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
@@ -228,6 +229,15 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
         const unsigned v0 = lane < nb3 ? h[lane] : 0u, v1 = lane + 64 < nb3 ? h[lane + 64] : 0u; // (padding bins: count 0)
         row[lane] = (CT)(v0 ^ bias);
         row[lane + 64] = (CT)(v1 ^ bias);
+        if (packed) { // the host knows which two 16-bin blocks can be live (spfh_compute): the packed copy K7 gathers is written
+                      // here, from the registers that hold the row, instead of by a kernel of its own re-reading the table
+            uint8_t *pk = packed + i * 32;
+            const int blk = lane >> 4, sub = lane & 15; // bin `lane` is in block blk, bin lane + 64 in block 4 + blk
+            if (blk == pack_b0) pk[sub] = (uint8_t)(v0 ^ bias);
+            if (blk == pack_b1) pk[16 + sub] = (uint8_t)(v0 ^ bias);
+            if (4 + blk == pack_b0) pk[sub] = (uint8_t)(v1 ^ bias);
+            if (4 + blk == pack_b1) pk[16 + sub] = (uint8_t)(v1 ^ bias);
+        }
         const unsigned long long n0 = __ballot(v0 != 0u), n1 = __ballot(v1 != 0u);
         unsigned mask = 0u;
 #pragma unroll
@@ -798,7 +808,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
 #define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
     SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
               nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov, \
-              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max)
+              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max, fused_packed, fused_b0, fused_b1)
 #define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
@@ -818,11 +828,26 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     case 4: { SF_SPFH_LAUNCH(CT, 4); } break;                    \
     default: { SF_SPFH_LAUNCH(CT, 0); } break;                   \
     }
+    uint8_t *fused_packed = nullptr;
+    int fused_b0 = -1, fused_b1 = -1;
     if (sp->elem_bytes == 1) {
         // alpha pinned to one bin => only the 16-bin blocks that hold that bin's n_bins^2 slots can receive a count
         unsigned det = 0u;
         if (alpha_bin >= 0)
             for (int blk = (alpha_bin * nbn * nbn) / 16; blk <= ((alpha_bin + 1) * nbn * nbn - 1) / 16; ++blk) det |= 1u << blk;
+        // Steady state of a resident table (every pass after the first with the same parameters): the device's mask already
+        // holds `det`, it names at most two blocks and the packed copy was written under it -- and the host KNOWS all that
+        // (host_live mirrors live[] exactly while mask_known).  Then K6 writes the packed rows itself and none of the four
+        // little kernels around it (mask OR, pack, repack check, signature) has anything left to do.
+        const unsigned m8 = sp->host_live[0] & 0xffu;
+        if (det && sp->mask_known && sp->host_live_valid && (m8 | det) == m8 && __builtin_popcount(m8) <= 2 && sp->host_live[1] == m8) {
+            fused_packed = sp->packed;
+            fused_b0 = m8 ? __builtin_ffs((int)m8) - 1 : 0;
+            const unsigned rest = m8 & (m8 - 1u);
+            fused_b1 = rest ? __builtin_ffs((int)rest) - 1 : (fused_b0 + 1) & 7; // (same pairing as spfh_pack_row)
+            SF_SPFH_DISPATCH(uint8_t)
+            return SF_OK;
+        }
         if (det) SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_live_or, dim3(1), dim3(1), sp->live, det);
         SF_SPFH_DISPATCH(uint8_t)
         // rows [self_begin, self_begin + m) are new: pack their live blocks (a no-op on the device when more than two are)
