@@ -229,14 +229,14 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
         const unsigned v0 = lane < nb3 ? h[lane] : 0u, v1 = lane + 64 < nb3 ? h[lane + 64] : 0u; // (padding bins: count 0)
         row[lane] = (CT)(v0 ^ bias);
         row[lane + 64] = (CT)(v1 ^ bias);
-        if (packed) { // the host knows which two 16-bin blocks can be live (spfh_compute): the packed copy K7 gathers is written
-                      // here, from the registers that hold the row, instead of by a kernel of its own re-reading the table
-            uint8_t *pk = packed + i * 32;
-            const int blk = lane >> 4, sub = lane & 15; // bin `lane` is in block blk, bin lane + 64 in block 4 + blk
-            if (blk == pack_b0) pk[sub] = (uint8_t)(v0 ^ bias);
-            if (blk == pack_b1) pk[16 + sub] = (uint8_t)(v0 ^ bias);
-            if (4 + blk == pack_b0) pk[sub] = (uint8_t)(v1 ^ bias);
-            if (4 + blk == pack_b1) pk[16 + sub] = (uint8_t)(v1 ^ bias);
+        if (packed && lane < 8) { // the host knows which two 16-bin blocks can be live (spfh_compute): the packed copy K7 gathers is
+                                  // written here, straight from the LDS histogram, instead of by a kernel of its own re-reading the
+                                  // table: lane l takes bins 4 (l & 3) .. + 3 of block (l < 4 ? b0 : b1), eight dwords = the 32-byte row
+            const int first = 16 * (lane < 4 ? pack_b0 : pack_b1) + 4 * (lane & 3);
+            unsigned w = 0u;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w |= (((first + t < nb3 ? h[first + t] : 0u) ^ bias) & 0xffu) << (8 * t);
+            reinterpret_cast<unsigned *>(packed + i * 32)[lane] = w;
         }
         const unsigned long long n0 = __ballot(v0 != 0u), n1 = __ballot(v1 != 0u);
         unsigned mask = 0u;

@@ -22,7 +22,21 @@
 
 // rocPRIM's radix sort falls back to a merge sort up to 2^20 items (a 1M-point cloud: block sort + 10 merge passes
 // x 2 kernels = 21 launches, 0.16 ms); Onesweep above 64k items does the 16-17 cell-id bits in a few launches.
-using sf_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+// ... and rocPRIM 4.2 carries no tuned Onesweep configuration for gfx950: the generic one sorts 4 bits per pass.  Ten bits per
+// pass (1024-thread blocks, 6 items per thread, match ranking) sorts the 20-bit cell ids of a 1M-point cloud in two passes:
+// 0.117 -> 0.068 ms (8 bits: 0.092-0.102, 11 bits: 0.090, 12 bits: does not fit LDS; tools/ab_k1.sh)
+#ifndef SF_SORT_BITS
+#define SF_SORT_BITS 10
+#endif
+#ifndef SF_SORT_BLOCK
+#define SF_SORT_BLOCK 1024
+#endif
+#ifndef SF_SORT_ITEMS
+#define SF_SORT_ITEMS 6
+#endif
+using sf_onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<SF_SORT_BLOCK, SF_SORT_ITEMS>, rocprim::kernel_config<SF_SORT_BLOCK, SF_SORT_ITEMS>,
+                                                        SF_SORT_BITS, rocprim::block_radix_rank_algorithm::match>;
+using sf_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, sf_onesweep, 65536>;
 
 namespace {
 
@@ -129,13 +143,15 @@ __global__ void k_gather_normals(const double *__restrict__ nrm, const int32_t *
     rec[6 * i + 5] = nrm[3 * o + 2];
 }
 
-__global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t base, int64_t n, int64_t ncell,
+__global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t cid_base, int64_t base, int64_t n, int64_t ncell,
                              int32_t *__restrict__ cell_start)
 {
+    // (sorted_cid holds cell id - cid_base: a block build sorts ids relative to its slab's first cell -- fewer key bits)
     // cell_start[c] = first sorted position whose cell id >= c (lower bound over the n populated positions that
     // start at `base`); cells before / after the populated slab come out empty
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c > ncell) return;
+    c -= cid_base;
     int64_t lo = 0, hi = n;
     // (a rank's slab populates an eighth of the cells of an 8-rank cloud: the others need no search)
     if (n > 0 && c <= (int64_t)sorted_cid[0]) hi = 0;
@@ -144,7 +160,7 @@ __global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t bas
         int64_t mid = (lo + hi) >> 1;
         if ((int64_t)sorted_cid[mid] < c) lo = mid + 1; else hi = mid;
     }
-    cell_start[c] = (int32_t)(base + lo);
+    cell_start[c + cid_base] = (int32_t)(base + lo);
 }
 
 #define SF_MAX_LAYERS 4096
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(256) void k_layer_hist_fold(const unsigned int *__r
 __global__ __launch_bounds__(256) void k_select_slab(const double *__restrict__ z, const double *__restrict__ xyz, int64_t n,
                                                      int64_t chunk, sf_grid_desc g, int zlo, int zhi,
                                                      const unsigned int *__restrict__ mat, int32_t *__restrict__ sel,
-                                                     int32_t *__restrict__ cid)
+                                                     int32_t *__restrict__ cid, int cid_base)
 {
     __shared__ unsigned long long red[4];
     __shared__ unsigned int wave_tot[4];
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(256) void k_select_slab(const double *__restrict__ 
                 const int cy = sf_cell_coord(xyz[3 * o + 1], g.lo[1], g.inv_cell, g.dim[1]);
                 const int cz = sf_cell_coord(xyz[3 * o + 2], g.lo[2], g.inv_cell, g.dim[2]);
                 sel[at] = (int32_t)o;
-                cid[at] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+                cid[at] = (cz * g.dim[1] + cy) * g.dim[0] + cx - cid_base; // relative to the slab's first cell
                 ++at;
             }
     }
@@ -493,6 +509,7 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     sf_grid_desc g = sf_make_grid_desc(c);
     int bits = 1;
     while (((int64_t)1 << bits) < ncell) ++bits;
+    int64_t cid_base = 0;                      // the sorted keys are cell id - cid_base
 
     int64_t base = 0, ns = n;                  // populated slice [base, base + ns) of the global order
     int32_t *key_in = nullptr, *val_in = nullptr; // what gets sorted
@@ -542,10 +559,15 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         ns = zhi >= zlo ? first[(size_t)zhi + 1] - base : 0;
         // ---- pass B: the points of those layers in index order, with their cell ids ----------------------
         if (ns > 0) {
+            // keys relative to the slab's first cell: 19 bits instead of 23 at config 5 -- two sort passes instead of three
+            const int64_t layer_cells = (int64_t)c->dim[0] * c->dim[1];
+            cid_base = (int64_t)zlo * layer_cells;
+            bits = 1;
+            while (((int64_t)1 << bits) < (int64_t)(zhi - zlo + 1) * layer_cells) ++bits;
             SF_CHECK(tmp.alloc(&key_in, (size_t)ns + 1));
             SF_CHECK(tmp.alloc(&val_in, (size_t)ns + 1));
             SF_LAUNCH(ctx, "k1_select_slab", k_select_slab, dim3(nblocks), dim3(256), (const double *)c->z_orig,
-                      (const double *)c->xyz_orig, n, chunk, g, zlo, zhi, (const unsigned int *)dmat, val_in, key_in);
+                      (const double *)c->xyz_orig, n, chunk, g, zlo, zhi, (const unsigned int *)dmat, val_in, key_in, (int)cid_base);
         }
     }
     c->pop_begin = base;
@@ -567,7 +589,7 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
     // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
     c->normals_sorted = c->nrm_orig != nullptr;
-    SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, base, ns,
+    SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, cid_base, base, ns,
               ncell, c->cell_start);
     return SF_OK;
 }

@@ -37,7 +37,21 @@ sf_grid_desc sf_make_grid_desc(const sf_cloud *c)
 }
 
 // (see grid.hip: Onesweep instead of the merge-sort fallback up to 2^20 items)
-using sf_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+// ... and rocPRIM 4.2 carries no tuned Onesweep configuration for gfx950: the generic one sorts 4 bits per pass.  Ten bits per
+// pass (1024-thread blocks, 6 items per thread, match ranking) sorts the 20-bit cell ids of a 1M-point cloud in two passes:
+// 0.117 -> 0.068 ms (8 bits: 0.092-0.102, 11 bits: 0.090, 12 bits: does not fit LDS; tools/ab_k1.sh)
+#ifndef SF_SORT_BITS
+#define SF_SORT_BITS 10
+#endif
+#ifndef SF_SORT_BLOCK
+#define SF_SORT_BLOCK 1024
+#endif
+#ifndef SF_SORT_ITEMS
+#define SF_SORT_ITEMS 6
+#endif
+using sf_onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<SF_SORT_BLOCK, SF_SORT_ITEMS>, rocprim::kernel_config<SF_SORT_BLOCK, SF_SORT_ITEMS>,
+                                                        SF_SORT_BITS, rocprim::block_radix_rank_algorithm::match>;
+using sf_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, sf_onesweep, 65536>;
 
 namespace {
 
@@ -153,7 +167,11 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
         const double px = __shfl(pxv, 16 * qi), py = __shfl(pyv, 16 * qi), pz = __shfl(pzv, 16 * qi);
         // two of the boundaries between runs and the number of pair slots, as scalars
         const int b4 = __shfl(first_slot, 16 * qi + 4), b8 = __shfl(first_slot, 16 * qi + 8);
+#ifdef SF_K2_ABLATE // TIMING ONLY (tools/ab_libs.sh): sweep this percentage of the candidate slots -- what a finer z split could save at best
+        const int nslots = sf_uniform(__shfl(first_slot, 16 * qi + 9)) * SF_K2_ABLATE / 100;
+#else
         const int nslots = sf_uniform(__shfl(first_slot, 16 * qi + 9)); // lane 9 has npairs = 0: its exclusive sum is the total
+#endif
         int total = 0;
         const int64_t out = MODE == 1 ? offset[q] : q * (int64_t)cap;
         const int room = MODE == 2 ? cap : 0x7fffffff;

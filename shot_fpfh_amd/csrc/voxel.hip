@@ -38,6 +38,11 @@ struct sf_voxels {
     int32_t *start = nullptr;    // nvox + 1: first sorted element of every voxel
 };
 
+// (no tuned Onesweep configuration for gfx950 in rocPRIM 4.2: see grid.hip)
+using sf_vox_onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 4>, rocprim::kernel_config<1024, 4>, 10,
+                                                            rocprim::block_radix_rank_algorithm::match>;
+using sf_vox_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, sf_vox_onesweep, 65536>;
+
 namespace {
 
 // numpy's floor_divide for float64 (npy_floor_divide / npy_divmod), a >= 0 or not, b != 0
@@ -282,10 +287,10 @@ extern "C" sf_voxels *sf_voxels_build(sf_ctx *ctx, const double *xyz, int64_t n,
     {
         sf_launch_timer t_(ctx, "v2_voxel_sort");
         size_t tb = 0;
-        ok = ok && rocprim::radix_sort_pairs(nullptr, tb, key, skey, val, v->perm, (size_t)n, 0, bx + by + bz, ctx->stream) == hipSuccess;
+        ok = ok && rocprim::radix_sort_pairs<sf_vox_sort_config>(nullptr, tb, key, skey, val, v->perm, (size_t)n, 0, bx + by + bz, ctx->stream) == hipSuccess;
         void *ts = nullptr;
         ok = ok && sf_ctx_scratch(ctx, tb, &ts) == SF_OK;
-        ok = ok && rocprim::radix_sort_pairs(ts, tb, key, skey, val, v->perm, (size_t)n, 0, bx + by + bz, ctx->stream) == hipSuccess;
+        ok = ok && rocprim::radix_sort_pairs<sf_vox_sort_config>(ts, tb, key, skey, val, v->perm, (size_t)n, 0, bx + by + bz, ctx->stream) == hipSuccess;
     }
     {
         sf_launch_timer t_(ctx, "v3_voxel_runs");
