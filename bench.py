@@ -862,8 +862,8 @@ def main() -> int:
                             "achieved_gbs": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 if k3 > 0 else None,
                             "frac_of_8000": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS if k3 > 0 else None,
                             "frac_of_6290": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 / HBM_COPY_GBS if k3 > 0 else None,
-                            "note": "48 B per query are compulsory; the kernel gathers ~110 neighbours x 24 B per query through L2 and "
-                                    "solves a 3x3 eigenproblem per lane: latency / VALU bound (DESIGN kernel table)"},
+                            "note": "48 B per query are compulsory; the kernels gather ~110 neighbours x 24 B per query through L2 and "
+                                    "solve a 3x3 eigenproblem per query: gather / latency bound (DESIGN kernel table)"},
             "host_to_host_s": min(ts), "normals_per_s_host_to_host": n_total / min(ts),
             "parity_max_abs_err_up_to_sign": nerr, "parity_rows": int(pick.size), "parity_ok": bool(nerr <= 1e-5),
         }

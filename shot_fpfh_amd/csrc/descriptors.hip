@@ -69,8 +69,12 @@ __global__ __launch_bounds__(256) void k_pca(const double *__restrict__ rec, con
                                              const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
                                              int64_t m, const double *__restrict__ pre, double *__restrict__ out_n,
                                              double *__restrict__ out_w, double *__restrict__ out_v,
-                                             double *__restrict__ out_m)
+                                             double *__restrict__ out_m, const double *__restrict__ cov_in = nullptr,
+                                             const double *__restrict__ bary_in = nullptr)
 {
+    // cov_in / bary_in: the covariance (6 per query) and the barycentre relative to the query (3) are already there
+    // (k_pca_cov, the fast form below): the two sweeps that compute them are skipped and the decomposition -- hence the
+    // moments on top of it -- is bit for bit the one sf_pca returns without moments
     const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
     const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
     if (q0 >= m) return;
@@ -83,6 +87,13 @@ __global__ __launch_bounds__(256) void k_pca(const double *__restrict__ rec, con
     const double pxm = qx[qm], pym = qy[qm], pzm = qz[qm];
     double c11 = 0, c21 = 0, c31 = 0, c22 = 0, c32 = 0, c33 = 0;
     double bx = 0, by = 0, bz = 0; // barycentre relative to the query (kept for the moments)
+    if (cov_in) {
+        if (mine) {
+            const double *cc = cov_in + 6 * qm, *bb = bary_in + 3 * qm;
+            c11 = cc[0]; c21 = cc[1]; c31 = cc[2]; c22 = cc[3]; c32 = cc[4]; c33 = cc[5];
+            bx = bb[0]; by = bb[1]; bz = bb[2];
+        }
+    } else
     for (int r = 0; r < 16; ++r) {
         const int src = 16 * rw + r;
         const int64_t s = __shfl(smine, src);
@@ -178,6 +189,98 @@ __global__ __launch_bounds__(256) void k_pca(const double *__restrict__ rec, con
             double *o = out_m + 8 * row;
             o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3; o[4] = m4; o[5] = m5; o[6] = m6; o[7] = m7;
         }
+    }
+}
+
+// K3, fast form (lists of at most 256 points, normals and the plain decomposition): TWO kernels.
+//   k_pca_cov<NCH>   one WAVE per query: every neighbour is gathered once into registers (one index round trip, one
+//                    gather round trip -- k_pca's 16-lane rows take two dependent round trips per 16 neighbours, twice over),
+//                    the barycentre and the centred second moments are wave reductions (the second "sweep" of
+//                    pca_based_descriptors.py:21-23 runs on registers), 6 doubles per query go to memory;
+//   k_pca_solve<M>   one eigen-solve per lane on those, outputs as k_pca writes them.
+// Same arithmetic per term as k_pca (coordinates relative to the query, mean subtracted before the products, / k); only
+// the association of the sums differs, as it already did between k_pca's lane-strided partial sums and NumPy's.
+template <int NCH>
+__global__ __launch_bounds__(128) void k_pca_cov(const double *__restrict__ rec, const double *__restrict__ qx,
+                                                 const double *__restrict__ qy, const double *__restrict__ qz,
+                                                 const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+                                                 const int32_t *__restrict__ idx, int64_t m, double *__restrict__ cov,
+                                                 double *__restrict__ bary)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = sf_uniform64(sf_xcd_block() * 2 + (threadIdx.x >> 6));
+    if (q >= m) return;
+    const int64_t s = offset[q];
+    const int k = sf_uniform(cnt[q]);
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    int jj[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = c * 64 + lane;
+        jj[c] = -1;
+        if (c == 0 || c * 64 < k) jj[c] = t < k ? idx[s + t] : -1;
+    }
+    double x[NCH], y[NCH], z[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        x[c] = y[c] = z[c] = 0.0;
+        if (c == 0 || c * 64 < k) {
+            double gx, gy, gz;
+            sf_load_xyz(rec, jj[c] < 0 ? 0 : jj[c], gx, gy, gz);
+            const bool on = jj[c] >= 0;
+            x[c] = on ? gx - px : 0.0;
+            y[c] = on ? gy - py : 0.0;
+            z[c] = on ? gz - pz : 0.0;
+        }
+    }
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { sx += x[c]; sy += y[c]; sz += z[c]; }
+    const double kk = (double)k;
+    const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
+    double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool on = jj[c] >= 0;
+        const double ax = on ? x[c] - mx : 0.0, ay = on ? y[c] - my : 0.0, az = on ? z[c] - mz : 0.0;
+        part[0] += ax * ax;
+        part[1] += ay * ax;
+        part[2] += az * ax;
+        part[3] += ay * ay;
+        part[4] += az * ay;
+        part[5] += az * az;
+    }
+    const double tot = sf_wave_sum8(part); // lanes 8 i .. 8 i + 7 hold the sum of part[i]
+    const int e = lane >> 3;
+    if ((lane & 7) == 0 && e < 6) cov[6 * q + e] = tot / kk; // c11 c21 c31 c22 c32 c33
+    if (bary && lane == 0) { bary[3 * q] = mx; bary[3 * q + 1] = my; bary[3 * q + 2] = mz; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_pca_solve(const double *__restrict__ cov, const int32_t *__restrict__ qrow, int64_t m,
+                                                  const double *__restrict__ pre, double *__restrict__ out_n,
+                                                  double *__restrict__ out_w, double *__restrict__ out_v)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const double *c = cov + 6 * q;
+    const sf_eig::eig3 e = sf_eig::eigh3_lower(c[0], c[1], c[2], c[3], c[4], c[5]);
+    const int64_t row = qrow ? (int64_t)qrow[q] : q;
+    if (MODE == 0) {
+        double nx = e.v11, ny = e.v21, nz = e.v31;
+        if (pre) {
+            const double dot = (nx * pre[3 * row] + ny * pre[3 * row + 1]) + nz * pre[3 * row + 2];
+            if (dot < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+        }
+        out_n[3 * row + 0] = nx;
+        out_n[3 * row + 1] = ny;
+        out_n[3 * row + 2] = nz;
+    } else {
+        out_w[3 * row + 0] = e.w1; out_w[3 * row + 1] = e.w2; out_w[3 * row + 2] = e.w3;
+        double *v = out_v + 9 * row; // row-major: v[3 i + k] = component i of eigenvector k
+        v[0] = e.v11; v[1] = e.v12; v[2] = e.v13;
+        v[3] = e.v21; v[4] = e.v22; v[5] = e.v23;
+        v[6] = e.v31; v[7] = e.v32; v[8] = e.v33;
     }
 }
 
@@ -1074,6 +1177,28 @@ static int stage_sync(sf_ctx *ctx, int flags)
     return SF_OK;
 }
 
+// the fast form of K3 (k_pca_cov + k_pca_solve) for lists of at most 256 points; SF_K3_ROWS=1 forces the one-kernel form
+static bool k3_fast(const sf_nbrs *nb)
+{
+    static const bool off = getenv("SF_K3_ROWS") && getenv("SF_K3_ROWS")[0] == '1';
+    return !off && nb->max_count <= 256;
+}
+
+static int launch_pca_cov(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *cov, double *bary = nullptr)
+{
+    const int64_t m = nb->m;
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, 2))), block(128);
+    const int nch = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+#define SF_K3_COV(NCH)                                                                                                  \
+    SF_LAUNCH(ctx, "k3_normals", k_pca_cov<NCH>, grid, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, m, cov, bary)
+    if (nch <= 1) { SF_K3_COV(1); }
+    else if (nch == 2) { SF_K3_COV(2); }
+    else if (nch == 3) { SF_K3_COV(3); }
+    else { SF_K3_COV(4); }
+#undef SF_K3_COV
+    return SF_OK;
+}
+
 extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *pre, double *out, int flags)
 {
     SF_CHECK(check_nbrs(ctx, c, nb, "sf_normals"));
@@ -1084,7 +1209,13 @@ extern "C" int sf_normals(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *p
     double *dout;
     SF_CHECK(stage_in(tmp, pre, (size_t)m * 3, flags, &dpre));
     SF_CHECK(stage_out(tmp, out, (size_t)m * 3, flags, &dout));
-    if (m) {
+    if (m && k3_fast(nb)) {
+        double *cov = nullptr;
+        SF_CHECK(tmp.alloc(&cov, (size_t)m * 6));
+        SF_CHECK(launch_pca_cov(ctx, c, nb, cov));
+        SF_LAUNCH(ctx, "k3_normals", k_pca_solve<0>, dim3((unsigned)sf_div_up(m, 64)), dim3(64), (const double *)cov,
+                  (const int32_t *)nb->qrow, m, dpre, dout, (double *)nullptr, (double *)nullptr);
+    } else if (m) {
         SF_LAUNCH(ctx, "k3_normals", k_pca<0>, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx,
                   nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, dpre, dout, (double *)nullptr,
                   (double *)nullptr, (double *)nullptr);
@@ -1106,9 +1237,23 @@ extern "C" int sf_pca(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *eigenvalues
     if (moments) SF_CHECK(stage_out(tmp, moments, (size_t)m * 8, flags, &dm));
     if (m) {
         const dim3 grid(sf_xcd_grid(sf_div_up(m, 256))), block(256);
-        if (moments) {
+        if (moments && k3_fast(nb)) {
+            double *cov = nullptr, *bary = nullptr;
+            SF_CHECK(tmp.alloc(&cov, (size_t)m * 6));
+            SF_CHECK(tmp.alloc(&bary, (size_t)m * 3));
+            SF_CHECK(launch_pca_cov(ctx, c, nb, cov, bary));
+            SF_LAUNCH(ctx, "k3_pca_moments", k_pca<2>, grid, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count,
+                      nb->idx, nb->qrow, m, (const double *)nullptr, (double *)nullptr, dw, dv, dm, (const double *)cov,
+                      (const double *)bary);
+        } else if (moments) {
             SF_LAUNCH(ctx, "k3_pca_moments", k_pca<2>, grid, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count,
                       nb->idx, nb->qrow, m, (const double *)nullptr, (double *)nullptr, dw, dv, dm);
+        } else if (k3_fast(nb)) {
+            double *cov = nullptr;
+            SF_CHECK(tmp.alloc(&cov, (size_t)m * 6));
+            SF_CHECK(launch_pca_cov(ctx, c, nb, cov));
+            SF_LAUNCH(ctx, "k3_pca", k_pca_solve<1>, dim3((unsigned)sf_div_up(m, 64)), dim3(64), (const double *)cov,
+                      (const int32_t *)nb->qrow, m, (const double *)nullptr, (double *)nullptr, dw, dv);
         } else {
             SF_LAUNCH(ctx, "k3_pca", k_pca<1>, grid, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count,
                       nb->idx, nb->qrow, m, (const double *)nullptr, (double *)nullptr, dw, dv, (double *)nullptr);
