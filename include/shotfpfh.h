@@ -70,6 +70,10 @@ void *sf_stream(sf_ctx *ctx); /* hipStream_t the kernels are launched on */
 int sf_fork(sf_ctx *ctx);
 int sf_switch(sf_ctx *ctx, int side);
 int sf_join(sf_ctx *ctx);
+/* sf_mark: remember the point reached on the current stream; sf_wait_mark: the current stream waits for that point -- and
+ * only for it, not for work issued on the marked stream later (sf_join waits for everything). */
+int sf_mark(sf_ctx *ctx);
+int sf_wait_mark(sf_ctx *ctx);
 
 /* ---- raw device memory (for callers that keep results resident) ------------------------- */
 void *sf_dev_alloc(sf_ctx *ctx, size_t bytes);

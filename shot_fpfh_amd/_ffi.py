@@ -35,6 +35,8 @@ SIGNATURES = {
     "sf_fork": (_int, [_vp]),
     "sf_switch": (_int, [_vp, _int]),
     "sf_join": (_int, [_vp]),
+    "sf_mark": (_int, [_vp]),
+    "sf_wait_mark": (_int, [_vp]),
     "sf_dev_alloc": (_vp, [_vp, _sz]),
     "sf_dev_free": (_int, [_vp, _vp]),
     "sf_host_alloc": (_vp, [_vp, _sz]),

@@ -51,6 +51,7 @@ struct sf_ctx {
     hipStream_t stream = nullptr;   // the stream calls are issued on (one of streams[])
     hipStream_t streams[2] = {nullptr, nullptr};
     hipEvent_t join_event = nullptr;
+    hipEvent_t mark_event = nullptr; // sf_mark / sf_wait_mark
     bool profiling = false;
     std::string prof_only; // sf_profile_only: time launches of this name only ("" = all)
     std::map<std::string, sf_prof_entry> prof;

@@ -48,6 +48,7 @@ extern "C" sf_ctx *sf_create(int device)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->streams[1], hipStreamNonBlocking, prio_hi);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->mark_event, hipEventDisableTiming);
     if (e != hipSuccess) {
         sf_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         delete ctx;
@@ -137,6 +138,23 @@ extern "C" int sf_join(sf_ctx *ctx)
     SF_HIP(hipEventRecord(ctx->join_event, ctx->streams[1]));
     SF_HIP(hipStreamWaitEvent(ctx->streams[0], ctx->join_event, 0));
     ctx->stream = ctx->streams[0];
+    return SF_OK;
+}
+
+// A finer dependency than sf_join: sf_mark remembers the point reached on the CURRENT stream, sf_wait_mark makes the
+// current stream wait for that point only -- not for what was issued on the marked stream afterwards.  (The sharded pass:
+// the boundary keypoints of K7 wait for the row exchange on the side stream, not for the eigen-solves queued behind it.)
+extern "C" int sf_mark(sf_ctx *ctx)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    SF_HIP(hipEventRecord(ctx->mark_event, ctx->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_wait_mark(sf_ctx *ctx)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    SF_HIP(hipStreamWaitEvent(ctx->stream, ctx->mark_event, 0));
     return SF_OK;
 }
 

@@ -242,6 +242,14 @@ class Engine:
     def switch(self, side: int) -> None:
         _ffi.check(self.lib.sf_switch(self.h, int(side)), "sf_switch")
 
+    def mark(self) -> None:
+        """Remember the point reached on the current stream (see wait_mark)."""
+        _ffi.check(self.lib.sf_mark(self.h), "sf_mark")
+
+    def wait_mark(self) -> None:
+        """The current stream waits for the marked point -- not for what was queued on the marked stream after it."""
+        _ffi.check(self.lib.sf_wait_mark(self.h), "sf_wait_mark")
+
     def join(self) -> None:
         """Back on the main stream, ordered after the side stream."""
         _ffi.check(self.lib.sf_join(self.h), "sf_join")

@@ -231,19 +231,16 @@ class DescriptorJob:
                 forked = True
                 if not self.emulate_peers:
                     spfh.exchange_rows(xp.ops)
+                eng.mark()  # the borrowed rows are in place from here on
                 if shared:
                     nb.lrf_raw_from_moments(self.moments, 0, self.lrf_out)
                 eng.switch(0)
-                first_piece = True
                 for lo, view in views:
-                    if not (first_piece and (lo, lo + view.m) == (i0, i1)) and forked:
-                        eng.join()  # boundary keypoints read the borrowed rows
-                        forked = False
+                    if (lo, lo + view.m) != (i0, i1):
+                        eng.wait_mark()  # boundary keypoints read the borrowed rows (not the eigen-solves queued after them)
                     spfh.fpfh(view, None, out=self.fpfh_out, out_row=lo - b)
-                    first_piece = False
-                if forked:
-                    eng.join()
-                    forked = False
+                eng.join()  # K5 needs the frames
+                forked = False
                 if shared:
                     nb.shot_from_raw_lrf(self.lrf_out, self.normalize, self.min_nb, self.shot_out)
                 elif self.do_shot:

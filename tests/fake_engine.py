@@ -197,6 +197,12 @@ class FakeEngine:
     def join(self):
         pass
 
+    def mark(self):
+        pass
+
+    def wait_mark(self):
+        pass
+
     def cloud(self, points, normals=None):
         return FakeCloud(points, normals)
 
