@@ -607,7 +607,10 @@ def main() -> int:
             roof_all["k5_shot"]["valu_issue"] = {
                 "vector_instructions_per_keypoint": sq["SQ_INSTS_VALU_per_wave"], "busy_cycles_per_keypoint": cyc,
                 "simds": 1024, "clock_mhz": sq["clock_mhz"], "ceiling_ms": round(ceiling_ms, 4),
-                "frac_of_ceiling": round(ceiling_ms / roof_all["k5_shot"]["ms_per_step"], 4), "source": sq_src}
+                "ceiling_over_measured": round(ceiling_ms / roof_all["k5_shot"]["ms_per_step"], 4),
+                "note": "counters and clock were taken under the profiler (the kernel runs ~8 % slower there, at a lower clock): a "
+                        "ratio within a few per cent of 1 means the kernel's time IS its vector-issue time",
+                "source": sq_src}
         out = {
             "metric": "descriptors/sec (SHOT+FPFH) on 1M-pt cloud",
             "value": value,

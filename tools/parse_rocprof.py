@@ -22,7 +22,7 @@ SHORT = [
     ("k_lrf_from_cov", "k4_lrf_from_cov"), ("k_shot_lrf", "k4_shot_lrf"), ("k_lrf_", "k4_shot_lrf"), ("k_shot", "k5_shot"), ("k_fpfh", "k7_fpfh"), ("k_spfh_export", "k6_spfh_export"),
     ("k_spfh", "k6_spfh"), ("k_radius<2>", "k2_radius_slots"), ("k_radius<1>", "k2_radius_fill"), ("k_radius<0>", "k2_radius_count"),
     ("k_radius<true>", "k2_radius_fill"), ("k_radius<false>", "k2_radius_count"), ("k_export_lists", "k2_export_lists"),
-    ("k_radius", "k2_radius"), ("k_normals", "k3_normals"), ("k_match_tile", "k8_match_tile"), ("k_ransac", "k9_ransac_score"),
+    ("k_radius", "k2_radius"), ("k_normals_max", "k1_normals_max"), ("k_pca_cov", "k3_normals"), ("k_pca_solve", "k3_normals"), ("k_normals", "k3_normals"), ("k_match_tile", "k8_match_tile"), ("k_ransac", "k9_ransac_score"),
     ("k_match_half", "k8_match_half"), ("k_half_convert", "k8_half_convert"), ("k_half_final", "k8_half_final"),
     ("k_half_window", "k8_half_window"), ("k_half_max", "k8_half_max"), ("k_match_gemm", "k8_match_gemm"),
     ("k_match_decide", "k8_match_decide"), ("k_row_sqnorm", "k8_row_sqnorm"),
