@@ -928,7 +928,9 @@ static int spfh_wire_parts(sf_ctx *ctx, sf_spfh *sp, spfh_part parts[2])
         const unsigned m8 = sp->host_live[0] & 0xffu;
         const bool sparse = sp->mask_known && sp->host_live_valid && __builtin_popcount(m8) <= 2 && sp->host_live[1] == m8;
         if (!sparse) { // rows from other ranks' K6 under masks this rank cannot know: every block counts as live
-            SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->stream));
+            // (on the MAIN stream whatever the current one is: the exchange itself may be running on the side stream, and the
+            // K7 launches that must see the new mask are queued on the main stream after this call returns)
+            SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->streams[0]));
             sp->host_live[0] = sp->host_live[1] = ~0u;
             sp->host_live_valid = sp->mask_known = true;
         }

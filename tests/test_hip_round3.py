@@ -163,8 +163,10 @@ def test_config_c4_shaped_pair_gives_the_reference_match_vector(eng):
 
 
 # ---- block build + borrowed halo rows ----------------------------------------------------------------------------------
-@pytest.mark.parametrize("world", [2, 3, 7])
-@pytest.mark.parametrize("n,radius,n_bins", [(30000, 0.06, 5), (9000, 0.1, 4)])
+@pytest.mark.parametrize("world,n,radius,n_bins", [(2, 30000, 0.06, 5), (3, 30000, 0.06, 5), (7, 30000, 0.06, 5), (2, 9000, 0.1, 4),
+                                                    (3, 9000, 0.1, 4), (7, 9000, 0.1, 4),
+                                                    (9, 400, 0.3, 5),    # blocks thinner than a z-layer: halos span several ranks
+                                                    (70, 60, 0.45, 5)])  # more ranks than points: empty blocks at the end
 def test_neighbor_mode_blocks_equal_the_unsharded_pass_bit_for_bit(eng, world, n, radius, n_bins):
     """Every rank's pass in spfh_exchange="neighbor" (block build with reach 1, K2 / K6 on the block only, K7 split into
     interior and boundary keypoints), the peers' rows standing in the table as they would after the exchange
@@ -192,19 +194,23 @@ def test_neighbor_mode_blocks_equal_the_unsharded_pass_bit_for_bit(eng, world, n
     assert (seen == 1).all()
 
 
-def test_two_ranks_on_one_device_exchange_through_the_wire_image(eng):
+@pytest.mark.parametrize("n_bins", [5, 4])
+def test_two_ranks_on_one_device_exchange_through_the_wire_image(eng, n_bins):
     """Ranks 0 and 1 of 2 as two jobs on one device: each computes its block's SPFH rows only, the rows of the
     exchange plan travel as wire images through host memory (sf_spfh_rows_image), then each reduces its block.  Equal to
     the one-rank pass bit for bit -- and a missing exchange is noticed (the borrowed rows are poisoned first)."""
     from shot_fpfh_amd.sharding import DescriptorJob, exchange_plan
 
+    # (5 bins: packed rows travel; 4 bins: alpha has an edge at 0, every block counts as live once rows are borrowed, the
+    # full byte rows travel and the FULL matrix-core form reduces them)
     n, radius = 20000, 0.07
     p, nr, _ = synth_cloud(n, 5)
-    one = DescriptorJob(eng, p, nr, radius, min_neighborhood_size=5)
+    one = DescriptorJob(eng, p, nr, radius, n_bins=n_bins, min_neighborhood_size=5)
     one.step()
     f1 = one.fpfh_out.to_host()
     one.close()
-    jobs = [DescriptorJob(eng, p, nr, radius, min_neighborhood_size=5, world=2, rank=r, spfh_exchange="neighbor") for r in (0, 1)]
+    jobs = [DescriptorJob(eng, p, nr, radius, n_bins=n_bins, min_neighborhood_size=5, world=2, rank=r, spfh_exchange="neighbor")
+            for r in (0, 1)]
     mail = {}
 
     class Staged:
