@@ -527,6 +527,21 @@ def main() -> int:
             try:
                 uid = ctl.bcast(eng.comm_unique_id() if rank == 0 else None) if ctl else eng.comm_unique_id()
                 eng.comm_init(uid, world, rank)
+                # pre-flight: the three RCCL call shapes of the run, on a few bytes, checked -- a node where point-to-point
+                # between two GPUs does not work should say so here, not inside the timed loop
+                probe = eng.empty((2 * world + 2,), np.uint64).from_host(np.full(2 * world + 2, rank + 1, dtype=np.uint64))
+                up, down = (rank + 1) % world, (rank - 1) % world
+                eng.exchange([(up, probe, 0, 8, probe, 8 * (world + 1), 8)] if world == 1 else
+                             [(up, probe, 0, 8, probe, 8 * world, 8), (down, probe, 0, 8, probe, 8 * (world + 1), 8)])
+                eng.allgather(probe, 8)
+                eng.sync()
+                got = probe.to_host()
+                want_gather = np.arange(1, world + 1, dtype=np.uint64)
+                if world > 1 and not (np.array_equal(got[:world], want_gather) and got[world] == up + 1 and got[world + 1] == down + 1):
+                    raise RuntimeError(f"RCCL pre-flight returned wrong data on rank {rank}: {got.tolist()}")
+                eng.allreduce_min_u64(probe, 1)
+                eng.sync()
+                probe.free()
             except Exception as exc:  # noqa: BLE001 -- reported in the record
                 err = f"{type(exc).__name__}: {exc}"
             errs = ctl.allgather(err) if ctl else [err]
