@@ -121,7 +121,7 @@ int sf_ctx_scratch(sf_ctx *ctx, size_t bytes, void **out);
 #define SF_FLAG_ROWS_GATHER 1
 #define SF_FLAG_VOXEL_ORDER 2
 int sf_ctx_check_flag(sf_ctx *ctx); // after a stream synchronisation: SF_OK, or SF_ERR_ARG with the message of the raised bit(s)
-#define SF_PINNED_BYTES 4096
+#define SF_PINNED_BYTES 32768
 int sf_ctx_pinned(sf_ctx *ctx, void **out);
 hipEvent_t sf_ctx_event(sf_ctx *ctx);
 
@@ -200,6 +200,10 @@ struct sf_cloud {
     // first cell-sorted position of every z-layer of cells (dim[2] + 1 entries, host): written by the block build
     // (which needs it anyway), fetched from cell_start on demand after a whole-cloud build (sf_cloud_layer_table)
     std::vector<int64_t> layer_first;
+    // mean and maximum list length of the last radius search on this cloud, per radius: what the NEXT search with that
+    // radius sizes its slots from instead of counting a sample first (search.hip::run_search).  A capacity hint, nothing
+    // more: a list that outgrows its slot is re-done exactly whatever the slot size was.
+    std::map<double, std::pair<double, int64_t>> list_stats;
 };
 
 struct sf_nbrs {
@@ -216,6 +220,22 @@ struct sf_nbrs {
     int32_t *count = nullptr; // per processing slot
     int64_t *offset = nullptr; // m + 1, per processing slot
     int32_t *idx = nullptr;    // total, sorted positions
+    int32_t *idx_ovf = nullptr; // lists of the queries that overflowed their slot (offset[q] points into it RELATIVE TO idx)
+    int64_t cap = 0;            // slot capacity of the single-sweep search (0: exact CSR)
+    int64_t n_overflow = 0;     // queries whose list did not fit its slot (re-done exactly, those alone)
+    // ---- per-keypoint dispatch of the list-driven kernels (K3, K5, K6, K7) -------------------------------------------
+    // The register-cached / matrix-core kernels hold lists of at most 255 points (four 64-neighbour chunks).  The queries
+    // whose OWN list is longer are left out by the main launch -- which takes the instantiation `main_chunks` that covers
+    // the longest list it does serve -- and are served by a second launch over `tail_sel` (their processing slots,
+    // ascending) in the streaming forms.  One long list never moves the other keypoints to a slower form, and which form
+    // serves a keypoint depends on its own list alone (bit-identical rows for any sharding).
+    int64_t hist[5] = {0, 0, 0, 0, 0}; // queries with count <= 64, <= 128, <= 192, <= 255, > 255
+    bool planned = false;          // main_chunks / tail_* below were set from the statistics of a radius search
+    int main_chunks = 4;
+    int tail_limit = 0x7fffffff;   // lists longer than this belong to the tail launch
+    int32_t *tail_sel = nullptr;   // n_tail processing slots (of the OWNING list set), ascending; shared with views
+    int64_t n_tail = 0;
+    int64_t view_first = 0;        // a view's first slot in the owner's numbering (tail_sel entries are owner slots)
 };
 
 struct sf_spfh {
@@ -236,6 +256,10 @@ struct sf_spfh {
                               // [1]: the mask under which EVERY row of `packed` was last written (~0: not valid).
     uint8_t *packed = nullptr; // uint8 table only: n x 32 bytes, the (at most) two live blocks of each row side by side --
                                // four rows per cache line instead of one for K7's gather
+    uint8_t *hi = nullptr;     // uint8 table whose longest list exceeds 255 points: n x 128 bytes, count >> 8 of the rows of the
+                               // points with MORE than 255 neighbours (the other rows are never written nor read).  `counts`
+                               // holds count & 255 (^ 128): a long point's bins are lo + 256 hi, everybody else's rows -- and the
+                               // matrix-core K7 of every keypoint whose own list fits it -- stay what they are without long points
     unsigned host_live[2] = {0xffu, ~0u}; // the two words of `live` as last read back ...
     bool host_live_valid = false;         // ... valid until the next K6 whose blocks the data decides (sf_fpfh reads them back once)
     bool mask_known = false;              // every mask that ever went into live[0] was known on the host: host_live is exact
@@ -243,3 +267,29 @@ struct sf_spfh {
 };
 
 static inline int64_t sf_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// How a list-driven kernel is launched over these lists (see sf_nbrs): the register-cached instantiation of the main launch
+// (chunks = 1 .. 4; 0: only the streaming form fits), the list length above which the main launch leaves a query out, and
+// the selection a second launch serves.  Lists that did not come out of a radius search (k-NN lists: all of one length) are
+// dispatched by their longest list, as a whole.
+struct sf_dispatch {
+    int chunks = 4;
+    int limit = 0x7fffffff;
+    const int32_t *tail_sel = nullptr;
+    int64_t n_tail = 0, view_first = 0;
+};
+static inline sf_dispatch sf_nbrs_dispatch(const sf_nbrs *nb)
+{
+    sf_dispatch d;
+    if (nb->planned) {
+        d.chunks = nb->main_chunks;
+        d.limit = nb->tail_limit;
+        d.tail_sel = nb->tail_sel;
+        d.n_tail = nb->n_tail;
+        d.view_first = nb->view_first;
+    } else {
+        const int64_t mx = nb->max_count > 0 ? nb->max_count : 1;
+        d.chunks = mx <= 256 ? (int)sf_div_up(mx, 64) : 0;
+    }
+    return d;
+}

@@ -200,55 +200,88 @@ __global__ __launch_bounds__(256) void k_pca(const double *__restrict__ rec, con
 //   k_pca_solve<M>   one eigen-solve per lane on those, outputs as k_pca writes them.
 // Same arithmetic per term as k_pca (coordinates relative to the query, mean subtracted before the products, / k); only
 // the association of the sums differs, as it already did between k_pca's lane-strided partial sums and NumPy's.
-template <int NCH>
+// NCH = 0: streaming form for any list length (two passes over the list, as the reference's `centred = x - mean` makes).
+// limit / SEL: dispatch by list length, per query (sf_nbrs_dispatch) -- the main launch leaves out the queries whose own
+// list exceeds its form, a second launch (SEL, NCH = 0) serves exactly those.
+template <int NCH, bool SEL>
 __global__ __launch_bounds__(128) void k_pca_cov(const double *__restrict__ rec, const double *__restrict__ qx,
                                                  const double *__restrict__ qy, const double *__restrict__ qz,
                                                  const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
                                                  const int32_t *__restrict__ idx, int64_t m, double *__restrict__ cov,
-                                                 double *__restrict__ bary)
+                                                 double *__restrict__ bary, int limit, const int32_t *__restrict__ sel,
+                                                 int64_t nsel, int64_t view_first)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t q = sf_uniform64(sf_xcd_block() * 2 + (threadIdx.x >> 6));
+    int64_t q = sf_uniform64(sf_xcd_block() * 2 + (threadIdx.x >> 6));
+    if (SEL) {
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
     if (q >= m) return;
     const int64_t s = offset[q];
     const int k = sf_uniform(cnt[q]);
+    if (!SEL && k > limit) return;
     const double px = qx[q], py = qy[q], pz = qz[q];
-    int jj[NCH];
+    const double kk = (double)k;
+    constexpr int NC = NCH > 0 ? NCH : 1;
+    int jj[NC];
+    double x[NC], y[NC], z[NC];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    if (NCH > 0) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int t = c * 64 + lane;
-        jj[c] = -1;
-        if (c == 0 || c * 64 < k) jj[c] = t < k ? idx[s + t] : -1;
-    }
-    double x[NCH], y[NCH], z[NCH];
+        for (int c = 0; c < NC; ++c) {
+            const int t = c * 64 + lane;
+            jj[c] = -1;
+            if (c == 0 || c * 64 < k) jj[c] = t < k ? idx[s + t] : -1;
+        }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        x[c] = y[c] = z[c] = 0.0;
-        if (c == 0 || c * 64 < k) {
+        for (int c = 0; c < NC; ++c) {
+            x[c] = y[c] = z[c] = 0.0;
+            if (c == 0 || c * 64 < k) {
+                double gx, gy, gz;
+                sf_load_xyz(rec, jj[c] < 0 ? 0 : jj[c], gx, gy, gz);
+                const bool on = jj[c] >= 0;
+                x[c] = on ? gx - px : 0.0;
+                y[c] = on ? gy - py : 0.0;
+                z[c] = on ? gz - pz : 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { sx += x[c]; sy += y[c]; sz += z[c]; }
+    } else {
+        for (int t = lane; t < k; t += 64) {
             double gx, gy, gz;
-            sf_load_xyz(rec, jj[c] < 0 ? 0 : jj[c], gx, gy, gz);
-            const bool on = jj[c] >= 0;
-            x[c] = on ? gx - px : 0.0;
-            y[c] = on ? gy - py : 0.0;
-            z[c] = on ? gz - pz : 0.0;
+            sf_load_xyz(rec, idx[s + t], gx, gy, gz);
+            sx += gx - px; sy += gy - py; sz += gz - pz;
         }
     }
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) { sx += x[c]; sy += y[c]; sz += z[c]; }
-    const double kk = (double)k;
     const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
     double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (NCH > 0) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const bool on = jj[c] >= 0;
-        const double ax = on ? x[c] - mx : 0.0, ay = on ? y[c] - my : 0.0, az = on ? z[c] - mz : 0.0;
-        part[0] += ax * ax;
-        part[1] += ay * ax;
-        part[2] += az * ax;
-        part[3] += ay * ay;
-        part[4] += az * ay;
-        part[5] += az * az;
+        for (int c = 0; c < NC; ++c) {
+            const bool on = jj[c] >= 0;
+            const double ax = on ? x[c] - mx : 0.0, ay = on ? y[c] - my : 0.0, az = on ? z[c] - mz : 0.0;
+            part[0] += ax * ax;
+            part[1] += ay * ax;
+            part[2] += az * ax;
+            part[3] += ay * ay;
+            part[4] += az * ay;
+            part[5] += az * az;
+        }
+    } else {
+        for (int t = lane; t < k; t += 64) {
+            double gx, gy, gz;
+            sf_load_xyz(rec, idx[s + t], gx, gy, gz);
+            const double ax = (gx - px) - mx, ay = (gy - py) - my, az = (gz - pz) - mz;
+            part[0] += ax * ax;
+            part[1] += ay * ax;
+            part[2] += az * ax;
+            part[3] += ay * ay;
+            part[4] += az * ay;
+            part[5] += az * az;
+        }
     }
     const double tot = sf_wave_sum8(part); // lanes 8 i .. 8 i + 7 hold the sum of part[i]
     const int e = lane >> 3;
@@ -555,45 +588,94 @@ __device__ inline double untag_value(unsigned long long s)
     return fmax(-__longlong_as_double((long long)s), 0.0);
 }
 
+__device__ inline double sf_dot3(double a0, double a1, double a2, double b0, double b1, double b2)
+{
+    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+}
+
+// FUSED: `lrf` holds the raw axes (k_shot_lrf raw mode / k_lrf_from_cov); the sign votes (shot.py:40-45) are taken in the
+// gate sweep and the finished frame is written back, as the register-cached form does.  SEL: the launch serves the
+// processing slots listed in `sel` (the owner's numbering; a view keeps those of its own range) -- the keypoints whose lists
+// are too long for the register-cached form of the main launch.
+template <bool FUSED, bool SEL>
 __global__ __launch_bounds__(64) void k_shot(const double *__restrict__ rec,
                                              const double *__restrict__ qx, const double *__restrict__ qy,
                                              const double *__restrict__ qz, const int64_t *__restrict__ offset,
                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                              const int32_t *__restrict__ qrow,
-                                             int64_t m, double radius, const double *__restrict__ lrf, int normalize,
-                                             int64_t min_nb, double *__restrict__ out)
+                                             int64_t m, double radius, double *__restrict__ lrf, int normalize,
+                                             int64_t min_nb, double *__restrict__ out, const int32_t *__restrict__ sel,
+                                             int64_t nsel, int64_t view_first)
 {
     __shared__ unsigned long long sA[352], sB[352], sG[352], sCD[176], sEF[176];
     __shared__ double sD[176], sF[176];
     const int lane = threadIdx.x;
-    const int64_t q = sf_xcd_block();
+    int64_t q = sf_xcd_block();
+    if (SEL) {
+        if (q >= nsel) return;
+        q = (int64_t)sel[q] - view_first;
+        if (q < 0) return;
+    }
     if (q >= m) return;
     const int64_t s = offset[q];
     const int k = cnt[q];
     const int64_t row = qrow ? qrow[q] : q;
     double *o = out + (int64_t)SF_SHOT_LEN * row;
     const double px = qx[q], py = qy[q], pz = qz[q];
+    double rx0 = 0, rx1 = 0, rx2 = 0, rz0 = 0, rz1 = 0, rz2 = 0;
+    if (FUSED) {
+        const double *lr = lrf + 9 * row;
+        rx0 = lr[0]; rx1 = lr[1]; rx2 = lr[2]; rz0 = lr[3]; rz1 = lr[4]; rz2 = lr[5];
+    }
 
     // gate: strictly more than min_nb neighbours at non-zero distance (shot.py:212, 306)
-    int npos = 0;
+    int npos = 0, xneg = 0, zneg = 0;
     for (int t0 = 0; t0 < k; t0 += 64) {
         const int t = t0 + lane;
-        bool pos = false;
+        bool pos = false, xn = false, zn = false;
         if (t < k) {
             double x, y, z;
             sf_load_xyz(rec, idx[s + t], x, y, z);
             const double cx = x - px, cy = y - py, cz = z - pz;
             pos = ((cx * cx + cy * cy) + cz * cz) > 0.0;
+            if (FUSED) {
+                xn = sf_dot3(cx, cy, cz, rx0, rx1, rx2) < 0.0;
+                zn = sf_dot3(cx, cy, cz, rz0, rz1, rz2) < 0.0;
+            }
         }
         npos += __popcll(__ballot(pos));
+        if (FUSED) {
+            xneg += __popcll(__ballot(xn));
+            zneg += __popcll(__ballot(zn));
+        }
+    }
+    double E[9];
+    if (FUSED) { // (the frame is written whether or not the descriptor passes the gate, as in the cached form)
+        if (xneg > k - xneg) { rx0 = -rx0; rx1 = -rx1; rx2 = -rx2; }
+        if (zneg > k - zneg) { rz0 = -rz0; rz1 = -rz1; rz2 = -rz2; }
+        const double y0 = rz1 * rx2 - rz2 * rx1, y1 = rz2 * rx0 - rz0 * rx2, y2 = rz0 * rx1 - rz1 * rx0; // cross(z, x)
+        if (k == 0) { // shot.py:24-25
+            E[0] = 1.0; E[1] = 0.0; E[2] = 0.0; E[3] = 0.0; E[4] = 1.0; E[5] = 0.0; E[6] = 0.0; E[7] = 0.0; E[8] = 1.0;
+        } else {
+            E[0] = rx0; E[1] = y0; E[2] = rz0;
+            E[3] = rx1; E[4] = y1; E[5] = rz1;
+            E[6] = rx2; E[7] = y2; E[8] = rz2;
+        }
+        if (lane < 9) {
+            double v = E[0];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) v = lane == i ? E[i] : v;
+            lrf[9 * row + lane] = v;
+        }
     }
     if (!((int64_t)npos > min_nb)) {
         for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
         return;
     }
-    double E[9];
+    if (!FUSED) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+        for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+    }
 
     for (int b = lane; b < 352; b += 64) { sA[b] = 0; sB[b] = 0; sG[b] = 0; }
     for (int b = lane; b < 176; b += 64) { sCD[b] = 0; sEF[b] = 0; sD[b] = 0.0; sF[b] = 0.0; }
@@ -776,11 +858,6 @@ __device__ inline double sf_acos_abs_quadrants(double az)
     const double as = r * p; // asin(r) / (pi/2)
     // |z| <= 1/2: 1 - as ;  |z| > 1/2: 2 as
     return big ? as + as : 1.0 - as;
-}
-
-__device__ inline double sf_dot3(double a0, double a1, double a2, double b0, double b1, double b2)
-{
-    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
 }
 
 __device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
@@ -1117,13 +1194,15 @@ __global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                     const int32_t *__restrict__ qrow,
                                                     int64_t m, shot_consts K, double *__restrict__ lrf,
-                                                    int normalize, int64_t min_nb, double *__restrict__ out)
+                                                    int normalize, int64_t min_nb, double *__restrict__ out, int limit)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long slots[SF_SHOT_WPB][704];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned long long *const slot = slots[wave];
     const int64_t q = sf_xcd_block() * SF_SHOT_WPB + wave;
     if (q >= m) return;
+    // (a keypoint whose own list is longer than this launch's form holds belongs to the second launch: launch_shot)
+    if (sf_uniform(cnt[q]) > limit) return;
     // The kernel is instantiated for the LONGEST list of the launch (a 1M-point uniform cloud at 110 neighbours on average
     // has one of 160+), but nearly every keypoint fits one chunk less: a wave-uniform branch picks the body that
     // matches THIS keypoint, so the gather, votes and distance tests of an empty last chunk are never issued.
@@ -1177,24 +1256,28 @@ static int stage_sync(sf_ctx *ctx, int flags)
     return SF_OK;
 }
 
-// the fast form of K3 (k_pca_cov + k_pca_solve) for lists of at most 256 points; SF_K3_ROWS=1 forces the one-kernel form
+// the fast form of K3 (k_pca_cov + k_pca_solve); SF_K3_ROWS=1 forces the one-kernel form
 static bool k3_fast(const sf_nbrs *nb)
 {
     static const bool off = getenv("SF_K3_ROWS") && getenv("SF_K3_ROWS")[0] == '1';
-    return !off && nb->max_count <= 256;
+    (void)nb;
+    return !off;
 }
 
 static int launch_pca_cov(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *cov, double *bary = nullptr)
 {
     const int64_t m = nb->m;
     const dim3 grid(sf_xcd_grid(sf_div_up(m, 2))), block(128);
-    const int nch = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
-#define SF_K3_COV(NCH)                                                                                                  \
-    SF_LAUNCH(ctx, "k3_normals", k_pca_cov<NCH>, grid, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, m, cov, bary)
-    if (nch <= 1) { SF_K3_COV(1); }
-    else if (nch == 2) { SF_K3_COV(2); }
-    else if (nch == 3) { SF_K3_COV(3); }
-    else { SF_K3_COV(4); }
+    const sf_dispatch d = sf_nbrs_dispatch(nb);
+#define SF_K3_COV(NAME, NCH, SEL, GRID)                                                                                 \
+    SF_LAUNCH(ctx, NAME, (k_pca_cov<NCH, SEL>), GRID, block, c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, m, cov, \
+              bary, d.limit, d.tail_sel, d.n_tail, d.view_first)
+    if (d.chunks == 1) { SF_K3_COV("k3_normals", 1, false, grid); }
+    else if (d.chunks == 2) { SF_K3_COV("k3_normals", 2, false, grid); }
+    else if (d.chunks == 3) { SF_K3_COV("k3_normals", 3, false, grid); }
+    else if (d.chunks == 4) { SF_K3_COV("k3_normals", 4, false, grid); }
+    else { SF_K3_COV("k3_normals", 0, false, grid); }
+    if (d.n_tail) { SF_K3_COV("k3_normals_tail", 0, true, dim3(sf_xcd_grid(sf_div_up(d.n_tail, 2)))); }
 #undef SF_K3_COV
     return SF_OK;
 }
@@ -1281,28 +1364,32 @@ extern "C" int sf_shot_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *lrf, i
     return stage_sync(ctx, flags);
 }
 
-// launch K5 on resident buffers; fused != 0: dlrf holds raw axes (k_shot_lrf raw mode) and receives the frames
+// launch K5 on resident buffers; fused != 0: dlrf holds raw axes (k_shot_lrf raw mode) and receives the frames.
+// Dispatch by list length, per keypoint (sf_nbrs_dispatch): the register-cached form of the main launch leaves out the
+// keypoints whose own list exceeds it, and the streaming form serves exactly those in a second launch.
 static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int normalize, int64_t min_nb, double *dout,
                        bool fused)
 {
     const int64_t m = nb->m;
     if (!m) return SF_OK;
-    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), grid_streaming(sf_xcd_grid(m)), block(64 * SF_SHOT_WPB), block_streaming(64);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), block(64 * SF_SHOT_WPB), block_streaming(64);
 #define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m
     const double r_ = nb->radius;
     const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2)}; // the reference's own expressions (shot.py:95-117, 235)
-    const int64_t chunks = sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+    const sf_dispatch d = sf_nbrs_dispatch(nb);
 #define SF_SHOT_CASE(N)                                                                                              \
-    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout); } \
-    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout); }
-    if (chunks <= 1) { SF_SHOT_CASE(1) }
-    else if (chunks == 2) { SF_SHOT_CASE(2) }
-    else if (chunks == 3) { SF_SHOT_CASE(3) }
-    else if (chunks == 4) { SF_SHOT_CASE(4) }
-    else {
-        if (fused) { sf_set_error("internal: fused SHOT needs neighbourhoods of at most 256 points"); return SF_ERR_STATE; }
-        SF_LAUNCH(ctx, "k5_shot", k_shot, grid_streaming, block_streaming, SF_SHOT_ARGS, r_, (const double *)dlrf, normalize, min_nb, dout);
-    }
+    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit); } \
+    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit); }
+#define SF_SHOT_STREAM(NAME, SEL, GRID, SELP, NSEL)                                                                   \
+    if (fused) { SF_LAUNCH(ctx, NAME, (k_shot<true, SEL>), dim3(sf_xcd_grid(GRID)), block_streaming, SF_SHOT_ARGS, r_, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); } \
+    else { SF_LAUNCH(ctx, NAME, (k_shot<false, SEL>), dim3(sf_xcd_grid(GRID)), block_streaming, SF_SHOT_ARGS, r_, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); }
+    if (d.chunks == 1) { SF_SHOT_CASE(1) }
+    else if (d.chunks == 2) { SF_SHOT_CASE(2) }
+    else if (d.chunks == 3) { SF_SHOT_CASE(3) }
+    else if (d.chunks == 4) { SF_SHOT_CASE(4) }
+    else { SF_SHOT_STREAM("k5_shot", false, m, (const int32_t *)nullptr, (int64_t)0) }
+    if (d.n_tail) { SF_SHOT_STREAM("k5_shot_tail", true, d.n_tail, d.tail_sel, d.n_tail) }
+#undef SF_SHOT_STREAM
 #undef SF_SHOT_CASE
 #undef SF_SHOT_ARGS
     return SF_OK;
@@ -1404,7 +1491,7 @@ extern "C" int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int n
         dlrf = own_lrf;
     }
     SF_CHECK(stage_out(tmp, out, (size_t)m * SF_SHOT_LEN, flags, &dout));
-    const bool fused = nb->max_count <= 256;
+    const bool fused = true; // (the streaming K5 votes too: no list is too long for the fused path)
     if (m) {
         SF_LAUNCH(ctx, "k4_shot_lrf", k_shot_lrf, dim3(sf_xcd_grid(sf_div_up(m, 256))), dim3(256), c->rec, nb->qx, nb->qy,
                   nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, nb->radius, fused ? 1 : 0, 0, dlrf);
@@ -1423,8 +1510,8 @@ extern "C" int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const
 {
     SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_from_moments"));
     if (!out || !cov_dev) { sf_set_error("sf_shot_from_moments: null argument"); return SF_ERR_ARG; }
-    if (nb->qrow || nb->max_count > 256) {
-        sf_set_error("sf_shot_from_moments: needs a self search with lists of at most 256 points");
+    if (nb->qrow) {
+        sf_set_error("sf_shot_from_moments: needs a self search");
         return SF_ERR_UNSUPPORTED;
     }
     SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
@@ -1466,7 +1553,6 @@ extern "C" int sf_shot_from_raw_lrf(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, doubl
 {
     SF_CHECK(check_nbrs(ctx, c, nb, "sf_shot_from_raw_lrf"));
     if (!lrf_dev || !out_dev) { sf_set_error("sf_shot_from_raw_lrf: null argument"); return SF_ERR_ARG; }
-    if (nb->max_count > 256) { sf_set_error("sf_shot_from_raw_lrf: lists of at most 256 points"); return SF_ERR_UNSUPPORTED; }
     SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
     return launch_shot(ctx, c, nb, lrf_dev, normalize, min_nb, out_dev, true);
 }

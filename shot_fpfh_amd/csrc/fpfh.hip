@@ -106,7 +106,9 @@ __device__ inline int theta_bin_fast(const fpfh_edges &ed, int nb, double a, dou
 #define SF_SPFH_WPB 2 // waves (= points) per workgroup (0.655 / 0.643 / 0.645 ms at C3 for 4 / 2 / 1)
 #endif
 
-template <typename CT, int NCH, int NB>
+// limit / SEL: dispatch by list length, per point (sf_nbrs_dispatch) -- the main launch leaves out the points whose own list
+// exceeds its form, a second launch (SEL, the streaming form) serves exactly those.
+template <typename CT, int NCH, int NB, bool SEL>
 __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_eu(6))) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
@@ -114,18 +116,28 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
                                               CT *__restrict__ counts, int32_t *__restrict__ kout, unsigned bias,
                                               double *__restrict__ p4, double mom_radius, double *__restrict__ cov,
                                               unsigned *__restrict__ live, int alpha_bin, double nrm_max,
-                                              uint8_t *__restrict__ packed, int pack_b0, int pack_b1)
+                                              uint8_t *__restrict__ packed, int pack_b0, int pack_b1,
+                                              uint8_t *__restrict__ hi, int limit, const int32_t *__restrict__ sel,
+                                              int64_t nsel, int64_t view_first)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = sf_uniform64(sf_xcd_block() * SF_SPFH_WPB + wave);
+    int64_t q = sf_uniform64(sf_xcd_block() * SF_SPFH_WPB + wave);
+    if (SEL) {
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
     if (q >= m) return; // whole wave exits together; no block-wide barrier below
     unsigned int *h = hist[wave];
     for (int b = lane; b < nb3; b += 64) h[b] = 0;
     const int64_t i = self_begin + q; // cell-sorted position of this point
     const int64_t s = offset[q];
     const int k = cnt[q];
+#ifndef SF_AB_NOLIMIT
+    if (!SEL && sf_uniform(k) > limit) return; // (a point of the second launch)
+#endif
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const double ux = rec[6 * i + 3], uy = rec[6 * i + 4], uz = rec[6 * i + 5];
     __builtin_amdgcn_wave_barrier();
@@ -227,8 +239,12 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
     CT *row = counts + i * (int64_t)stride;
     if (live) { // uint8 table: 128 bins, two per lane; which 16-bin blocks of this row hold a count goes into the table-wide mask
         const unsigned v0 = lane < nb3 ? h[lane] : 0u, v1 = lane + 64 < nb3 ? h[lane + 64] : 0u; // (padding bins: count 0)
-        row[lane] = (CT)(v0 ^ bias);
+        row[lane] = (CT)(v0 ^ bias); // (the uint8 table keeps count & 255; a point with more than 255 neighbours also has ...
         row[lane + 64] = (CT)(v1 ^ bias);
+        if (hi && sf_uniform(k) > 255) { // ... count >> 8 in the table of high bytes)
+            hi[i * 128 + lane] = (uint8_t)(v0 >> 8);
+            hi[i * 128 + lane + 64] = (uint8_t)(v1 >> 8);
+        }
         if (packed && lane < 8) { // the host knows which two 16-bin blocks can be live (spfh_compute): the packed copy K7 gathers is
                                   // written here, straight from the LDS histogram, instead of by a kernel of its own re-reading the
                                   // table: lane l takes bins 4 (l & 3) .. + 3 of block (l < 4 ? b0 : b1), eight dwords = the 32-byte row
@@ -454,14 +470,16 @@ __device__ inline void fpfh_mc_wrong_form(const unsigned *__restrict__ live, dou
 // for eight waves it fits 64 without spilling (the 4-chunk form spills five dwords), and the kernel -- which lives on the
 // number of waves that cover its LDS-DMA round trips -- runs 11 % faster at C3 (1.48 -> 1.31 ms).  LDS (4.6 KB per wave)
 // allows 8.5 waves per SIMD.  The same request made K5 and K6 spill and lose (2.13 / 0.98 ms instead of 1.70 / 0.82).
-template <int NKS>
+// HI: some point of the table has more than 255 neighbours (sf_spfh::hi); the instantiation without it is the kernel of
+// rounds 1-3, instruction for instruction.
+template <int NKS, bool HI>
 __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const double *__restrict__ p4, const unsigned *__restrict__ live,
                                                  const uint8_t *__restrict__ packed, unsigned packed_bytes,
-                                                 double *__restrict__ out)
+                                                 double *__restrict__ out, const uint8_t *__restrict__ hi, int limit)
 {
     __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // 32 rows of 128 B
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
@@ -475,19 +493,19 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
         fpfh_mc_wrong_form(live, out, q, nb3);
         return;
     }
-    fpfh_mc_body<NKS>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
-                      abuf_all[wv_id]);
+    fpfh_mc_body<NKS, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
+                          abuf_all[wv_id], hi, limit);
 }
 
 // K7 when at most two of the table's eight 16-bin blocks hold anything at all (K6's OR over every row): the reference's
 // un-normalised v keeps alpha in ONE of its bins whenever the radius is well below that bin's width, so 100 of the 125
 // bins are structurally empty -- only those blocks are streamed and multiplied (fpfh_mc_body_sparse)
-template <int NKS>
+template <int NKS, bool HI>
 __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fpfh_mc_sparse(
     const double *__restrict__ rec, const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx, int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m, int nb3,
     const uint8_t *__restrict__ counts, unsigned table_bytes, const double *__restrict__ p4, const unsigned *__restrict__ live,
-    const uint8_t *__restrict__ packed, unsigned packed_bytes, double *__restrict__ out)
+    const uint8_t *__restrict__ packed, unsigned packed_bytes, double *__restrict__ out, const uint8_t *__restrict__ hi, int limit)
 {
     __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // four steps of 32 rows x 32 B
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
@@ -505,12 +523,122 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     // ... from the packed copy (32 bytes per row: four rows per cache line) when every row of it was written under this
     // very mask, else from the table itself
     if (sf_uniform(live[1]) == mask) {
-        fpfh_mc_body_sparse<NKS, true>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q,
-                                       b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
+        fpfh_mc_body_sparse<NKS, true, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q,
+                                           b0, b1, rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
     } else {
-        fpfh_mc_body_sparse<NKS, false>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q,
-                                        b0, b1, rowbuf_all[wv_id], abuf_all[wv_id]);
+        fpfh_mc_body_sparse<NKS, false, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q,
+                                            b0, b1, rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
     }
+}
+
+// K7 for the keypoints whose own list exceeds the matrix-core form (more than 255 points, or more than the chunks of the
+// main launch): the vector ALU on the byte table.  One wave per keypoint; a 128-byte row is eight 16-byte pieces, so ONE
+// load instruction fetches the rows of eight neighbours (lane group g = lane / 8 takes neighbour tt + g, lane p of the
+// group the bins 16 p .. 16 p + 15); a neighbour with more than 255 neighbours of its own adds its row of high bytes
+// (count = lo + 256 hi).  Sixteen float64 accumulators per lane, lane groups summed at the end, group g writes bins
+// g and g + 8 of every piece.  SEL: the keypoints are the processing slots listed in `sel` (owner numbering; a view keeps
+// its own range); without it (keypoints by index) every keypoint is looked at and those of the main launch return at once.
+// SPARSE: at most two 16-bin blocks of the table are live and the packed copy is valid (32-byte rows {block b0, block b1}):
+// two lanes per row, the rows of 32 neighbours per load instruction.
+template <bool SEL, bool SPARSE>
+__global__ __launch_bounds__(256) void k_fpfh_tail(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                                   const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                   int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m, int nb3,
+                                                   const uint8_t *__restrict__ counts, const uint8_t *__restrict__ hi,
+                                                   const double *__restrict__ p4, double *__restrict__ out, int limit,
+                                                   const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first,
+                                                   const uint8_t *__restrict__ packed, int b0, int b1)
+{
+    constexpr int LPR = SPARSE ? 2 : 8;  // lanes per row
+    constexpr int RPI = 64 / LPR;        // rows per load instruction
+    const int lane = threadIdx.x & 63;
+    int64_t q = sf_uniform64(sf_xcd_block() * 4 + (threadIdx.x >> 6));
+    if (SEL) {
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
+    if (q >= m) return;
+    const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
+    const int64_t slot = i - nbrs_begin;
+    const int k = sf_uniform(cnt[slot]);
+    if (k <= limit) return; // (the main launch's keypoint)
+    const int64_t s = offset[slot];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const int grp = lane / LPR, piece = lane % LPR;
+    const int blk = SPARSE ? (piece ? b1 : b0) : piece; // the 16-bin block this lane accumulates
+    double acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    auto add_words = [&](const uint4 &v, double ww) { // sixteen counts, one per byte
+        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[4 * u + e] = __builtin_fma((double)((wd[u] >> (8 * e)) & 0xffu), ww, acc[4 * u + e]);
+    };
+    for (int t0 = 0; t0 < k; t0 += 64) {
+        const int t = t0 + lane;
+        int j = 0;
+        double w = 0.0;
+        bool lng = false;
+        if (t < k) {
+            j = idx[s + t];
+            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j);
+            const double2 u0 = pp[0], u1 = pp[1];
+            const double cx = u0.x - px, cy = u0.y - py, cz = u1.x - pz;
+            const double d2 = (cx * cx + cy * cy) + cz * cz;
+            const double kd = u1.y, xx = d2 * (kd * kd);
+            const double y0 = __builtin_amdgcn_rsq(xx);
+            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+            w = d2 > 0.0 ? y2 : 0.0; // d == 0 is masked out (fpfh.py:110-114)
+            lng = kd > 255.0;
+        }
+        const int n_here = min(64, k - t0);
+        for (int tt = 0; tt < n_here; tt += RPI) {
+            const int src = (tt + grp) & 63; // (past the end of the list the weight is 0 and row 0 is read)
+            const int jj = __shfl(j, src);
+            const double ww = __shfl(w, src);
+            const bool ll = __shfl((int)lng, src) != 0;
+            uint4 v = SPARSE ? *reinterpret_cast<const uint4 *>(packed + (size_t)jj * 32 + 16 * piece)
+                             : *reinterpret_cast<const uint4 *>(counts + (size_t)jj * 128 + 16 * piece);
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; // stored as count ^ 128
+            add_words(v, ww);
+            if (ll) add_words(*reinterpret_cast<const uint4 *>(hi + (size_t)jj * 128 + 16 * blk), ww * 256.0);
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += __shfl_xor(acc[e], off);
+    const double kd = (double)k;
+    double inv_k = __builtin_amdgcn_rcp(kd);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    double *o = out + q * (int64_t)nb3;
+    auto own_count = [&](int b) -> double {
+        unsigned own = (unsigned)counts[i * 128 + b] ^ 128u;
+        if (k > 255) own += 256u * (unsigned)hi[i * 128 + b];
+        return (double)own;
+    };
+    // every lane group holds the complete sums; group g writes bin(s) g (+ 8) of its lane's block
+    constexpr int BPL = SPARSE ? 1 : 2; // bins per lane: 16 bins of a block over 16 (of 32) resp. 8 groups
+    if (!SPARSE || grp < 16) {
+#pragma unroll
+        for (int half = 0; half < BPL; ++half) {
+            constexpr int NG = 16 / BPL;
+            double a = acc[NG * half];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) a = grp == g ? acc[NG * half + g] : a;
+            const int b = 16 * blk + NG * half + grp;
+            if (b < nb3) o[b] = own_count(b) / kd + a * inv_k; // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
+        }
+    }
+    if (SPARSE) // the bins of the dead blocks: no neighbour has a count there
+        for (int b = lane; b < nb3; b += 64)
+            if ((b >> 4) != b0 && (b >> 4) != b1) o[b] = own_count(b) / kd;
 }
 
 
@@ -562,13 +690,15 @@ __global__ void k_spfh_pack_done(unsigned *__restrict__ live)
 template <typename CT>
 __global__ void k_spfh_export(const CT *__restrict__ counts, const int32_t *__restrict__ kk,
                               const int32_t *__restrict__ perm, int64_t n, int nb3, int stride, unsigned bias,
-                              double *__restrict__ out)
+                              double *__restrict__ out, const uint8_t *__restrict__ hi)
 {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n * nb3) return;
     int64_t i = g / nb3;
     int b = (int)(g - i * nb3);
-    out[(int64_t)perm[i] * nb3 + b] = (double)((unsigned)counts[i * stride + b] ^ bias) / (double)kk[i];
+    unsigned cnt = (unsigned)counts[i * stride + b] ^ bias;
+    if (hi && kk[i] > 255) cnt += 256u * (unsigned)hi[i * stride + b]; // (byte table: a long point's high bytes)
+    out[(int64_t)perm[i] * nb3 + b] = (double)cnt / (double)kk[i];
 }
 
 // ---- any bin count (n_bins > SF_FAST_FPFH_BINS): the reference takes whatever `n_bins` it is given (fpfh.py:16) ---------
@@ -696,7 +826,9 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     sp->nb3 = n_bins * n_bins * n_bins;
     // neighbourhoods of at most 255 points and at most 128 bins: one BYTE per bin, biased by 128 (a 128-byte row the
     // matrix-core K7 consumes as int8); else uint16, uint32 beyond 65535
-    sp->elem_bytes = (max_count <= 255 && sp->nb3 <= 128) ? 1 : (max_count > 65535 ? 4 : 2);
+    // (lists longer than 255 points: the byte table keeps count & 255 and the long points' rows get a table of high bytes
+    // beside it -- one long list does not move every point's row to 16 bits and every keypoint to the vector K7)
+    sp->elem_bytes = (max_count <= 65535 && sp->nb3 <= 128) ? 1 : (max_count > 65535 ? 4 : 2);
     if (n_bins > SF_FAST_FPFH_BINS) sp->elem_bytes = 4; // the generic kernels keep 32-bit counts
     sp->bias = sp->elem_bytes == 1 ? 128 : 0;
     // rows padded to a multiple of 128 elements: lane l of a wave owns elements 2l, 2l+1 of each 128-element
@@ -716,6 +848,7 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     if (hipMalloc(&sp->counts, nn * sp->stride * sp->elem_bytes) != hipSuccess ||
         hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess ||
         (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess) ||
+        (sp->elem_bytes == 1 && max_count > 255 && hipMalloc(&sp->hi, nn * 128) != hipSuccess) ||
         (sp->elem_bytes == 1 && (hipMalloc(&sp->live, 4 * sizeof(unsigned)) != hipSuccess ||
                                  hipMalloc(&sp->packed, nn * 32) != hipSuccess ||
                                  hipMemset(sp->live, 0, 4 * sizeof(unsigned)) != hipSuccess ||
@@ -742,6 +875,7 @@ extern "C" void sf_spfh_free(sf_ctx *ctx, sf_spfh *sp)
     if (sp->p4) (void)hipFree(sp->p4);
     if (sp->live) (void)hipFree(sp->live);
     if (sp->packed) (void)hipFree(sp->packed);
+    if (sp->hi) (void)hipFree(sp->hi);
     delete sp;
 }
 
@@ -750,12 +884,12 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     if (!ctx || !c || !nb || !sp || !edges) { sf_set_error("sf_spfh_compute: null argument"); return SF_ERR_ARG; }
     if (!nb->self) { sf_set_error("sf_spfh_compute: needs a sf_radius_search_self result"); return SF_ERR_ARG; }
     if (sp->n != c->n || nb->self_begin + nb->m > sp->n) { sf_set_error("sf_spfh_compute: table/cloud size mismatch"); return SF_ERR_ARG; }
-    if (sp->elem_bytes == 1 && nb->max_count > 255) {
+    if (sp->elem_bytes == 1 && nb->max_count > 255 && !sp->hi) {
         sf_set_error("sf_spfh_compute: neighbourhood of %lld points needs a wider table (pass max_count to sf_spfh_create)",
                      (long long)nb->max_count);
         return SF_ERR_ARG;
     }
-    if (sp->elem_bytes == 2 && nb->max_count > 65535) {
+    if (sp->elem_bytes <= 2 && nb->max_count > 65535) {
         sf_set_error("sf_spfh_compute: neighbourhood of %lld points needs a 32-bit table (pass max_count to sf_spfh_create)",
                      (long long)nb->max_count);
         return SF_ERR_ARG;
@@ -803,31 +937,35 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
         if (getenv("SF_FPFH_NO_ALPHA_SHORTCUT")) alpha_bin = -1;
     }
     const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SPFH_WPB))), block(64 * SF_SPFH_WPB);
-    int chunks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
-    if (chunks > 4) chunks = 0; // streaming kernel
-#define SF_SPFH_NB(CT, NCH, NB)                                                                                        \
-    SF_LAUNCH(ctx, "k6_spfh", (k_spfh<CT, NCH, NB>), grid, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
+    const sf_dispatch dsp = sf_nbrs_dispatch(nb);
+    const dim3 grid_tail(sf_xcd_grid(sf_div_up(dsp.n_tail > 0 ? dsp.n_tail : 1, SF_SPFH_WPB)));
+    uint8_t *const hi_rows = sp->elem_bytes == 1 ? sp->hi : nullptr;
+#define SF_SPFH_NB(NAME, GRID, CT, NCH, NB, SEL)                                                                        \
+    SF_LAUNCH(ctx, NAME, (k_spfh<CT, NCH, NB, SEL>), GRID, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
               nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov, \
-              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max, fused_packed, fused_b0, fused_b1)
-#define SF_SPFH_LAUNCH(CT, NCH)                                                                                        \
+              sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max, fused_packed, fused_b0, fused_b1,   \
+              hi_rows, dsp.limit, dsp.tail_sel, dsp.n_tail, dsp.view_first)
+#define SF_SPFH_LAUNCH(NAME, GRID, CT, NCH, SEL)                                                                        \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
-    case 1: { SF_SPFH_NB(CT, NCH, 1); } break;                                                                         \
-    case 2: { SF_SPFH_NB(CT, NCH, 2); } break;                                                                         \
-    case 3: { SF_SPFH_NB(CT, NCH, 3); } break;                                                                         \
-    case 4: { SF_SPFH_NB(CT, NCH, 4); } break;                                                                         \
-    case 5: { SF_SPFH_NB(CT, NCH, 5); } break;                                                                         \
-    case 6: { SF_SPFH_NB(CT, NCH, 6); } break;                                                                         \
-    case 7: { SF_SPFH_NB(CT, NCH, 7); } break;                                                                         \
-    default: { SF_SPFH_NB(CT, NCH, 8); } break;                                                                        \
+    case 1: { SF_SPFH_NB(NAME, GRID, CT, NCH, 1, SEL); } break;                                                        \
+    case 2: { SF_SPFH_NB(NAME, GRID, CT, NCH, 2, SEL); } break;                                                        \
+    case 3: { SF_SPFH_NB(NAME, GRID, CT, NCH, 3, SEL); } break;                                                        \
+    case 4: { SF_SPFH_NB(NAME, GRID, CT, NCH, 4, SEL); } break;                                                        \
+    case 5: { SF_SPFH_NB(NAME, GRID, CT, NCH, 5, SEL); } break;                                                        \
+    case 6: { SF_SPFH_NB(NAME, GRID, CT, NCH, 6, SEL); } break;                                                        \
+    case 7: { SF_SPFH_NB(NAME, GRID, CT, NCH, 7, SEL); } break;                                                        \
+    default: { SF_SPFH_NB(NAME, GRID, CT, NCH, 8, SEL); } break;                                                       \
     }
-#define SF_SPFH_DISPATCH(CT)                                     \
-    switch (chunks) {                                            \
-    case 1: { SF_SPFH_LAUNCH(CT, 1); } break;                    \
-    case 2: { SF_SPFH_LAUNCH(CT, 2); } break;                    \
-    case 3: { SF_SPFH_LAUNCH(CT, 3); } break;                    \
-    case 4: { SF_SPFH_LAUNCH(CT, 4); } break;                    \
-    default: { SF_SPFH_LAUNCH(CT, 0); } break;                   \
-    }
+    // the main launch in the register-cached form the lists call for, then the points it left out in the streaming form
+#define SF_SPFH_DISPATCH(CT)                                                        \
+    switch (dsp.chunks) {                                                           \
+    case 1: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 1, false); } break;               \
+    case 2: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 2, false); } break;               \
+    case 3: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 3, false); } break;               \
+    case 4: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 4, false); } break;               \
+    default: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 0, false); } break;              \
+    }                                                                               \
+    if (dsp.n_tail) { SF_SPFH_LAUNCH("k6_spfh_tail", grid_tail, CT, 0, true); }
     uint8_t *fused_packed = nullptr;
     int fused_b0 = -1, fused_b1 = -1;
     if (sp->elem_bytes == 1) {
@@ -910,6 +1048,10 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
         char *pb = (char *)sp->p4;
         SF_CHECK(sf_comm_allgather(ctx, pb + (size_t)ctx->rank * rows_per_rank * 32, pb, (size_t)rows_per_rank * 32));
     }
+    if (sp->hi) {
+        char *hb = (char *)sp->hi;
+        SF_CHECK(sf_comm_allgather(ctx, hb + (size_t)ctx->rank * rows_per_rank * 128, hb, (size_t)rows_per_rank * 128));
+    }
     // the gathered rows come from other ranks' K6: every block of the table counts as live from here on
     if (sp->live) {
         SF_HIP(hipMemsetAsync(sp->live, 0xff, 2 * sizeof(unsigned), ctx->stream));
@@ -922,8 +1064,10 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
 // The two arrays that make up the wire image of a table row (see sf_spfh_exchange_rows), decided from the table's storage and
 // the HOST-known block mask alone.  A byte table whose mask the data decided is switched to "every block live" first.
 struct spfh_part { char *base; size_t row; };
-static int spfh_wire_parts(sf_ctx *ctx, sf_spfh *sp, spfh_part parts[2])
+#define SF_WIRE_PARTS 3 // (unused parts have row == 0)
+static int spfh_wire_parts(sf_ctx *ctx, sf_spfh *sp, spfh_part parts[SF_WIRE_PARTS])
 {
+    parts[2] = spfh_part{nullptr, 0};
     if (sp->elem_bytes == 1) {
         const unsigned m8 = sp->host_live[0] & 0xffu;
         const bool sparse = sp->mask_known && sp->host_live_valid && __builtin_popcount(m8) <= 2 && sp->host_live[1] == m8;
@@ -936,6 +1080,8 @@ static int spfh_wire_parts(sf_ctx *ctx, sf_spfh *sp, spfh_part parts[2])
         }
         parts[0] = sparse ? spfh_part{(char *)sp->packed, 32} : spfh_part{(char *)sp->counts, 128};
         parts[1] = spfh_part{(char *)sp->p4, 32};
+        // a table with long lists (every rank sizes its table by the longest list of ANY rank): the high bytes travel too
+        if (sp->hi) parts[2] = spfh_part{(char *)sp->hi, 128};
     } else {
         parts[0] = spfh_part{(char *)sp->counts, (size_t)sp->stride * sp->elem_bytes};
         parts[1] = spfh_part{(char *)sp->k, sizeof(int32_t)};
@@ -950,14 +1096,15 @@ extern "C" int sf_spfh_rows_image(sf_ctx *ctx, sf_spfh *sp, int64_t begin, int64
 {
     if (!ctx || !sp || begin < 0 || begin > end || end > sp->n) { sf_set_error("sf_spfh_rows_image: bad argument"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
-    spfh_part parts[2];
+    spfh_part parts[SF_WIRE_PARTS];
     SF_CHECK(spfh_wire_parts(ctx, sp, parts));
-    const size_t rows = (size_t)(end - begin), need = rows * (parts[0].row + parts[1].row);
+    const size_t rows = (size_t)(end - begin), need = rows * (parts[0].row + parts[1].row + parts[2].row);
     if (bytes) *bytes = need;
     if (!host) return SF_OK; // size query
     if (cap < need) { sf_set_error("sf_spfh_rows_image: %zu bytes needed, %zu given", need, cap); return SF_ERR_ARG; }
     char *h = (char *)host;
     for (const spfh_part &pt : parts) {
+        if (!pt.row) continue;
         char *d = pt.base + (size_t)begin * pt.row;
         if (rows) {
             if (write_back) SF_HIP(hipMemcpyAsync(d, h, rows * pt.row, hipMemcpyHostToDevice, ctx->stream));
@@ -992,7 +1139,7 @@ extern "C" int sf_spfh_exchange_rows(sf_ctx *ctx, sf_spfh *sp, int n_ops, const 
             return SF_ERR_ARG;
         }
     SF_HIP(hipSetDevice(ctx->device));
-    spfh_part parts[2];
+    spfh_part parts[SF_WIRE_PARTS];
     SF_CHECK(spfh_wire_parts(ctx, sp, parts));
     std::vector<int> peers;
     std::vector<const void *> sends;
@@ -1000,6 +1147,7 @@ extern "C" int sf_spfh_exchange_rows(sf_ctx *ctx, sf_spfh *sp, int n_ops, const 
     std::vector<size_t> sbytes, rbytes;
     for (int i = 0; i < n_ops; ++i)
         for (const spfh_part &pt : parts) {
+            if (!pt.row) continue;
             peers.push_back(peer[i]);
             sends.push_back(pt.base + (size_t)send_begin[i] * pt.row);
             sbytes.push_back((size_t)(send_end[i] - send_begin[i]) * pt.row);
@@ -1024,13 +1172,13 @@ extern "C" int sf_spfh_export(sf_ctx *ctx, sf_cloud *c, sf_spfh *sp, double *out
         const dim3 grid((unsigned)sf_div_up(tot, 256)), block(256);
         if (sp->elem_bytes == 1) {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint8_t>, grid, block, (const uint8_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, (unsigned)sp->bias, dout);
+                      c->perm, n, sp->nb3, sp->stride, (unsigned)sp->bias, dout, (const uint8_t *)sp->hi);
         } else if (sp->elem_bytes == 2) {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint16_t>, grid, block, (const uint16_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, 0u, dout);
+                      c->perm, n, sp->nb3, sp->stride, 0u, dout, (const uint8_t *)nullptr);
         } else {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint32_t>, grid, block, (const uint32_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, 0u, dout);
+                      c->perm, n, sp->nb3, sp->stride, 0u, dout, (const uint8_t *)nullptr);
         }
     }
     if (owned) {
@@ -1084,15 +1232,23 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
 {
     const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_MC_WPB))), block(64 * SF_MC_WPB);
     const size_t tb = (size_t)sp->rows_alloc * 128;
-    if (tb >= ((size_t)1 << 32) || sp->stride != 128 || nb->max_count > 255) {
+    if (tb >= ((size_t)1 << 32) || sp->stride != 128 || (nb->max_count > 255 && !sp->hi)) {
         sf_set_error("sf_fpfh: uint8 SPFH table of %zu bytes / lists of %lld points outside the matrix-core kernel's range", tb,
                      (long long)nb->max_count);
         return SF_ERR_UNSUPPORTED;
     }
-    const int nks = (int)sf_div_up(nb->max_count > 0 ? nb->max_count : 1, 64);
+    // Dispatch by list length, per keypoint: the matrix-core form of the main launch (at most 255 points) leaves out the
+    // keypoints whose own list exceeds it; k_fpfh_tail serves exactly those.
+    sf_dispatch d = sf_nbrs_dispatch(nb);
+    if (d.chunks == 0 || d.limit > 255) { // (lists not planned by a radius search: everything the matrix-core form holds)
+        d.chunks = d.chunks == 0 ? 4 : d.chunks;
+        d.limit = 255;
+    }
+    const bool any_tail = nb->max_count > d.limit;
+    const uint8_t *hi = sp->hi;
 #define SF_MC_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, sp->nb3, (const uint8_t *)sp->counts,       \
                    (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, (const uint8_t *)sp->packed,                \
-                   (unsigned)((size_t)sp->rows_alloc * 32), dout
+                   (unsigned)((size_t)sp->rows_alloc * 32), dout, hi, d.limit
     // Which form runs is decided here, on the table-wide block mask -- read back once per K6 (8 bytes; the one host
     // round trip of sf_fpfh: it waits for K6, so a caller that wants it hidden queues independent work first, as
     // DescriptorJob does with the frame eigen-solves on the side stream).  Both kernels re-check the mask on the device.
@@ -1109,15 +1265,38 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
         }
     }
     const bool sparse = __builtin_popcount(sp->host_live[0] & 0xffu) <= 2;
+#define SF_MC_LAUNCH2(NKS, HI)                                                                                       \
+    if (sparse) { SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh_mc_sparse<NKS, HI>), grid, block, SF_MC_ARGS); }                 \
+    else { SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh_mc<NKS, HI>), grid, block, SF_MC_ARGS); }
 #define SF_MC_LAUNCH(NKS)                                                                                            \
-    if (sparse) { SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc_sparse<NKS>, grid, block, SF_MC_ARGS); }                       \
-    else { SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_mc<NKS>, grid, block, SF_MC_ARGS); }
-    if (nks <= 1) { SF_MC_LAUNCH(1); }
-    else if (nks == 2) { SF_MC_LAUNCH(2); }
-    else if (nks == 3) { SF_MC_LAUNCH(3); }
+    if (hi) { SF_MC_LAUNCH2(NKS, true) } else { SF_MC_LAUNCH2(NKS, false) }
+    if (d.chunks <= 1) { SF_MC_LAUNCH(1); }
+    else if (d.chunks == 2) { SF_MC_LAUNCH(2); }
+    else if (d.chunks == 3) { SF_MC_LAUNCH(3); }
     else { SF_MC_LAUNCH(4); }
 #undef SF_MC_LAUNCH
+#undef SF_MC_LAUNCH2
 #undef SF_MC_ARGS
+    if (any_tail) {
+        // (ONE form whatever the table's block mask: the float64 sums of this kernel depend on which lane group adds which
+        // neighbour, and a keypoint's row must not depend on the mask -- a sharded job switches to "every block live" when it
+        // borrows rows.  A 2-lanes-per-row form on the packed rows was twice as fast on sparse tables (0.56 against 1.22 ms for
+        // the 128 000 long lists of the clustered 1M-point cloud) and gave other last bits: not used.)
+        const bool packed_ok = false;
+        const int pb0 = 0, pb1 = 1;
+#define SF_TAIL_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, sp->nb3, (const uint8_t *)sp->counts, hi, \
+                     (const double *)sp->p4, dout, d.limit
+#define SF_TAIL_LAUNCH(SEL, GRID, SELP, NSEL, VF)                                                                        \
+        if (packed_ok) { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_tail<SEL, true>), dim3(sf_xcd_grid(sf_div_up(GRID, 4))), dim3(256), SF_TAIL_ARGS, SELP, NSEL, VF, (const uint8_t *)sp->packed, pb0, pb1); } \
+        else { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_tail<SEL, false>), dim3(sf_xcd_grid(sf_div_up(GRID, 4))), dim3(256), SF_TAIL_ARGS, SELP, NSEL, VF, (const uint8_t *)sp->packed, pb0, pb1); }
+        if (!kp_pos && d.n_tail) {
+            SF_TAIL_LAUNCH(true, d.n_tail, d.tail_sel, d.n_tail, d.view_first)
+        } else { // keypoints by index (or lists without a selection): every keypoint is looked at
+            SF_TAIL_LAUNCH(false, m, (const int32_t *)nullptr, (int64_t)0, (int64_t)0)
+        }
+#undef SF_TAIL_LAUNCH
+#undef SF_TAIL_ARGS
+    }
     return SF_OK;
 }
 

@@ -68,9 +68,11 @@ __device__ __forceinline__ void fpfh_mc_list(const int32_t *__restrict__ idx, in
 // weights 1 / (k_j d_j) of all neighbours from their 32-byte records {x, y, z, k} (one rsqrt + two Newton steps each; d == 0
 // is masked out, fpfh.py:110-114), the fixed-point exponent S = 61 - floor(log2 of the largest), and jv clamped to valid
 // rows for the gathers that follow
-template <int NKS>
+// HI: lm[c] = the lanes of chunk c whose neighbour has more than 255 neighbours of its own (its bins are lo + 256 hi: the
+// table of high bytes, fpfh_mc_hi)
+template <int NKS, bool HI>
 __device__ __forceinline__ int fpfh_mc_weights(const double *__restrict__ p4, double px, double py, double pz, int k,
-                                               int (&jv)[NKS], double (&wv)[NKS])
+                                               int (&jv)[NKS], double (&wv)[NKS], unsigned long long (&lm)[NKS])
 {
     double gx[NKS], gy[NKS], gz[NKS], gk[NKS];
 #pragma unroll
@@ -96,6 +98,9 @@ __device__ __forceinline__ int fpfh_mc_weights(const double *__restrict__ p4, do
             const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
             wv[c] = (jv[c] >= 0 && d2 > 0.0) ? y2 : 0.0;
             wmax = fmax(wmax, wv[c]);
+            if (HI) lm[c] = __ballot(wv[c] > 0.0 && kd > 255.0);
+        } else if (HI) {
+            lm[c] = 0ull;
         }
         jv[c] = jv[c] < 0 ? 0 : jv[c];
     }
@@ -103,6 +108,47 @@ __device__ __forceinline__ int fpfh_mc_weights(const double *__restrict__ p4, do
     // fixed point: W = floor(w 2^S) < 2^62 with S = 61 - floor(log2 wmax)
     const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
     return 61 - e2;
+}
+
+// The part of sum_j w_j c_jb that the byte table does not hold: 256 sum_{j long} w_j hi_jb for the two bins this lane
+// writes, in float64, neighbour after neighbour in list order (the same order on every rank and in every form, so the rows
+// stay reproducible bit for bit).  Wave-uniform loop over the set bits of the masks: a keypoint without long neighbours --
+// every keypoint of a cloud without long lists -- executes nothing.
+template <int NKS>
+__device__ __forceinline__ void fpfh_mc_hi(const uint8_t *__restrict__ hi, const int (&jv)[NKS], const double (&wv)[NKS],
+                                           const unsigned long long (&lm)[NKS], int o0, int o1, double &c0, double &c1)
+{
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+        unsigned long long mk = lm[c];
+        while (mk) { // four long neighbours per round: their eight byte loads are in flight together
+            int t[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                on[u] = mk != 0ull;
+                t[u] = on[u] ? __builtin_ctzll(mk) : t[0];
+                mk &= mk - 1; // (0 stays 0)
+            }
+            unsigned b0[4], b1[4];
+            double w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = __builtin_amdgcn_readlane(jv[c], t[u]);
+                const uint8_t *r = hi + (size_t)j * 128;
+                b0[u] = r[o0];
+                b1[u] = r[o1];
+                const double wu = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wv[c]), t[u]),
+                                                   __builtin_amdgcn_readlane(__double2loint(wv[c]), t[u]));
+                w[u] = on[u] ? wu * 256.0 : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { // (list order: the same sums on every rank and in every form)
+                c0 = __builtin_fma(w[u], (double)b0[u], c0);
+                c1 = __builtin_fma(w[u], (double)b1[u], c1);
+            }
+        }
+    }
 }
 
 // This lane's weight as EIGHT signed-byte limbs: W = floor(w 2^S) < 2^62 is written in the signed-digit form
@@ -131,19 +177,21 @@ __device__ __forceinline__ long fpfh_mc_a_operand(const unsigned char *abuf, int
     return (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
 }
 
-template <int NKS>
+template <int NKS, bool HI>
 __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                              int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
                                              const uint8_t *__restrict__ counts, unsigned table_bytes,
                                              const double *__restrict__ p4, double *__restrict__ out, int64_t q,
-                                             unsigned *rowbuf /* 4 KB */, unsigned char *abuf /* 576 B */)
+                                             unsigned *rowbuf /* 4 KB */, unsigned char *abuf /* 576 B */,
+                                             const uint8_t *__restrict__ hi, int limit)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
     const int64_t slot = i - nbrs_begin;
     const int64_t s = offset[slot];
     const int k = cnt[slot];
+    if (sf_uniform(k) > limit) return; // (a keypoint whose own list exceeds this form: the second launch, launch_fpfh_mc)
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
@@ -178,9 +226,10 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     }
     int jv[NKS];
     double wv[NKS];
+    unsigned long long lm[NKS];
     fpfh_mc_list<NKS>(idx, s, k, lane, jv);
     SF_MC_DMA(0) // in flight while the weights are computed
-    const int S = fpfh_mc_weights<NKS>(p4, px, py, pz, k, jv, wv);
+    const int S = fpfh_mc_weights<NKS, HI>(p4, px, py, pz, k, jv, wv, lm);
 
     v4i acc[8]; // acc[bb]: column a = bin 16 bb + a, rows = limbs 4 kb .. 4 kb + 3
 #pragma unroll
@@ -258,8 +307,10 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
         double s0 = c0 * inv_k, s1 = c1 * inv_k;
         s0 = __builtin_fma(__builtin_fma(-s0, kd, c0), inv_k, s0);
         s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
-        if (b0 < nb3) o[b0] = s0 + vsel0 * inv_k;
-        if (b1 < nb3) o[b1] = s1 + vsel1 * inv_k;
+        double h0 = 0.0, h1 = 0.0;
+        if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, b0, b1, h0, h1);
+        if (b0 < nb3) o[b0] = s0 + (HI ? vsel0 + h0 : vsel0) * inv_k;
+        if (b1 < nb3) o[b1] = s1 + (HI ? vsel1 + h1 : vsel1) * inv_k;
     }
 }
 
@@ -275,20 +326,22 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
 // --------------------------------------------------------------------------------------------------
 // PACKED: the two chunks come from K6's packed copy of the table (`rows`: 32 bytes per row = {chunk b0, chunk b1}) instead
 // of the table itself (`rows` = counts, 128 bytes per row): four rows per cache line for the gather.
-template <int NKS, bool PACKED>
+template <int NKS, bool PACKED, bool HI>
 __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                     int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
                                                     const uint8_t *__restrict__ counts, const uint8_t *__restrict__ rows,
                                                     unsigned rows_bytes, const double *__restrict__ p4,
                                                     double *__restrict__ out, int64_t q, int b0, int b1,
-                                                    unsigned *rowbuf /* 4 KB: four steps of 1 KB */, unsigned char *abuf /* 576 B */)
+                                                    unsigned *rowbuf /* 4 KB: four steps of 1 KB */, unsigned char *abuf /* 576 B */,
+                                                    const uint8_t *__restrict__ hi, int limit)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
     const int64_t slot = i - nbrs_begin;
     const int64_t s = offset[slot];
     const int k = cnt[slot];
+    if (sf_uniform(k) > limit) return; // (the second launch's keypoint)
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(rows), 0, (int)rows_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
@@ -317,6 +370,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     }
     int jv[NKS];
     double wv[NKS];
+    unsigned long long lm[NKS];
     fpfh_mc_list<NKS>(idx, s, k, lane, jv);
     // The image of a step is 1 KB, so the 4 KB row buffer holds FOUR steps: the rows of the first two chunks (128
     // neighbours -- the whole list for nine keypoints in ten) are all requested here, in flight while the weights are
@@ -325,7 +379,7 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     if (32 < k) SF_MCS_DMA(1)
     if (NKS >= 2 && 64 < k) SF_MCS_DMA(2)
     if (NKS >= 2 && 96 < k) SF_MCS_DMA(3)
-    const int S = fpfh_mc_weights<NKS>(p4, px, py, pz, k, jv, wv);
+    const int S = fpfh_mc_weights<NKS, HI>(p4, px, py, pz, k, jv, wv, lm);
 
     v4i acc0 = v4i{0, 0, 0, 0}, acc1 = v4i{0, 0, 0, 0}, accp = v4i{0, 0, 0, 0}; // blocks b0, b1, and the padding column
     const long Bpad = (long)0x8080808080808080ull; // eight neighbours' padding bin: -128 each
@@ -387,8 +441,10 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
         s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
         const double v0 = bb0 == b0 ? tot0 : (bb0 == b1 ? tot1 : 0.0);
         const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
-        if (o0 < nb3) o[o0] = s0 + v0 * inv_k;
-        if (o1 < nb3) o[o1] = s1 + v1 * inv_k;
+        double h0 = 0.0, h1 = 0.0;
+        if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, o0, o1, h0, h1);
+        if (o0 < nb3) o[o0] = s0 + (HI ? v0 + h0 : v0) * inv_k;
+        if (o1 < nb3) o[o1] = s1 + (HI ? v1 + h1 : v1) * inv_k;
     }
 }
 

@@ -143,24 +143,55 @@ __global__ void k_gather_normals(const double *__restrict__ nrm, const int32_t *
     rec[6 * i + 5] = nrm[3 * o + 2];
 }
 
-__global__ void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t cid_base, int64_t base, int64_t n, int64_t ncell,
-                             int32_t *__restrict__ cell_start)
+// cell_start[c] = first sorted position whose cell id >= c (lower bound over the n populated positions that start at
+// `base`; cells before / after the populated slab come out empty).  One thread per sorted POSITION i (and one past the
+// last): the cells (id[i - 1], id[i]] all start at i.  (Until round 3: one thread per CELL with a binary search over the
+// ids -- 20 dependent loads per cell, 0.45 ms for the 1.8e8 mostly empty fine cells of a clustered cloud.  The table is now
+// written once, at streaming speed: a gap of more than a few cells is filled by the whole wave, 64 cells per store.)
+// (sorted_cid holds cell id - cid_base: a block build sorts ids relative to its slab's first cell -- fewer key bits)
+#define SF_LONG_GAP 65536 // cells: a longer run of empty cells is filled by the whole grid (k_cell_fill_long), not by one wave
+struct sf_gap { int64_t lo, len; int32_t val, pad; };
+__global__ __launch_bounds__(256) void k_cell_start(const int32_t *__restrict__ sorted_cid, int64_t cid_base, int64_t base, int64_t n,
+                                                    int64_t ncell, int32_t *__restrict__ cell_start, sf_gap *__restrict__ gaps,
+                                                    unsigned *__restrict__ n_gaps)
 {
-    // (sorted_cid holds cell id - cid_base: a block build sorts ids relative to its slab's first cell -- fewer key bits)
-    // cell_start[c] = first sorted position whose cell id >= c (lower bound over the n populated positions that
-    // start at `base`); cells before / after the populated slab come out empty
-    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > ncell) return;
-    c -= cid_base;
-    int64_t lo = 0, hi = n;
-    // (a rank's slab populates an eighth of the cells of an 8-rank cloud: the others need no search)
-    if (n > 0 && c <= (int64_t)sorted_cid[0]) hi = 0;
-    else if (n > 0 && c > (int64_t)sorted_cid[n - 1]) lo = n;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)sorted_cid[mid] < c) lo = mid + 1; else hi = mid;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t lo = 0, len = 0;
+    if (i <= n) {
+        lo = i == 0 ? 0 : (int64_t)sorted_cid[i - 1] + cid_base + 1;
+        const int64_t hi = i == n ? ncell : (int64_t)sorted_cid[i] + cid_base; // inclusive
+        len = hi - lo + 1;
+        if (len < 0) len = 0;
     }
-    cell_start[c + cid_base] = (int32_t)(base + lo);
+    const int32_t val = (int32_t)(base + i);
+    if (len > SF_LONG_GAP) { // (the cells outside a rank's slab, the void between two far-apart parts of a cloud)
+        const unsigned e = atomicAdd(n_gaps, 1u);
+        gaps[e] = sf_gap{lo, len, val, 0};
+        len = 0;
+    }
+    const bool wide = len > 8;
+    if (!wide)
+        for (int64_t t = 0; t < len; ++t) cell_start[lo + t] = val;
+    unsigned long long todo = __ballot(wide);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t l0 = __shfl(lo, src), ln = __shfl(len, src);
+        const int32_t v = __shfl(val, src);
+        for (int64_t t = lane; t < ln; t += 64) cell_start[l0 + t] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cell_fill_long(const sf_gap *__restrict__ gaps, const unsigned *__restrict__ n_gaps,
+                                                        int32_t *__restrict__ cell_start)
+{
+    const unsigned ng = *n_gaps;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (unsigned e = 0; e < ng; ++e) {
+        const sf_gap g = gaps[e];
+        for (int64_t t = tid; t < g.len; t += nt) cell_start[g.lo + t] = g.val;
+    }
 }
 
 #define SF_MAX_LAYERS 4096
@@ -589,8 +620,18 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
     // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
     c->normals_sorted = c->nrm_orig != nullptr;
-    SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ncell + 1, 256)), dim3(256), cid_sorted, cid_base, base, ns,
-              ncell, c->cell_start);
+    {
+        sf_pool_guard gtmp(ctx);
+        sf_gap *gaps = nullptr;
+        unsigned *n_gaps = nullptr;
+        SF_CHECK(gtmp.alloc(&gaps, (size_t)(ncell / SF_LONG_GAP + 2)));
+        SF_CHECK(gtmp.alloc(&n_gaps, 1));
+        SF_HIP(hipMemsetAsync(n_gaps, 0, sizeof(unsigned), ctx->stream));
+        SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ns + 1, 256)), dim3(256), cid_sorted, cid_base, base, ns,
+                  ncell, c->cell_start, gaps, n_gaps);
+        SF_LAUNCH(ctx, "k1_cell_start", k_cell_fill_long, dim3(1024), dim3(256), (const sf_gap *)gaps, (const unsigned *)n_gaps,
+                  c->cell_start);
+    }
     return SF_OK;
 }
 

@@ -13,6 +13,8 @@
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
@@ -87,13 +89,17 @@ struct __attribute__((aligned(8))) sf_dbl2 {
 #define SF_K2_WPB 8 // waves per workgroup, four queries each (0.521 / 0.516 / 0.498 / 0.489 ms at C3 for 1 / 2 / 4 / 8)
 #endif
 
-template <int MODE>
+// SEL: the launch serves the `m` queries named by qsel (processing slots) instead of queries 0 .. m - 1 -- the sample a
+// search sizes its slots from (MODE 0: counts go to the COMPACT array count[0 .. m)), and the queries whose lists overflowed
+// their slot (MODE 1: fill at offset[q], which by then points into the overflow area).
+template <int MODE, bool SEL>
 __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const int32_t *__restrict__ cell_start,
                                                 const double *__restrict__ xs, const double *__restrict__ ys,
                                                 const double *__restrict__ zs, const double *__restrict__ qx,
                                                 const double *__restrict__ qy, const double *__restrict__ qz,
                                                 int64_t m, double r2, int cap, int32_t *__restrict__ count,
-                                                int64_t *__restrict__ offset, int32_t *__restrict__ idx)
+                                                int64_t *__restrict__ offset, int32_t *__restrict__ idx,
+                                                const int32_t *__restrict__ qsel)
 {
     // A wave serves FOUR consecutive queries.  The run tables of all four are built at once, one query per 16-lane
     // DPP row (lanes 0..8 of a row describe its query's nine runs): the ~150 instructions of that set-up -- band gaps,
@@ -104,7 +110,8 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
     const int64_t q0 = sf_uniform64((sf_xcd_block() * SF_K2_WPB + (threadIdx.x >> 6)) * 4);
     if (q0 >= m) return;
     const int nq = (int)(m - q0 < 4 ? m - q0 : 4);
-    const int64_t qm = q0 + (rw < nq ? rw : 0);
+    const int64_t qm0 = q0 + (rw < nq ? rw : 0);
+    const int64_t qm = SEL ? (int64_t)qsel[qm0] : qm0;
     const double pxv = qx[qm], pyv = qy[qm], pzv = qz[qm]; // this row's query
     int y0, y1, z0, z1;
     stencil_bounds(pyv, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
     }
     __builtin_amdgcn_wave_barrier(); // the tables are written and read by this wave only
     for (int qi = 0; qi < nq; ++qi) {
-        const int64_t q = q0 + qi;
+        const int64_t q = SEL ? (int64_t)sf_uniform(__shfl((int)qm, 16 * qi)) : q0 + qi;
         const int4 *const tab = tabs[qi];
         const double px = __shfl(pxv, 16 * qi), py = __shfl(pyv, 16 * qi), pz = __shfl(pzv, 16 * qi);
         // two of the boundaries between runs and the number of pair slots, as scalars
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
         }
         if (lane == 0) {
             if (MODE != 1) {
-                count[q] = total;
-                if (q == m - 1) count[m] = 0; // (the one element past the last query: no memset of the arrays needed)
+                count[SEL ? q0 + qi : q] = total;
+                if (!SEL && q == m - 1) count[m] = 0; // (the one element past the last query: no memset of the arrays needed)
             }
             if (MODE == 2) {
                 offset[q] = out;
@@ -469,64 +476,219 @@ __global__ __launch_bounds__(256) void k_knn_take(int64_t nres, int k, const int
 
 } // namespace
 
-struct to_i64_sum {
-    __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
-};
-
-// max and sum of the per-query counts (two small rocPRIM reductions), read back with one sync
-// sum and maximum of the per-query counts: per-block partials in one pass, folded on the host after ONE small
-// read-back into page-locked memory (two library reductions + two pageable copies cost several idle gaps per step)
+// ---- list statistics -------------------------------------------------------------------------------------------------
+// Sum, maximum and a five-class histogram of the per-query counts (<= 64, <= 128, <= 192, <= 255, longer), plus the number
+// and the total length of the lists longer than `cap` (the slot capacity of the single sweep; 0x7fffffff: none can be):
+// per-block partials in ONE pass, folded on the host after ONE small read-back into page-locked memory (library
+// reductions + pageable copies cost several idle gaps per step).
 #define SF_STATS_BLOCKS 128
-__global__ __launch_bounds__(256) void k_count_stats(const int32_t *__restrict__ count, int64_t m,
-                                                     long long *__restrict__ psum, int *__restrict__ pmax)
+#define SF_K2_SAMPLE 2048 // queries whose lists are counted before a first search sizes its slots
+struct sf_stats_parts { // device / pinned image, one entry per block
+    long long sum[SF_STATS_BLOCKS], ovf_sum[SF_STATS_BLOCKS];
+    int mx[SF_STATS_BLOCKS], gmx[SF_STATS_BLOCKS], n_ovf[SF_STATS_BLOCKS], hist[5][SF_STATS_BLOCKS];
+};
+static_assert(sizeof(sf_stats_parts) <= SF_PINNED_BYTES, "statistics exceed the pinned words");
+
+__global__ __launch_bounds__(256) void k_count_stats(const int32_t *__restrict__ count, int64_t m, int cap, sf_stats_parts *__restrict__ out)
 {
-    long long sacc = 0;
-    int macc = 0;
+    long long sacc = 0, oacc = 0;
+    int macc = 0, nov = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
         const int v = count[i];
         sacc += v;
         macc = max(macc, v);
+        if (v > cap) { ++nov; oacc += v; }
+        h0 += v <= 64;
+        h1 += v > 64 && v <= 128;
+        h2 += v > 128 && v <= 192;
+        h3 += v > 192 && v <= 255;
+        h4 += v > 255;
     }
     for (int off = 32; off > 0; off >>= 1) {
         sacc += __shfl_xor(sacc, off);
+        oacc += __shfl_xor(oacc, off);
         macc = max(macc, __shfl_xor(macc, off));
+        nov += __shfl_xor(nov, off);
+        h0 += __shfl_xor(h0, off); h1 += __shfl_xor(h1, off); h2 += __shfl_xor(h2, off);
+        h3 += __shfl_xor(h3, off); h4 += __shfl_xor(h4, off);
     }
-    __shared__ long long ss[4];
-    __shared__ int sm[4];
-    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = sacc; sm[threadIdx.x >> 6] = macc; }
+    __shared__ long long ss[4], so[4];
+    __shared__ int sm[4], sn[4], sh[5][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        ss[w] = sacc; so[w] = oacc; sm[w] = macc; sn[w] = nov;
+        sh[0][w] = h0; sh[1][w] = h1; sh[2][w] = h2; sh[3][w] = h3; sh[4][w] = h4;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        psum[blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
-        pmax[blockIdx.x] = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        const int b = blockIdx.x;
+        out->sum[b] = ss[0] + ss[1] + ss[2] + ss[3];
+        out->ovf_sum[b] = so[0] + so[1] + so[2] + so[3];
+        out->mx[b] = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        out->n_ovf[b] = sn[0] + sn[1] + sn[2] + sn[3];
+        for (int c = 0; c < 5; ++c) out->hist[c][b] = sh[c][0] + sh[c][1] + sh[c][2] + sh[c][3];
     }
 }
 
-static int count_stats(sf_ctx *ctx, sf_nbrs *nb, int64_t *total, int32_t *mx)
+// fills nb->total / max_count / max_count_all / hist / n_overflow; *ovf_total = summed length of the lists longer than cap
+static int count_stats(sf_ctx *ctx, sf_nbrs *nb, int cap, int64_t *ovf_total)
 {
     const int64_t m = nb->m;
-    const size_t bytes = SF_STATS_BLOCKS * (sizeof(long long) + 2 * sizeof(int));
-    static_assert(SF_STATS_BLOCKS * (sizeof(long long) + 2 * sizeof(int)) <= SF_PINNED_BYTES, "statistics exceed the pinned words");
     sf_pool_guard tmp(ctx);
-    char *dev = nullptr;
+    sf_stats_parts *dev = nullptr;
     void *pin = nullptr;
-    SF_CHECK(tmp.alloc(&dev, bytes));
+    SF_CHECK(tmp.alloc(&dev, 1));
     SF_CHECK(sf_ctx_pinned(ctx, &pin));
-    long long *psum = (long long *)dev;
-    int *pmax = (int *)(psum + SF_STATS_BLOCKS), *gmax = pmax + SF_STATS_BLOCKS;
-    SF_LAUNCH(ctx, "k2_reduce", k_count_stats, dim3(SF_STATS_BLOCKS), dim3(256), (const int32_t *)nb->count, m, psum, pmax);
+    SF_LAUNCH(ctx, "k2_reduce", k_count_stats, dim3(SF_STATS_BLOCKS), dim3(256), (const int32_t *)nb->count, m, cap, dev);
     // sf_comm_collective_stats: the longest list over every rank (the ranks size their SPFH tables by it)
     const bool fold = ctx->collective_stats && ctx->comm;
-    if (fold) SF_CHECK(sf_comm_allreduce_max_i32(ctx, pmax, gmax, SF_STATS_BLOCKS));
-    SF_HIP(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (fold) SF_CHECK(sf_comm_allreduce_max_i32(ctx, dev->mx, dev->gmx, SF_STATS_BLOCKS));
+    SF_HIP(hipMemcpyAsync(pin, dev, sizeof(sf_stats_parts), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    const long long *hs = (const long long *)pin;
-    const int *hm = (const int *)(hs + SF_STATS_BLOCKS), *hg = hm + SF_STATS_BLOCKS;
-    int64_t t = 0;
+    const sf_stats_parts *h = (const sf_stats_parts *)pin;
+    int64_t t = 0, ot = 0, nov = 0;
     int32_t mm = 0, ga = 0;
-    for (int b = 0; b < SF_STATS_BLOCKS; ++b) { t += hs[b]; mm = std::max<int32_t>(mm, hm[b]); ga = std::max<int32_t>(ga, hg[b]); }
-    *total = t;
-    *mx = mm;
+    for (int c = 0; c < 5; ++c) nb->hist[c] = 0;
+    for (int b = 0; b < SF_STATS_BLOCKS; ++b) {
+        t += h->sum[b];
+        ot += h->ovf_sum[b];
+        nov += h->n_ovf[b];
+        mm = std::max<int32_t>(mm, h->mx[b]);
+        if (fold) ga = std::max<int32_t>(ga, h->gmx[b]);
+        for (int c = 0; c < 5; ++c) nb->hist[c] += h->hist[c][b];
+    }
+    nb->total = t;
+    nb->max_count = mm;
     nb->max_count_all = fold ? std::max(ga, mm) : mm;
+    nb->n_overflow = nov;
+    if (ovf_total) *ovf_total = ot;
+    return SF_OK;
+}
+
+// ---- selections of queries by list length ------------------------------------------------------------------------------
+struct count_longer {
+    const int32_t *count;
+    int limit;
+    __host__ __device__ bool operator()(int32_t q) const { return count[q] > limit; }
+};
+struct count_of {
+    const int32_t *count;
+    __host__ __device__ int64_t operator()(int32_t q) const { return (int64_t)count[q]; }
+};
+
+// the processing slots whose list is longer than `limit`, ascending (`expect` of them: known from the statistics)
+static int select_longer(sf_ctx *ctx, const int32_t *count, int64_t m, int limit, int64_t expect, int32_t **out)
+{
+    sf_pool_guard tmp(ctx);
+    size_t *dnum = nullptr;
+    SF_CHECK(tmp.alloc(&dnum, 1));
+    SF_CHECK(sf_palloc(ctx, out, (size_t)expect + 1));
+    rocprim::counting_iterator<int32_t> first(0);
+    size_t tb = 0;
+    SF_HIP(rocprim::select(nullptr, tb, first, *out, dnum, (size_t)m, count_longer{count, limit}, ctx->stream));
+    char *scratch = nullptr;
+    SF_CHECK(tmp.alloc(&scratch, tb ? tb : 8));
+    {
+        sf_launch_timer t_(ctx, "k2_select");
+        SF_HIP(rocprim::select(scratch, tb, first, *out, dnum, (size_t)m, count_longer{count, limit}, ctx->stream));
+    }
+    return SF_OK;
+}
+
+__global__ void k_iota_stride(int32_t *__restrict__ out, int64_t n, int64_t stride)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)(i * stride);
+}
+
+__global__ void k_patch_offsets(const int32_t *__restrict__ sel, const int64_t *__restrict__ off, int64_t n, int64_t delta,
+                                int64_t *__restrict__ offset)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) offset[sel[i]] = delta + off[i];
+}
+
+// Which instantiation the list-driven kernels take for these lists, and which queries a second launch serves (see sf_nbrs).
+static int plan_dispatch(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
+{
+    const int64_t m = nb->m;
+    if (m >= SF_K2_SAMPLE) {
+        if (c->list_stats.size() > 64) c->list_stats.clear();
+        c->list_stats[nb->radius] = {(double)nb->total / (double)m, nb->max_count};
+    }
+    // WHICH form serves a keypoint depends on its own list alone -- longer than 255 points: the second launch -- so that a
+    // keypoint gets the same bits whatever else is in the launch (another block of a sharded job, a slice, a subset); the
+    // chunk count of the main launch's instantiation only has to cover the longest list it serves (the instantiations of
+    // one form agree bit for bit: chunks past a list's end contribute nothing).
+    const int64_t longest_main = std::min<int64_t>(nb->max_count > 0 ? nb->max_count : 1, 255);
+    int chunks = (int)sf_div_up(longest_main, 64);
+    if (const char *e = getenv("SF_MAIN_CHUNKS")) { const int v = atoi(e); if (v >= chunks && v <= 4) chunks = v; } // (experiments)
+    nb->planned = true;
+    nb->main_chunks = chunks;
+    nb->tail_limit = 255;
+    nb->n_tail = nb->hist[4];
+    if (nb->max_count <= nb->tail_limit) { nb->tail_limit = 0x7fffffff; nb->n_tail = 0; }
+    if (nb->n_tail) SF_CHECK(select_longer(ctx, nb->count, m, nb->tail_limit, nb->n_tail, &nb->tail_sel));
+    return SF_OK;
+}
+
+// Slot capacity of the single sweep from a SAMPLE of the search itself: the lists of every (m / 2048)-th query are counted
+// first (one small launch, 8 KB read back) and the slots sized by their mean and maximum.  (Until round 3 the capacity came
+// from the mean density of the bounding box: right for a cloud that fills its box, an order of magnitude low for a surface
+// scan -- every list overflowed and the "single" sweep was followed by a scan and a second sweep.)
+// 2.25 x the mean + 32 (what a Poisson-like cloud never exceeds: C3's lists reach 1.5 x their mean), at least 1.15 x the
+// longest list seen; a multiple of 32.  Lists beyond it are re-done on their own (run_search).
+static int64_t capacity_from(const sf_cloud *c, double mean, int64_t mx)
+{
+    int64_t v = (int64_t)(std::max(mean * 2.25, 1.15 * (double)mx)) + 32;
+    return std::min<int64_t>(((v + 31) / 32) * 32, std::max<int64_t>(((c->n + 31) / 32) * 32, 32));
+}
+
+static int sample_capacity(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const sf_grid_desc &g, double r2, int64_t *cap)
+{
+    const int64_t m = nb->m, stride = m / SF_K2_SAMPLE;
+    sf_pool_guard tmp(ctx);
+    int32_t *sel = nullptr, *cnt = nullptr;
+    void *pin = nullptr;
+    SF_CHECK(tmp.alloc(&sel, (size_t)SF_K2_SAMPLE));
+    SF_CHECK(tmp.alloc(&cnt, (size_t)SF_K2_SAMPLE));
+    SF_CHECK(sf_ctx_pinned(ctx, &pin));
+    static_assert(SF_K2_SAMPLE * sizeof(int32_t) <= SF_PINNED_BYTES, "sample exceeds the pinned words");
+    SF_LAUNCH(ctx, "k2_sample", k_iota_stride, dim3(SF_K2_SAMPLE / 256), dim3(256), sel, (int64_t)SF_K2_SAMPLE, stride);
+    SF_LAUNCH(ctx, "k2_sample", (k_radius<0, true>), dim3(sf_xcd_grid(sf_div_up(SF_K2_SAMPLE, 4 * SF_K2_WPB))), dim3(64 * SF_K2_WPB), g,
+              c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, (int64_t)SF_K2_SAMPLE, r2, 0, cnt, (int64_t *)nullptr,
+              (int32_t *)nullptr, (const int32_t *)sel);
+    SF_HIP(hipMemcpyAsync(pin, cnt, SF_K2_SAMPLE * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    const int32_t *h = (const int32_t *)pin;
+    double sum = 0.0;
+    int32_t mx = 0;
+    for (int i = 0; i < SF_K2_SAMPLE; ++i) { sum += h[i]; mx = std::max(mx, h[i]); }
+    *cap = capacity_from(c, sum / SF_K2_SAMPLE, mx);
+    return SF_OK;
+}
+
+static int exact_scan_fill(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const sf_grid_desc &g, const dim3 &grid, const dim3 &block, double r2)
+{
+    const int64_t m = nb->m;
+    auto in = rocprim::make_transform_iterator(nb->count, to_i64());
+    size_t tb1 = 0;
+    SF_HIP(rocprim::exclusive_scan(nullptr, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
+                                   ctx->stream));
+    void *tmp = nullptr;
+    SF_CHECK(sf_pool_alloc(ctx, tb1 ? tb1 : 8, &tmp));
+    {
+        sf_launch_timer t_(ctx, "k2_scan");
+        SF_HIP(rocprim::exclusive_scan(tmp, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
+                                       ctx->stream));
+    }
+    sf_pool_release(ctx, tmp);
+    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)nb->total + 4));
+    nb->cap = 0;
+    if (nb->total) {
+        SF_LAUNCH(ctx, "k2_radius_fill", (k_radius<1, false>), grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
+                  nb->qz, m, r2, 0, nb->count, nb->offset, nb->idx, (const int32_t *)nullptr);
+    }
     return SF_OK;
 }
 
@@ -545,58 +707,76 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     sf_grid_desc g = sf_make_grid_desc(c);
     const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4 * SF_K2_WPB))), block(64 * SF_K2_WPB); // waves x 4 queries
     if (!m) {
+        // (an empty block of a sharded job still takes part in the all-reduce of the list statistics its peers are in)
+        if (ctx->collective_stats && ctx->comm) SF_CHECK(count_stats(ctx, nb, 0x7fffffff, nullptr));
         SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)8));
         return SF_OK;
     }
-    // ---- optimistic single pass into fixed-capacity slots -----------------------------------------
-    // capacity from the mean density of the bounding box (x2.25 + 32, multiple of 32); skipped when the slots
-    // would take more than 24 GiB or the estimate is meaningless
-    double vol = 1.0;
-    for (int a = 0; a < 3; ++a) vol *= std::max((double)(a == 0 ? c->dim[0] / c->xsub : c->dim[a]) * c->cell, 1e-300);
-    const double expect = (double)c->n * 4.18879020478639 * nb->radius * nb->radius * nb->radius / vol;
-    int64_t cap = (int64_t)(expect * 2.25) + 32;
-    cap = std::min<int64_t>(((cap + 31) / 32) * 32, std::max<int64_t>(c->n, 32));
-    const bool optimistic = std::isfinite(expect) && cap * m * 4 <= ((int64_t)24 << 30) && cap < 0x7fffffff;
+    // ---- single sweep into fixed-capacity slots, sized from a sample of the lists ------------------------------------------
+    // (small query sets take the exact count -> scan -> fill scheme: two sweeps of next to nothing.  So do searches whose
+    // slots would take more than 24 GiB.)
+    int64_t cap = 0;
+    bool optimistic = m >= 8 * SF_K2_SAMPLE && !getenv("SF_K2_EXACT");
     if (optimistic) {
-        SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)(cap * m) + 4)); // +4: consumers read indices 16 B at a time
-        SF_LAUNCH(ctx, "k2_radius_slots", k_radius<2>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
-                  nb->qz, m, r2, (int)cap, nb->count, nb->offset, nb->idx);
-        int64_t total = 0;
-        int32_t mx = 0;
-        SF_CHECK(count_stats(ctx, nb, &total, &mx));
-        nb->total = total;
-        nb->max_count = mx;
-        if (mx <= cap) return SF_OK;
-        sf_pool_release(ctx, nb->idx); // some list overflowed its slot: redo exactly
+        // the lists of the previous search with this radius on this cloud say how long this one's will be (same cloud, same
+        // radius: the same lists, or a sub-range of them); the first search counts a sample instead.  SF_K2_NO_HINT=1: always.
+        auto hint = c->list_stats.find(nb->radius);
+        if (hint != c->list_stats.end() && !getenv("SF_K2_NO_HINT")) cap = capacity_from(c, hint->second.first, hint->second.second);
+        else SF_CHECK(sample_capacity(ctx, c, nb, g, r2, &cap));
+        // slots of at most 24 GiB: a cloud whose longest list is far above its mean keeps the slots of the mean and re-does
+        // the long lists
+        if (const char *e = getenv("SF_K2_CAP")) { const long v = atol(e); if (v >= 32) cap = (v / 32) * 32; } // (tests: force the slot size)
+        const int64_t most = std::max<int64_t>(((((int64_t)24 << 30) / (4 * m)) / 32) * 32, 32);
+        if (cap > most) cap = std::max<int64_t>(most, 64);
+        optimistic = cap * m * 4 <= ((int64_t)24 << 30) && cap < 0x7fffffff;
+    }
+    if (!optimistic) {
+        SF_LAUNCH(ctx, "k2_radius_count", (k_radius<0, false>), grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
+                  nb->qz, m, r2, 0, nb->count, nb->offset, (int32_t *)nullptr, (const int32_t *)nullptr);
+        SF_CHECK(count_stats(ctx, nb, 0x7fffffff, nullptr));
+        SF_CHECK(exact_scan_fill(ctx, c, nb, g, grid, block, r2));
+        return plan_dispatch(ctx, c, nb);
+    }
+    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)(cap * m) + 4)); // +4: consumers read indices 16 B at a time
+    nb->cap = cap;
+    SF_LAUNCH(ctx, "k2_radius_slots", (k_radius<2, false>), grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
+              nb->qz, m, r2, (int)cap, nb->count, nb->offset, nb->idx, (const int32_t *)nullptr);
+    int64_t ovf_total = 0;
+    SF_CHECK(count_stats(ctx, nb, (int)cap, &ovf_total));
+    if (nb->n_overflow * 2 > m) { // the sample misjudged the cloud as a whole: redo exactly
+        sf_pool_release(ctx, nb->idx);
         nb->idx = nullptr;
-    } else {
-        SF_LAUNCH(ctx, "k2_radius_count", k_radius<0>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
-                  nb->qz, m, r2, 0, nb->count, nb->offset, (int32_t *)nullptr);
-        int64_t total = 0;
-        int32_t mx = 0;
-        SF_CHECK(count_stats(ctx, nb, &total, &mx));
-        nb->total = total;
-        nb->max_count = mx;
+        nb->n_overflow = 0;
+        SF_CHECK(exact_scan_fill(ctx, c, nb, g, grid, block, r2));
+        return plan_dispatch(ctx, c, nb);
     }
-    // ---- exact two-pass scheme: counts are known, scan them, fill ---------------------------------------
-    auto in = rocprim::make_transform_iterator(nb->count, to_i64());
-    size_t tb1 = 0;
-    SF_HIP(rocprim::exclusive_scan(nullptr, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
-                                   ctx->stream));
-    void *tmp = nullptr;
-    SF_CHECK(sf_pool_alloc(ctx, tb1 ? tb1 : 8, &tmp));
-    {
-        sf_launch_timer t_(ctx, "k2_scan");
-        SF_HIP(rocprim::exclusive_scan(tmp, tb1, in, nb->offset, (int64_t)0, (size_t)(m + 1), rocprim::plus<int64_t>(),
-                                       ctx->stream));
+    if (nb->n_overflow) {
+        // ---- the lists that did not fit their slot, and only those: exact offsets in an area of their own ---------------------
+        const int64_t no = nb->n_overflow;
+        sf_pool_guard tmp(ctx);
+        int32_t *sel = nullptr;
+        int64_t *off = nullptr;
+        SF_CHECK(select_longer(ctx, nb->count, m, (int)cap, no, &sel));
+        tmp.held.push_back(sel);
+        SF_CHECK(tmp.alloc(&off, (size_t)no));
+        auto in = rocprim::make_transform_iterator((const int32_t *)sel, count_of{nb->count});
+        size_t tb = 0;
+        SF_HIP(rocprim::exclusive_scan(nullptr, tb, in, off, (int64_t)0, (size_t)no, rocprim::plus<int64_t>(), ctx->stream));
+        char *scratch = nullptr;
+        SF_CHECK(tmp.alloc(&scratch, tb ? tb : 8));
+        {
+            sf_launch_timer t_(ctx, "k2_scan");
+            SF_HIP(rocprim::exclusive_scan(scratch, tb, in, off, (int64_t)0, (size_t)no, rocprim::plus<int64_t>(), ctx->stream));
+        }
+        SF_CHECK(sf_palloc(ctx, &nb->idx_ovf, (size_t)ovf_total + 4));
+        // offset[q] is an element offset from nb->idx: the overflow area is addressed through the same base pointer
+        const int64_t delta = (int64_t)(((intptr_t)nb->idx_ovf - (intptr_t)nb->idx) / (intptr_t)sizeof(int32_t));
+        SF_LAUNCH(ctx, "k2_select", k_patch_offsets, dim3((unsigned)sf_div_up(no, 256)), dim3(256), (const int32_t *)sel,
+                  (const int64_t *)off, no, delta, nb->offset);
+        SF_LAUNCH(ctx, "k2_radius_refill", (k_radius<1, true>), dim3(sf_xcd_grid(sf_div_up(no, 4 * SF_K2_WPB))), block, g, c->cell_start,
+                  c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, no, r2, 0, nb->count, nb->offset, nb->idx, (const int32_t *)sel);
     }
-    sf_pool_release(ctx, tmp);
-    SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)nb->total + 4));
-    if (nb->total) {
-        SF_LAUNCH(ctx, "k2_radius_fill", k_radius<1>, grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
-                  nb->qz, m, r2, 0, nb->count, nb->offset, nb->idx);
-    }
-    return SF_OK;
+    return plan_dispatch(ctx, c, nb);
 }
 
 static int ensure_grid(sf_ctx *ctx, sf_cloud *c, double radius, int64_t need_begin = 0, int64_t need_end = -1)
@@ -899,6 +1079,15 @@ extern "C" sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nb, int64_t first, int64
     v->idx = nb->idx;
     v->max_count = nb->max_count;
     v->max_count_all = nb->max_count_all;
+    // (a view runs the owner's dispatch: same main form, the owner's tail selection filtered to the view's range)
+    for (int c = 0; c < 5; ++c) v->hist[c] = nb->hist[c];
+    v->planned = nb->planned;
+    v->main_chunks = nb->main_chunks;
+    v->tail_limit = nb->tail_limit;
+    v->tail_sel = nb->tail_sel;
+    v->n_tail = nb->n_tail;
+    v->view_first = nb->view_first + first;
+    v->cap = nb->cap;
     v->total = -1; // unknown without a device read; views are for compute, not export
     return v;
 }
@@ -990,5 +1179,7 @@ extern "C" void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nb)
     sf_pool_release(ctx, nb->count);
     sf_pool_release(ctx, nb->offset);
     sf_pool_release(ctx, nb->idx);
+    sf_pool_release(ctx, nb->idx_ovf);
+    sf_pool_release(ctx, nb->tail_sel);
     delete nb;
 }

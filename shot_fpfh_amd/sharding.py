@@ -161,7 +161,13 @@ class DescriptorJob:
         self.last_pairs = 0
 
     def _spfh_table(self, max_count: int) -> Spfh:
-        wide = 0 if (max_count <= 255 and self.n_bins**3 <= 128) else (2 if max_count > 65535 else 1)  # table kind
+        # table kind: bytes (3: with the high-byte rows of the points that have more than 255 neighbours), 16 or 32 bits
+        if max_count <= 65535 and self.n_bins**3 <= 128:
+            wide = 0 if max_count <= 255 else 3
+        else:
+            wide = 2 if max_count > 65535 else 1
+        if wide == 0 and self._spfh_wide == 3:
+            wide = 3  # (a byte table that has its high-byte rows serves short lists as it is)
         if self.spfh is None or wide != self._spfh_wide:
             if self.spfh is not None:
                 self.spfh.free()
@@ -213,7 +219,7 @@ class DescriptorJob:
             spfh = self._spfh_table(max(nb.max_count_all, nb.max_count))
             if self.emulate_peers and self._spfh_wide != kind and kind != -1:
                 raise RuntimeError("emulate_peers: the table changed its storage after the halo rows were filled")
-            shared = self.share_sweep and nb.max_count <= 256
+            shared = self.share_sweep  # (any list length: the kernels dispatch per keypoint, sf_nbrs_dispatch)
             if shared:
                 if self.moments is None or self.moments.shape[0] < nb.m:
                     if self.moments is not None:
@@ -276,7 +282,7 @@ class DescriptorJob:
                 two_streams = self.overlap and self.do_fpfh and self.do_shot
                 if self.do_fpfh:
                     spfh = self._spfh_table(nb.max_count)  # (allocates on first use: before forking)
-                shared = self.share_sweep and nb.max_count <= 256  # (the fused K5's limit)
+                shared = self.share_sweep  # (any list length: the kernels dispatch per keypoint, sf_nbrs_dispatch)
                 if shared:
                     if self.moments is None or self.moments.shape[0] < nb.m:
                         if self.moments is not None:
