@@ -55,7 +55,7 @@ class ShotMultiprocessor:
         (shot_parallelization.py:157-166)."""
         if voxel is None:
             return Cloud(self._eng(), point_cloud, normals)
-        keep = grid_subsampling(np.asarray(point_cloud), voxel)
+        keep = grid_subsampling(np.asarray(point_cloud), voxel, engine=self._eng())
         if self.verbose:
             logging.info(
                 f"Keeping a support of {keep.shape[0]} points out of {np.asarray(point_cloud).shape[0]} "

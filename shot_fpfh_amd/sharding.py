@@ -216,7 +216,10 @@ class DescriptorJob:
                 nb.shot_single_scale(self.normalize, self.min_nb, out=self.shot_out, lrf_out=self.lrf_out)
                 return
             kind = self._spfh_wide
-            spfh = self._spfh_table(max(nb.max_count_all, nb.max_count))
+            longest = max(nb.max_count_all, nb.max_count)
+            if getattr(eng, "fold_max_count", None) is not None and not self.emulate_peers:
+                longest = eng.fold_max_count(longest)  # (a transport without RCCL folds the maximum itself: bench.py, staged)
+            spfh = self._spfh_table(longest)
             if self.emulate_peers and self._spfh_wide != kind and kind != -1:
                 raise RuntimeError("emulate_peers: the table changed its storage after the halo rows were filled")
             shared = self.share_sweep  # (any list length: the kernels dispatch per keypoint, sf_nbrs_dispatch)

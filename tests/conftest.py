@@ -11,8 +11,42 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+_LAUNCHER = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Tests that run whole programs on the GPU (bench.py with several ranks) must not start them from this process once it
+    # holds the GPU itself: a helper that never touches the GPU is started NOW, before any test has run, and starts them.
+    global _LAUNCHER
+    expr = config.getoption("-m", default="") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        import subprocess
+
+        _LAUNCHER = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_launcher.py")], stdin=subprocess.PIPE,
+                                     stdout=subprocess.PIPE, text=True, cwd=ROOT)
+
+
+def pytest_unconfigure(config):
+    global _LAUNCHER
+    if _LAUNCHER is not None:
+        try:
+            _LAUNCHER.stdin.close()
+            _LAUNCHER.wait(timeout=30)
+        except Exception:  # noqa: BLE001
+            _LAUNCHER.kill()
+        _LAUNCHER = None
+
+
+def run_program(argv, env=None, timeout=900):
+    """Run a program through the GPU-free launcher: {"rc", "stdout", "stderr"}.  Only in `-m gpu` sessions."""
+    import json
+
+    if _LAUNCHER is None:
+        pytest.skip("no launcher: not a -m gpu session")
+    _LAUNCHER.stdin.write(json.dumps({"argv": list(argv), "env": env or {}, "timeout": timeout, "cwd": ROOT}) + "\n")
+    _LAUNCHER.stdin.flush()
+    return json.loads(_LAUNCHER.stdout.readline())
 
 
 def load_golden(name):

@@ -1,0 +1,64 @@
+"""The `bench.py --gpus N` path the driver launches on a multi-GPU node, exercised on ONE GPU (-m gpu): N ranks oversubscribed
+on the device (every exchange staged through host memory over the authenticated control plane -- RCCL refuses two ranks on
+one device), the N = 1 run of the same cloud for the 64-bit fingerprint of all descriptor rows, and one emulated rank.
+The programs are started by tests/_launcher.py, a process that never touches the GPU."""
+import json
+import sys
+
+import pytest
+
+from conftest import run_program
+
+pytestmark = pytest.mark.gpu
+
+COMMON = ["--points-per-gpu", "60000", "--radius", "0.08", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sustained-seconds", "0",
+          "--no-density", "--no-defaults", "--no-dropin", "--no-normals", "--no-ransac", "--parity-rows", "60"]
+
+
+def bench(*flags, timeout=900):
+    r = run_program([sys.executable, "bench.py", *COMMON, *flags], timeout=timeout)
+    assert r["rc"] == 0, r["stderr"][-2000:]
+    lines = [ln for ln in r["stdout"].splitlines() if ln.strip()]
+    assert len(lines) == 1, r["stdout"][-2000:]  # stdout carries exactly ONE line
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def one_rank():
+    return bench("--gpus", "1", "--checksum", "--no-match")
+
+
+def test_one_rank_record_is_scale_ready(one_rank):
+    d = one_rank
+    assert d["n_gpus"] == 1 and d["emulated"] is False and d["rccl_ranks"] == 1
+    assert d["parity"]["ok"] and d["value"] > 0 and len(d["per_rank_ms_per_step"]) == 1
+    assert d["roofline"]["frac"] > 0 and "value_includes" in d
+
+
+def test_two_ranks_on_one_device_reproduce_the_one_rank_rows(one_rank):
+    """`bench.py --gpus 2 --oversubscribe` as the driver would start it (it spawns its ranks itself): rendezvous, the
+    descriptor pass with the neighbour exchange of SPFH rows, strong-scaling pass of the N = 1 cloud, config 5's tail.  The
+    strong-scaling pass runs the SAME 60000-point cloud as the N = 1 run: equal 64-bit fingerprints = every FPFH and SHOT
+    row bit-identical."""
+    d = bench("--gpus", "2", "--oversubscribe", "--checksum", "--match-rows", "20000", "--match-steps", "1")
+    assert d["n_gpus"] == 2 and d["emulated"] is False
+    assert d["parity"]["ok"] and all(p["ok"] for p in d["parity"]["per_rank"]) and len(d["parity"]["per_rank"]) == 2
+    assert len(d["per_rank_ms_per_step"]) == 2
+    assert "staged through host memory" in d["config"]["exchange"] and d["rccl_ranks"] == 0
+    ss = d["strong_scaling"]
+    assert ss["parity_ok"] and ss["checksum"] == one_rank["checksum"], (ss["checksum"], one_rank["checksum"])
+    em = d["exchange_match"]
+    assert em["matches"] > 0 and em["matches_recovering_true_correspondence"] > 0.8
+
+
+def test_three_ranks_oversubscribed(one_rank):
+    d = bench("--gpus", "3", "--oversubscribe", "--checksum", "--no-match")
+    assert d["parity"]["ok"] and len(d["per_rank_ms_per_step"]) == 3
+    assert d["strong_scaling"]["checksum"] == one_rank["checksum"]
+
+
+def test_emulated_rank_record_cannot_be_read_as_a_multi_gpu_result():
+    d = bench("--gpus", "8", "--emulate-rank", "3", "--no-match")
+    assert d["emulated"] is True and d["emulated_rank"] == 3 and d["emulated_world"] == 8
+    assert d["n_gpus"] == 1 and d["value"] is None and d["projected_value_upper_bound"] > 0
+    assert d["parity"]["ok"]
