@@ -779,6 +779,27 @@ __device__ inline void sf_sqrt_rsqrt(double x, double &root, double &inv)
     }
 }
 
+// Phase markers for tools/k5_phases.py (an ANALYSIS build only, -DSF_K5_MARK_BUILD: scheduling barriers + an assembler
+// comment; the shipped build compiles them to nothing): instruction counts per phase of the register-cached K5.
+#ifdef SF_K5_MARK_BUILD
+#define SF_K5_MARK(id, nch)                                                     \
+    do {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+        asm volatile("; K5MARK %0 %1" ::"n"(id), "n"(nch));                     \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+    } while (0)
+// (pure arithmetic sinks to its first use whatever barrier stands between: the values a phase produces are pinned in front
+// of the next mark)
+#define SF_K5_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define SF_K5_MARK(id, nch) do { } while (0)
+#define SF_K5_PIN(x) (void)(x)
+#endif
+// ids: 1 header+clear, 2 gather, 3 frame votes, 4 gate, 5 geometry (sub: 50 sqrt/rsqrt, 51 local coords + cosine, 52 cosine bin,
+// 53 octant, 54 centre-ray cross/dot + neighbour octant, 55 lz/rho + packing), 6 election A (atomic max), 7 who-writes-what
+// (key reads), 8 weights (sub: 80 atan fraction, 81 radial shells, 82 acos, 83 elevation + sum), 9 A store (CAS), 10 S3/S4 S6/S7
+// adds, 11 S1 S9 elections + adds, 12 read-back + normalise + store
+
 struct shot_kept {
     double rho, dc, tcross, tdot, lzr; // tcross / tdot: (lx, ly) against the octant's centre ray; lzr = lz / rho
     unsigned bins0, bins1;            // base | bcos << 9 | bth << 18 ; bins1: bit 31 = valid, bits 28-30 = election flags
@@ -864,7 +885,10 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
                                      const double *E, double half_r, shot_kept &o)
 {
     double rho, inv_rho;
+    SF_K5_MARK(50, 0);
     sf_sqrt_rsqrt(d2, rho, inv_rho);
+    SF_K5_PIN(rho); SF_K5_PIN(inv_rho);
+    SF_K5_MARK(51, 0);
     // (neighbors - point) @ eigenvectors and normals @ eigenvectors[:, 2] (shot.py:214-215) as the multiply-add chain an
     // FMA BLAS kernel runs over the inner index -- what the reference's NumPy does on any current x86 / OpenBLAS
     const double lx = sf_dot3(cx, cy, cz, E[0], E[3], E[6]);
@@ -872,10 +896,18 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     const double lz = sf_dot3(cx, cy, cz, E[2], E[5], E[8]);
     double cosine = sf_dot3(nx, ny, nz, E[2], E[5], E[8]);
     cosine = fmin(fmax(cosine, -1.0), 1.0);
+    double lxp = lx, lyp = ly, lzp = lz;
+    SF_K5_PIN(lxp); SF_K5_PIN(lyp); SF_K5_PIN(lzp); SF_K5_PIN(cosine);
+    SF_K5_MARK(52, 0);
     const double cpos = (cosine + 1.0) * 11.0 / 2.0 - 0.5;
     const double cf = rint(cpos);
-    const int ci = (int)cf;
-    const int ti = azimuth_octant_wave(lx, ly);
+    int ci = (int)cf;
+    double dcp = cpos - cf;
+    SF_K5_PIN(ci); SF_K5_PIN(dcp);
+    SF_K5_MARK(53, 0);
+    int ti = azimuth_octant_wave(lx, ly);
+    SF_K5_PIN(ti);
+    SF_K5_MARK(54, 0);
     const int pi_ = lz > 0.0 ? 1 : 0;
     const int ri = rho > half_r ? 1 : 0; // (radius / 2 is exact: the host passes that very double)
     const double dc = cpos - cf;
@@ -904,6 +936,12 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     const unsigned base = (unsigned)(((ci * 8 + ti) * 2 + pi_) * 2 + ri);
     const unsigned bcos = (unsigned)(((cin * 8 + ti) * 2 + pi_) * 2 + ri);
     const unsigned bth = (unsigned)(((ci * 8 + tin) * 2 + pi_) * 2 + ri);
+    {
+        double crp = cross, dtp = dot;
+        unsigned b0p = base, b1p = bcos, b2p = bth;
+        SF_K5_PIN(crp); SF_K5_PIN(dtp); SF_K5_PIN(b0p); SF_K5_PIN(b1p); SF_K5_PIN(b2p);
+    }
+    SF_K5_MARK(55, 0);
     // lz / rho through the reciprocal, then one residual correction: acos has an unbounded derivative at +-1, so for a
     // neighbour on the frame's z axis a one-ulp error of the quotient would be a 1.5e-8 error of phi (the reference's
     // correctly rounded division gives exactly +-1 there)
@@ -938,17 +976,21 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
     const double adc = fabs(g.dc);
     // |dth|: angle off the octant's centre ray as a fraction of the octant, clipped to 1/2.  lx = ly = 0 has dot = 0:
     // the reference's atan2(0, 0) = 0 sits 3.5 octants from octant 0's start -> 1/2.
+    SF_K5_MARK(80, 0);
     const bool fwd = g.tdot > 0.0;
     const double tq = fmin(fabs(g.tcross) * sf_rcp(fwd ? g.tdot : 1.0), 0.4146);
     const double at = fmin(sf_atan_octant_fraction(tq), 0.5);
     adth = fwd ? at : 0.5;
+    SF_K5_PIN(adth);
     // radial shells (interpolate_on_adjacent_husks): rho == r/2 belongs to neither and gets all three terms zero
     // The two shells mirror each other about rho = r/2: with s = |rho - r/2| the distance to the current shell's centre
     // is |s - r/4| and the distance "towards the other shell" (3r/4 - rho outside, rho - r/4 inside) is r/4 - s, in both.
+    SF_K5_MARK(81, 0);
     const bool off_half = rho != k.half_r;
     const double ds = fabs(rho - k.half_r) - k.q1;
     const double cur = off_half ? 1.0 - fabs(ds) * k.inv_hr : 0.0;
     v_cd = off_half ? fmax(-ds, 0.0) * k.inv_hr : 0.0;
+    { double curp = cur; SF_K5_PIN(curp); SF_K5_PIN(v_cd); }
     // elevation (interpolate_vertical_volumes).  With u = phi / (pi/2) the reference's terms are
     //   current = 1 - |u - 1/2| for phi < pi/2, 1 - |u - 3/2| for phi >= pi/2;
     //   lower  = [phi < pi/2 and (not near or z > 0) and phi >= pi/4] (u - 1/2), counted for z > 0 writers;
@@ -957,7 +999,10 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
     // t = acos(|z|) / (pi/2) in [0, 1] all three are ONE expression per neighbour whatever the sign of z:
     //   current = 1 - |t - 1/2| ;  lower resp. upper = max(t - 1/2, 0), with the single exception the masks leave:
     //   a writer with z > 0 whose phi ROUNDS to pi/2 (t = 1 exactly) fails "phi < pi/2" and gets 0.
-    const double t = sf_acos_abs_quadrants(fmin(fabs(g.lzr), 1.0));
+    SF_K5_MARK(82, 0);
+    double t = sf_acos_abs_quadrants(fmin(fabs(g.lzr), 1.0));
+    SF_K5_PIN(t);
+    SF_K5_MARK(83, 0);
     const double curv = 1.0 - fabs(t - 0.5);
     const bool side = !z_pos | (t < 1.0);
     v_ef = side ? fmax(t - 0.5, 0.0) : 0.0;
@@ -993,6 +1038,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // register file, not LDS, set the occupancy.  A CD / EF slot carries ONE value plus a flag in bit 62
     // (unused by doubles below 2.0): the S3/S4 pair of a winner has a single non-zero member, selected by
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
+    SF_K5_MARK(1, NCH);
     unsigned long long *const sA = slot;
     const int lane = threadIdx.x & 63;
     const int64_t s = offset[q];
@@ -1004,6 +1050,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // (only the election / accumulator half: sX is cleared before each of its two uses; 16 bytes per lane and store)
     for (int b = lane; b < 176; b += 64) reinterpret_cast<ulonglong2 *>(slot)[b] = make_ulonglong2(0ull, 0ull);
 
+    SF_K5_MARK(2, NCH);
     // one gather for all chunks
     double cx[NCH], cy[NCH], cz[NCH], nx[NCH], ny[NCH], nz[NCH];
 #pragma unroll
@@ -1017,6 +1064,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         cy[c] = y - py;
         cz[c] = z - pz;
     }
+    SF_K5_MARK(3, NCH);
     double E[9];
     if (FUSED) {
         double *lr = lrf + 9 * row;
@@ -1053,6 +1101,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
     }
 
+    SF_K5_MARK(4, NCH);
     // gate (shot.py:212): neighbours at non-zero distance; padding lanes get d2 = 0
     double d2[NCH];
     int npos = 0;
@@ -1087,13 +1136,16 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         g[c].bins1 = 0u;
+        SF_K5_MARK(5, NCH);
         if (d2[c] > 0.0) {
             shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, K.half_r, g[c]);
+            SF_K5_MARK(6, NCH);
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             atomicMax(&sA[g[c].bins0 & 511u], key);
         }
     }
     SF_SHOT_SYNC();
+    SF_K5_MARK(7, NCH);
     // who writes what (all reads of the keys come before the first winner replaces its key by a value)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -1119,11 +1171,13 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     for (int c = 0; c < NCH; ++c) {
         v_cd[c] = 0.0;
         v_ef[c] = 0.0;
+        SF_K5_MARK(8, NCH);
         if (g[c].bins1 >> 31) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             const unsigned iA = g[c].bins0 & 511u;
             double vA, adth;
             shot_weights(g[c], K, vA, v_cd[c], v_ef[c], adth);
+            SF_K5_MARK(9, NCH);
             g[c].tdot = adth;
             // compare-and-swap, not a plain store: two neighbours at exactly the same distance (duplicated points) hold the
             // same key, and the ADDS below must come from one of them only (their values are equal; which one of two
@@ -1132,6 +1186,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         }
     }
     SF_SHOT_SYNC();
+    SF_K5_MARK(10, NCH);
     // S3/S4 and S6/S7: the writer adds into the bin with the OTHER radial / elevation bit than its own
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -1142,6 +1197,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         }
     }
     SF_SHOT_SYNC();
+    SF_K5_MARK(11, NCH);
     // S1 (value |dc|) and S9 (value |dth|): elect in sX, add into the accumulator
 #pragma unroll
     for (int stmt = 0; stmt < 2; ++stmt) {
@@ -1166,6 +1222,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         }
         SF_SHOT_SYNC();
     }
+    SF_K5_MARK(12, NCH);
     // every slot of the accumulator is +0 (nothing written) or minus the bin's value
     double vals[6];
     double ss = 0.0;
@@ -1186,6 +1243,200 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// K5 for lists of ANY length (the keypoints whose own list exceeds the register-cached form: dense regions, and the
+// reference's default configuration -- a support subsampled at radius / 10 puts 300-500 voxels' points into a ball on a
+// surface scan).  Same arithmetic as the cached form (shot_geometry / shot_weights: the short polynomial forms, the octant
+// fast path, S3/S4 and S6/S7 writers read off the S2 election), streamed: the list is swept three times, 128 neighbours in
+// flight -- (V) sign votes of the frame + the gate, (1) geometry -> the three elections (64-bit LDS atomic max on rho's bit
+// pattern for S2.., S1, S9), (2) geometry again -> weights -> every elected writer claims its (statement, bin) once (a bit
+// per slot: two neighbours at exactly the same distance hold the same key) and ADDS its value into a float64 accumulator
+// row with ds_add_f64.  LDS per wave: 3 x 352 keys + 352 accumulators + 3 x 352 claim bits = 11.4 KB.  A wave's LDS
+// instructions execute in program order and no two lanes of one instruction target the same slot (one claimed writer per
+// statement and bin), so every bit of the row is reproducible.  (Until round 4 this was `k_shot`, a two-sweep kernel on
+// libm's atan2 / acos with five election tables: 2.3x the time per neighbour of the cached form.)
+// --------------------------------------------------------------------------------------------------
+#ifndef SF_SHOT_LONG_WPB
+#define SF_SHOT_LONG_WPB 2
+#endif
+struct shot_long_lds {
+    unsigned long long keyA[352], keyB[352], keyG[352];
+    double acc[352];
+    unsigned claim[3][12];
+};
+
+template <bool FUSED, bool SEL>
+__global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const double *__restrict__ rec,
+                                             const double *__restrict__ qx, const double *__restrict__ qy,
+                                             const double *__restrict__ qz, const int64_t *__restrict__ offset,
+                                             const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                             const int32_t *__restrict__ qrow,
+                                             int64_t m, shot_consts K, double *__restrict__ lrf, int normalize,
+                                             int64_t min_nb, double *__restrict__ out, const int32_t *__restrict__ sel,
+                                             int64_t nsel, int64_t view_first)
+{
+    __shared__ __attribute__((aligned(16))) shot_long_lds lds_all[SF_SHOT_LONG_WPB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    shot_long_lds &L = lds_all[wave];
+    int64_t q = sf_xcd_block() * SF_SHOT_LONG_WPB + wave;
+    if (SEL) {
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
+    if (q >= m) return;
+    const int64_t s = offset[q];
+    const int k = sf_uniform(cnt[q]);
+    const int64_t row = qrow ? qrow[q] : q;
+    double *o = out + (int64_t)SF_SHOT_LEN * row;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    {
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(&L);
+        for (int b = lane; b < (int)(sizeof(shot_long_lds) / 8); b += 64) w[b] = 0ull;
+    }
+    double rx0 = 0, rx1 = 0, rx2 = 0, rz0 = 0, rz1 = 0, rz2 = 0;
+    if (FUSED) {
+        const double *lr = lrf + 9 * row;
+        rx0 = lr[0]; rx1 = lr[1]; rx2 = lr[2]; rz0 = lr[3]; rz1 = lr[4]; rz2 = lr[5];
+    }
+    // ---- sweep V: gate (shot.py:212, 306) and the frame's sign votes (shot.py:40-45) ----
+    int npos = 0, xneg = 0, zneg = 0;
+    for (int t0 = 0; t0 < k; t0 += 128) {
+        int jj[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = t0 + 64 * u + lane;
+            jj[u] = t < k ? idx[s + t] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double x, y, z;
+            sf_load_xyz(rec, jj[u] < 0 ? 0 : jj[u], x, y, z);
+            const double cx = x - px, cy = y - py, cz = z - pz;
+            const bool on = jj[u] >= 0;
+            npos += __popcll(__ballot(on && ((cx * cx + cy * cy) + cz * cz) > 0.0));
+            if (FUSED) {
+                xneg += __popcll(__ballot(on && sf_dot3(cx, cy, cz, rx0, rx1, rx2) < 0.0));
+                zneg += __popcll(__ballot(on && sf_dot3(cx, cy, cz, rz0, rz1, rz2) < 0.0));
+            }
+        }
+    }
+    double E[9];
+    if (FUSED) { // (the frame is written whether or not the descriptor passes the gate, as in the cached form)
+        if (xneg > k - xneg) { rx0 = -rx0; rx1 = -rx1; rx2 = -rx2; }
+        if (zneg > k - zneg) { rz0 = -rz0; rz1 = -rz1; rz2 = -rz2; }
+        const double y0 = rz1 * rx2 - rz2 * rx1, y1 = rz2 * rx0 - rz0 * rx2, y2 = rz0 * rx1 - rz1 * rx0; // cross(z, x)
+        if (k == 0) { // shot.py:24-25
+            E[0] = 1.0; E[1] = 0.0; E[2] = 0.0; E[3] = 0.0; E[4] = 1.0; E[5] = 0.0; E[6] = 0.0; E[7] = 0.0; E[8] = 1.0;
+        } else {
+            E[0] = rx0; E[1] = y0; E[2] = rz0;
+            E[3] = rx1; E[4] = y1; E[5] = rz1;
+            E[6] = rx2; E[7] = y2; E[8] = rz2;
+        }
+        if (lane < 9) {
+            double v = E[0];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) v = lane == i ? E[i] : v;
+            lrf[9 * row + lane] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+    }
+    if (!((int64_t)npos > min_nb)) {
+        for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
+        return;
+    }
+    SF_SHOT_SYNC(); // (the cleared tables)
+    // one step of a sweep: 128 neighbours gathered together, their geometry
+    auto geometry128 = [&](int t0, shot_kept (&g)[2]) {
+        int jj[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = t0 + 64 * u + lane;
+            jj[u] = t < k ? idx[s + t] : -1;
+        }
+        double cx[2], cy[2], cz[2], nx[2], ny[2], nz[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double x, y, z;
+            sf_load_pn(rec, jj[u] < 0 ? 0 : jj[u], x, y, z, nx[u], ny[u], nz[u]);
+            cx[u] = x - px; cy[u] = y - py; cz[u] = z - pz;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            g[u].bins1 = 0u;
+            const double d2 = (cx[u] * cx[u] + cy[u] * cy[u]) + cz[u] * cz[u];
+            if (jj[u] >= 0 && d2 > 0.0) shot_geometry(cx[u], cy[u], cz[u], d2, nx[u], ny[u], nz[u], E, K.half_r, g[u]);
+        }
+    };
+    // ---- sweep 1: the three elections ----
+    for (int t0 = 0; t0 < k; t0 += 128) {
+        shot_kept g[2];
+        geometry128(t0, g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (g[u].bins1 >> 31) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(g[u].rho);
+                atomicMax(&L.keyA[g[u].bins0 & 511u], key);
+                atomicMax(&L.keyB[(g[u].bins0 >> 9) & 511u], key);
+                atomicMax(&L.keyG[(g[u].bins0 >> 18) & 511u], key);
+            }
+    }
+    SF_SHOT_SYNC();
+    // ---- sweep 2: every elected writer claims its slot and adds its value ----
+    auto claim = [&](int table, unsigned slot_) -> bool { // true for exactly one of the neighbours holding the winning key
+        const unsigned bit = 1u << (slot_ & 31u);
+        return (atomicOr(&L.claim[table][slot_ >> 5], bit) & bit) == 0u;
+    };
+    for (int t0 = 0; t0 < k; t0 += 128) {
+        shot_kept g[2];
+        geometry128(t0, g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (g[u].bins1 >> 31) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(g[u].rho);
+                const unsigned iA = g[u].bins0 & 511u, iB = (g[u].bins0 >> 9) & 511u, iG = (g[u].bins0 >> 18) & 511u;
+                const bool up = iA & 2u, odd = iA & 1u; // (bit 1: z > 0, bit 0: outer shell)
+                const unsigned long long own = L.keyA[iA], other_shell = L.keyA[iA ^ 1u], other_half = L.keyA[iA ^ 2u];
+                const bool winB = L.keyB[iB] == key, winG = L.keyG[iG] == key;
+                double vA, v_cd, v_ef, adth;
+                shot_weights(g[u], K, vA, v_cd, v_ef, adth);
+                if (own == key && claim(0, iA)) {
+                    unsafeAtomicAdd(&L.acc[iA], vA);
+                    // S3/S4: the farthest neighbour of the cell over BOTH shells (every rho of the outer shell exceeds every
+                    // rho of the inner one); S6/S7: the farther of the two half-spaces' winners (equal distances: undefined in
+                    // the reference -- unstable argsort, shot.py:218 --, z > 0 here, as in the cached form)
+                    if ((odd || other_shell == 0ull) && v_cd != 0.0) unsafeAtomicAdd(&L.acc[iA ^ 1u], v_cd);
+                    if ((key > other_half || (key == other_half && up)) && v_ef != 0.0) unsafeAtomicAdd(&L.acc[iA ^ 2u], v_ef);
+                }
+                const double adc = fabs(g[u].dc);
+                if (winB && claim(1, iB) && adc != 0.0) unsafeAtomicAdd(&L.acc[iB], adc);
+                if (winG && claim(2, iG) && adth != 0.0) unsafeAtomicAdd(&L.acc[iG], adth);
+            }
+        }
+    }
+    SF_SHOT_SYNC();
+    double vals[6];
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int b = lane + 64 * u;
+        const double v = b < 352 ? L.acc[b] : 0.0;
+        vals[u] = v;
+        ss += v * v;
+    }
+    double nrm, inv_nrm;
+    sf_sqrt_rsqrt(sf_wave_sum(ss), nrm, inv_nrm);
+    const double scale = nrm > 0.0 ? (normalize ? inv_nrm : 1.0) : 0.0; // shot.py:301-305
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int b = lane + 64 * u;
+        if (b < 352) o[b] = vals[u] * scale;
+    }
+}
 
 template <int NCH, bool FUSED>
 __global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *__restrict__ rec,
@@ -1372,7 +1623,7 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
 {
     const int64_t m = nb->m;
     if (!m) return SF_OK;
-    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), block(64 * SF_SHOT_WPB), block_streaming(64);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), block(64 * SF_SHOT_WPB), block_streaming(64 * SF_SHOT_LONG_WPB);
 #define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m
     const double r_ = nb->radius;
     const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2)}; // the reference's own expressions (shot.py:95-117, 235)
@@ -1381,8 +1632,8 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit); } \
     else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit); }
 #define SF_SHOT_STREAM(NAME, SEL, GRID, SELP, NSEL)                                                                   \
-    if (fused) { SF_LAUNCH(ctx, NAME, (k_shot<true, SEL>), dim3(sf_xcd_grid(GRID)), block_streaming, SF_SHOT_ARGS, r_, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); } \
-    else { SF_LAUNCH(ctx, NAME, (k_shot<false, SEL>), dim3(sf_xcd_grid(GRID)), block_streaming, SF_SHOT_ARGS, r_, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); }
+    if (fused) { SF_LAUNCH(ctx, NAME, (k_shot_long<true, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); } \
+    else { SF_LAUNCH(ctx, NAME, (k_shot_long<false, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); }
     if (d.chunks == 1) { SF_SHOT_CASE(1) }
     else if (d.chunks == 2) { SF_SHOT_CASE(2) }
     else if (d.chunks == 3) { SF_SHOT_CASE(3) }
