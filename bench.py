@@ -658,6 +658,9 @@ def main() -> int:
     if args.sustained_seconds > 0 and not args.no_kernel_timers:
         sustained = sustained_window(job, eng, ms_per_step, args.sustained_seconds, args.sustained_steps, barrier, max_over_ranks)
         sustained["vs_timed_steps"] = sustained["ms_per_step_median"] / ms_per_step
+        ck, ck_src = load_stamped("r04_sustained_clock.json", build)
+        sustained["clock_mhz"] = None if ck is None else ck.get("clock_mhz_time_weighted_hot_kernels")
+        sustained["clock_source"] = ck_src if ck is None else ck.get("_source")
         if abs(sustained["vs_timed_steps"] - 1.0) > 0.02:
             value = n_desc / (sustained["ms_per_step_median"] * 1e-3)
             value_source = (f"the sustained window's median step ({sustained['ms_per_step_median']:.4f} ms over {sustained['steps']} steps): "
@@ -691,7 +694,7 @@ def main() -> int:
 
         alg_bytes = alg_bytes_of(dom)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        tj, traffic_src = load_stamped("r03_traffic.json", build)
+        tj, traffic_src = load_stamped("r04_traffic.json", build)
         traffic = None if tj is None else tj.get(dom)
         # ---- every kernel of the step against both HBM ceilings (per STEP: a kernel launched in pieces counts once) ------------
         roof_all = {}
@@ -703,7 +706,7 @@ def main() -> int:
                            "launches_per_step": round(launches_per_step.get(k, 0), 2), "achieved_gbs": round(gbs, 1),
                            "frac_of_8000": round(gbs / HBM_PEAK_GBS, 4), "frac_of_6290": round(gbs / HBM_COPY_GBS, 4),
                            "hbm_bytes_measured": None if tj is None else tj.get(k)}
-        sq, sq_src = load_stamped("r03_k5_sq.json", build)
+        sq, sq_src = load_stamped("r04_k5_sq.json", build)
         if sq is not None and "k5_shot" in roof_all:
             # float64 issue ceiling: a wave's vector instructions occupy its SIMD for SQ_ACTIVE_INST_VALU quad-cycles (x 4
             # cycles); one keypoint = one wave; 256 CUs x 4 SIMDs share the keypoints

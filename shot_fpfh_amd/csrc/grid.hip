@@ -104,9 +104,10 @@ __global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_de
 // written) instead of waiting for sf_cloud_ensure_sorted_normals' own gather
 __global__ void k_gather_sorted(const double *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ perm,
                                 int64_t base, int64_t n, double *__restrict__ xs, double *__restrict__ ys,
-                                double *__restrict__ zs, double *__restrict__ rec)
+                                double *__restrict__ zs, double *__restrict__ rec, unsigned *__restrict__ zero_word)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && zero_word) *zero_word = 0u; // (the long-gap counter of the cell-table kernel that follows: no memset launch)
     if (i >= n) return;
     i += base;
     int64_t o = perm[i];
@@ -603,6 +604,10 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     }
     c->pop_begin = base;
     c->pop_end = base + ns;
+    sf_gap *gaps = nullptr; // (the cell-table kernel's list of long runs of empty cells)
+    unsigned *n_gaps = nullptr;
+    SF_CHECK(tmp.alloc(&gaps, (size_t)(ncell / SF_LONG_GAP + 2)));
+    SF_CHECK(tmp.alloc(&n_gaps, 1));
     if (ns > 0) {
         size_t tmp_bytes = 0;
         SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
@@ -615,18 +620,13 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
                                              ctx->stream));
         }
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,
-                  (const double *)c->nrm_orig, c->perm, base, ns, c->xs, c->ys, c->zs, c->rec);
+                  (const double *)c->nrm_orig, c->perm, base, ns, c->xs, c->ys, c->zs, c->rec, n_gaps);
     }
     // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
     // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
     c->normals_sorted = c->nrm_orig != nullptr;
     {
-        sf_pool_guard gtmp(ctx);
-        sf_gap *gaps = nullptr;
-        unsigned *n_gaps = nullptr;
-        SF_CHECK(gtmp.alloc(&gaps, (size_t)(ncell / SF_LONG_GAP + 2)));
-        SF_CHECK(gtmp.alloc(&n_gaps, 1));
-        SF_HIP(hipMemsetAsync(n_gaps, 0, sizeof(unsigned), ctx->stream));
+        if (ns <= 0) SF_HIP(hipMemsetAsync(n_gaps, 0, sizeof(unsigned), ctx->stream)); // (else zeroed by the gather kernel)
         SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ns + 1, 256)), dim3(256), cid_sorted, cid_base, base, ns,
                   ncell, c->cell_start, gaps, n_gaps);
         SF_LAUNCH(ctx, "k1_cell_start", k_cell_fill_long, dim3(1024), dim3(256), (const sf_gap *)gaps, (const unsigned *)n_gaps,

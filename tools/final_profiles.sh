@@ -2,14 +2,14 @@
 # Round-end evidence on ONE MI355X box (run through gpurun): everything profiles/ quotes for the library that is in place.
 #   tools/final_profiles.sh <tag>      e.g. r03
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
 mkdir -p gpurun_out
 # 1. kernel trace + HBM counters of the bench command -> profiles/<tag>_summary.md, profiles/<tag>_traffic.json (stamped)
 bash tools/profile_gpu.sh ${TAG} --no-match --no-normals > gpurun_out/${TAG}_profile.log 2>&1
 python tools/parse_rocprof.py ${TAG} > /dev/null 2>> gpurun_out/${TAG}_profile.log
-# 2. SQ counters of K5 -> profiles/r03_k5_sq.json (stamped)
+# 2. SQ counters of K5 -> profiles/<tag>_k5_sq.json (stamped)
 bash tools/pmc_k5.sh ${TAG} > gpurun_out/${TAG}_k5.log 2>&1
 # 3. the bench record itself (now quoting 1. and 2.), the emulated ranks of an 8-GPU job, config 4
 python bench.py > profiles/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
@@ -17,5 +17,5 @@ for r in 0 3 7; do python bench.py --gpus 8 --emulate-rank $r --no-strong > prof
 python tools/run_config4.py > profiles/${TAG}_config4.txt 2>&1
 python tools/show_bench.py profiles/${TAG}_bench.json profiles/${TAG}_emulated_rank0_of_8.json profiles/${TAG}_emulated_rank3_of_8.json profiles/${TAG}_emulated_rank7_of_8.json
 tail -12 profiles/${TAG}_config4.txt
-mkdir -p gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* profiles/r03_k5_sq.json profiles/r03_traffic.json gpurun_out/${TAG}_profiles/ 2>/dev/null
+mkdir -p gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* gpurun_out/${TAG}_profiles/ 2>/dev/null
 tail -3 gpurun_out/${TAG}_k5.log

@@ -123,7 +123,7 @@ def main() -> int:
             tot.update(c)
             rows.append(f"| {pid}: {PHASES.get(pid, '?')} | " + " | ".join(str(c[k]) for k in cls) + " |")
         rows.append("| **total of the body** | " + " | ".join(f"**{tot[k]}**" for k in cls) + " |\n")
-    rows.append("(The counters of `profiles/r03_k5_sq.json` -- 783 VALU, 350 SALU, 40 LDS instructions per keypoint at C3 -- are the 0.92 / 0.08 "
+    rows.append("(The counters of `profiles/r04_k5_sq.json` -- 783 VALU, 350 SALU, 40 LDS instructions per keypoint at C3 -- are the 0.92 / 0.08 "
                 "mix of the two bodies as EXECUTED: the wave-uniform fallbacks inside `geometry` and `sqrt` are in the static counts above and "
                 "not in the executed ones.)\n")
     open(a.out, "w").write("\n".join(rows) + "\n")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_k5.sh's counters of the fused SHOT kernel -> profiles/r03_k5_sq.json, stamped with sf_version() of the library
+"""tools/pmc_k5.sh's counters of the fused SHOT kernel -> profiles/<tag>_k5_sq.json, stamped with sf_version() of the library
 they were measured on (bench.py quotes the file only for that very build).
 
 Per wave (= per keypoint: one wave each): SQ_INSTS_VALU (vector instructions issued), SQ_ACTIVE_INST_VALU (quad-cycles the
@@ -46,7 +46,7 @@ def main():
 
     rec = {
         "_build": _ffi.load().sf_version().decode(),
-        "_source": f"profiles/r03_k5_sq.json: rocprofv3 --pmc passes of tools/pmc_k5.sh {tag} (k_shot_cached, {n} dispatches under "
+        "_source": f"profiles/{tag}_k5_sq.json: rocprofv3 --pmc passes of tools/pmc_k5.sh {tag} (k_shot_cached, {n} dispatches under "
                    "the profiler)",
         "waves_per_launch": waves,
         "SQ_INSTS_VALU_per_wave": round(avg["SQ_INSTS_VALU"] / waves, 1),
@@ -57,7 +57,7 @@ def main():
         "clock_mhz": round(clock, 0) if clock else 2400.0,
         "clock_source": "GRBM_GUI_ACTIVE / dispatch duration" if clock else "assumed (MI355X peak engine clock)",
     }
-    json.dump(rec, open(os.path.join(ROOT, "profiles", "r03_k5_sq.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(ROOT, "profiles", f"{tag}_k5_sq.json"), "w"), indent=1)
     print(json.dumps(rec))
 
 

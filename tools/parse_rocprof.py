@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile_gpu.sh run (rocprofv3 CSVs under gpurun_out/prof_<tag>/) into
-profiles/<tag>_summary.md and profiles/r03_traffic.json (HBM bytes per launch of each hot kernel, stamped with the
-library's build id so that bench.py never quotes it for another build).
+profiles/<tag>_summary.md, profiles/<tag>_traffic.json (HBM bytes per launch of each hot kernel) and
+profiles/<tag>_sustained_clock.json (shader clock per kernel: GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration), both stamped
+with the library's build id so that bench.py never quotes them for another build.
 
 HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are collected in SEPARATE --pmc passes, are reported in KiB, and on gfx950 FETCH_SIZE counts
@@ -33,7 +34,20 @@ SHORT = [
 ]
 
 
+# round 4: second launches and selections (checked before the table above; template arguments as rocprofv3 prints them)
+SHORT_RE = [
+    (r"radix_sort", "rocprim_radix_sort"), (r"k_radius<2, ", "k2_radius_slots"), (r"k_radius<1, true>", "k2_radius_refill"), (r"k_radius<1, false>", "k2_radius_fill"),
+    (r"k_radius<0, true>", "k2_sample"), (r"k_radius<0, false>", "k2_radius_count"), (r"k_iota_stride", "k2_sample"),
+    (r"k_patch_offsets", "k2_select"), (r"select|partition", "rocprim_select"), (r"k_shot_long", "k5_shot_tail"),
+    (r"k_fpfh_tail", "k7_fpfh_tail"), (r"k_spfh<[^>]*, true>", "k6_spfh_tail"), (r"k_pca_cov<0, true>", "k3_normals_tail"),
+    (r"k_cell_fill_long", "k1_cell_start"),
+]
+
+
 def short(name):
+    for pat, s in SHORT_RE:
+        if re.search(pat, name):
+            return s
     for pat, s in SHORT:
         if pat in name:
             return s
@@ -52,7 +66,8 @@ def read_counter(path, counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    cmd = sys.argv[2] if len(sys.argv) > 2 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dropin --no-parity"
+    cmd = sys.argv[2] if len(sys.argv) > 2 else ("python3 bench.py --no-cpu-baseline --no-dropin --no-parity --no-density --no-defaults "
+                                                 "--no-match --no-normals (20 timed steps + the >= 2 s sustained window)")
     bench_run = len(sys.argv) <= 2  # only the bench profile feeds bench.py's roofline.traffic
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     stats = defaultdict(lambda: [0, 0.0])
@@ -94,7 +109,28 @@ def main():
 
         traffic["_build"] = _ffi.load().sf_version().decode()
         traffic["_source"] = f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{cmd}`)"
-        json.dump(traffic, open(os.path.join(ROOT, "profiles", "r03_traffic.json"), "w"), indent=1)
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
+        # shader clock during every kernel of the run (the sustained window included): GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        cpath = os.path.join(base, "pmc_clock", "pmc_counter_collection.csv")
+        if os.path.exists(cpath):
+            per = defaultdict(lambda: [0.0, 0.0, 0])  # kernel -> [cycles, ns, dispatches]
+            for row in csv.DictReader(open(cpath)):
+                if row["Counter_Name"] != "GRBM_GUI_ACTIVE":
+                    continue
+                d = per[short(row["Kernel_Name"])]
+                d[0] += float(row["Counter_Value"])
+                d[1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                d[2] += 1
+            clk = {k: {"clock_mhz": round(v[0] / 8.0 / v[1] * 1e3, 1), "dispatches": v[2], "avg_us": round(v[1] / v[2] / 1e3, 1)}
+                   for k, v in per.items() if v[1] > 0 and k.startswith("k")}
+            hot = [k for k in ("k5_shot", "k6_spfh", "k7_fpfh", "k2_radius_slots") if k in per]
+            tot_c, tot_t = sum(per[k][0] for k in hot), sum(per[k][1] for k in hot)
+            rec = {"_build": traffic["_build"],
+                   "_source": f"profiles/{tag}_sustained_clock.json: rocprofv3 --pmc GRBM_GUI_ACTIVE pass of `{cmd}` (the run that contains "
+                              "the sustained window; under counter collection the dispatches are serialised)",
+                   "clock_mhz_time_weighted_hot_kernels": round(tot_c / 8.0 / tot_t * 1e3, 1) if tot_t else None,
+                   "kernels": clk}
+            json.dump(rec, open(os.path.join(ROOT, "profiles", f"{tag}_sustained_clock.json"), "w"), indent=1)
     print("\n".join(lines))
 
 

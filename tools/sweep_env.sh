@@ -2,7 +2,7 @@
 # usage: tools/sweep_env.sh VAR v1 v2 ... -- runs the descriptor bench once per value and prints the kernel times
 var=$1; shift
 for x in "$@"; do
-  env $var=$x python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-match --no-dropin --no-parity 2>/dev/null > /tmp/sweep_$x.json
+  env $var=$x python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-match --no-dropin --no-parity --sustained-seconds 0 --no-density --no-defaults 2>/dev/null > /tmp/sweep_$x.json
   python - "$x" /tmp/sweep_$x.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[2]).read()); k=d["kernels_ms_per_step"]
