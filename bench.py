@@ -946,11 +946,9 @@ def main() -> int:
         nout = eng.empty((n_total, 3))
         reps = 5
 
-        def normals_pass():
+        def normals_pass():  # K1 + the fused sweep (no neighbour lists) + the eigen-solves
             ncloud.build_grid(radius)
-            nb = ncloud.radius_search_self(radius)
-            nb.normals(out=nout)
-            nb.free()
+            ncloud.normals_radius_self(radius, nout)
 
         normals_pass()
         eng.sync()
@@ -963,7 +961,7 @@ def main() -> int:
         t_n = (time.perf_counter() - t0) / reps
         eng.profile(False)
         nrep = {k: v[1] / reps for k, v in eng.profile_report().items() if v[1] > 0}
-        k3 = nrep.get("k3_normals", 0.0)
+        k3 = nrep.get("k3_normals", 0.0) + nrep.get("k23_radius_cov", 0.0)
         # parity of the resident result: a sample against the oracle, up to the sign LAPACK leaves open
         from oracle import oracle as O
 
@@ -984,15 +982,16 @@ def main() -> int:
             ts.append(time.perf_counter() - t0)
         out["normals"] = {
             "what": f"compute_normals(query_points = cloud_points = the {n_total}-point cloud, radius={radius}) "
-                    "(pca_based_descriptors.py:29-59): K1 + K2 + K3, result resident / host to host",
+                    "(pca_based_descriptors.py:29-59): K1 + one fused K2/K3 sweep (hits reduced to the covariance in LDS, no lists) + "
+                    "eigen-solves, result resident / host to host",
             "resident_ms_per_pass": 1000.0 * t_n, "normals_per_s_resident": n_total / t_n,
             "kernels_ms_per_pass": {k: round(v, 4) for k, v in sorted(nrep.items())},
             "k3_roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": ALG_BYTES["k3_normals"] * n_total, "avg_launch_ms": k3,
                             "achieved_gbs": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 if k3 > 0 else None,
                             "frac_of_8000": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS if k3 > 0 else None,
                             "frac_of_6290": ALG_BYTES["k3_normals"] * n_total / (k3 * 1e-3) / 1e9 / HBM_COPY_GBS if k3 > 0 else None,
-                            "note": "48 B per query are compulsory; the kernels gather ~110 neighbours x 24 B per query through L2 and "
-                                    "solve a 3x3 eigenproblem per query: gather / latency bound (DESIGN kernel table)"},
+                            "note": "48 B per query are compulsory; the fused sweep tests ~3 candidates per neighbour (K2's own work) and "
+                                    "solves a 3x3 eigenproblem per query: VALU-issue bound like K2 (DESIGN K3)"},
             "host_to_host_s": min(ts), "normals_per_s_host_to_host": n_total / min(ts),
             "parity_max_abs_err_up_to_sign": nerr, "parity_rows": int(pick.size), "parity_ok": bool(nerr <= 1e-5),
         }

@@ -150,6 +150,13 @@ void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nbrs);
 /* ---- PCA normals: compute_normals radius branch (pca_based_descriptors.py:15-59), K3 ----
  * `nbrs` = lists of the query points. pre (m x 3, nullable) = pre_computed_normals. Without it the
  * sign is the one LAPACK dsyevd returns for the lower-triangle covariance (emulated on device). */
+/* compute_normals(query_points, cloud_points, radius=...) -- pca_based_descriptors.py:29-59, the radius branch (:48) -- in ONE
+ * sweep: the neighbour lists are never materialised (the hits of the candidate sweep are reduced to the covariance in LDS).
+ * queries == NULL: the cloud's own points at cell-sorted positions [begin, end) (row i of `out` = position begin + i; m is
+ * ignored); else m coordinate queries, rows in the caller's order.  `pre` (nullable): pre_computed_normals, m x 3.
+ * Bit-identical to sf_radius_search(_self) followed by sf_normals. */
+int sf_normals_radius(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, int64_t begin, int64_t end, double radius,
+                      const double *pre, double *out /* m x 3 */, int flags);
 int sf_normals(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, const double *pre, double *out /* m x 3 */,
                int flags);
 /* Local PCA of every query's neighbourhood, same kernel (K3) with the full decomposition as output: replaces

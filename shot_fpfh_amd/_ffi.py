@@ -64,6 +64,7 @@ SIGNATURES = {
     "sf_nbrs_export": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sf_nbrs_free": (None, [_vp, _vp]),
     "sf_normals": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
+    "sf_normals_radius": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp, _vp, _int]),
     "sf_pca": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "sf_shot_lrf": (_int, [_vp, _vp, _vp, _vp, _int]),
     "sf_shot": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _int]),

@@ -478,16 +478,10 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
 // S7 -> elevation bin 0].  Sweep 1 elects winners with 64-bit LDS atomicMax on the bit pattern of rho
 // (positive doubles order like unsigned integers); sweep 2 lets each winner overwrite its slot with its
 // value, tagged by the sign bit (all values are >= 0) so that later lanes cannot mistake it for a key.
-// One wave per keypoint; this streaming form keeps all five tables in LDS (14 KB per wave) and serves lists of
-// any length -- the register-cached form below (5.5 KB, two phases) takes every list of at most 256 points.
+// One wave per keypoint: the register-cached form (k_shot_cached, 5.5 KB of LDS, two phases) takes every list of at most
+// 255 points, the streamed form (k_shot_long) the longer ones.
 // --------------------------------------------------------------------------------------------------
 #define SHOT_PI 3.141592653589793
-
-struct shot_sample {
-    double rho;
-    int base, bcos, bth, cd, ef;
-    double vA, vB, vG, vC, vD, vE, vF;
-};
 
 __device__ inline int azimuth_octant(double x, double y) // get_azimuth_idx, shot.py:51-70
 {
@@ -515,235 +509,17 @@ __global__ void k_azimuth_idx(const double *__restrict__ x, const double *__rest
     if (i < n) out[i] = azimuth_octant(x[i], y[i]);
 }
 
-template <bool VALUES>
-__device__ inline void shot_eval(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
-                                 const double *E /* row-major, columns x y z */, double radius, shot_sample &o)
-{
-    const double rho = sqrt(d2);
-    o.rho = rho;
-    const double lx = (cx * E[0] + cy * E[3]) + cz * E[6]; // (neighbors - point) @ eigenvectors  :214
-    const double ly = (cx * E[1] + cy * E[4]) + cz * E[7];
-    const double lz = (cx * E[2] + cy * E[5]) + cz * E[8];
-    double cosine = (nx * E[2] + ny * E[5]) + nz * E[8]; // normals @ eigenvectors[:, 2]  :215
-    cosine = fmin(fmax(cosine, -1.0), 1.0);
-    const double cpos = (cosine + 1.0) * 11.0 / 2.0 - 0.5; // :228
-    const double cf = rint(cpos);                          // np.rint, half to even  :229
-    const int ci = (int)cf;
-    const int ti = azimuth_octant(lx, ly);                 // :230-232
-    const int pi_ = lz > 0.0 ? 1 : 0;                      // :234
-    const int ri = rho > radius / 2 ? 1 : 0;               // :235
-    const double dc = cpos - cf;
-    const double sc = (double)((dc > 0.0) - (dc < 0.0));
-    int cin = (int)(cf + sc) % 11;
-    if (cin < 0) cin += 11;
-    const double theta = atan2(ly, lx); // :224
-    const double tsz = 2 * SHOT_PI / 8;
-    double dth = (theta - (-SHOT_PI + ti * tsz)) / tsz - 0.5; // :283-287
-    dth = fmin(fmax(dth, -0.5), 0.5);
-    const double sth = (double)((dth > 0.0) - (dth < 0.0));
-    int tin = (int)((double)ti + sth) % 8;
-    if (tin < 0) tin += 8;
-    o.cd = (ci * 8 + ti) * 2 + pi_;
-    o.ef = (ci * 8 + ti) * 2 + ri;
-    o.base = o.cd * 2 + ri;
-    o.bcos = ((cin * 8 + ti) * 2 + pi_) * 2 + ri;
-    o.bth = ((ci * 8 + tin) * 2 + pi_) * 2 + ri;
-    if (VALUES) {
-        const double adc = sc * dc, adth = sth * dth;
-        const double half_r = radius / 2, q1 = radius / 4, q3 = radius * 3 / 4;
-        // interpolate_on_adjacent_husks, shot.py:73-118
-        const double inner = (double)((rho > half_r) && (rho < q3)) * (q3 - rho) / half_r;
-        const double outer = (double)((rho < half_r) && (rho > q1)) * (rho - q1) / half_r;
-        const double cur = (double)(rho < half_r) * (1 - fabs(rho - q1) / half_r) +
-                           (double)(rho > half_r) * (1 - fabs(rho - q3) / half_r);
-        // interpolate_vertical_volumes, shot.py:121-171
-        double lzr = lz / rho;
-        lzr = fmin(fmax(lzr, -1.0), 1.0);
-        const double phi = acos(lzr); // :225
-        const double hpi = SHOT_PI / 2, pi34 = SHOT_PI * 3 / 4, pi4 = SHOT_PI / 4;
-        const double upper =
-            (double)(((phi > hpi) || ((fabs(phi - hpi) < 1e-10) && (lz <= 0.0))) && (phi <= pi34)) * (pi34 - phi) / hpi;
-        const double lower =
-            (double)(((phi < hpi) && ((fabs(phi - hpi) >= 1e-10) || (lz > 0.0))) && (phi >= pi4)) * (phi - pi4) / hpi;
-        const double curv = (double)(phi < hpi) * (1 - fabs(phi - pi4) / hpi) +
-                            (double)(phi >= hpi) * (1 - fabs(phi - pi34) / hpi);
-        o.vB = adc * (double)((cf > -0.5) && (cf < 11 - 0.5)); // S1  :249-251
-        o.vA = (((1 - adc) + cur) + curv) + (1 - adth);         // S2 + S5 + S8 + S10
-        o.vC = outer * (double)(ri == 0);                       // S3  :258-260
-        o.vD = inner * (double)(ri == 1);                       // S4  :261-263
-        o.vE = upper * (double)(pi_ == 0);                      // S6  :270-272
-        o.vF = lower * (double)(pi_ == 1);                      // S7  :273-275
-        o.vG = adth;                                            // S9  :289-295
-    }
-}
-
 // A resolved slot holds the NEGATED value (values are >= 0, so the sign bit marks it); an unresolved key is
 // the bit pattern of rho > 0 and an empty slot is +0.  Decoding is therefore max(-x, 0): one instruction.
 __device__ inline unsigned long long tag_value(double v)
 {
     return (unsigned long long)__double_as_longlong(v) | 0x8000000000000000ull;
 }
-__device__ inline double untag_value(unsigned long long s)
-{
-    return fmax(-__longlong_as_double((long long)s), 0.0);
-}
 
 __device__ inline double sf_dot3(double a0, double a1, double a2, double b0, double b1, double b2)
 {
     return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
 }
-
-// FUSED: `lrf` holds the raw axes (k_shot_lrf raw mode / k_lrf_from_cov); the sign votes (shot.py:40-45) are taken in the
-// gate sweep and the finished frame is written back, as the register-cached form does.  SEL: the launch serves the
-// processing slots listed in `sel` (the owner's numbering; a view keeps those of its own range) -- the keypoints whose lists
-// are too long for the register-cached form of the main launch.
-template <bool FUSED, bool SEL>
-__global__ __launch_bounds__(64) void k_shot(const double *__restrict__ rec,
-                                             const double *__restrict__ qx, const double *__restrict__ qy,
-                                             const double *__restrict__ qz, const int64_t *__restrict__ offset,
-                                             const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-                                             const int32_t *__restrict__ qrow,
-                                             int64_t m, double radius, double *__restrict__ lrf, int normalize,
-                                             int64_t min_nb, double *__restrict__ out, const int32_t *__restrict__ sel,
-                                             int64_t nsel, int64_t view_first)
-{
-    __shared__ unsigned long long sA[352], sB[352], sG[352], sCD[176], sEF[176];
-    __shared__ double sD[176], sF[176];
-    const int lane = threadIdx.x;
-    int64_t q = sf_xcd_block();
-    if (SEL) {
-        if (q >= nsel) return;
-        q = (int64_t)sel[q] - view_first;
-        if (q < 0) return;
-    }
-    if (q >= m) return;
-    const int64_t s = offset[q];
-    const int k = cnt[q];
-    const int64_t row = qrow ? qrow[q] : q;
-    double *o = out + (int64_t)SF_SHOT_LEN * row;
-    const double px = qx[q], py = qy[q], pz = qz[q];
-    double rx0 = 0, rx1 = 0, rx2 = 0, rz0 = 0, rz1 = 0, rz2 = 0;
-    if (FUSED) {
-        const double *lr = lrf + 9 * row;
-        rx0 = lr[0]; rx1 = lr[1]; rx2 = lr[2]; rz0 = lr[3]; rz1 = lr[4]; rz2 = lr[5];
-    }
-
-    // gate: strictly more than min_nb neighbours at non-zero distance (shot.py:212, 306)
-    int npos = 0, xneg = 0, zneg = 0;
-    for (int t0 = 0; t0 < k; t0 += 64) {
-        const int t = t0 + lane;
-        bool pos = false, xn = false, zn = false;
-        if (t < k) {
-            double x, y, z;
-            sf_load_xyz(rec, idx[s + t], x, y, z);
-            const double cx = x - px, cy = y - py, cz = z - pz;
-            pos = ((cx * cx + cy * cy) + cz * cz) > 0.0;
-            if (FUSED) {
-                xn = sf_dot3(cx, cy, cz, rx0, rx1, rx2) < 0.0;
-                zn = sf_dot3(cx, cy, cz, rz0, rz1, rz2) < 0.0;
-            }
-        }
-        npos += __popcll(__ballot(pos));
-        if (FUSED) {
-            xneg += __popcll(__ballot(xn));
-            zneg += __popcll(__ballot(zn));
-        }
-    }
-    double E[9];
-    if (FUSED) { // (the frame is written whether or not the descriptor passes the gate, as in the cached form)
-        if (xneg > k - xneg) { rx0 = -rx0; rx1 = -rx1; rx2 = -rx2; }
-        if (zneg > k - zneg) { rz0 = -rz0; rz1 = -rz1; rz2 = -rz2; }
-        const double y0 = rz1 * rx2 - rz2 * rx1, y1 = rz2 * rx0 - rz0 * rx2, y2 = rz0 * rx1 - rz1 * rx0; // cross(z, x)
-        if (k == 0) { // shot.py:24-25
-            E[0] = 1.0; E[1] = 0.0; E[2] = 0.0; E[3] = 0.0; E[4] = 1.0; E[5] = 0.0; E[6] = 0.0; E[7] = 0.0; E[8] = 1.0;
-        } else {
-            E[0] = rx0; E[1] = y0; E[2] = rz0;
-            E[3] = rx1; E[4] = y1; E[5] = rz1;
-            E[6] = rx2; E[7] = y2; E[8] = rz2;
-        }
-        if (lane < 9) {
-            double v = E[0];
-#pragma unroll
-            for (int i = 1; i < 9; ++i) v = lane == i ? E[i] : v;
-            lrf[9 * row + lane] = v;
-        }
-    }
-    if (!((int64_t)npos > min_nb)) {
-        for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
-        return;
-    }
-    if (!FUSED) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
-    }
-
-    for (int b = lane; b < 352; b += 64) { sA[b] = 0; sB[b] = 0; sG[b] = 0; }
-    for (int b = lane; b < 176; b += 64) { sCD[b] = 0; sEF[b] = 0; sD[b] = 0.0; sF[b] = 0.0; }
-    __syncthreads();
-
-    // sweep 1: elect the max-rho writer of every (key, bin)
-    for (int t = lane; t < k; t += 64) {
-        double x, y, z, nx_, ny_, nz_;
-        sf_load_pn(rec, idx[s + t], x, y, z, nx_, ny_, nz_);
-        const double cx = x - px, cy = y - py, cz = z - pz;
-        const double d2 = (cx * cx + cy * cy) + cz * cz;
-        if (d2 > 0.0) {
-            shot_sample sm;
-            shot_eval<false>(cx, cy, cz, d2, nx_, ny_, nz_, E, radius, sm);
-            const unsigned long long key = (unsigned long long)__double_as_longlong(sm.rho);
-            atomicMax(&sA[sm.base], key);
-            atomicMax(&sB[sm.bcos], key);
-            atomicMax(&sG[sm.bth], key);
-            atomicMax(&sCD[sm.cd], key);
-            atomicMax(&sEF[sm.ef], key);
-        }
-    }
-    __syncthreads();
-    // sweep 2: winners replace their key by their (tagged) value
-    for (int t = lane; t < k; t += 64) {
-        double x, y, z, nx_, ny_, nz_;
-        sf_load_pn(rec, idx[s + t], x, y, z, nx_, ny_, nz_);
-        const double cx = x - px, cy = y - py, cz = z - pz;
-        const double d2 = (cx * cx + cy * cy) + cz * cz;
-        if (d2 > 0.0) {
-            shot_sample sm;
-            shot_eval<true>(cx, cy, cz, d2, nx_, ny_, nz_, E, radius, sm);
-            const unsigned long long key = (unsigned long long)__double_as_longlong(sm.rho);
-            if (sA[sm.base] == key) sA[sm.base] = tag_value(sm.vA);
-            if (sB[sm.bcos] == key) sB[sm.bcos] = tag_value(sm.vB);
-            if (sG[sm.bth] == key) sG[sm.bth] = tag_value(sm.vG);
-            if (sCD[sm.cd] == key) { sCD[sm.cd] = tag_value(sm.vC); sD[sm.cd] = sm.vD; }
-            if (sEF[sm.ef] == key) { sEF[sm.ef] = tag_value(sm.vE); sF[sm.ef] = sm.vF; }
-        }
-    }
-    __syncthreads();
-    // assemble the 352 bins (C order: cosine slowest, radial fastest) and normalise (shot.py:301-305)
-    double vals[6];
-    double ss = 0.0;
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int b = lane + 64 * u;
-        double v = 0.0;
-        if (b < 352) {
-            const int cdi = b >> 1, efi = ((b >> 2) << 1) | (b & 1);
-            const int rb = b & 1, pb = (b >> 1) & 1;
-            v = untag_value(sB[b]);
-            v += untag_value(sA[b]);
-            v += rb ? untag_value(sCD[cdi]) : sD[cdi];
-            v += pb ? untag_value(sEF[efi]) : sF[efi];
-            v += untag_value(sG[b]);
-        }
-        vals[u] = v;
-        ss += v * v;
-    }
-    const double nrm = sqrt(sf_wave_sum(ss));
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int b = lane + 64 * u;
-        if (b < 352) o[b] = nrm > 0.0 ? (normalize ? vals[u] / nrm : vals[u]) : 0.0;
-    }
-}
-
 
 // --------------------------------------------------------------------------------------------------
 // K5, register-cached form for neighbourhoods of at most 64*NCH points (the common case; the streaming
@@ -1530,6 +1306,15 @@ static int launch_pca_cov(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *cov, do
     else { SF_K3_COV("k3_normals", 0, false, grid); }
     if (d.n_tail) { SF_K3_COV("k3_normals_tail", 0, true, dim3(sf_xcd_grid(sf_div_up(d.n_tail, 2)))); }
 #undef SF_K3_COV
+    return SF_OK;
+}
+
+// (for search.hip::sf_normals_radius: the eigen-solves of the fused K2 + K3 sweep)
+int sf_launch_pca_solve_normals(sf_ctx *ctx, const double *cov, const int32_t *qrow, int64_t m, const double *pre, double *out)
+{
+    if (!m) return SF_OK;
+    SF_LAUNCH(ctx, "k3_normals", k_pca_solve<0>, dim3((unsigned)sf_div_up(m, 64)), dim3(64), cov, qrow, m, pre, out, (double *)nullptr,
+              (double *)nullptr);
     return SF_OK;
 }
 

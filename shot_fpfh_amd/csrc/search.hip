@@ -227,6 +227,189 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// K2 + K3 in one sweep: compute_normals(radius=...) needs the covariance of every neighbourhood, not the neighbourhood --
+// the candidate sweep of k_radius keeps the hits' offsets from the query in LDS (in the very order k_radius would have
+// written their indices), and the barycentre / centred second moments are formed from there exactly as k_pca_cov forms them
+// from the materialised list (same terms, same lane assignment t -> lane t % 64, same reductions): the six numbers per query
+// are bit-identical to sf_radius_search + sf_normals, and neither the 4 B per pair of the lists nor the 24 B per pair of
+// their gather ever touch HBM.  Lists of at most 256 points sit in LDS whole (6 KB per wave); a longer one (wave-uniform,
+// per query) is swept twice more through the same LDS as a ring -- whenever 64 consecutive list positions are complete the
+// lanes consume them -- once for the barycentre, once for the moments: the streaming form of k_pca_cov, again bit for bit.
+// Set-up and sweep are k_radius's (four queries per wave, run tables per 16-lane row, candidate pairs).
+// --------------------------------------------------------------------------------------------------
+#ifndef SF_K2C_WPB
+#define SF_K2C_WPB 4
+#endif
+struct sf_cov_list { double x[256], y[256], z[256]; };
+
+__global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, const int32_t *__restrict__ cell_start,
+                                                const double *__restrict__ xs, const double *__restrict__ ys,
+                                                const double *__restrict__ zs, const double *__restrict__ qx,
+                                                const double *__restrict__ qy, const double *__restrict__ qz,
+                                                int64_t m, double r2, double *__restrict__ cov, double *__restrict__ bary,
+                                                int32_t *__restrict__ count)
+{
+    const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
+    const int64_t q0 = sf_uniform64((sf_xcd_block() * SF_K2C_WPB + (threadIdx.x >> 6)) * 4);
+    if (q0 >= m) return;
+    const int nq = (int)(m - q0 < 4 ? m - q0 : 4);
+    const int64_t qm = q0 + (rw < nq ? rw : 0);
+    const double pxv = qx[qm], pyv = qy[qm], pzv = qz[qm]; // this row's query
+    int y0, y1, z0, z1;
+    stencil_bounds(pyv, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
+    stencil_bounds(pzv, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
+    __shared__ int4 runs[SF_K2C_WPB][4][12];
+    __shared__ sf_cov_list lists[SF_K2C_WPB];
+    int4(*const tabs)[12] = runs[threadIdx.x >> 6];
+    sf_cov_list &L = lists[threadIdx.x >> 6];
+    int first_slot = 0;
+    { // (the run tables: see k_radius)
+        const int r = sl < 9 ? sl : 8;
+        const int cz = z0 + r / 3, cy = y0 + r % 3;
+        bool ok = sl < 9 && rw < nq && cz <= z1 && cy <= y1;
+        const int64_t row = ((int64_t)(ok ? cz : z0) * g.dim[1] + (ok ? cy : y0)) * g.dim[0];
+        const double pxr = pxv - g.lo[0], pyr = pyv - g.lo[1], pzr = pzv - g.lo[2];
+        const double by0 = (double)cy * g.cell, bz0 = (double)cz * g.cell;
+        const double slack_y = 1e-9 * g.cell + 1e-15 * (fabs(pyr) + by0 + g.cell);
+        const double slack_z = 1e-9 * g.cell + 1e-15 * (fabs(pzr) + bz0 + g.cell);
+        const double dy = fmax(fmax(by0 - pyr, pyr - (by0 + g.cell)) - slack_y, 0.0);
+        const double dz = fmax(fmax(bz0 - pzr, pzr - (bz0 + g.cell)) - slack_z, 0.0);
+        const double w2 = (r2 * (1.0 + 1e-9) - dy * dy) - dz * dz;
+        ok = ok && w2 >= 0.0;
+        const double w = sf_sqrt_fast(fmax(w2, 0.0)) * (1.0 + 1e-9) + 1e-9 * g.cell +
+                         1e-15 * (fabs(pxr) + (double)g.dim[0] * (g.cell / (double)g.xsub));
+        int s = 0, e = 0;
+        if (sl < 9) {
+            s = cell_start[row + sf_cell_coord(pxr - w, 0.0, g.inv_cell_x, g.dim[0])];
+            e = cell_start[row + sf_cell_coord(pxr + w, 0.0, g.inv_cell_x, g.dim[0]) + 1];
+        }
+        if (!ok) { s = 0; e = 0; }
+        const int base = s & ~1;
+        const int npairs = (e - base + 1) >> 1;
+        int inc = npairs;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);
+        first_slot = inc - npairs;
+        if (sl < 12) tabs[rw][sl] = make_int4(base - 2 * first_slot, s, e, first_slot);
+    }
+    __builtin_amdgcn_wave_barrier();
+#define SF_K2C_LDS_SYNC()                                                                                            \
+    do {                                                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                      \
+    } while (0)
+    for (int qi = 0; qi < nq; ++qi) {
+        const int64_t q = q0 + qi;
+        const int4 *const tab = tabs[qi];
+        const double px = __shfl(pxv, 16 * qi), py = __shfl(pyv, 16 * qi), pz = __shfl(pzv, 16 * qi);
+        const int b4 = __shfl(first_slot, 16 * qi + 4), b8 = __shfl(first_slot, 16 * qi + 8);
+        const int nslots = sf_uniform(__shfl(first_slot, 16 * qi + 9));
+        // one sweep over the candidates; hits land in L at (list position & 255) when that position is below `keep`;
+        // after_step(total so far) runs once per 128 candidates
+        auto sweep = [&](int keep, auto &&after_step) -> int {
+            int total = 0;
+            for (int f0 = 0; f0 < nslots; f0 += 64) {
+                const int f = f0 + lane;
+                int r = f >= b4 ? 4 : 0;
+                r += f >= tab[r + 2].w ? 2 : 0;
+                r += f >= tab[r + 1].w ? 1 : 0;
+                r = f >= b8 ? 8 : r;
+                const int4 t = tab[r];
+                const bool live = f < nslots;
+                const int j = live ? t.x + 2 * f : 0;
+                const bool in0 = live & (j >= t.y), in1 = live & (j + 1 < t.z);
+                const double2 X = *reinterpret_cast<const double2 *>(xs + j);
+                const double2 Y = *reinterpret_cast<const double2 *>(ys + j);
+                const double2 Z = *reinterpret_cast<const double2 *>(zs + j);
+                const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
+                const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
+                const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
+                const bool hit0 = in0 & (d2a <= r2);
+                const bool hit1 = in1 & (d2b <= r2);
+                const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+                const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
+                if (hit0 && pos < keep) { L.x[pos & 255] = dxa; L.y[pos & 255] = dya; L.z[pos & 255] = dza; }
+                const int pos1 = pos + (hit0 ? 1 : 0);
+                if (hit1 && pos1 < keep) { L.x[pos1 & 255] = dxb; L.y[pos1 & 255] = dyb; L.z[pos1 & 255] = dzb; }
+                total += __popcll(m0) + __popcll(m1);
+                after_step(total);
+            }
+            return total;
+        };
+        SF_K2C_LDS_SYNC(); // (the previous query's reads of L are done)
+        const int k = sweep(256, [](int) {});
+        SF_K2C_LDS_SYNC();
+        const double kk = (double)k;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double mx, my, mz;
+        if (k <= 256) {
+            for (int t = lane; t < k; t += 64) { sx += L.x[t]; sy += L.y[t]; sz += L.z[t]; }
+            mx = sf_wave_sum(sx) / kk; my = sf_wave_sum(sy) / kk; mz = sf_wave_sum(sz) / kk;
+            for (int t = lane; t < k; t += 64) {
+                const double ax = L.x[t] - mx, ay = L.y[t] - my, az = L.z[t] - mz;
+                part[0] += ax * ax;
+                part[1] += ay * ax;
+                part[2] += az * ax;
+                part[3] += ay * ay;
+                part[4] += az * ay;
+                part[5] += az * az;
+            }
+        } else { // (a long list: two more sweeps, the hits consumed 64 list positions at a time)
+            int done = 0;
+            auto bary_step = [&](int total) {
+                if (done + 64 <= total) {
+                    SF_K2C_LDS_SYNC();
+                    while (done + 64 <= total) {
+                        const int t = (done + lane) & 255;
+                        sx += L.x[t]; sy += L.y[t]; sz += L.z[t];
+                        done += 64;
+                    }
+                    SF_K2C_LDS_SYNC();
+                }
+            };
+            sweep(0x7fffffff, bary_step);
+            SF_K2C_LDS_SYNC();
+            if (done + lane < k) { const int t = (done + lane) & 255; sx += L.x[t]; sy += L.y[t]; sz += L.z[t]; }
+            mx = sf_wave_sum(sx) / kk; my = sf_wave_sum(sy) / kk; mz = sf_wave_sum(sz) / kk;
+            auto add_moments = [&](int t) {
+                const double ax = L.x[t] - mx, ay = L.y[t] - my, az = L.z[t] - mz;
+                part[0] += ax * ax;
+                part[1] += ay * ax;
+                part[2] += az * ax;
+                part[3] += ay * ay;
+                part[4] += az * ay;
+                part[5] += az * az;
+            };
+            done = 0;
+            auto mom_step = [&](int total) {
+                if (done + 64 <= total) {
+                    SF_K2C_LDS_SYNC();
+                    while (done + 64 <= total) {
+                        add_moments((done + lane) & 255);
+                        done += 64;
+                    }
+                    SF_K2C_LDS_SYNC();
+                }
+            };
+            SF_K2C_LDS_SYNC();
+            sweep(0x7fffffff, mom_step);
+            SF_K2C_LDS_SYNC();
+            if (done + lane < k) add_moments((done + lane) & 255);
+        }
+        const double tot = sf_wave_sum8(part); // lanes 8 i .. 8 i + 7 hold the sum of part[i]
+        const int e = lane >> 3;
+        if ((lane & 7) == 0 && e < 6) cov[6 * q + e] = tot / kk; // c11 c21 c31 c22 c32 c33
+        if (bary && lane == 0) { bary[3 * q] = mx; bary[3 * q + 1] = my; bary[3 * q + 2] = mz; }
+        if (count && lane == 0) count[q] = k;
+    }
+#undef SF_K2C_LDS_SYNC
+}
+
 __global__ void k_query_cells(const double *__restrict__ q, int64_t m, sf_grid_desc g, int32_t *__restrict__ cid,
                               int32_t *__restrict__ val)
 {
@@ -887,6 +1070,56 @@ extern "C" sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *c, const double *que
     return nb;
 }
 
+
+int sf_launch_pca_solve_normals(sf_ctx *ctx, const double *cov, const int32_t *qrow, int64_t m, const double *pre, double *out); // descriptors.hip
+
+// compute_normals(query_points, cloud_points, radius=...) (pca_based_descriptors.py:29-59) without materialising the
+// neighbour lists: K1 (if needed), the fused sweep k_radius_cov, one eigen-solve per query.  queries == NULL: the cloud's own
+// points at cell-sorted positions [begin, end) (row i of `out` = position begin + i); else m coordinate queries (rows in the
+// caller's order).  Bit-identical to sf_radius_search(_self) + sf_normals.
+extern "C" int sf_normals_radius(sf_ctx *ctx, sf_cloud *c, const double *queries, int64_t m, int64_t begin, int64_t end, double radius,
+                                 const double *pre, double *out, int flags)
+{
+    if (!ctx || !c || !out) { sf_set_error("sf_normals_radius: null argument"); return SF_ERR_ARG; }
+    if (!queries) {
+        if (begin < 0 || end > c->n || begin > end) { sf_set_error("sf_normals_radius: bad range [%lld, %lld)", (long long)begin, (long long)end); return SF_ERR_ARG; }
+        m = end - begin;
+    } else if (m < 0 || m > 2147483000LL) {
+        sf_set_error("sf_normals_radius: bad query count %lld", (long long)m);
+        return SF_ERR_ARG;
+    }
+    SF_HIP(hipSetDevice(ctx->device));
+    SF_CHECK(queries ? ensure_grid(ctx, c, radius) : ensure_grid(ctx, c, radius, begin, end));
+    sf_nbrs q; // (query coordinates only: no lists are made)
+    q.m = m;
+    q.radius = radius;
+    struct release_queries {
+        sf_ctx *ctx; sf_nbrs *q; bool own;
+        ~release_queries() { if (own) { sf_pool_release(ctx, q->qx); sf_pool_release(ctx, q->qy); sf_pool_release(ctx, q->qz); } sf_pool_release(ctx, q->qrow); }
+    } rel{ctx, &q, queries != nullptr};
+    if (queries) SF_CHECK(prepare_queries(ctx, c, &q, queries, flags));
+    else { q.self = true; q.self_begin = begin; q.qx = c->xs + begin; q.qy = c->ys + begin; q.qz = c->zs + begin; }
+    sf_pool_guard tmp(ctx);
+    double *cov = nullptr, *dout = out;
+    const double *dpre = pre;
+    SF_CHECK(tmp.alloc(&cov, (size_t)(m ? m : 1) * 6));
+    if (!(flags & SF_OUT_DEVICE)) SF_CHECK(tmp.alloc(&dout, (size_t)(m ? m : 1) * 3));
+    if (pre && !(flags & SF_IN_DEVICE)) {
+        double *p = nullptr;
+        SF_CHECK(tmp.alloc(&p, (size_t)(m ? m : 1) * 3));
+        if (m) SF_HIP(hipMemcpyAsync(p, pre, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+        dpre = p;
+    }
+    if (m) {
+        sf_grid_desc g = sf_make_grid_desc(c);
+        SF_LAUNCH(ctx, "k23_radius_cov", k_radius_cov, dim3(sf_xcd_grid(sf_div_up(m, 4 * SF_K2C_WPB))), dim3(64 * SF_K2C_WPB), g,
+                  c->cell_start, c->xs, c->ys, c->zs, q.qx, q.qy, q.qz, m, radius * radius, cov, (double *)nullptr, (int32_t *)nullptr);
+        SF_CHECK(sf_launch_pca_solve_normals(ctx, cov, q.qrow, m, dpre, dout));
+        if (dout != out) SF_HIP(hipMemcpyAsync(out, dout, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if ((flags & (SF_IN_DEVICE | SF_OUT_DEVICE)) != (SF_IN_DEVICE | SF_OUT_DEVICE)) SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
 
 int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3]); // grid.hip
 

@@ -29,7 +29,9 @@ def compute_normals(
     eng = engine or default_engine()
     cloud = Cloud(eng, cloud_points)
     try:
-        nbrs = cloud.knn_search(query_points, k) if k is not None else cloud.radius_search(query_points, radius)
+        if k is None:  # the radius branch (:48): one sweep, no lists (sf_normals_radius)
+            return cloud.normals_radius(query_points, radius, pre_computed_normals)
+        nbrs = cloud.knn_search(query_points, k)
         try:
             return nbrs.normals(pre_computed_normals)
         finally:

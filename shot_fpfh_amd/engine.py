@@ -517,6 +517,25 @@ class Cloud:
         )
         return Neighbors(self, h)
 
+    def normals_radius(self, queries, radius: float, pre_computed_normals=None) -> np.ndarray:
+        """compute_normals(queries, cloud, radius=...) in one sweep: the neighbour lists are never materialised
+        (sf_normals_radius); bit-identical to radius_search(queries, radius).normals(pre_computed_normals)."""
+        q = _f64(queries, 3)
+        pre = None if pre_computed_normals is None else _f64(pre_computed_normals, 3)
+        if pre is not None and pre.shape[0] != q.shape[0]:
+            raise ValueError("pre_computed_normals must have one row per query point")
+        out = np.zeros((q.shape[0], 3))
+        _ffi.check(self.engine.lib.sf_normals_radius(self.engine.h, self.h, _ptr(q), q.shape[0], 0, 0, float(radius), _ptr(pre),
+                                                    _ptr(out), SF_HOST), "sf_normals_radius")
+        return out
+
+    def normals_radius_self(self, radius: float, out: DeviceArray, begin: int = 0, end: Optional[int] = None) -> DeviceArray:
+        """The same for the cloud's own points at cell-sorted positions [begin, end), result resident (row i = position begin + i)."""
+        end = self.n if end is None else end
+        _ffi.check(self.engine.lib.sf_normals_radius(self.engine.h, self.h, None, 0, begin, end, float(radius), None, out.ptr,
+                                                    SF_IN_DEVICE | SF_OUT_DEVICE), "sf_normals_radius")
+        return out
+
     def radius_search_self(self, radius: float, begin: int = 0, end: Optional[int] = None) -> "Neighbors":
         end = self.n if end is None else end
         h = _ffi.check_handle(

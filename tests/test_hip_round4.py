@@ -335,3 +335,53 @@ def test_empty_block_takes_part_in_the_collective_statistics():
         cloud.free()
     finally:
         e.close()
+
+
+# ---- compute_normals(radius) in one sweep --------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["uniform", "surface", "blobs", "cap"])
+def test_fused_normals_sweep_is_bit_identical_to_search_plus_normals(eng, O, kind):
+    """sf_normals_radius (hits reduced to the covariance in LDS, no lists) == sf_radius_search + sf_normals, bit for bit: the
+    cloud's own points and coordinate queries, with and without pre_computed_normals, lists of up to 256 points (LDS list)
+    and longer ones (the ring: two more sweeps); and against the oracle."""
+    if kind == "uniform":
+        p, _, _ = synth_cloud(40000, 21)
+        r = 0.06
+    elif kind == "surface":
+        p, _ = config1_cloud(40000, 21)
+        r = 0.04
+    elif kind == "blobs":
+        p, _ = clustered(40000, seed=21)
+        r = 0.016
+    else:
+        p, _ = dense_cap(40000, seed=21)
+        r = 0.025
+    cloud = eng.cloud(p)
+    nb = cloud.radius_search_self(r)
+    cnt = nb.counts()
+    if kind in ("blobs", "cap"):
+        assert (cnt > 256).sum() > 100 and (cnt <= 256).sum() > 100
+    want = eng.empty((cloud.n, 3))
+    nb.normals(out=want)
+    got = eng.empty((cloud.n, 3))
+    cloud.normals_radius_self(r, got)
+    assert np.array_equal(got.to_host(), want.to_host())
+    nb.free()
+    # a block of positions
+    part = eng.empty((5000, 3))
+    cloud.normals_radius_self(r, part, 12000, 17000)
+    assert np.array_equal(part.to_host(), want.to_host()[12000:17000])
+    # coordinate queries (off-cloud points among them), with pre_computed_normals
+    rng = np.random.default_rng(2)
+    q = np.vstack([p[rng.choice(p.shape[0], 3000, replace=False)], rng.random((500, 3))])
+    pre = np.tile(np.array([[0.0, 0.0, 1.0]]), (q.shape[0], 1))
+    nbq = cloud.radius_search(q, r)
+    a = nbq.normals(pre)
+    b = cloud.normals_radius(q, r, pre)
+    has = nbq.counts() > 0
+    nbq.free()
+    assert np.array_equal(a[has], b[has])  # (queries without any neighbour: 0 / 0 on both paths)
+    ok = nbq_ok = has & (np.arange(q.shape[0]) < 3000)
+    wo = O.compute_normals(q[ok][:400], p, radius=r, pre_computed_normals=pre[ok][:400])
+    assert np.abs(b[ok][:400] - wo).max() < 1e-9
+    for obj in (want, got, part, cloud):
+        obj.free()
