@@ -531,15 +531,18 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-// K7 for the keypoints whose own list exceeds the matrix-core form (more than 255 points, or more than the chunks of the
-// main launch): the vector ALU on the byte table.  One wave per keypoint; a 128-byte row is eight 16-byte pieces, so ONE
-// load instruction fetches the rows of eight neighbours (lane group g = lane / 8 takes neighbour tt + g, lane p of the
-// group the bins 16 p .. 16 p + 15); a neighbour with more than 255 neighbours of its own adds its row of high bytes
-// (count = lo + 256 hi).  Sixteen float64 accumulators per lane, lane groups summed at the end, group g writes bins
-// g and g + 8 of every piece.  SEL: the keypoints are the processing slots listed in `sel` (owner numbering; a view keeps
-// its own range); without it (keypoints by index) every keypoint is looked at and those of the main launch return at once.
-// SPARSE: at most two 16-bin blocks of the table are live and the packed copy is valid (32-byte rows {block b0, block b1}):
-// two lanes per row, the rows of 32 neighbours per load instruction.
+// K7 for the keypoints whose own list exceeds the matrix-core form (more than 255 points): the vector ALU on the byte table,
+// with EXACT sums.  The weights 1 / (k_j d_j) become 52-bit fixed point scaled by the keypoint's largest weight (a first pass
+// over the list finds it) and are cut into two 26-bit limbs held as doubles; limb x count products (count = low byte +
+// 256 x high byte < 2^16) are below 2^42, so float64 FMAs accumulate them WITHOUT rounding for 1024 neighbours at a time
+// (< 2^52), across lanes and lane groups alike; after every 1024 neighbours the exact sums are folded into the running
+// float64 totals, block after block.  A row therefore does not depend on which lane adds which neighbour: the 2-lanes-per-row
+// form on the packed 32-byte rows (SPARSE: at most two live 16-bin blocks, 32 neighbours per load instruction) and the
+// 8-lanes-per-row form on the full rows give the same bits -- as they must, since a sharded job switches the table to
+// "every block live" when it borrows rows.  (The float64-accumulating version of the first round-4 commit took 1.24 ms for
+// the 128 000 long lists of the clustered 1M-point cloud in its one usable form.)
+// One wave per keypoint.  SEL: the keypoints are the processing slots listed in `sel` (owner numbering; a view keeps its own
+// range); without it (keypoints by index) every keypoint is looked at and those of the main launch return at once.
 template <bool SEL, bool SPARSE>
 __global__ __launch_bounds__(256) void k_fpfh_tail(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                    const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
@@ -567,52 +570,95 @@ __global__ __launch_bounds__(256) void k_fpfh_tail(const double *__restrict__ re
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const int grp = lane / LPR, piece = lane % LPR;
     const int blk = SPARSE ? (piece ? b1 : b0) : piece; // the 16-bin block this lane accumulates
-    double acc[16];
+    // weight of the lane's neighbour of the chunk starting at t0 (0 past the end and at distance 0, fpfh.py:110-114)
+    auto weight = [&](int t0, int &j, bool &lng) -> double {
+        const int t = t0 + lane;
+        j = 0;
+        lng = false;
+        if (t >= k) return 0.0;
+        j = idx[s + t];
+        const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j);
+        const double2 u0 = pp[0], u1 = pp[1];
+        const double cx = u0.x - px, cy = u0.y - py, cz = u1.x - pz;
+        const double d2 = (cx * cx + cy * cy) + cz * cz;
+        const double kd = u1.y, xx = d2 * (kd * kd);
+        const double y0 = __builtin_amdgcn_rsq(xx);
+        const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+        const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+        lng = kd > 255.0;
+        return d2 > 0.0 ? y2 : 0.0;
+    };
+    // ---- pass 0: the largest weight -> the fixed-point exponent ----
+    double wmax = 0.0;
+    for (int t0 = 0; t0 < k; t0 += 64) {
+        int j;
+        bool lng;
+        wmax = fmax(wmax, weight(t0, j, lng));
+    }
+    wmax = sf_wave_max_nonneg(wmax);
+    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
+    const int S = 51 - e2; // W = floor(w 2^S) < 2^52
+    double acc0[16], acc1[16]; // exact sums of (low / high 26-bit limb) x count over this lane's neighbours of the block
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
-    auto add_words = [&](const uint4 &v, double ww) { // sixteen counts, one per byte
+    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.0;
+    constexpr int BPL = SPARSE ? 1 : 2;  // bins per lane in the end: 16 bins of a block over 16 (of 32) resp. 8 groups
+    constexpr int NG = 16 / BPL;
+    double tot[BPL];
+#pragma unroll
+    for (int u = 0; u < BPL; ++u) tot[u] = 0.0;
+    const double unscale = ldexp(1.0, -S);
+    auto add_words = [&](const uint4 &v, double w0, double w1) { // sixteen counts, one per byte: exact FMAs
         const unsigned wd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[4 * u + e] = __builtin_fma((double)((wd[u] >> (8 * e)) & 0xffu), ww, acc[4 * u + e]);
+            for (int e = 0; e < 4; ++e) {
+                const double c = (double)((wd[u] >> (8 * e)) & 0xffu);
+                acc0[4 * u + e] = __builtin_fma(c, w0, acc0[4 * u + e]);
+                acc1[4 * u + e] = __builtin_fma(c, w1, acc1[4 * u + e]);
+            }
+    };
+    auto fold = [&]() { // the block's exact sums over all lane groups (still exact: < 2^52), then into the float64 totals
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc0[e] += __shfl_xor(acc0[e], off);
+                acc1[e] += __shfl_xor(acc1[e], off);
+            }
+#pragma unroll
+        for (int u = 0; u < BPL; ++u) {
+            double a0 = acc0[NG * u], a1 = acc1[NG * u];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                a0 = grp == g ? acc0[NG * u + g] : a0;
+                a1 = grp == g ? acc1[NG * u + g] : a1;
+            }
+            tot[u] += __builtin_fma(a1, 67108864.0, a0) * unscale; // (2^26; one rounding per block and bin)
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.0;
     };
     for (int t0 = 0; t0 < k; t0 += 64) {
-        const int t = t0 + lane;
-        int j = 0;
-        double w = 0.0;
-        bool lng = false;
-        if (t < k) {
-            j = idx[s + t];
-            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j);
-            const double2 u0 = pp[0], u1 = pp[1];
-            const double cx = u0.x - px, cy = u0.y - py, cz = u1.x - pz;
-            const double d2 = (cx * cx + cy * cy) + cz * cz;
-            const double kd = u1.y, xx = d2 * (kd * kd);
-            const double y0 = __builtin_amdgcn_rsq(xx);
-            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
-            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
-            w = d2 > 0.0 ? y2 : 0.0; // d == 0 is masked out (fpfh.py:110-114)
-            lng = kd > 255.0;
-        }
+        int j;
+        bool lng;
+        const double w = weight(t0, j, lng);
+        const double W = floor(ldexp(w, S)); // < 2^52, exact
         const int n_here = min(64, k - t0);
         for (int tt = 0; tt < n_here; tt += RPI) {
             const int src = (tt + grp) & 63; // (past the end of the list the weight is 0 and row 0 is read)
             const int jj = __shfl(j, src);
-            const double ww = __shfl(w, src);
+            const double Ws = __shfl(W, src);
             const bool ll = __shfl((int)lng, src) != 0;
+            const double w1 = floor(Ws * (1.0 / 67108864.0)), w0 = __builtin_fma(-w1, 67108864.0, Ws); // two 26-bit limbs
             uint4 v = SPARSE ? *reinterpret_cast<const uint4 *>(packed + (size_t)jj * 32 + 16 * piece)
                              : *reinterpret_cast<const uint4 *>(counts + (size_t)jj * 128 + 16 * piece);
             v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; // stored as count ^ 128
-            add_words(v, ww);
-            if (ll) add_words(*reinterpret_cast<const uint4 *>(hi + (size_t)jj * 128 + 16 * blk), ww * 256.0);
+            add_words(v, w0, w1);
+            if (ll) add_words(*reinterpret_cast<const uint4 *>(hi + (size_t)jj * 128 + 16 * blk), w0 * 256.0, w1 * 256.0);
         }
+        if (((t0 + 64) & 1023) == 0 || t0 + 64 >= k) fold();
     }
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] += __shfl_xor(acc[e], off);
     const double kd = (double)k;
     double inv_k = __builtin_amdgcn_rcp(kd);
     inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
@@ -624,16 +670,11 @@ __global__ __launch_bounds__(256) void k_fpfh_tail(const double *__restrict__ re
         return (double)own;
     };
     // every lane group holds the complete sums; group g writes bin(s) g (+ 8) of its lane's block
-    constexpr int BPL = SPARSE ? 1 : 2; // bins per lane: 16 bins of a block over 16 (of 32) resp. 8 groups
     if (!SPARSE || grp < 16) {
 #pragma unroll
-        for (int half = 0; half < BPL; ++half) {
-            constexpr int NG = 16 / BPL;
-            double a = acc[NG * half];
-#pragma unroll
-            for (int g = 1; g < NG; ++g) a = grp == g ? acc[NG * half + g] : a;
-            const int b = 16 * blk + NG * half + grp;
-            if (b < nb3) o[b] = own_count(b) / kd + a * inv_k; // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
+        for (int u = 0; u < BPL; ++u) {
+            const int b = 16 * blk + NG * u + grp;
+            if (b < nb3) o[b] = own_count(b) / kd + tot[u] * inv_k; // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
         }
     }
     if (SPARSE) // the bins of the dead blocks: no neighbour has a count there
@@ -1278,12 +1319,13 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
 #undef SF_MC_LAUNCH2
 #undef SF_MC_ARGS
     if (any_tail) {
-        // (ONE form whatever the table's block mask: the float64 sums of this kernel depend on which lane group adds which
-        // neighbour, and a keypoint's row must not depend on the mask -- a sharded job switches to "every block live" when it
-        // borrows rows.  A 2-lanes-per-row form on the packed rows was twice as fast on sparse tables (0.56 against 1.22 ms for
-        // the 128 000 long lists of the clustered 1M-point cloud) and gave other last bits: not used.)
-        const bool packed_ok = false;
-        const int pb0 = 0, pb1 = 1;
+        // (the packed 32-byte rows when the table has at most two live blocks and its packed copy is current: both forms sum
+        // exactly, so which one runs changes no bit of a row)
+        const unsigned m8 = sp->host_live[0] & 0xffu;
+        const bool packed_ok = sparse && sp->host_live[1] == m8 && !getenv("SF_FPFH_TAIL_DENSE");
+        const int pb0 = m8 ? __builtin_ffs((int)m8) - 1 : 0;
+        const unsigned rest = m8 & (m8 - 1u);
+        const int pb1 = rest ? __builtin_ffs((int)rest) - 1 : (pb0 + 1) & 7; // (same pairing as spfh_pack_row)
 #define SF_TAIL_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, sp->nb3, (const uint8_t *)sp->counts, hi, \
                      (const double *)sp->p4, dout, d.limit
 #define SF_TAIL_LAUNCH(SEL, GRID, SELP, NSEL, VF)                                                                        \

@@ -243,14 +243,15 @@ def test_config_c4_full_size_chain_with_cpu_checked_match_rows(eng, O):
     assert winner is not None, "the returned transform is not the fit of any seeded draw"
     assert abs(winner[1] - best_count) <= 2 and earlier_best <= winner[1] + 2, (winner, best_count, earlier_best)
     # refitting on the winning transform's inliers (this test only; the reference does not refit) recovers the motion to rounding
-    # (two passes: the 0.01 inliers still hold a few WRONG matches -- a wrong match often lands on a near neighbour of the
+    # (three passes: the 0.01 inliers still hold a few WRONG matches -- a wrong match often lands on a near neighbour of the
     # right point, 0.006 away on average -- which bias the first fit at the 1e-5 level; at 1e-3 around that fit only true
     # matches remain)
     inl = np.linalg.norm((sp @ tf.rotation.T + tf.translation) - rp, axis=1) <= 0.01
     refit = solver_point_to_point(sp[inl], rp[inl])
-    inl = np.linalg.norm((sp @ refit.rotation.T + refit.translation) - rp, axis=1) <= 1e-3
-    assert inl.mean() > 0.9
-    refit = solver_point_to_point(sp[inl], rp[inl])
+    for thr in (1e-3, 1e-6):  # (at 1e-3 a handful of wrong matches that land within a millimetre of the right point still bias the
+        inl = np.linalg.norm((sp @ refit.rotation.T + refit.translation) - rp, axis=1) <= thr  # fit at the 1e-8 level)
+        assert inl.mean() > 0.9
+        refit = solver_point_to_point(sp[inl], rp[inl])
     assert np.abs(refit.rotation - rot).max() < 1e-9 and np.abs(refit.translation - t).max() < 1e-9
     # the winning draw's inlier count equals the NumPy expression of ransac.py:60-67 for that transform
     best_inl = (np.linalg.norm((scan[si] @ tf.rotation.T + tf.translation) - ref[ri], axis=1) <= 0.01).sum()
