@@ -243,22 +243,40 @@ __global__ __launch_bounds__(256) void k_layer_hist_fold(const unsigned int *__r
 // pass B: the points of layers [zlo, zhi], in ascending original index (the stable sort that follows keeps that order
 // inside a cell), with their cell ids.  A chunk's first output slot is the number of kept points in the chunks before
 // it -- a sum over rows of pass A's matrix -- and inside the chunk the order comes from ballots and a running count.
+// first output slot of every chunk of pass B: exclusive prefix over the chunks of "points of layers [zlo, zhi] in the chunk"
+// (one workgroup; until round 4 every workgroup of pass B summed the rows of all chunks before its own -- quadratic in the
+// number of chunks, and most of the pass's 0.08 ms at 1024 of them)
+__global__ __launch_bounds__(256) void k_chunk_prefix(const unsigned int *__restrict__ mat, int nblocks, int nl, int zlo, int zhi,
+                                                      unsigned long long *__restrict__ first)
+{
+    __shared__ unsigned long long part[256];
+    const int per = (nblocks + 255) / 256, b0 = threadIdx.x * per, b1 = min(b0 + per, nblocks);
+    unsigned long long s = 0;
+    for (int b = b0; b < b1; ++b)
+        for (int l = zlo; l <= zhi; ++l) s += mat[(int64_t)b * nl + l];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 256; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) {
+        first[b] = run;
+        for (int l = zlo; l <= zhi; ++l) run += mat[(int64_t)b * nl + l];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_select_slab(const double *__restrict__ z, const double *__restrict__ xyz, int64_t n,
                                                      int64_t chunk, sf_grid_desc g, int zlo, int zhi,
-                                                     const unsigned int *__restrict__ mat, int32_t *__restrict__ sel,
+                                                     const unsigned long long *__restrict__ first, int32_t *__restrict__ sel,
                                                      int32_t *__restrict__ cid, int cid_base)
 {
-    __shared__ unsigned long long red[4];
     __shared__ unsigned int wave_tot[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nl = g.dim[2];
-    unsigned long long before = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += blockDim.x)
-        for (int l = zlo; l <= zhi; ++l) before += mat[(int64_t)b * nl + l];
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
-    if (lane == 0) red[wave] = before;
-    __syncthreads();
-    int64_t pos = (int64_t)(red[0] + red[1] + red[2] + red[3]); // next output slot of this chunk
+    int64_t pos = (int64_t)first[blockIdx.x]; // next output slot of this chunk
     const int64_t c0 = (int64_t)blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
     const double2 *z2 = reinterpret_cast<const double2 *>(z);
     for (int64_t t0 = c0; t0 < c1; t0 += 2 * (int64_t)blockDim.x) { // (block-uniform trip count)
@@ -558,8 +576,11 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
             SF_LAUNCH(ctx, "k1_extract_z", k_extract_z, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, c->z_orig);
         }
         const int nl = c->dim[2];
-        // chunks: as many workgroups as keep the per-chunk histogram matrix within a megaword (1024 up to 1024 layers)
-        const int nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(64, ((int64_t)1 << 20) / nl));
+        // chunks: as many workgroups as keep the per-chunk histogram matrix within a megaword (1024 up to 1024 layers).  (More
+        // chunks do not help -- 4096: pass B 0.078 -> 0.11 ms, tools/ab_block_chunks.sh -- the pass already moves ~256 MB at
+        // config 5: 64 MB of z and nearly every line of the 192 MB AoS cloud, one kept point in six.)
+        static const int max_chunks = getenv("SF_BLOCK_CHUNKS") ? std::max(64, atoi(getenv("SF_BLOCK_CHUNKS"))) : 1024;
+        const int nblocks = (int)std::min<int64_t>(max_chunks, std::max<int64_t>(64, ((int64_t)1 << 20) / nl));
         const int64_t chunk = 2 * sf_div_up(sf_div_up(n, 2), nblocks);
         unsigned int *dmat = nullptr, *dhist = nullptr;
         SF_CHECK(tmp.alloc(&dmat, (size_t)nblocks * nl));
@@ -598,8 +619,11 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
             while (((int64_t)1 << bits) < (int64_t)(zhi - zlo + 1) * layer_cells) ++bits;
             SF_CHECK(tmp.alloc(&key_in, (size_t)ns + 1));
             SF_CHECK(tmp.alloc(&val_in, (size_t)ns + 1));
+            unsigned long long *dfirst = nullptr;
+            SF_CHECK(tmp.alloc(&dfirst, (size_t)nblocks));
+            SF_LAUNCH(ctx, "k1_select_slab", k_chunk_prefix, dim3(1), dim3(256), (const unsigned int *)dmat, nblocks, nl, zlo, zhi, dfirst);
             SF_LAUNCH(ctx, "k1_select_slab", k_select_slab, dim3(nblocks), dim3(256), (const double *)c->z_orig,
-                      (const double *)c->xyz_orig, n, chunk, g, zlo, zhi, (const unsigned int *)dmat, val_in, key_in, (int)cid_base);
+                      (const double *)c->xyz_orig, n, chunk, g, zlo, zhi, (const unsigned long long *)dfirst, val_in, key_in, (int)cid_base);
         }
     }
     c->pop_begin = base;

@@ -36,6 +36,7 @@ struct sf_voxels {
     int32_t *perm = nullptr;     // n: points grouped by voxel (key order), ascending index inside a voxel
     int32_t *rank = nullptr;     // n: voxel rank of sorted element i
     int32_t *start = nullptr;    // nvox + 1: first sorted element of every voxel
+    int32_t max_pop = 0;         // points of the fullest voxel (decides whether the wave-per-voxel pass has anything to do)
 };
 
 // (no tuned Onesweep configuration for gfx950 in rocPRIM 4.2: see grid.hip)
@@ -102,6 +103,17 @@ __global__ void k_voxel_starts(const int32_t *__restrict__ head, const int32_t *
     rank[i] = r;
     if (head[i]) start[r] = (int32_t)i;
     if (i == n - 1) start[r + 1] = (int32_t)n;
+}
+
+// points of the fullest voxel: bad[1] = max over run heads of (next run's first element - this one's)
+__global__ void k_voxel_maxpop(const int32_t *__restrict__ head, const int32_t *__restrict__ rank, const int32_t *__restrict__ start,
+                               int64_t n, int *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int len = 0;
+    if (i < n && head[i]) len = start[rank[i] + 1] - (int32_t)i;
+    for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off));
+    if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
 }
 
 __global__ void k_voxel_inverse(const int32_t *__restrict__ perm, const int32_t *__restrict__ rank, int64_t n,
@@ -274,11 +286,11 @@ extern "C" sf_voxels *sf_voxels_build(sf_ctx *ctx, const double *xyz, int64_t n,
     int32_t *val = nullptr, *head = nullptr, *scan = nullptr;
     int *bad = nullptr;
     if (tmp.alloc(&key, (size_t)n) != SF_OK || tmp.alloc(&skey, (size_t)n) != SF_OK || tmp.alloc(&val, (size_t)n) != SF_OK ||
-        tmp.alloc(&head, (size_t)n) != SF_OK || tmp.alloc(&scan, (size_t)n) != SF_OK || tmp.alloc(&bad, 1) != SF_OK ||
+        tmp.alloc(&head, (size_t)n) != SF_OK || tmp.alloc(&scan, (size_t)n) != SF_OK || tmp.alloc(&bad, 2) != SF_OK ||
         sf_palloc(ctx, &v->perm, (size_t)n) != SF_OK || sf_palloc(ctx, &v->rank, (size_t)n) != SF_OK)
         return fail();
     const dim3 grid((unsigned)sf_div_up(n, 256)), block(256);
-    bool ok = hipMemsetAsync(bad, 0, sizeof(int), ctx->stream) == hipSuccess;
+    bool ok = hipMemsetAsync(bad, 0, 2 * sizeof(int), ctx->stream) == hipSuccess; // [0]: non-finite input, [1]: fullest voxel
     {
         sf_launch_timer t_(ctx, "v1_voxel_keys");
         hipLaunchKernelGGL(k_voxel_keys, grid, block, 0, ctx->stream, v->xyz, n, v->lo[0], v->lo[1], v->lo[2], voxel, by, bz, key,
@@ -301,15 +313,17 @@ extern "C" sf_voxels *sf_voxels_build(sf_ctx *ctx, const double *xyz, int64_t n,
         ok = ok && sf_ctx_scratch(ctx, tb, &ts) == SF_OK;
         ok = ok && rocprim::inclusive_scan(ts, tb, head, scan, (size_t)n, rocprim::plus<int32_t>(), ctx->stream) == hipSuccess;
         hipLaunchKernelGGL(k_voxel_starts, grid, block, 0, ctx->stream, head, scan, n, v->rank, v->start);
+        hipLaunchKernelGGL(k_voxel_maxpop, grid, block, 0, ctx->stream, head, v->rank, v->start, n, bad + 1);
     }
     int32_t last = 0;
-    int hbad = 0;
+    int hbad2[2] = {0, 0};
     ok = ok && hipMemcpyAsync(&last, scan + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(hbad2, bad, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess;
     if (!ok) { sf_set_error("sf_voxels_build: device error"); return fail(); }
-    if (hbad) { sf_set_error("sf_voxels_build: non-finite coordinates"); return fail(); }
+    if (hbad2[0]) { sf_set_error("sf_voxels_build: non-finite coordinates"); return fail(); }
     v->nvox = last;
+    v->max_pop = hbad2[1];
     return v;
 }
 
@@ -344,8 +358,9 @@ extern "C" int sf_voxels_select(sf_ctx *ctx, sf_voxels *v, const int64_t *order,
     if (counts) SF_CHECK(tmp.alloc(&dcnt, (size_t)v->nvox));
     SF_LAUNCH(ctx, "v4_voxel_select", k_voxel_select, dim3((unsigned)sf_div_up(v->nvox, 128)), dim3(128), v->xyz, v->n, v->start,
               v->nvox, v->perm, (const int64_t *)dorder, dsel, dcnt, ctx->dev_flag);
-    // (voxels above SF_VOXEL_WAVE points exist only when some voxel holds more than its share: skip the launch otherwise)
-    if (v->n > (int64_t)SF_VOXEL_WAVE)
+    // (a wave per voxel for the voxels above SF_VOXEL_WAVE points -- launched only when the fullest voxel is one: with
+    // typical voxel sizes none is, and the launch was millions of workgroups that returned at once)
+    if (v->max_pop > (int32_t)SF_VOXEL_WAVE)
         SF_LAUNCH(ctx, "v4_voxel_select", k_voxel_select_wave, dim3((unsigned)v->nvox), dim3(64), v->xyz, v->n, v->start, v->nvox,
                   v->perm, (const int64_t *)dorder, dsel, ctx->dev_flag);
     SF_HIP(hipMemcpyAsync(selected, dsel, (size_t)v->nvox * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
