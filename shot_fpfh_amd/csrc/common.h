@@ -163,9 +163,16 @@ struct sf_launch_timer {
 
 struct sf_cloud {
     int64_t n = 0;
-    // original order (as uploaded)
-    double *xyz_orig = nullptr;     // n x 3 AoS
-    double *nrm_orig = nullptr;     // n x 3 AoS or null
+    // The uploaded points, kept SORTED BY z (stable: ties in ascending caller index) -- done once per upload, whatever radius
+    // is searched later: every z-layer of any grid is then a contiguous run of this "internal" order, so a rank of a sharded
+    // job reads only its own slab when it builds its block of the grid (until round 4 it looked at the whole replicated
+    // cloud twice per build), and the gather of a grid build reads a layer's points from one stretch of the array.  Sorting
+    // cell ids is stable on THIS order for every build, whole or block, so cell-sorted positions -- hence every result bit --
+    // do not depend on how many ranks share the cloud.
+    double *xyz_orig = nullptr;     // n x 3 AoS, internal (z-sorted) order
+    double *nrm_orig = nullptr;     // n x 3 AoS or null, internal order
+    int32_t *zperm = nullptr;       // internal index -> the caller's point index
+    int32_t *perm_int = nullptr;    // cell-sorted position -> internal index (what gathers from xyz_orig / nrm_orig use)
     // bounding box of the uploaded points: a property of the (immutable) cloud, computed by the first grid build and
     // kept -- every later build (another radius, a k-NN retry, the next pass over a resident cloud) skips the
     // reduction kernels and the device-to-host read-back of their six numbers
@@ -193,9 +200,8 @@ struct sf_cloud {
     // cell-sorted positions that are actually populated: [0, n) after sf_cloud_build_grid, the slab a block needs
     // after sf_cloud_build_grid_block (positions keep their GLOBAL numbering either way)
     int64_t pop_begin = 0, pop_end = 0;
-    // z coordinates alone, in the uploaded order (made by the first block build and kept, like the bounding box): the two
-    // whole-cloud passes of a block build -- layer histogram, slab selection -- read 8 bytes per point instead of
-    // pulling the 24-byte AoS records through the fabric
+    // the z coordinates alone, ascending (the sort keys of the upload): a block build finds every z-layer's first point by a
+    // binary search in it
     double *z_orig = nullptr;
     // first cell-sorted position of every z-layer of cells (dim[2] + 1 entries, host): written by the block build
     // (which needs it anyway), fetched from cell_start on demand after a whole-cloud build (sf_cloud_layer_table)

@@ -86,23 +86,72 @@ __global__ __launch_bounds__(384) void k_bbox_final(const double *__restrict__ p
     if (lane == 0) out6[a] = v;
 }
 
-__global__ void k_cell_ids(const double *__restrict__ xyz, int64_t n, sf_grid_desc g, int32_t *__restrict__ cid,
-                           int32_t *__restrict__ val)
+// cell ids of the internal points [first, first + n) (the whole cloud, or the slab of a block build -- a contiguous run of
+// the z-sorted internal order), relative to cid_base, with their internal indices as the values to be sorted along
+__global__ void k_cell_ids(const double *__restrict__ xyz, int64_t first, int64_t n, sf_grid_desc g, int32_t *__restrict__ cid,
+                           int32_t *__restrict__ val, int cid_base)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int cx = sf_cell_coord(xyz[3 * i + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
-    int cy = sf_cell_coord(xyz[3 * i + 1], g.lo[1], g.inv_cell, g.dim[1]);
-    int cz = sf_cell_coord(xyz[3 * i + 2], g.lo[2], g.inv_cell, g.dim[2]);
-    cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx;
-    val[i] = (int32_t)i;
+    const int64_t o = first + i;
+    int cx = sf_cell_coord(xyz[3 * o + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
+    int cy = sf_cell_coord(xyz[3 * o + 1], g.lo[1], g.inv_cell, g.dim[1]);
+    int cz = sf_cell_coord(xyz[3 * o + 2], g.lo[2], g.inv_cell, g.dim[2]);
+    cid[i] = (cz * g.dim[1] + cy) * g.dim[0] + cx - cid_base;
+    val[i] = (int32_t)o;
 }
 
-// positions: SoA (for the candidate sweeps of K2) + slots 0..2 of the AoS records (for gathers) + inv_perm
-// (positions [base, base + n): the whole cloud, or the slab a block build populates)
-// nrm != NULL: the cloud has normals already -- they travel in the same pass (one read of perm, whole 48-byte records
-// written) instead of waiting for sf_cloud_ensure_sorted_normals' own gather
-__global__ void k_gather_sorted(const double *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ perm,
+// upload: the z coordinates as sort keys with the caller's indices as values; the gather into internal order afterwards
+__global__ void k_upload_keys(const double *__restrict__ xyz, int64_t n, double *__restrict__ z, int32_t *__restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    z[i] = xyz[3 * i + 2];
+    idx[i] = (int32_t)i;
+}
+
+__global__ void k_upload_gather(const double *__restrict__ src, const int32_t *__restrict__ zperm, int64_t n, double *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = zperm[i];
+    dst[3 * i + 0] = src[3 * o + 0];
+    dst[3 * i + 1] = src[3 * o + 1];
+    dst[3 * i + 2] = src[3 * o + 2];
+}
+
+// first internal point of every z-layer of cells (= the layer's first cell-sorted position: layers are the slowest axis of
+// the cell numbering): lower bound of the layer index in the ascending z array.  One WAVE per layer, 64 probes per round
+// (four dependent rounds for 8M points instead of the 23 of a binary search: the build waits for this table on the host).
+__global__ __launch_bounds__(256) void k_layer_bounds(const double *__restrict__ z, int64_t n, double lo, double inv_cell, int nlayers,
+                                                      int64_t *__restrict__ first)
+{
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l > nlayers) return;
+    int64_t a = 0, b = n; // the answer (first i with layer(z[i]) >= l; the layer of a coordinate is monotone in it) lies in [a, b]
+    while (b - a > 64) {
+        const int64_t step = (b - a + 63) / 64;
+        const int64_t i = a + (int64_t)lane * step; // probes a, a + step, ...: `below` is true for a prefix of the lanes
+        const bool below = i < b && sf_cell_coord(z[i], lo, inv_cell, nlayers) < l;
+        const int k = __popcll(__ballot(below));
+        if (k == 0) { b = a; break; }
+        const int64_t na = a + (int64_t)(k - 1) * step + 1; // probe k - 1 is below: the answer is past it
+        const int64_t nb = k < 64 ? a + (int64_t)k * step : b;  // probe k (if any) is not below: the answer is at or before it
+        a = na;
+        b = nb < b ? nb : b;
+    }
+    if (b > a) {
+        const int64_t i = a + lane;
+        const bool below = i < b && sf_cell_coord(z[i], lo, inv_cell, nlayers) < l;
+        a += __popcll(__ballot(below));
+    }
+    if (lane == 0) first[l] = l == nlayers ? n : a;
+}
+
+// perm_int holds the sorted values (internal indices); perm gets the caller's numbering through zperm
+__global__ void k_gather_sorted(const double *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ perm_int,
+                                const int32_t *__restrict__ zperm, int32_t *__restrict__ perm,
                                 int64_t base, int64_t n, double *__restrict__ xs, double *__restrict__ ys,
                                 double *__restrict__ zs, double *__restrict__ rec, unsigned *__restrict__ zero_word)
 {
@@ -110,7 +159,8 @@ __global__ void k_gather_sorted(const double *__restrict__ xyz, const double *__
     if (i == 0 && zero_word) *zero_word = 0u; // (the long-gap counter of the cell-table kernel that follows: no memset launch)
     if (i >= n) return;
     i += base;
-    int64_t o = perm[i];
+    int64_t o = perm_int[i];
+    perm[i] = zperm[o];
     const double x = xyz[3 * o + 0], y = xyz[3 * o + 1], z = xyz[3 * o + 2];
     xs[i] = x; ys[i] = y; zs[i] = z;
     rec[6 * i + 0] = x; rec[6 * i + 1] = y; rec[6 * i + 2] = z;
@@ -195,124 +245,6 @@ __global__ __launch_bounds__(256) void k_cell_fill_long(const sf_gap *__restrict
     }
 }
 
-#define SF_MAX_LAYERS 4096
-// ---- block build (one rank of a sharded job) ------------------------------------------------------------------
-// The replicated cloud is in no particular order, so a rank has to look at every point to find the ones of its slab;
-// both whole-cloud passes read the 8-byte z coordinate only (sf_cloud::z_orig).
-__global__ void k_extract_z(const double *__restrict__ xyz, int64_t n, double *__restrict__ z)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) z[i] = xyz[3 * i + 2];
-}
-
-// Both passes cut the cloud into `gridDim.x` contiguous chunks of `chunk` points (an even number), one per workgroup.
-// pass A: points per z-layer of cells, per chunk: row b of `mat` (nblocks x nlayers).  The column sums give every layer's
-// first cell-sorted position; the rows tell pass B where each chunk's kept points start in the (index-ordered) selection,
-// so that pass needs no scan of its own.
-__global__ __launch_bounds__(256) void k_layer_hist_z(const double *__restrict__ z, int64_t n, int64_t chunk, double lo,
-                                                      double inv_cell, int nlayers, unsigned int *__restrict__ mat)
-{
-    __shared__ unsigned int sh[SF_MAX_LAYERS];
-    for (int b = threadIdx.x; b < nlayers; b += blockDim.x) sh[b] = 0;
-    __syncthreads();
-    const int64_t c0 = (int64_t)blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
-    const double2 *z2 = reinterpret_cast<const double2 *>(z);
-    for (int64_t i = c0 + 2 * (int64_t)threadIdx.x; i < c1; i += 2 * (int64_t)blockDim.x) {
-        const double2 v = z2[i >> 1]; // (c0 and the stride are even; the array has two doubles of padding)
-        atomicAdd(&sh[sf_cell_coord(v.x, lo, inv_cell, nlayers)], 1u);
-        if (i + 1 < c1) atomicAdd(&sh[sf_cell_coord(v.y, lo, inv_cell, nlayers)], 1u);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < nlayers; b += blockDim.x) mat[(int64_t)blockIdx.x * nlayers + b] = sh[b];
-}
-
-// column sums of pass A's matrix: one workgroup per layer
-__global__ __launch_bounds__(256) void k_layer_hist_fold(const unsigned int *__restrict__ mat, int nblocks, int nlayers,
-                                                         unsigned int *__restrict__ hist)
-{
-    __shared__ unsigned int part[4];
-    const int l = blockIdx.x;
-    unsigned int s = 0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += mat[(int64_t)b * nlayers + l];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) hist[l] = part[0] + part[1] + part[2] + part[3];
-}
-
-// pass B: the points of layers [zlo, zhi], in ascending original index (the stable sort that follows keeps that order
-// inside a cell), with their cell ids.  A chunk's first output slot is the number of kept points in the chunks before
-// it -- a sum over rows of pass A's matrix -- and inside the chunk the order comes from ballots and a running count.
-// first output slot of every chunk of pass B: exclusive prefix over the chunks of "points of layers [zlo, zhi] in the chunk"
-// (one workgroup; until round 4 every workgroup of pass B summed the rows of all chunks before its own -- quadratic in the
-// number of chunks, and most of the pass's 0.08 ms at 1024 of them)
-__global__ __launch_bounds__(256) void k_chunk_prefix(const unsigned int *__restrict__ mat, int nblocks, int nl, int zlo, int zhi,
-                                                      unsigned long long *__restrict__ first)
-{
-    __shared__ unsigned long long part[256];
-    const int per = (nblocks + 255) / 256, b0 = threadIdx.x * per, b1 = min(b0 + per, nblocks);
-    unsigned long long s = 0;
-    for (int b = b0; b < b1; ++b)
-        for (int l = zlo; l <= zhi; ++l) s += mat[(int64_t)b * nl + l];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int t = 0; t < 256; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; }
-    }
-    __syncthreads();
-    unsigned long long run = part[threadIdx.x];
-    for (int b = b0; b < b1; ++b) {
-        first[b] = run;
-        for (int l = zlo; l <= zhi; ++l) run += mat[(int64_t)b * nl + l];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_select_slab(const double *__restrict__ z, const double *__restrict__ xyz, int64_t n,
-                                                     int64_t chunk, sf_grid_desc g, int zlo, int zhi,
-                                                     const unsigned long long *__restrict__ first, int32_t *__restrict__ sel,
-                                                     int32_t *__restrict__ cid, int cid_base)
-{
-    __shared__ unsigned int wave_tot[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nl = g.dim[2];
-    int64_t pos = (int64_t)first[blockIdx.x]; // next output slot of this chunk
-    const int64_t c0 = (int64_t)blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
-    const double2 *z2 = reinterpret_cast<const double2 *>(z);
-    for (int64_t t0 = c0; t0 < c1; t0 += 2 * (int64_t)blockDim.x) { // (block-uniform trip count)
-        const int64_t i = t0 + 2 * (int64_t)threadIdx.x;
-        bool k0 = false, k1 = false;
-        if (i < c1) {
-            const double2 v = z2[i >> 1];
-            const int a = sf_cell_coord(v.x, g.lo[2], g.inv_cell, nl);
-            k0 = a >= zlo && a <= zhi;
-            if (i + 1 < c1) {
-                const int b = sf_cell_coord(v.y, g.lo[2], g.inv_cell, nl);
-                k1 = b >= zlo && b <= zhi;
-            }
-        }
-        const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
-        const int mine = sf_prefix_count(b0) + sf_prefix_count(b1); // kept points of the lanes below
-        __syncthreads(); // (the previous tile's wave_tot has been read by everybody)
-        if (lane == 0) wave_tot[wave] = (unsigned)(__popcll(b0) + __popcll(b1));
-        __syncthreads();
-        int64_t at = pos + mine;
-        for (int w = 0; w < wave; ++w) at += wave_tot[w];
-        pos += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (h == 0 ? k0 : k1) {
-                const int64_t o = i + h;
-                const int cx = sf_cell_coord(xyz[3 * o + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
-                const int cy = sf_cell_coord(xyz[3 * o + 1], g.lo[1], g.inv_cell, g.dim[1]);
-                const int cz = sf_cell_coord(xyz[3 * o + 2], g.lo[2], g.inv_cell, g.dim[2]);
-                sel[at] = (int32_t)o;
-                cid[at] = (cz * g.dim[1] + cy) * g.dim[0] + cx - cid_base; // relative to the slab's first cell
-                ++at;
-            }
-    }
-}
-
 // first cell-sorted position of every z-layer, read off the cell table (after a whole-cloud build)
 __global__ void k_layer_first(const int32_t *__restrict__ cell_start, int64_t layer_cells, int nl, int64_t *__restrict__ out)
 {
@@ -324,18 +256,77 @@ __global__ void k_layer_first(const int32_t *__restrict__ cell_start, int64_t la
 
 static void cloud_release_grid(sf_ctx *ctx, sf_cloud *c)
 {
-    void *ptrs[] = {c->cell_start, c->perm, c->inv_perm, c->xs, c->ys, c->zs, c->rec};
+    void *ptrs[] = {c->cell_start, c->perm, c->perm_int, c->inv_perm, c->xs, c->ys, c->zs, c->rec};
     for (void *p : ptrs)
         if (p) {
             if (ctx) sf_pool_release(ctx, p); else (void)hipFree(p);
         }
-    c->cell_start = c->perm = c->inv_perm = nullptr;
+    c->cell_start = c->perm = c->perm_int = c->inv_perm = nullptr;
     c->inv_perm_valid = false;
     c->xs = c->ys = c->zs = c->rec = nullptr;
     c->normals_sorted = false;
     c->cell = 0.0;
     c->pop_begin = c->pop_end = 0;
     c->layer_first.clear();
+}
+
+// internal (z-sorted) copy of a caller-ordered n x 3 array: through a pooled staging buffer unless the source is on the device
+static int upload_in_zorder(sf_ctx *ctx, sf_cloud *c, const double *src, int flags, double *dst)
+{
+    const int64_t n = c->n;
+    if (!n) return SF_OK;
+    sf_pool_guard tmp(ctx);
+    const double *dsrc = src;
+    if (!(flags & SF_IN_DEVICE)) {
+        double *stage = nullptr;
+        SF_CHECK(tmp.alloc(&stage, (size_t)n * 3));
+        SF_HIP(hipMemcpyAsync(stage, src, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+        dsrc = stage;
+    }
+    SF_LAUNCH(ctx, "k0_upload", k_upload_gather, dim3((unsigned)sf_div_up(n, 256)), dim3(256), dsrc, (const int32_t *)c->zperm, n, dst);
+    SF_HIP(hipStreamSynchronize(ctx->stream)); // (the caller's buffer / the staging block are free again)
+    return SF_OK;
+}
+
+static int cloud_upload(sf_ctx *ctx, sf_cloud *c, const double *xyz, const double *normals, int flags)
+{
+    const int64_t n = c->n;
+    const size_t bytes = (size_t)(n ? n : 1) * 3 * sizeof(double);
+    SF_HIP(hipMalloc(&c->xyz_orig, bytes));
+    SF_HIP(hipMalloc(&c->zperm, (size_t)(n ? n : 1) * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&c->z_orig, (size_t)(n + 2) * sizeof(double)));
+    if (n) {
+        // ---- the z-sorted internal order: sort (z, caller index) once, stable ----
+        sf_pool_guard tmp(ctx);
+        const double *dsrc = xyz;
+        if (!(flags & SF_IN_DEVICE)) {
+            double *stage = nullptr;
+            SF_CHECK(tmp.alloc(&stage, (size_t)n * 3));
+            SF_HIP(hipMemcpyAsync(stage, xyz, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+            dsrc = stage;
+        }
+        double *zkey = nullptr;
+        int32_t *idx = nullptr;
+        SF_CHECK(tmp.alloc(&zkey, (size_t)n));
+        SF_CHECK(tmp.alloc(&idx, (size_t)n));
+        SF_LAUNCH(ctx, "k0_upload", k_upload_keys, dim3((unsigned)sf_div_up(n, 256)), dim3(256), dsrc, n, zkey, idx);
+        size_t tb = 0;
+        SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tb, zkey, c->z_orig, idx, c->zperm, (size_t)n, 0, 64, ctx->stream));
+        char *stmp = nullptr;
+        SF_CHECK(tmp.alloc(&stmp, tb ? tb : 8));
+        {
+            sf_launch_timer t_(ctx, "k0_upload");
+            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(stmp, tb, zkey, c->z_orig, idx, c->zperm, (size_t)n, 0, 64, ctx->stream));
+        }
+        SF_LAUNCH(ctx, "k0_upload", k_upload_gather, dim3((unsigned)sf_div_up(n, 256)), dim3(256), dsrc, (const int32_t *)c->zperm, n,
+                  c->xyz_orig);
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (normals) {
+        SF_HIP(hipMalloc(&c->nrm_orig, bytes));
+        SF_CHECK(upload_in_zorder(ctx, c, normals, flags, c->nrm_orig));
+    }
+    return SF_OK;
 }
 
 extern "C" sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const double *normals, int64_t n, int flags)
@@ -347,25 +338,9 @@ extern "C" sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const doubl
     SF_HIP_NULL(hipSetDevice(ctx->device));
     sf_cloud *c = new sf_cloud();
     c->n = n;
-    size_t bytes = (size_t)(n ? n : 1) * 3 * sizeof(double);
-    hipMemcpyKind kind = (flags & SF_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (hipMalloc(&c->xyz_orig, bytes) != hipSuccess) {
-        sf_set_error("sf_cloud_upload: out of device memory");
-        delete c;
+    if (cloud_upload(ctx, c, xyz, normals, flags) != SF_OK) {
+        sf_cloud_free(ctx, c);
         return nullptr;
-    }
-    if (n) {
-        hipError_t e = hipMemcpyAsync(c->xyz_orig, xyz, (size_t)n * 24, kind, ctx->stream);
-        if (e == hipSuccess && normals) {
-            e = hipMalloc(&c->nrm_orig, bytes);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->nrm_orig, normals, (size_t)n * 24, kind, ctx->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) {
-            sf_set_error("sf_cloud_upload: %s", hipGetErrorString(e));
-            sf_cloud_free(ctx, c);
-            return nullptr;
-        }
     }
     return c;
 }
@@ -373,11 +348,10 @@ extern "C" sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const doubl
 extern "C" int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *c, const double *normals, int flags)
 {
     if (!ctx || !c || !normals) { sf_set_error("sf_cloud_set_normals: null argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
     size_t bytes = (size_t)(c->n ? c->n : 1) * 24;
     if (!c->nrm_orig) SF_HIP(hipMalloc(&c->nrm_orig, bytes));
-    hipMemcpyKind kind = (flags & SF_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (c->n) SF_HIP(hipMemcpyAsync(c->nrm_orig, normals, (size_t)c->n * 24, kind, ctx->stream));
-    SF_HIP(hipStreamSynchronize(ctx->stream));
+    SF_CHECK(upload_in_zorder(ctx, c, normals, flags, c->nrm_orig));
     c->normals_sorted = false;
     c->nrm_max2 = -1.0;
     return SF_OK;
@@ -445,7 +419,7 @@ int sf_cloud_ensure_sorted_normals(sf_ctx *ctx, sf_cloud *c)
     const int64_t np = c->pop_end - c->pop_begin;
     if (np > 0) {
         SF_LAUNCH(ctx, "k1_gather_normals", k_gather_normals, dim3((unsigned)sf_div_up(np, 256)), dim3(256),
-                  c->nrm_orig, c->perm, c->pop_begin, np, c->rec);
+                  c->nrm_orig, c->perm_int, c->pop_begin, np, c->rec);
         // The flag below is per cloud, not per stream: while the context is forked (sf_fork) a consumer on the OTHER
         // stream would see it set and read rec[3..5] with nothing ordering that read after this gather.  Make the
         // other stream wait for it.
@@ -542,6 +516,7 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     size_t nn = (size_t)(n ? n : 1);
     SF_CHECK(sf_palloc(ctx, &c->cell_start, (size_t)(ncell + 1)));
     SF_CHECK(sf_palloc(ctx, &c->perm, nn));
+    SF_CHECK(sf_palloc(ctx, &c->perm_int, nn));
     SF_CHECK(sf_palloc(ctx, &c->inv_perm, nn));
     SF_CHECK(sf_palloc(ctx, &c->xs, nn + 2)); // +2: K2 reads candidates in pairs (one element past the end)
     SF_CHECK(sf_palloc(ctx, &c->ys, nn + 2));
@@ -563,42 +538,28 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
 
     int64_t base = 0, ns = n;                  // populated slice [base, base + ns) of the global order
     int32_t *key_in = nullptr, *val_in = nullptr; // what gets sorted
-    const bool whole = block_end < 0 || c->dim[2] > SF_MAX_LAYERS; // (the layer histogram lives in LDS)
+    const bool whole = block_end < 0;
     if (whole) {
         SF_CHECK(tmp.alloc(&key_in, nn));
         SF_CHECK(tmp.alloc(&val_in, nn));
-        SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, g, key_in,
-                  val_in);
+        SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, (int64_t)0, n, g, key_in,
+                  val_in, 0);
     } else {
-        // ---- pass A: which z-layers does the block need? ------------------------------------------
-        if (!c->z_orig) {
-            SF_HIP(hipMalloc(&c->z_orig, (nn + 2) * sizeof(double)));
-            SF_LAUNCH(ctx, "k1_extract_z", k_extract_z, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, n, c->z_orig);
-        }
+        // ---- which z-layers does the block need?  The internal order is ascending in z (sf_cloud), so every layer is a run of
+        //      it and a layer's first point is a binary search away: nl + 1 searches, one small read-back. ----
         const int nl = c->dim[2];
-        // chunks: as many workgroups as keep the per-chunk histogram matrix within a megaword (1024 up to 1024 layers).  (More
-        // chunks do not help -- 4096: pass B 0.078 -> 0.11 ms, tools/ab_block_chunks.sh -- the pass already moves ~256 MB at
-        // config 5: 64 MB of z and nearly every line of the 192 MB AoS cloud, one kept point in six.)
-        static const int max_chunks = getenv("SF_BLOCK_CHUNKS") ? std::max(64, atoi(getenv("SF_BLOCK_CHUNKS"))) : 1024;
-        const int nblocks = (int)std::min<int64_t>(max_chunks, std::max<int64_t>(64, ((int64_t)1 << 20) / nl));
-        const int64_t chunk = 2 * sf_div_up(sf_div_up(n, 2), nblocks);
-        unsigned int *dmat = nullptr, *dhist = nullptr;
-        SF_CHECK(tmp.alloc(&dmat, (size_t)nblocks * nl));
-        SF_CHECK(tmp.alloc(&dhist, (size_t)nl));
-        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_z, dim3(nblocks), dim3(256), (const double *)c->z_orig, n, chunk, c->lo[2],
-                  c->inv_cell, nl, dmat);
-        SF_LAUNCH(ctx, "k1_layer_hist", k_layer_hist_fold, dim3((unsigned)nl), dim3(256), (const unsigned int *)dmat, nblocks, nl,
-                  dhist);
-        std::vector<unsigned int> hist((size_t)nl);
+        int64_t *dfirst = nullptr;
+        SF_CHECK(tmp.alloc(&dfirst, (size_t)nl + 1));
+        SF_LAUNCH(ctx, "k1_layer_bounds", k_layer_bounds, dim3((unsigned)sf_div_up(nl + 1, 4)), dim3(256), (const double *)c->z_orig, n,
+                  c->lo[2], c->inv_cell, nl, dfirst);
+        std::vector<int64_t> &first = c->layer_first; // global position (= internal index) of each layer's first point
+        first.assign((size_t)nl + 1, 0);
         void *pin = nullptr;
         SF_CHECK(sf_ctx_pinned(ctx, &pin));
-        unsigned int *dst = (size_t)nl * sizeof(unsigned int) <= SF_PINNED_BYTES ? (unsigned int *)pin : hist.data();
-        SF_HIP(hipMemcpyAsync(dst, dhist, (size_t)nl * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        int64_t *dst = ((size_t)nl + 1) * sizeof(int64_t) <= SF_PINNED_BYTES ? (int64_t *)pin : first.data();
+        SF_HIP(hipMemcpyAsync(dst, dfirst, ((size_t)nl + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         SF_HIP(hipStreamSynchronize(ctx->stream));
-        if (dst != hist.data()) std::copy(dst, dst + nl, hist.begin());
-        std::vector<int64_t> &first = c->layer_first; // global position of each layer's first point
-        first.assign((size_t)nl + 1, 0);
-        for (int z = 0; z < nl; ++z) first[(size_t)z + 1] = first[(size_t)z] + hist[(size_t)z];
+        if (dst != first.data()) std::copy(dst, dst + nl + 1, first.begin());
         int zb = 0, ze = nl - 1;
         if (block_begin < block_end) {
             while (zb + 1 < nl && first[(size_t)zb + 1] <= block_begin) ++zb;          // layer holding position block_begin
@@ -610,7 +571,7 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         const int zlo = std::max(zb - reach, 0), zhi = block_begin < block_end ? std::min(ze + reach, nl - 1) : -1;
         base = zhi >= zlo ? first[(size_t)zlo] : 0;
         ns = zhi >= zlo ? first[(size_t)zhi + 1] - base : 0;
-        // ---- pass B: the points of those layers in index order, with their cell ids ----------------------
+        // ---- the slab's points are the internal points [base, base + ns): their cell ids, nothing else of the cloud is read ----
         if (ns > 0) {
             // keys relative to the slab's first cell: 19 bits instead of 23 at config 5 -- two sort passes instead of three
             const int64_t layer_cells = (int64_t)c->dim[0] * c->dim[1];
@@ -619,11 +580,8 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
             while (((int64_t)1 << bits) < (int64_t)(zhi - zlo + 1) * layer_cells) ++bits;
             SF_CHECK(tmp.alloc(&key_in, (size_t)ns + 1));
             SF_CHECK(tmp.alloc(&val_in, (size_t)ns + 1));
-            unsigned long long *dfirst = nullptr;
-            SF_CHECK(tmp.alloc(&dfirst, (size_t)nblocks));
-            SF_LAUNCH(ctx, "k1_select_slab", k_chunk_prefix, dim3(1), dim3(256), (const unsigned int *)dmat, nblocks, nl, zlo, zhi, dfirst);
-            SF_LAUNCH(ctx, "k1_select_slab", k_select_slab, dim3(nblocks), dim3(256), (const double *)c->z_orig,
-                      (const double *)c->xyz_orig, n, chunk, g, zlo, zhi, (const unsigned long long *)dfirst, val_in, key_in, (int)cid_base);
+            SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig, base, ns, g, key_in,
+                      val_in, (int)cid_base);
         }
     }
     c->pop_begin = base;
@@ -634,17 +592,18 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     SF_CHECK(tmp.alloc(&n_gaps, 1));
     if (ns > 0) {
         size_t tmp_bytes = 0;
-        SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
+        SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm_int + base, (size_t)ns, 0, bits,
                                          ctx->stream));
         char *stmp = nullptr;
         SF_CHECK(tmp.alloc(&stmp, tmp_bytes ? tmp_bytes : 8));
         {
             sf_launch_timer t_(ctx, "k1_radix_sort");
-            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(stmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm + base, (size_t)ns, 0, bits,
+            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(stmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm_int + base, (size_t)ns, 0, bits,
                                              ctx->stream));
         }
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,
-                  (const double *)c->nrm_orig, c->perm, base, ns, c->xs, c->ys, c->zs, c->rec, n_gaps);
+                  (const double *)c->nrm_orig, (const int32_t *)c->perm_int, (const int32_t *)c->zperm, c->perm, base, ns, c->xs, c->ys, c->zs,
+                  c->rec, n_gaps);
     }
     // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
     // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
@@ -752,5 +711,6 @@ extern "C" void sf_cloud_free(sf_ctx *ctx, sf_cloud *c)
     if (c->xyz_orig) (void)hipFree(c->xyz_orig);
     if (c->nrm_orig) (void)hipFree(c->nrm_orig);
     if (c->z_orig) (void)hipFree(c->z_orig);
+    if (c->zperm) (void)hipFree(c->zperm);
     delete c;
 }
