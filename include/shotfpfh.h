@@ -200,8 +200,11 @@ int sf_shot_serial(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int64_t min_neig
  * for every query of `self_nbrs` in cell-sorted order (m must equal its query count; with a
  * sf_nbrs_slice view this is how a shard reduces only its own block).
  * sf_spfh_export writes the float64 SPFH table (n x n_bins^3, original numbering).
- * max_count (the largest neighbourhood the table will see, sf_nbrs_max_count) picks the storage of the integer
- * bin counts: bytes up to 255 points (and n_bins <= 5), 16 bits up to 65535, 32 bits beyond.
+ * max_count (the largest neighbourhood the table will see, sf_nbrs_max_count; over every rank of a sharded job:
+ * sf_nbrs_max_count_all) picks the storage of the integer bin counts: bytes for n_bins <= 5 and lists of at most 65535
+ * points -- with a second table for count >> 8 of the points that have more than 255 neighbours, allocated when max_count
+ * exceeds 255 --, else 16 bits up to 65535, 32 bits beyond.  Every list-driven entry point dispatches per keypoint by list
+ * length: a list of more than 255 points is served by a second launch, it never changes the kernels the others run.
  * On the byte table sf_spfh_compute also records which 16-bin blocks of the rows hold any count; sf_fpfh reads that
  * mask back (8 bytes, once per sf_spfh_compute: it waits for K6 on the context's stream) and, when at most two of the
  * eight blocks do, multiplies only those -- same results, bit for bit. */

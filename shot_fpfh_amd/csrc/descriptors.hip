@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_pca(const double *__restrict__ rec, con
     }
 }
 
-// K3, fast form (lists of at most 256 points, normals and the plain decomposition): TWO kernels.
+// K3 from materialised lists (normals and the plain decomposition): TWO kernels.
 //   k_pca_cov<NCH>   one WAVE per query: every neighbour is gathered once into registers (one index round trip, one
 //                    gather round trip -- k_pca's 16-lane rows take two dependent round trips per 16 neighbours, twice over),
 //                    the barycentre and the centred second moments are wave reductions (the second "sweep" of
@@ -1540,7 +1540,7 @@ extern "C" int sf_shot_single_scale(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int n
 }
 
 // sf_shot_single_scale with the frame moments already computed by sf_spfh_compute_moments on the SAME lists (self
-// search, every list <= 256 points): eigen-solves only, then the fused K5.  cov: m x 6 on the device.
+// search; lists of any length: launch_shot dispatches per keypoint): eigen-solves only, then the fused K5.  cov: m x 6 on the device.
 extern "C" int sf_shot_from_moments(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const double *cov_dev, int normalize, int64_t min_nb,
                                     double *lrf, double *out, int flags)
 {
