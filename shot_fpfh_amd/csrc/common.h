@@ -241,6 +241,12 @@ struct sf_nbrs {
     int tail_limit = 0x7fffffff;   // lists longer than this belong to the tail launch
     int32_t *tail_sel = nullptr;   // n_tail processing slots (of the OWNING list set), ascending; shared with views
     int64_t n_tail = 0;
+    // A small share of lists that need MORE chunks than the bulk (but fit the register-cached forms: <= 255 points) gets a
+    // launch of its own in the 4-chunk instantiation of the SAME form -- the instantiations of one form agree bit for bit,
+    // so which launch serves such a keypoint changes nothing but the bulk's speed: main_chunks covers all but <= 2 % of the
+    // lists of at most 255 points, `mid_sel` names the rest (lists of 64 main_chunks + 1 .. 255 points).
+    int32_t *mid_sel = nullptr;
+    int64_t n_mid = 0;
     int64_t view_first = 0;        // a view's first slot in the owner's numbering (tail_sel entries are owner slots)
 };
 
@@ -280,18 +286,24 @@ static inline int64_t sf_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; 
 // dispatched by their longest list, as a whole.
 struct sf_dispatch {
     int chunks = 4;
-    int limit = 0x7fffffff;
+    int limit = 0x7fffffff;       // the main launch leaves out lists longer than this
+    int tail_limit = 0x7fffffff;  // lists longer than this belong to the streaming / vector forms (255 when there are any)
     const int32_t *tail_sel = nullptr;
     int64_t n_tail = 0, view_first = 0;
+    const int32_t *mid_sel = nullptr; // lists of limit + 1 .. 255 points: same form, 4 chunks, a launch of their own
+    int64_t n_mid = 0;
 };
 static inline sf_dispatch sf_nbrs_dispatch(const sf_nbrs *nb)
 {
     sf_dispatch d;
     if (nb->planned) {
         d.chunks = nb->main_chunks;
-        d.limit = nb->tail_limit;
+        d.limit = nb->n_mid ? 64 * nb->main_chunks : nb->tail_limit;
+        d.tail_limit = nb->tail_limit;
         d.tail_sel = nb->tail_sel;
         d.n_tail = nb->n_tail;
+        d.mid_sel = nb->mid_sel;
+        d.n_mid = nb->n_mid;
         d.view_first = nb->view_first;
     } else {
         const int64_t mx = nb->max_count > 0 ? nb->max_count : 1;

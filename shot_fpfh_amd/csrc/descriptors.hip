@@ -1221,12 +1221,18 @@ __global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                     const int32_t *__restrict__ qrow,
                                                     int64_t m, shot_consts K, double *__restrict__ lrf,
-                                                    int normalize, int64_t min_nb, double *__restrict__ out, int limit)
+                                                    int normalize, int64_t min_nb, double *__restrict__ out, int limit,
+                                                    const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long slots[SF_SHOT_WPB][704];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned long long *const slot = slots[wave];
-    const int64_t q = sf_xcd_block() * SF_SHOT_WPB + wave;
+    int64_t q = sf_xcd_block() * SF_SHOT_WPB + wave;
+    if (sel) { // (the launch of the lists that need more chunks than the bulk: sf_dispatch::mid_sel, owner numbering)
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
     if (q >= m) return;
     // (a keypoint whose own list is longer than this launch's form holds belongs to the second launch: launch_shot)
     if (sf_uniform(cnt[q]) > limit) return;
@@ -1304,6 +1310,10 @@ static int launch_pca_cov(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *cov, do
     else if (d.chunks == 3) { SF_K3_COV("k3_normals", 3, false, grid); }
     else if (d.chunks == 4) { SF_K3_COV("k3_normals", 4, false, grid); }
     else { SF_K3_COV("k3_normals", 0, false, grid); }
+    if (d.n_mid) {
+        SF_LAUNCH(ctx, "k3_normals_mid", (k_pca_cov<4, true>), dim3(sf_xcd_grid(sf_div_up(d.n_mid, 2))), block, c->rec, nb->qx, nb->qy, nb->qz,
+                  nb->offset, nb->count, nb->idx, m, cov, bary, 255, d.mid_sel, d.n_mid, d.view_first);
+    }
     if (d.n_tail) { SF_K3_COV("k3_normals_tail", 0, true, dim3(sf_xcd_grid(sf_div_up(d.n_tail, 2)))); }
 #undef SF_K3_COV
     return SF_OK;
@@ -1414,8 +1424,8 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2)}; // the reference's own expressions (shot.py:95-117, 235)
     const sf_dispatch d = sf_nbrs_dispatch(nb);
 #define SF_SHOT_CASE(N)                                                                                              \
-    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit); } \
-    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit); }
+    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); } \
+    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); }
 #define SF_SHOT_STREAM(NAME, SEL, GRID, SELP, NSEL)                                                                   \
     if (fused) { SF_LAUNCH(ctx, NAME, (k_shot_long<true, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); } \
     else { SF_LAUNCH(ctx, NAME, (k_shot_long<false, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); }
@@ -1424,6 +1434,11 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     else if (d.chunks == 3) { SF_SHOT_CASE(3) }
     else if (d.chunks == 4) { SF_SHOT_CASE(4) }
     else { SF_SHOT_STREAM("k5_shot", false, m, (const int32_t *)nullptr, (int64_t)0) }
+    if (d.n_mid) { // the few lists that need more chunks than the bulk: the same form, four chunks
+        const dim3 grid_mid(sf_xcd_grid(sf_div_up(d.n_mid, SF_SHOT_WPB)));
+        if (fused) { SF_LAUNCH(ctx, "k5_shot_mid", (k_shot_cached<4, true>), grid_mid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, 255, d.mid_sel, d.n_mid, d.view_first); }
+        else { SF_LAUNCH(ctx, "k5_shot_mid", (k_shot_cached<4, false>), grid_mid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, 255, d.mid_sel, d.n_mid, d.view_first); }
+    }
     if (d.n_tail) { SF_SHOT_STREAM("k5_shot_tail", true, d.n_tail, d.tail_sel, d.n_tail) }
 #undef SF_SHOT_STREAM
 #undef SF_SHOT_CASE

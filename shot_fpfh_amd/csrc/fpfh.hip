@@ -479,12 +479,18 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const double *__restrict__ p4, const unsigned *__restrict__ live,
                                                  const uint8_t *__restrict__ packed, unsigned packed_bytes,
-                                                 double *__restrict__ out, const uint8_t *__restrict__ hi, int limit)
+                                                 double *__restrict__ out, const uint8_t *__restrict__ hi, int limit,
+                                                 const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first)
 {
     __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // 32 rows of 128 B
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
     const int wv_id = threadIdx.x >> 6;
-    const int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
+    int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
+    if (sel) { // (the launch of the lists that need more chunks than the bulk: sf_dispatch::mid_sel)
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
     if (q >= m) return;
     // (the full and the sparse-block form are two kernels -- in ONE the full form's register allocation suffered, 1.45
     // instead of 1.29 ms on a table with all eight blocks live -- and the host launches the one the table-wide block mask
@@ -505,12 +511,18 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     const double *__restrict__ rec, const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx, int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m, int nb3,
     const uint8_t *__restrict__ counts, unsigned table_bytes, const double *__restrict__ p4, const unsigned *__restrict__ live,
-    const uint8_t *__restrict__ packed, unsigned packed_bytes, double *__restrict__ out, const uint8_t *__restrict__ hi, int limit)
+    const uint8_t *__restrict__ packed, unsigned packed_bytes, double *__restrict__ out, const uint8_t *__restrict__ hi, int limit,
+    const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first)
 {
     __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32]; // four steps of 32 rows x 32 B
     __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
     const int wv_id = threadIdx.x >> 6;
-    const int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
+    int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
+    if (sel) {
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
     if (q >= m) return;
     const unsigned mask = sf_uniform(*live) & 0xffu;
     if (__popc(mask) > 2) { // the full kernel's case
@@ -980,33 +992,36 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SPFH_WPB))), block(64 * SF_SPFH_WPB);
     const sf_dispatch dsp = sf_nbrs_dispatch(nb);
     const dim3 grid_tail(sf_xcd_grid(sf_div_up(dsp.n_tail > 0 ? dsp.n_tail : 1, SF_SPFH_WPB)));
+    const dim3 grid_mid(sf_xcd_grid(sf_div_up(dsp.n_mid > 0 ? dsp.n_mid : 1, SF_SPFH_WPB)));
     uint8_t *const hi_rows = sp->elem_bytes == 1 ? sp->hi : nullptr;
-#define SF_SPFH_NB(NAME, GRID, CT, NCH, NB, SEL)                                                                        \
+#define SF_SPFH_NB(NAME, GRID, CT, NCH, NB, SEL, SELP, NSEL)                                                            \
     SF_LAUNCH(ctx, NAME, (k_spfh<CT, NCH, NB, SEL>), GRID, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
               nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov, \
               sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max, fused_packed, fused_b0, fused_b1,   \
-              hi_rows, dsp.limit, dsp.tail_sel, dsp.n_tail, dsp.view_first)
-#define SF_SPFH_LAUNCH(NAME, GRID, CT, NCH, SEL)                                                                        \
+              hi_rows, dsp.limit, SELP, NSEL, dsp.view_first)
+#define SF_SPFH_LAUNCH(NAME, GRID, CT, NCH, SEL, SELP, NSEL)                                                            \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
-    case 1: { SF_SPFH_NB(NAME, GRID, CT, NCH, 1, SEL); } break;                                                        \
-    case 2: { SF_SPFH_NB(NAME, GRID, CT, NCH, 2, SEL); } break;                                                        \
-    case 3: { SF_SPFH_NB(NAME, GRID, CT, NCH, 3, SEL); } break;                                                        \
-    case 4: { SF_SPFH_NB(NAME, GRID, CT, NCH, 4, SEL); } break;                                                        \
-    case 5: { SF_SPFH_NB(NAME, GRID, CT, NCH, 5, SEL); } break;                                                        \
-    case 6: { SF_SPFH_NB(NAME, GRID, CT, NCH, 6, SEL); } break;                                                        \
-    case 7: { SF_SPFH_NB(NAME, GRID, CT, NCH, 7, SEL); } break;                                                        \
-    default: { SF_SPFH_NB(NAME, GRID, CT, NCH, 8, SEL); } break;                                                       \
+    case 1: { SF_SPFH_NB(NAME, GRID, CT, NCH, 1, SEL, SELP, NSEL); } break;                                            \
+    case 2: { SF_SPFH_NB(NAME, GRID, CT, NCH, 2, SEL, SELP, NSEL); } break;                                            \
+    case 3: { SF_SPFH_NB(NAME, GRID, CT, NCH, 3, SEL, SELP, NSEL); } break;                                            \
+    case 4: { SF_SPFH_NB(NAME, GRID, CT, NCH, 4, SEL, SELP, NSEL); } break;                                            \
+    case 5: { SF_SPFH_NB(NAME, GRID, CT, NCH, 5, SEL, SELP, NSEL); } break;                                            \
+    case 6: { SF_SPFH_NB(NAME, GRID, CT, NCH, 6, SEL, SELP, NSEL); } break;                                            \
+    case 7: { SF_SPFH_NB(NAME, GRID, CT, NCH, 7, SEL, SELP, NSEL); } break;                                            \
+    default: { SF_SPFH_NB(NAME, GRID, CT, NCH, 8, SEL, SELP, NSEL); } break;                                           \
     }
-    // the main launch in the register-cached form the lists call for, then the points it left out in the streaming form
-#define SF_SPFH_DISPATCH(CT)                                                        \
-    switch (dsp.chunks) {                                                           \
-    case 1: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 1, false); } break;               \
-    case 2: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 2, false); } break;               \
-    case 3: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 3, false); } break;               \
-    case 4: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 4, false); } break;               \
-    default: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 0, false); } break;              \
-    }                                                                               \
-    if (dsp.n_tail) { SF_SPFH_LAUNCH("k6_spfh_tail", grid_tail, CT, 0, true); }
+    // the main launch in the register-cached form the bulk of the lists calls for; the few lists that need more chunks in the
+    // 4-chunk instantiation of the same form; the points with more than 255 neighbours in the streaming form
+#define SF_SPFH_DISPATCH(CT)                                                                        \
+    switch (dsp.chunks) {                                                                           \
+    case 1: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 1, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
+    case 2: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 2, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
+    case 3: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 3, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
+    case 4: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 4, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
+    default: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 0, false, (const int32_t *)nullptr, (int64_t)0); } break;               \
+    }                                                                                               \
+    if (dsp.n_mid) { SF_SPFH_LAUNCH("k6_spfh_mid", grid_mid, CT, 4, true, dsp.mid_sel, dsp.n_mid); } \
+    if (dsp.n_tail) { SF_SPFH_LAUNCH("k6_spfh_tail", grid_tail, CT, 0, true, dsp.tail_sel, dsp.n_tail); }
     uint8_t *fused_packed = nullptr;
     int fused_b0 = -1, fused_b1 = -1;
     if (sp->elem_bytes == 1) {
@@ -1285,11 +1300,17 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
         d.chunks = d.chunks == 0 ? 4 : d.chunks;
         d.limit = 255;
     }
-    const bool any_tail = nb->max_count > d.limit;
+    if (kp_pos && d.n_mid) { // keypoints by index have no selections: one launch that holds every list of at most 255 points
+        d.chunks = 4;
+        d.limit = 255;
+        d.n_mid = 0;
+    }
+    const int long_limit = 255; // lists above it: k_fpfh_tail
+    const bool any_tail = nb->max_count > long_limit;
     const uint8_t *hi = sp->hi;
 #define SF_MC_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, sp->nb3, (const uint8_t *)sp->counts,       \
                    (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, (const uint8_t *)sp->packed,                \
-                   (unsigned)((size_t)sp->rows_alloc * 32), dout, hi, d.limit
+                   (unsigned)((size_t)sp->rows_alloc * 32), dout, hi
     // Which form runs is decided here, on the table-wide block mask -- read back once per K6 (8 bytes; the one host
     // round trip of sf_fpfh: it waits for K6, so a caller that wants it hidden queues independent work first, as
     // DescriptorJob does with the frame eigen-solves on the side stream).  Both kernels re-check the mask on the device.
@@ -1306,15 +1327,21 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
         }
     }
     const bool sparse = __builtin_popcount(sp->host_live[0] & 0xffu) <= 2;
-#define SF_MC_LAUNCH2(NKS, HI)                                                                                       \
-    if (sparse) { SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh_mc_sparse<NKS, HI>), grid, block, SF_MC_ARGS); }                 \
-    else { SF_LAUNCH(ctx, "k7_fpfh", (k_fpfh_mc<NKS, HI>), grid, block, SF_MC_ARGS); }
+#define SF_MC_LAUNCH2(NAME, GRID, NKS, HI, LIMIT, SELP, NSEL)                                                         \
+    if (sparse) { SF_LAUNCH(ctx, NAME, (k_fpfh_mc_sparse<NKS, HI>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); } \
+    else { SF_LAUNCH(ctx, NAME, (k_fpfh_mc<NKS, HI>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); }
 #define SF_MC_LAUNCH(NKS)                                                                                            \
-    if (hi) { SF_MC_LAUNCH2(NKS, true) } else { SF_MC_LAUNCH2(NKS, false) }
+    if (hi) { SF_MC_LAUNCH2("k7_fpfh", grid, NKS, true, d.limit, (const int32_t *)nullptr, (int64_t)0) }             \
+    else { SF_MC_LAUNCH2("k7_fpfh", grid, NKS, false, d.limit, (const int32_t *)nullptr, (int64_t)0) }
     if (d.chunks <= 1) { SF_MC_LAUNCH(1); }
     else if (d.chunks == 2) { SF_MC_LAUNCH(2); }
     else if (d.chunks == 3) { SF_MC_LAUNCH(3); }
     else { SF_MC_LAUNCH(4); }
+    if (d.n_mid) { // the few lists that need more chunks than the bulk: the same form, four chunks
+        const dim3 grid_mid(sf_xcd_grid(sf_div_up(d.n_mid, SF_MC_WPB)));
+        if (hi) { SF_MC_LAUNCH2("k7_fpfh_mid", grid_mid, 4, true, 255, d.mid_sel, d.n_mid) }
+        else { SF_MC_LAUNCH2("k7_fpfh_mid", grid_mid, 4, false, 255, d.mid_sel, d.n_mid) }
+    }
 #undef SF_MC_LAUNCH
 #undef SF_MC_LAUNCH2
 #undef SF_MC_ARGS
@@ -1327,7 +1354,7 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
         const unsigned rest = m8 & (m8 - 1u);
         const int pb1 = rest ? __builtin_ffs((int)rest) - 1 : (pb0 + 1) & 7; // (same pairing as spfh_pack_row)
 #define SF_TAIL_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, sp->nb3, (const uint8_t *)sp->counts, hi, \
-                     (const double *)sp->p4, dout, d.limit
+                     (const double *)sp->p4, dout, long_limit
 #define SF_TAIL_LAUNCH(SEL, GRID, SELP, NSEL, VF)                                                                        \
         if (packed_ok) { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_tail<SEL, true>), dim3(sf_xcd_grid(sf_div_up(GRID, 4))), dim3(256), SF_TAIL_ARGS, SELP, NSEL, VF, (const uint8_t *)sp->packed, pb0, pb1); } \
         else { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_tail<SEL, false>), dim3(sf_xcd_grid(sf_div_up(GRID, 4))), dim3(256), SF_TAIL_ARGS, SELP, NSEL, VF, (const uint8_t *)sp->packed, pb0, pb1); }

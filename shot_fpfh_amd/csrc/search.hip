@@ -754,13 +754,19 @@ struct count_longer {
     int limit;
     __host__ __device__ bool operator()(int32_t q) const { return count[q] > limit; }
 };
+struct count_between { // lo < count <= hi
+    const int32_t *count;
+    int lo, hi;
+    __host__ __device__ bool operator()(int32_t q) const { const int c = count[q]; return c > lo && c <= hi; }
+};
 struct count_of {
     const int32_t *count;
     __host__ __device__ int64_t operator()(int32_t q) const { return (int64_t)count[q]; }
 };
 
-// the processing slots whose list is longer than `limit`, ascending (`expect` of them: known from the statistics)
-static int select_longer(sf_ctx *ctx, const int32_t *count, int64_t m, int limit, int64_t expect, int32_t **out)
+// the processing slots whose list length satisfies `pred`, ascending (`expect` of them: known from the statistics)
+template <typename Pred>
+static int select_slots(sf_ctx *ctx, int64_t m, Pred pred, int64_t expect, int32_t **out)
 {
     sf_pool_guard tmp(ctx);
     size_t *dnum = nullptr;
@@ -768,14 +774,18 @@ static int select_longer(sf_ctx *ctx, const int32_t *count, int64_t m, int limit
     SF_CHECK(sf_palloc(ctx, out, (size_t)expect + 1));
     rocprim::counting_iterator<int32_t> first(0);
     size_t tb = 0;
-    SF_HIP(rocprim::select(nullptr, tb, first, *out, dnum, (size_t)m, count_longer{count, limit}, ctx->stream));
+    SF_HIP(rocprim::select(nullptr, tb, first, *out, dnum, (size_t)m, pred, ctx->stream));
     char *scratch = nullptr;
     SF_CHECK(tmp.alloc(&scratch, tb ? tb : 8));
     {
         sf_launch_timer t_(ctx, "k2_select");
-        SF_HIP(rocprim::select(scratch, tb, first, *out, dnum, (size_t)m, count_longer{count, limit}, ctx->stream));
+        SF_HIP(rocprim::select(scratch, tb, first, *out, dnum, (size_t)m, pred, ctx->stream));
     }
     return SF_OK;
+}
+static int select_longer(sf_ctx *ctx, const int32_t *count, int64_t m, int limit, int64_t expect, int32_t **out)
+{
+    return select_slots(ctx, m, count_longer{count, limit}, expect, out);
 }
 
 __global__ void k_iota_stride(int32_t *__restrict__ out, int64_t n, int64_t stride)
@@ -804,13 +814,32 @@ static int plan_dispatch(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     // chunk count of the main launch's instantiation only has to cover the longest list it serves (the instantiations of
     // one form agree bit for bit: chunks past a list's end contribute nothing).
     const int64_t longest_main = std::min<int64_t>(nb->max_count > 0 ? nb->max_count : 1, 255);
-    int chunks = (int)sf_div_up(longest_main, 64);
-    if (const char *e = getenv("SF_MAIN_CHUNKS")) { const int v = atoi(e); if (v >= chunks && v <= 4) chunks = v; } // (experiments)
+    const int need = (int)sf_div_up(longest_main, 64); // chunks that cover every list of at most 255 points
+    // ... but when only a small share of those lists needs the last chunks, the bulk runs the leaner instantiation and that
+    // share gets a launch of its own in the 4-chunk instantiation of the same form (bit-identical rows either way): the
+    // smallest chunk count that leaves at most 2 % of the (<= 255-point) lists to it.  (At C3 8 % of the lists need the third
+    // chunk: a split there costs more than it gains -- the second launch's scattered keypoints run 1.4x slower each, DESIGN
+    // fact 19.)
+    int chunks = need;
+    {
+        const int64_t fit = nb->hist[0] + nb->hist[1] + nb->hist[2] + nb->hist[3];
+        int64_t within = 0;
+        for (int c = 0; c < need; ++c) {
+            within += nb->hist[c];
+            if ((fit - within) * 50 <= fit) { chunks = c + 1; break; }
+        }
+        if (getenv("SF_NO_MID_LAUNCH")) chunks = need;
+    }
+    if (const char *e = getenv("SF_MAIN_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 4) chunks = std::min(v, need); } // (experiments)
     nb->planned = true;
     nb->main_chunks = chunks;
+    nb->n_mid = 0;
+    for (int c = chunks; c < 4; ++c) nb->n_mid += nb->hist[c];
+    if (chunks == need) nb->n_mid = 0;
     nb->tail_limit = 255;
     nb->n_tail = nb->hist[4];
     if (nb->max_count <= nb->tail_limit) { nb->tail_limit = 0x7fffffff; nb->n_tail = 0; }
+    if (nb->n_mid) SF_CHECK(select_slots(ctx, m, count_between{nb->count, 64 * chunks, 255}, nb->n_mid, &nb->mid_sel));
     if (nb->n_tail) SF_CHECK(select_longer(ctx, nb->count, m, nb->tail_limit, nb->n_tail, &nb->tail_sel));
     return SF_OK;
 }
@@ -1358,6 +1387,8 @@ extern "C" sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nb, int64_t first, int64
     v->tail_limit = nb->tail_limit;
     v->tail_sel = nb->tail_sel;
     v->n_tail = nb->n_tail;
+    v->mid_sel = nb->mid_sel;
+    v->n_mid = nb->n_mid;
     v->view_first = nb->view_first + first;
     v->cap = nb->cap;
     v->total = -1; // unknown without a device read; views are for compute, not export
@@ -1453,5 +1484,6 @@ extern "C" void sf_nbrs_free(sf_ctx *ctx, sf_nbrs *nb)
     sf_pool_release(ctx, nb->idx);
     sf_pool_release(ctx, nb->idx_ovf);
     sf_pool_release(ctx, nb->tail_sel);
+    sf_pool_release(ctx, nb->mid_sel);
     delete nb;
 }

@@ -385,3 +385,44 @@ def test_fused_normals_sweep_is_bit_identical_to_search_plus_normals(eng, O, kin
     assert np.abs(b[ok][:400] - wo).max() < 1e-9
     for obj in (want, got, part, cloud):
         obj.free()
+
+
+# ---- the few lists that need more chunks than the bulk ---------------------------------------------------------------------
+def test_a_launch_of_its_own_for_the_lists_that_need_more_chunks_changes_no_bit(eng, O):
+    """A uniform cloud at ~40 neighbours: 99 % of the lists fit one 64-neighbour chunk, a fraction of a per cent needs two.  The
+    bulk runs the 1-chunk instantiations, the rest a 4-chunk launch of the SAME forms over a selection (k*_mid) -- and every
+    row equals, bit for bit, the run that serves everybody with the 2-chunk instantiations (SF_NO_MID_LAUNCH=1)."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    p, nr, _ = synth_cloud(60000, 31)
+    r = 0.057
+    outs = []
+    for env in (None, "1"):
+        if env:
+            os.environ["SF_NO_MID_LAUNCH"] = env
+        try:
+            job = DescriptorJob(eng, p, nr, r, n_bins=5, min_neighborhood_size=5)
+            _, rep = launches(eng, job.step)
+            nrm = eng.empty((job.cloud.n, 3))
+            nb = job.cloud.radius_search_self(r)
+            cnt = nb.counts()
+            nb.normals(out=nrm)
+            nb.free()
+            orig = job.block_original_indices()
+            outs.append((job.fpfh_out.to_host(), job.shot_out.to_host(), job.lrf_out.to_host(), nrm.to_host(), rep))
+            nrm.free()
+            job.close()
+        finally:
+            os.environ.pop("SF_NO_MID_LAUNCH", None)
+    share = (cnt > 64).mean()
+    assert 0 < share <= 0.02 and cnt.max() <= 128, (share, cnt.max())
+    a, b = outs
+    for name in ("k5_shot_mid", "k6_spfh_mid", "k7_fpfh_mid"):
+        assert a[4].get(name) == 1 and name not in b[4], (name, a[4], b[4])
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y)
+    rows = np.sort(np.concatenate([np.flatnonzero(cnt > 64)[:60], np.arange(0, 60000, 1500)]))
+    want = O.compute_fpfh_descriptor_sample(orig[rows], p, nr, r, 5)
+    assert np.abs(a[0][rows] - want).max() < 1e-9
+    want_s = O.shot_single_scale(p, nr, p[orig[rows]], r, True, 5)
+    assert np.abs(a[1][rows] - want_s).max() < 1e-9
