@@ -415,6 +415,7 @@ def time_steps(job, eng, steps: int, warmup: int, barrier, max_over_ranks, with_
     elapsed = time.perf_counter() - t0
     eng.profile(False)
     eng.profile_only(None)
+    time_steps.own_elapsed = elapsed  # (this rank's own time: the record lists every rank's)
     elapsed = max_over_ranks(elapsed)
     rep = eng.profile_report()
     extra_rep, extra_steps = {}, 0
@@ -650,7 +651,8 @@ def main() -> int:
     n_desc = kinds * n_total
     ms_per_step = 1000.0 * elapsed / args.steps
     value = n_desc / (elapsed / args.steps)
-    per_rank_ms = [ms_per_step] if ctl is None else ctl.allgather(ms_per_step)
+    own_ms = 1000.0 * time_steps.own_elapsed / args.steps
+    per_rank_ms = [own_ms] if ctl is None else ctl.allgather(own_ms)
     # ---- sustained: the same step for >= 2 s (>= 500 steps), no per-kernel events; if it disagrees with the K-step figure by
     #      more than 2 % the sustained figure is the one `value` reports (and the record says so) ------------------------------
     sustained = None
