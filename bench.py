@@ -786,6 +786,29 @@ def main() -> int:
             if kinds == 2 else None,
         }
 
+    # ---- K2's slot capacity: the timed steps size it from the statistics of the previous search with this radius on the cloud
+    #      (a capacity hint, never an output: a list that outgrows its slot is re-done exactly).  What the step costs when
+    #      every search counts a fresh 2 048-query sample instead (SF_K2_NO_HINT=1, what a FIRST search on a cloud does): ------
+    if lead is not None and not args.no_kernel_timers and args.sustained_seconds > 0:
+        os.environ["SF_K2_NO_HINT"] = "1"
+        try:
+            job.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                job.step()
+            barrier()
+            t_nohint = max_over_ranks(time.perf_counter() - t0) / args.steps
+        finally:
+            del os.environ["SF_K2_NO_HINT"]
+        if lead:
+            out["k2_slot_capacity"] = {
+                "timed_steps_use": "mean and maximum list length of the previous search with this radius on this cloud (sf_cloud::list_stats)",
+                "ms_per_step_with_a_sample_counted_in_every_search": 1000.0 * t_nohint,
+                "ms_per_step_timed": ms_per_step,
+                "what": "SF_K2_NO_HINT=1: every radius search first counts the lists of 2 048 sampled queries (one small launch, "
+                        "8 KB read back) before it sizes its slots -- the cost of a first search on a cloud"}
+
     # ---- parity of what the timed steps left in HBM ------------------------------------------------------------------
     if not args.no_parity:
         par = parity_sample(job, points, normals, radius, args.parity_rows)
