@@ -316,3 +316,52 @@ def test_drop_in_calls_accept_numpy_argument_forms(eng):
     assert s.compute_fpfh_descriptor(np.zeros(0, dtype=np.int64), p, nr, r, 5).shape == (0, 125)
     with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
         assert sm.compute_descriptor_single_scale(p, nr, np.zeros((0, 3)), r).shape == (0, 352)
+
+
+# ---- round 4: the paths a small cloud never reaches -------------------------------------------------------------------------
+# 20 000 points (the single-sweep search with sampled slots, not the exact two-pass scheme of small query sets) at radii that
+# put hundreds of points into many balls: second launches for long lists (K3, K5, K6, K7), the table of high bytes, the
+# matrix-core form's high-byte term, lists overflowing their slots.  One seed by default (the oracle needs ~10 s per family).
+LONG_SEEDS = SEEDS[:1] if not _sweep else SEEDS
+
+
+@pytest.mark.parametrize("seed", LONG_SEEDS)
+@pytest.mark.parametrize("name", ["uniform", "clustered", "rough_plane", "duplicates", "far_origin", "slab"])
+def test_long_lists_vs_oracle(eng, O, name, seed):
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    rng = np.random.default_rng(FAMILIES.index(name) + 900 + 7919 * seed)
+    p, nr, ties, flat = family(name, 20000, rng)
+    n = p.shape[0]
+    if name in ("rough_plane", "slab"):  # consistent normals: bin counts close to the list length (high bytes really used)
+        nr = np.tile(np.array([[0.0, 0.0, 1.0]]), (n, 1))
+    r = _radius_for(p, rng, int(rng.choice([260, 320, 400])))
+    cloud = eng.cloud(p)
+    for _ in range(6):  # (the jittered radius may leave every list short: grow it until some list exceeds 255 points)
+        nb = cloud.radius_search_self(r)
+        cnt = nb.counts()[np.argsort(cloud.perm())]  # by original index
+        nb.free()
+        if cnt.max() > 300:
+            break
+        r *= 1.2
+    cloud.free()
+    assert cnt.max() > 255, (name, cnt.max())
+    # keypoints of every kind: the longest lists, lists around the 255 / 256 boundary, short ones, random ones
+    order = np.argsort(cnt)
+    near = order[np.searchsorted(cnt[order], 250):np.searchsorted(cnt[order], 262)][:30]
+    kp = np.unique(np.concatenate([order[-40:], near, order[:20], rng.choice(n, 60, replace=False)]))
+    n_bins = int(rng.choice([3, 4, 5]))
+    got = s.compute_fpfh_descriptor(kp, p, nr, r, n_bins, verbose=False)
+    want = O.compute_fpfh_descriptor(kp, p, nr, r, n_bins)
+    assert np.abs(got - want).max() < 1e-9, (name, n_bins, r, np.abs(got - want).max())
+    pre = np.tile(np.array([[0.0, 0.0, 1.0]]), (kp.size, 1))
+    a = s.compute_normals(p[kp], p, radius=r, pre_computed_normals=pre)
+    b = O.compute_normals(p[kp], p, radius=r, pre_computed_normals=pre)
+    if not flat:
+        assert np.abs(a - b).max() < 1e-9, (name, np.abs(a - b).max())
+    if not ties and not flat:
+        with ShotMultiprocessor(min_neighborhood_size=int(rng.choice([5, 100])), normalize=bool(rng.integers(0, 2)), verbose=False) as sm:
+            d = sm.compute_descriptor_single_scale(p, nr, p[kp], r)
+            do = O.shot_single_scale(p, nr, p[kp], r, sm.normalize, sm.min_neighborhood_size)
+        assert np.abs(d - do).max() < 1e-9, (name, np.abs(d - do).max())
