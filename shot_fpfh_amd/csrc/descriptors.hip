@@ -256,7 +256,11 @@ __global__ __launch_bounds__(128) void k_pca_cov(const double *__restrict__ rec,
             sx += gx - px; sy += gy - py; sz += gz - pz;
         }
     }
-    const double mx = sf_wave_sum(sx) / kk, my = sf_wave_sum(sy) / kk, mz = sf_wave_sum(sz) / kk;
+    // (ONE division per query: 1 / k, then products -- a float64 division is ~35 instructions executed by the whole wave, and
+    // the four of `mean = sum / k`, `cov = moments / k` were a fifth of this kernel; the quotients differ from true divisions
+    // in the last bit, as the sums already differ from NumPy's in their association.  k_radius_cov forms the same products.)
+    const double ik = 1.0 / kk;
+    const double mx = sf_wave_sum(sx) * ik, my = sf_wave_sum(sy) * ik, mz = sf_wave_sum(sz) * ik;
     double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (NCH > 0) {
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(128) void k_pca_cov(const double *__restrict__ rec,
     }
     const double tot = sf_wave_sum8(part); // lanes 8 i .. 8 i + 7 hold the sum of part[i]
     const int e = lane >> 3;
-    if ((lane & 7) == 0 && e < 6) cov[6 * q + e] = tot / kk; // c11 c21 c31 c22 c32 c33
+    if ((lane & 7) == 0 && e < 6) cov[6 * q + e] = tot * ik; // c11 c21 c31 c22 c32 c33
     if (bary && lane == 0) { bary[3 * q] = mx; bary[3 * q + 1] = my; bary[3 * q + 2] = mz; }
 }
 

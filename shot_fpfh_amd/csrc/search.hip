@@ -343,13 +343,13 @@ __global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, 
         SF_K2C_LDS_SYNC(); // (the previous query's reads of L are done)
         const int k = sweep(256, [](int) {});
         SF_K2C_LDS_SYNC();
-        const double kk = (double)k;
+        const double kk = (double)k, ik = 1.0 / kk; // (one division per query, as k_pca_cov)
         double sx = 0.0, sy = 0.0, sz = 0.0;
         double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         double mx, my, mz;
         if (k <= 256) {
             for (int t = lane; t < k; t += 64) { sx += L.x[t]; sy += L.y[t]; sz += L.z[t]; }
-            mx = sf_wave_sum(sx) / kk; my = sf_wave_sum(sy) / kk; mz = sf_wave_sum(sz) / kk;
+            mx = sf_wave_sum(sx) * ik; my = sf_wave_sum(sy) * ik; mz = sf_wave_sum(sz) * ik;
             for (int t = lane; t < k; t += 64) {
                 const double ax = L.x[t] - mx, ay = L.y[t] - my, az = L.z[t] - mz;
                 part[0] += ax * ax;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, 
             sweep(0x7fffffff, bary_step);
             SF_K2C_LDS_SYNC();
             if (done + lane < k) { const int t = (done + lane) & 255; sx += L.x[t]; sy += L.y[t]; sz += L.z[t]; }
-            mx = sf_wave_sum(sx) / kk; my = sf_wave_sum(sy) / kk; mz = sf_wave_sum(sz) / kk;
+            mx = sf_wave_sum(sx) * ik; my = sf_wave_sum(sy) * ik; mz = sf_wave_sum(sz) * ik;
             auto add_moments = [&](int t) {
                 const double ax = L.x[t] - mx, ay = L.y[t] - my, az = L.z[t] - mz;
                 part[0] += ax * ax;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, 
         }
         const double tot = sf_wave_sum8(part); // lanes 8 i .. 8 i + 7 hold the sum of part[i]
         const int e = lane >> 3;
-        if ((lane & 7) == 0 && e < 6) cov[6 * q + e] = tot / kk; // c11 c21 c31 c22 c32 c33
+        if ((lane & 7) == 0 && e < 6) cov[6 * q + e] = tot * ik; // c11 c21 c31 c22 c32 c33
         if (bary && lane == 0) { bary[3 * q] = mx; bary[3 * q + 1] = my; bary[3 * q + 2] = mz; }
         if (count && lane == 0) count[q] = k;
     }
