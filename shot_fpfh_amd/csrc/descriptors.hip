@@ -260,7 +260,9 @@ __global__ __launch_bounds__(128) void k_pca_cov(const double *__restrict__ rec,
     // the four of `mean = sum / k`, `cov = moments / k` were a fifth of this kernel; the quotients differ from true divisions
     // in the last bit, as the sums already differ from NumPy's in their association.  k_radius_cov forms the same products.)
     const double ik = 1.0 / kk;
-    const double mx = sf_wave_sum(sx) * ik, my = sf_wave_sum(sy) * ik, mz = sf_wave_sum(sz) * ik;
+    const double bs[4] = {sx, sy, sz, 0.0};
+    const double bt = sf_wave_sum4(bs); // (row i of 16 lanes: the sum of bs[i]; k_radius_cov reduces the same way)
+    const double mx = sf_read_lane(bt, 0) * ik, my = sf_read_lane(bt, 16) * ik, mz = sf_read_lane(bt, 32) * ik;
     double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (NCH > 0) {
 #pragma unroll

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
 // written their indices), and the barycentre / centred second moments are formed from there exactly as k_pca_cov forms them
 // from the materialised list (same terms, same lane assignment t -> lane t % 64, same reductions): the six numbers per query
 // are bit-identical to sf_radius_search + sf_normals, and neither the 4 B per pair of the lists nor the 24 B per pair of
-// their gather ever touch HBM.  Lists of at most 256 points sit in LDS whole (6 KB per wave); a longer one (wave-uniform,
+// their gather ever touch HBM.  Lists of at most SF_K2C_LIST points sit in LDS whole (4.6 KB per wave); a longer one (wave-uniform,
 // per query) is swept twice more through the same LDS as a ring -- whenever 64 consecutive list positions are complete the
 // lanes consume them -- once for the barycentre, once for the moments: the streaming form of k_pca_cov, again bit for bit.
 // Set-up and sweep are k_radius's (four queries per wave, run tables per 16-lane row, candidate pairs).
@@ -241,9 +241,12 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
 #ifndef SF_K2C_WPB
 #define SF_K2C_WPB 4
 #endif
-struct sf_cov_list { double x[256], y[256], z[256]; };
+#ifndef SF_K2C_LIST
+#define SF_K2C_LIST 192 // entries of the LDS list / ring: a multiple of 64, at least 192 (a sweep step adds up to 128 hits to < 64 unconsumed ones)
+#endif
+struct sf_cov_list { double x[SF_K2C_LIST], y[SF_K2C_LIST], z[SF_K2C_LIST]; };
 
-__global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, const int32_t *__restrict__ cell_start,
+__global__ __launch_bounds__(64 * SF_K2C_WPB) __attribute__((amdgpu_waves_per_eu(7))) void k_radius_cov(sf_grid_desc g, const int32_t *__restrict__ cell_start,
                                                 const double *__restrict__ xs, const double *__restrict__ ys,
                                                 const double *__restrict__ zs, const double *__restrict__ qx,
                                                 const double *__restrict__ qy, const double *__restrict__ qz,
@@ -308,9 +311,9 @@ __global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, 
         const double px = __shfl(pxv, 16 * qi), py = __shfl(pyv, 16 * qi), pz = __shfl(pzv, 16 * qi);
         const int b4 = __shfl(first_slot, 16 * qi + 4), b8 = __shfl(first_slot, 16 * qi + 8);
         const int nslots = sf_uniform(__shfl(first_slot, 16 * qi + 9));
-        // one sweep over the candidates; hits land in L at (list position & 255) when that position is below `keep`;
+        // one sweep over the candidates; hits land in L at (list position, modulo the list's size in ring mode) when that position is below `keep`;
         // after_step(total so far) runs once per 128 candidates
-        auto sweep = [&](int keep, auto &&after_step) -> int {
+        auto sweep = [&](int keep, bool wrap, auto &&after_step) -> int { // wrap: L is a ring (positions modulo its size)
             int total = 0;
             for (int f0 = 0; f0 < nslots; f0 += 64) {
                 const int f = f0 + lane;
@@ -332,24 +335,29 @@ __global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, 
                 const bool hit1 = in1 & (d2b <= r2);
                 const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
                 const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
-                if (hit0 && pos < keep) { L.x[pos & 255] = dxa; L.y[pos & 255] = dya; L.z[pos & 255] = dza; }
                 const int pos1 = pos + (hit0 ? 1 : 0);
-                if (hit1 && pos1 < keep) { L.x[pos1 & 255] = dxb; L.y[pos1 & 255] = dyb; L.z[pos1 & 255] = dzb; }
+                const int s0 = wrap ? pos % SF_K2C_LIST : pos, s1 = wrap ? pos1 % SF_K2C_LIST : pos1;
+                if (hit0 && pos < keep) { L.x[s0] = dxa; L.y[s0] = dya; L.z[s0] = dza; }
+                if (hit1 && pos1 < keep) { L.x[s1] = dxb; L.y[s1] = dyb; L.z[s1] = dzb; }
                 total += __popcll(m0) + __popcll(m1);
                 after_step(total);
             }
             return total;
         };
         SF_K2C_LDS_SYNC(); // (the previous query's reads of L are done)
-        const int k = sweep(256, [](int) {});
+        const int k = sweep(SF_K2C_LIST, false, [](int) {});
         SF_K2C_LDS_SYNC();
         const double kk = (double)k, ik = 1.0 / kk; // (one division per query, as k_pca_cov)
         double sx = 0.0, sy = 0.0, sz = 0.0;
         double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         double mx, my, mz;
-        if (k <= 256) {
+        if (k <= SF_K2C_LIST) {
             for (int t = lane; t < k; t += 64) { sx += L.x[t]; sy += L.y[t]; sz += L.z[t]; }
-            mx = sf_wave_sum(sx) * ik; my = sf_wave_sum(sy) * ik; mz = sf_wave_sum(sz) * ik;
+            {
+                const double bs[4] = {sx, sy, sz, 0.0};
+                const double bt = sf_wave_sum4(bs); // (as k_pca_cov)
+                mx = sf_read_lane(bt, 0) * ik; my = sf_read_lane(bt, 16) * ik; mz = sf_read_lane(bt, 32) * ik;
+            }
             for (int t = lane; t < k; t += 64) {
                 const double ax = L.x[t] - mx, ay = L.y[t] - my, az = L.z[t] - mz;
                 part[0] += ax * ax;
@@ -365,17 +373,21 @@ __global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, 
                 if (done + 64 <= total) {
                     SF_K2C_LDS_SYNC();
                     while (done + 64 <= total) {
-                        const int t = (done + lane) & 255;
+                        const int t = (done + lane) % SF_K2C_LIST;
                         sx += L.x[t]; sy += L.y[t]; sz += L.z[t];
                         done += 64;
                     }
                     SF_K2C_LDS_SYNC();
                 }
             };
-            sweep(0x7fffffff, bary_step);
+            sweep(0x7fffffff, true, bary_step);
             SF_K2C_LDS_SYNC();
-            if (done + lane < k) { const int t = (done + lane) & 255; sx += L.x[t]; sy += L.y[t]; sz += L.z[t]; }
-            mx = sf_wave_sum(sx) * ik; my = sf_wave_sum(sy) * ik; mz = sf_wave_sum(sz) * ik;
+            if (done + lane < k) { const int t = (done + lane) % SF_K2C_LIST; sx += L.x[t]; sy += L.y[t]; sz += L.z[t]; }
+            {
+                const double bs[4] = {sx, sy, sz, 0.0};
+                const double bt = sf_wave_sum4(bs); // (as k_pca_cov)
+                mx = sf_read_lane(bt, 0) * ik; my = sf_read_lane(bt, 16) * ik; mz = sf_read_lane(bt, 32) * ik;
+            }
             auto add_moments = [&](int t) {
                 const double ax = L.x[t] - mx, ay = L.y[t] - my, az = L.z[t] - mz;
                 part[0] += ax * ax;
@@ -390,16 +402,16 @@ __global__ __launch_bounds__(64 * SF_K2C_WPB) void k_radius_cov(sf_grid_desc g, 
                 if (done + 64 <= total) {
                     SF_K2C_LDS_SYNC();
                     while (done + 64 <= total) {
-                        add_moments((done + lane) & 255);
+                        add_moments((done + lane) % SF_K2C_LIST);
                         done += 64;
                     }
                     SF_K2C_LDS_SYNC();
                 }
             };
             SF_K2C_LDS_SYNC();
-            sweep(0x7fffffff, mom_step);
+            sweep(0x7fffffff, true, mom_step);
             SF_K2C_LDS_SYNC();
-            if (done + lane < k) add_moments((done + lane) & 255);
+            if (done + lane < k) add_moments((done + lane) % SF_K2C_LIST);
         }
         const double tot = sf_wave_sum8(part); // lanes 8 i .. 8 i + 7 hold the sum of part[i]
         const int e = lane >> 3;
