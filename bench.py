@@ -66,6 +66,7 @@ ALG_BYTES = {
     "k3_normals": 24 + 24,  # query in, normal out
     "k1_gather_sorted": 48 + 48 + 4,  # xyz + normal in, 48-byte record (+ SoA copy of xyz) out, perm
     "k1_radix_sort": 16,  # (cell id, index) pairs in and out, per pass of the sort -- one pass counted
+    "k1_cell_settle": 8 + 48 + 48 + 4 + 4,  # (index, cell) slot in, xyz + normal in, 48-byte record (+ SoA copy of xyz) out, both permutations
 }
 PER_PAIR = ("k2_radius_fill", "k2_radius_slots")
 C4_EULER, C4_T = (0.3, -0.2, 0.5), (0.1, -0.3, 0.2)  # SURVEY 8d, config C4's rigid motion

@@ -203,6 +203,15 @@ struct sf_cloud {
     // the z coordinates alone, ascending (the sort keys of the upload): a block build finds every z-layer's first point by a
     // binary search in it
     double *z_orig = nullptr;
+    // ... and a host copy of them, made by the first block build (up to SF_Z_HOST_MAX points): the layer bounds of a block build
+    // are then a few binary searches on the host -- no launch, no read-back, and the build no longer waits for whatever the
+    // stream still holds (a job's next pass is queued while the last kernels of the previous one run)
+    std::vector<double> z_host;
+    // the counting build's per-cell counters (grid.hip::k_cell_count): all zero between builds -- the scan that reads them
+    // puts the zeros back, so no build starts with a fill (count_dirty: a build failed in between; zeroed again before use)
+    int32_t *cell_count = nullptr;
+    int64_t cell_count_cap = 0;
+    bool count_dirty = false;
     // first cell-sorted position of every z-layer of cells (dim[2] + 1 entries, host): written by the block build
     // (which needs it anyway), fetched from cell_start on demand after a whole-cloud build (sf_cloud_layer_table)
     std::vector<int64_t> layer_first;

@@ -38,6 +38,15 @@ using sf_onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<S
                                                         SF_SORT_BITS, rocprim::block_radix_rank_algorithm::match>;
 using sf_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, sf_onesweep, 65536>;
 
+// The cell-id sort of a grid build: (key, value) pairs of int32, keys of `bits` bits.  (Smaller blocks / fewer items per thread
+// for small inputs were measured on a 190k-point slab: 45-56 us against 50 -- the sort's time there is its nine dependent
+// launches, not its bytes; such builds take the counting path below.)
+static hipError_t sort_cells(void *tmp, size_t &tmp_bytes, int32_t *key_in, int32_t *key_out, int32_t *val_in, int32_t *val_out, size_t n, int bits,
+                             hipStream_t stream)
+{
+    return rocprim::radix_sort_pairs<sf_sort_config>(tmp, tmp_bytes, key_in, key_out, val_in, val_out, n, 0, bits, stream);
+}
+
 namespace {
 
 __global__ void k_bbox_partial(const double *__restrict__ xyz, int64_t n, double *__restrict__ partial)
@@ -242,6 +251,161 @@ __global__ __launch_bounds__(256) void k_cell_fill_long(const sf_gap *__restrict
     for (unsigned e = 0; e < ng; ++e) {
         const sf_gap g = gaps[e];
         for (int64_t t = tid; t < g.len; t += nt) cell_start[g.lo + t] = g.val;
+    }
+}
+
+// ---- the counting build ------------------------------------------------------------------------------------------------
+// When the grid is not much sparser than the points (at most SF_COUNT_CELLS_PER_POINT cells of the populated slab per point:
+// every uniform or surface cloud at its own radius) the cell order comes from the cell table itself instead of a radix sort:
+//   count   every point adds one to its cell's counter; what the atomic returns is its (arbitrary) place among the cell's points
+//   scan    exclusive prefix sum of the counters = the cell table (one pass, decoupled look-back); cells outside the slab filled;
+//           the counters go back to zero (they belong to the cloud and are zero between builds: no fill launch)
+//   place   every point drops (its index, its cell) at cell start + that place
+//   settle  every position ranks its index among the cell's (a cell holds ~1 point; k points cost k compares each, which is
+//           k / 67 of what the radius search spends on the same point) and gathers its point to cell start + rank
+// = the stable order the radix sort gives (ascending internal index inside a cell), bit for bit, in four dependent GPU
+// operations instead of thirteen (rocPRIM's Onesweep alone is two kernels + two passes + five fills): a build of a 190k-point
+// slab is bound by that count, not by bytes.
+#define SF_COUNT_CELLS_PER_POINT 8
+#define SF_Z_HOST_MAX 67108864LL // points: up to here a block build keeps the sorted z coordinates on the host too (512 MB)
+#define SF_Z_HOST_LAYERS 4096    // ... and looks the layer bounds up there if the grid has at most this many z-layers
+#define SF_SCAN_TPB 256
+#define SF_SCAN_ITEMS 16
+#define SF_SCAN_TILE (SF_SCAN_TPB * SF_SCAN_ITEMS)
+#define SF_SCAN_AGGREGATE (1ull << 62)
+#define SF_SCAN_PREFIX (2ull << 62)
+
+__global__ void k_cell_count(const double *__restrict__ xyz, int64_t first, int64_t n, sf_grid_desc g, int cid_base,
+                             int32_t *__restrict__ count, int32_t *__restrict__ cid, int32_t *__restrict__ place,
+                             unsigned long long *__restrict__ status, int64_t n_status)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_status) status[i] = 0ull; // (the scan's ticket + tile states: no fill launch of their own)
+    if (i >= n) return;
+    const int64_t o = first + i;
+    const int cx = sf_cell_coord(xyz[3 * o + 0], g.lo[0], g.inv_cell_x, g.dim[0]);
+    const int cy = sf_cell_coord(xyz[3 * o + 1], g.lo[1], g.inv_cell, g.dim[1]);
+    const int cz = sf_cell_coord(xyz[3 * o + 2], g.lo[2], g.inv_cell, g.dim[2]);
+    const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx - cid_base;
+    cid[i] = c;
+    place[i] = atomicAdd(&count[c], 1);
+}
+
+// cell_start[cid_base + c] = base + (number of points in the slab's cells before c) from the counters count[c]; the cells
+// in front of the slab get base, those behind it (and the one-past-the-end entry) base + ns.  Blocks [0, slab_tiles) take the
+// slab's tiles in the order they START (a ticket), so a tile's predecessors are always resident: the look-back cannot starve.
+__global__ __launch_bounds__(SF_SCAN_TPB) void k_cell_scan(int32_t *__restrict__ count, int32_t *__restrict__ cell_start, int64_t ncell, int64_t cid_base,
+                                                           int64_t slab_cells, int64_t slab_tiles, int32_t base, int32_t ns,
+                                                           unsigned long long *__restrict__ status)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if ((int64_t)blockIdx.x >= slab_tiles) {
+        const int64_t b = (int64_t)blockIdx.x - slab_tiles, outside = ncell + 1 - slab_cells;
+        for (int k = 0; k < SF_SCAN_ITEMS; ++k) {
+            const int64_t j = b * SF_SCAN_TILE + (int64_t)k * SF_SCAN_TPB + tid;
+            if (j < outside) cell_start[j < cid_base ? j : j + slab_cells] = j < cid_base ? base : base + ns;
+        }
+        return;
+    }
+    __shared__ int64_t s_tile;
+    __shared__ int s_wave[SF_SCAN_TPB / 64];
+    __shared__ int s_prefix;
+    if (tid == 0) s_tile = (int64_t)atomicAdd(&status[0], 1ull);
+    __syncthreads();
+    const int64_t t = s_tile;
+    unsigned long long *st = status + 1;
+    const int64_t c0 = t * SF_SCAN_TILE + (int64_t)tid * SF_SCAN_ITEMS;
+    int32_t *p = cell_start + cid_base + c0, *q = count + c0;
+    const int64_t left = slab_cells - c0;
+    int v[SF_SCAN_ITEMS];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < SF_SCAN_ITEMS; ++k) {
+        const int x = k < left ? q[k] : 0;
+        v[k] = sum;
+        sum += x;
+    }
+#pragma unroll
+    for (int k = 0; k < SF_SCAN_ITEMS; ++k)
+        if (k < left) q[k] = 0; // (the counters are all zero again when the build is over: the next one starts without a fill)
+    int inc = sum; // inclusive scan of the threads' sums over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    int before = inc - sum, total = 0;
+#pragma unroll
+    for (int k = 0; k < SF_SCAN_TPB / 64; ++k) {
+        if (k < w) before += s_wave[k];
+        total += s_wave[k];
+    }
+    if (w == 0) {
+        int excl = 0;
+        if (t == 0) {
+            if (lane == 0) __hip_atomic_store(&st[0], SF_SCAN_PREFIX | (unsigned long long)(unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&st[t], SF_SCAN_AGGREGATE | (unsigned long long)(unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t pos = t - 1;; pos -= 64) {
+                const int64_t j = pos - lane;
+                unsigned long long s;
+                do {
+                    s = j >= 0 ? __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SF_SCAN_PREFIX;
+                } while (__ballot((s >> 62) == 0ull));
+                const unsigned long long have = __ballot((s >> 62) == 2ull);
+                const int stop = have ? __builtin_ctzll(have) : 64; // nearest predecessor that already knows its inclusive prefix
+                int val = lane <= stop ? (int)(unsigned)(s & 0xffffffffull) : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off);
+                excl += val;
+                if (have) break;
+            }
+            if (lane == 0) __hip_atomic_store(&st[t], SF_SCAN_PREFIX | (unsigned long long)(unsigned)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_prefix = excl;
+    }
+    __syncthreads();
+    const int add = base + s_prefix + before;
+#pragma unroll
+    for (int k = 0; k < SF_SCAN_ITEMS; ++k)
+        if (k < left) p[k] = add + v[k];
+}
+
+// slot[cell start + place - base] = (internal index, cell)
+__global__ void k_cell_place(const int32_t *__restrict__ cid, const int32_t *__restrict__ place, const int32_t *__restrict__ start_rel,
+                             int64_t first, int64_t n, int2 *__restrict__ slot)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cid[i];
+    slot[(int64_t)start_rel[c] + place[i] - first] = make_int2((int)(first + i), c);
+}
+
+// position p of the slab: the point that landed there goes to its cell's start + (number of the cell's points with a smaller
+// internal index), and is gathered there (what k_gather_sorted does after a radix sort)
+__global__ void k_cell_settle(const int2 *__restrict__ slot, const int32_t *__restrict__ start_rel, const double *__restrict__ xyz,
+                              const double *__restrict__ nrm, const int32_t *__restrict__ zperm, int32_t *__restrict__ perm,
+                              int32_t *__restrict__ perm_int, int64_t base, int64_t n, double *__restrict__ xs, double *__restrict__ ys,
+                              double *__restrict__ zs, double *__restrict__ rec)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int2 me = slot[p];
+    const int64_t cs = (int64_t)start_rel[me.y] - base, ce = (int64_t)start_rel[me.y + 1] - base;
+    int r = 0;
+    for (int64_t j = cs; j < ce; ++j) r += slot[j].x < me.x ? 1 : 0;
+    const int64_t i = base + cs + r, o = me.x;
+    perm_int[i] = me.x;
+    perm[i] = zperm[o];
+    const double x = xyz[3 * o + 0], y = xyz[3 * o + 1], z = xyz[3 * o + 2];
+    xs[i] = x; ys[i] = y; zs[i] = z;
+    rec[6 * i + 0] = x; rec[6 * i + 1] = y; rec[6 * i + 2] = z;
+    if (nrm) {
+        rec[6 * i + 3] = nrm[3 * o + 0];
+        rec[6 * i + 4] = nrm[3 * o + 1];
+        rec[6 * i + 5] = nrm[3 * o + 2];
     }
 }
 
@@ -529,37 +693,54 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     }
     // ---- cell ids, stable radix sort (ties keep ascending original index), SoA gather ---------
     sf_pool_guard tmp(ctx);
-    int32_t *cid_sorted = nullptr;
-    SF_CHECK(tmp.alloc(&cid_sorted, nn));
     sf_grid_desc g = sf_make_grid_desc(c);
     int bits = 1;
     while (((int64_t)1 << bits) < ncell) ++bits;
     int64_t cid_base = 0;                      // the sorted keys are cell id - cid_base
 
     int64_t base = 0, ns = n;                  // populated slice [base, base + ns) of the global order
-    int32_t *key_in = nullptr, *val_in = nullptr; // what gets sorted
+    int64_t slab_cells = ncell;                // ... and the cells it can fall into: [cid_base, cid_base + slab_cells)
     const bool whole = block_end < 0;
-    if (whole) {
-        SF_CHECK(tmp.alloc(&key_in, nn));
-        SF_CHECK(tmp.alloc(&val_in, nn));
-        SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(n, 256)), dim3(256), c->xyz_orig, (int64_t)0, n, g, key_in,
-                  val_in, 0);
-    } else {
+    if (!whole) {
         // ---- which z-layers does the block need?  The internal order is ascending in z (sf_cloud), so every layer is a run of
         //      it and a layer's first point is a binary search away: nl + 1 searches, one small read-back. ----
         const int nl = c->dim[2];
-        int64_t *dfirst = nullptr;
-        SF_CHECK(tmp.alloc(&dfirst, (size_t)nl + 1));
-        SF_LAUNCH(ctx, "k1_layer_bounds", k_layer_bounds, dim3((unsigned)sf_div_up(nl + 1, 4)), dim3(256), (const double *)c->z_orig, n,
-                  c->lo[2], c->inv_cell, nl, dfirst);
         std::vector<int64_t> &first = c->layer_first; // global position (= internal index) of each layer's first point
         first.assign((size_t)nl + 1, 0);
-        void *pin = nullptr;
-        SF_CHECK(sf_ctx_pinned(ctx, &pin));
-        int64_t *dst = ((size_t)nl + 1) * sizeof(int64_t) <= SF_PINNED_BYTES ? (int64_t *)pin : first.data();
-        SF_HIP(hipMemcpyAsync(dst, dfirst, ((size_t)nl + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        if (dst != first.data()) std::copy(dst, dst + nl + 1, first.begin());
+        const bool on_host = n <= SF_Z_HOST_MAX && nl <= SF_Z_HOST_LAYERS && !getenv("SF_K1_DEVICE_BOUNDS");
+        if (on_host) {
+            if ((int64_t)c->z_host.size() != n) { // (once per cloud)
+                c->z_host.resize((size_t)n);
+                SF_HIP(hipMemcpyAsync(c->z_host.data(), c->z_orig, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                SF_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            // the layer of a coordinate is monotone in it: lower bounds, each searched from the previous one (a galloping step
+            // first: consecutive layers are ~n / nl points apart, so the probes stay close together)
+            const double *z = c->z_host.data();
+            const double lo_z = c->lo[2], inv = c->inv_cell;
+            int64_t a = 0;
+            for (int l = 1; l <= nl; ++l) {
+                int64_t step = 1, hi = a; // first i >= a with layer(z[i]) >= l
+                while (hi < n && sf_cell_coord(z[hi], lo_z, inv, nl) < l) { a = hi + 1; hi += step; step *= 2; }
+                if (hi > n) hi = n;
+                while (a < hi) {
+                    const int64_t mid = a + (hi - a) / 2;
+                    if (sf_cell_coord(z[mid], lo_z, inv, nl) < l) a = mid + 1; else hi = mid;
+                }
+                first[(size_t)l] = l == nl ? n : a;
+            }
+        } else {
+            int64_t *dfirst = nullptr;
+            SF_CHECK(tmp.alloc(&dfirst, (size_t)nl + 1));
+            SF_LAUNCH(ctx, "k1_layer_bounds", k_layer_bounds, dim3((unsigned)sf_div_up(nl + 1, 4)), dim3(256), (const double *)c->z_orig, n,
+                      c->lo[2], c->inv_cell, nl, dfirst);
+            void *pin = nullptr;
+            SF_CHECK(sf_ctx_pinned(ctx, &pin));
+            int64_t *dst = ((size_t)nl + 1) * sizeof(int64_t) <= SF_PINNED_BYTES ? (int64_t *)pin : first.data();
+            SF_HIP(hipMemcpyAsync(dst, dfirst, ((size_t)nl + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SF_HIP(hipStreamSynchronize(ctx->stream));
+            if (dst != first.data()) std::copy(dst, dst + nl + 1, first.begin());
+        }
         int zb = 0, ze = nl - 1;
         if (block_begin < block_end) {
             while (zb + 1 < nl && first[(size_t)zb + 1] <= block_begin) ++zb;          // layer holding position block_begin
@@ -576,43 +757,84 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
             // keys relative to the slab's first cell: 19 bits instead of 23 at config 5 -- two sort passes instead of three
             const int64_t layer_cells = (int64_t)c->dim[0] * c->dim[1];
             cid_base = (int64_t)zlo * layer_cells;
+            slab_cells = (int64_t)(zhi - zlo + 1) * layer_cells;
             bits = 1;
-            while (((int64_t)1 << bits) < (int64_t)(zhi - zlo + 1) * layer_cells) ++bits;
-            SF_CHECK(tmp.alloc(&key_in, (size_t)ns + 1));
-            SF_CHECK(tmp.alloc(&val_in, (size_t)ns + 1));
-            SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig, base, ns, g, key_in,
-                      val_in, (int)cid_base);
+            while (((int64_t)1 << bits) < slab_cells) ++bits;
         }
     }
     c->pop_begin = base;
     c->pop_end = base + ns;
+    // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
+    // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
+    c->normals_sorted = c->nrm_orig != nullptr;
+    const bool force_radix = getenv("SF_K1_RADIX") != nullptr; // (read at every build: the tests compare the two paths in one process)
+    if (ns > 0 && !force_radix && slab_cells <= SF_COUNT_CELLS_PER_POINT * ns) {
+        // ---- the counting build (see k_cell_count): fill, count, scan, place, settle ----
+        const int64_t slab_tiles = sf_div_up(slab_cells, (int64_t)SF_SCAN_TILE), n_status = slab_tiles + 1;
+        const int64_t fill_blocks = sf_div_up(ncell + 1 - slab_cells, (int64_t)SF_SCAN_TILE);
+        int32_t *cid = nullptr, *place = nullptr;
+        int2 *slot = nullptr;
+        unsigned long long *status = nullptr;
+        SF_CHECK(tmp.alloc(&cid, (size_t)ns));
+        SF_CHECK(tmp.alloc(&place, (size_t)ns));
+        SF_CHECK(tmp.alloc(&slot, (size_t)ns));
+        SF_CHECK(tmp.alloc(&status, (size_t)n_status));
+        int32_t *start_rel = c->cell_start + cid_base;
+        if (c->cell_count_cap < slab_cells || c->count_dirty) { // (first build of this cloud with a slab this large)
+            if (c->cell_count_cap < slab_cells) {
+                if (c->cell_count) (void)hipFree(c->cell_count);
+                c->cell_count = nullptr;
+                c->cell_count_cap = 0;
+                SF_HIP(hipMalloc(&c->cell_count, (size_t)slab_cells * sizeof(int32_t)));
+                c->cell_count_cap = slab_cells;
+            }
+            sf_launch_timer t_(ctx, "k1_cell_zero");
+            SF_HIP(hipMemsetAsync(c->cell_count, 0, (size_t)c->cell_count_cap * sizeof(int32_t), ctx->stream));
+        }
+        c->count_dirty = true;
+        SF_LAUNCH(ctx, "k1_cell_count", k_cell_count, dim3((unsigned)sf_div_up(std::max(ns, n_status), 256)), dim3(256), c->xyz_orig, base, ns, g,
+                  (int)cid_base, c->cell_count, cid, place, status, n_status);
+        SF_LAUNCH(ctx, "k1_cell_scan", k_cell_scan, dim3((unsigned)(slab_tiles + fill_blocks)), dim3(SF_SCAN_TPB), c->cell_count, c->cell_start, ncell,
+                  cid_base, slab_cells, slab_tiles, (int32_t)base, (int32_t)ns, status);
+        c->count_dirty = false;
+        SF_LAUNCH(ctx, "k1_cell_place", k_cell_place, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), (const int32_t *)cid,
+                  (const int32_t *)place, (const int32_t *)start_rel, base, ns, slot);
+        SF_LAUNCH(ctx, "k1_cell_settle", k_cell_settle, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), (const int2 *)slot,
+                  (const int32_t *)start_rel, c->xyz_orig, (const double *)c->nrm_orig, (const int32_t *)c->zperm, c->perm, c->perm_int, base, ns,
+                  c->xs, c->ys, c->zs, c->rec);
+        return SF_OK;
+    }
+    // ---- sparse grids: cell ids, stable radix sort, gather, cell table from the sorted ids ----
+    int32_t *key_in = nullptr, *val_in = nullptr, *cid_sorted = nullptr; // what gets sorted; the sorted ids
+    SF_CHECK(tmp.alloc(&cid_sorted, (size_t)std::max<int64_t>(ns, 1)));
+    if (ns > 0) {
+        SF_CHECK(tmp.alloc(&key_in, (size_t)ns + 1));
+        SF_CHECK(tmp.alloc(&val_in, (size_t)ns + 1));
+        SF_LAUNCH(ctx, "k1_cell_ids", k_cell_ids, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig, base, ns, g, key_in, val_in,
+                  (int)cid_base);
+    }
     sf_gap *gaps = nullptr; // (the cell-table kernel's list of long runs of empty cells)
     unsigned *n_gaps = nullptr;
     SF_CHECK(tmp.alloc(&gaps, (size_t)(ncell / SF_LONG_GAP + 2)));
     SF_CHECK(tmp.alloc(&n_gaps, 1));
     if (ns > 0) {
         size_t tmp_bytes = 0;
-        SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm_int + base, (size_t)ns, 0, bits,
-                                         ctx->stream));
+        SF_HIP(sort_cells(nullptr, tmp_bytes, key_in, cid_sorted, val_in, c->perm_int + base, (size_t)ns, bits, ctx->stream));
         char *stmp = nullptr;
         SF_CHECK(tmp.alloc(&stmp, tmp_bytes ? tmp_bytes : 8));
         {
             sf_launch_timer t_(ctx, "k1_radix_sort");
-            SF_HIP(rocprim::radix_sort_pairs<sf_sort_config>(stmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm_int + base, (size_t)ns, 0, bits,
-                                             ctx->stream));
+            SF_HIP(sort_cells(stmp, tmp_bytes, key_in, cid_sorted, val_in, c->perm_int + base, (size_t)ns, bits, ctx->stream));
         }
         SF_LAUNCH(ctx, "k1_gather_sorted", k_gather_sorted, dim3((unsigned)sf_div_up(ns, 256)), dim3(256), c->xyz_orig,
                   (const double *)c->nrm_orig, (const int32_t *)c->perm_int, (const int32_t *)c->zperm, c->perm, base, ns, c->xs, c->ys, c->zs,
                   c->rec, n_gaps);
     }
-    // (the grid is built on the context's current stream, and a fork (sf_fork) orders the side stream after everything
-    // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
-    c->normals_sorted = c->nrm_orig != nullptr;
     {
         if (ns <= 0) SF_HIP(hipMemsetAsync(n_gaps, 0, sizeof(unsigned), ctx->stream)); // (else zeroed by the gather kernel)
         SF_LAUNCH(ctx, "k1_cell_start", k_cell_start, dim3((unsigned)sf_div_up(ns + 1, 256)), dim3(256), cid_sorted, cid_base, base, ns,
                   ncell, c->cell_start, gaps, n_gaps);
-        SF_LAUNCH(ctx, "k1_cell_start", k_cell_fill_long, dim3(1024), dim3(256), (const sf_gap *)gaps, (const unsigned *)n_gaps,
+        SF_LAUNCH(ctx, "k1_cell_fill_long", k_cell_fill_long, dim3(1024), dim3(256), (const sf_gap *)gaps, (const unsigned *)n_gaps,
                   c->cell_start);
     }
     return SF_OK;
@@ -711,6 +933,7 @@ extern "C" void sf_cloud_free(sf_ctx *ctx, sf_cloud *c)
     if (c->xyz_orig) (void)hipFree(c->xyz_orig);
     if (c->nrm_orig) (void)hipFree(c->nrm_orig);
     if (c->z_orig) (void)hipFree(c->z_orig);
+    if (c->cell_count) (void)hipFree(c->cell_count);
     if (c->zperm) (void)hipFree(c->zperm);
     delete c;
 }

@@ -426,3 +426,60 @@ def test_a_launch_of_its_own_for_the_lists_that_need_more_chunks_changes_no_bit(
     assert np.abs(a[0][rows] - want).max() < 1e-9
     want_s = O.shot_single_scale(p, nr, p[orig[rows]], r, True, 5)
     assert np.abs(a[1][rows] - want_s).max() < 1e-9
+
+
+# ---- K1: the counting build ----------------------------------------------------------------------------------------------
+def _grid_and_lists(eng, p, r, block, launch_names):
+    cloud = eng.cloud(p)
+    try:
+        def go():
+            if block is None:
+                cloud.build_grid(r)
+                return cloud.radius_search_self(r)
+            cloud.build_grid(r, block=block, reach=1)
+            return cloud.radius_search_self(r, *block)
+
+        nb, rep = launches(eng, go)
+        launch_names.append(set(rep))
+        off, idx = nb.export()
+        lo, hi = (0, cloud.n) if block is None else block
+        perm = cloud.perm()[lo:hi]
+        nb.free()
+        return perm, off, idx
+    finally:
+        cloud.free()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "surface", "duplicates", "clustered"])
+@pytest.mark.parametrize("block", [None, (9000, 23000)])
+def test_counting_build_gives_the_order_of_the_stable_sort(eng, kind, block):
+    """K1 orders a dense-enough grid through its own cell table (count, scan, place, settle) instead of a radix sort of the
+    cell ids: the cell-sorted order (ties: ascending internal index), hence every list downstream, is the same bit for bit.
+    Duplicated points put many points into one cell (the rank-within-the-cell loop); a clustered cloud's grid is sparse and
+    stays on the radix sort."""
+    if kind == "uniform":
+        p, _, _ = synth_cloud(40000, 5)
+        r = 0.05
+    elif kind == "surface":
+        p, _ = config1_cloud(40000, 5)
+        r = 0.04
+    elif kind == "duplicates":
+        q, _, _ = synth_cloud(5000, 5)
+        p = np.concatenate([q] * 8)[np.random.default_rng(1).permutation(40000)]
+        r = 0.06
+    else:
+        p, _ = clustered(40000)
+        r = 0.02
+    names = []
+    os.environ.pop("SF_K1_RADIX", None)
+    a = _grid_and_lists(eng, p, r, block, names)
+    os.environ["SF_K1_RADIX"] = "1"
+    try:
+        b = _grid_and_lists(eng, p, r, block, names)
+    finally:
+        del os.environ["SF_K1_RADIX"]
+    assert "k1_radix_sort" in names[1] and "k1_cell_settle" not in names[1], names[1]
+    if kind != "clustered":
+        assert "k1_cell_settle" in names[0] and "k1_radix_sort" not in names[0], names[0]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
