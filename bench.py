@@ -826,7 +826,10 @@ def main() -> int:
         sp_pts, sp_nrm = make_cloud(args.points_per_gpu, 3)
         sjob = DescriptorJob(eng, sp_pts, sp_nrm, args.radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world,
                              rank=rank, spfh_exchange=args.spfh_exchange, emulate_peers=emulated)
-        s_elapsed, _, _, _, _ = time_steps(sjob, eng, args.steps, min(args.warmup, 3), barrier, max_over_ranks, False)
+        # (a block is 1 / world of the N = 1 step: `world` times the steps and warm-up steps -- the same device time and the same
+        # number of descriptors as the weak line, so the two are timed at the same clocks)
+        s_steps, s_warm = args.steps * world, max(args.warmup, 1) * world
+        s_elapsed, _, _, _, _ = time_steps(sjob, eng, s_steps, s_warm, barrier, max_over_ranks, False)
         spar = None if args.no_parity else parity_sample(sjob, sp_pts, sp_nrm, args.radius, min(args.parity_rows, 100))
         if ctl is not None and spar is not None:
             spar = {"ok": all(p["ok"] for p in ctl.allgather(spar))}
@@ -839,8 +842,8 @@ def main() -> int:
             out["strong_scaling"] = {
                 "what": f"the {args.points_per_gpu}-point cloud of N = 1 (radius {args.radius}) cut into {world} blocks of "
                         f"{-(-args.points_per_gpu // world)} keypoints: total work fixed",
-                "ms_per_step": 1000.0 * s_elapsed / args.steps,
-                "value": 2 * args.points_per_gpu / (s_elapsed / args.steps), "unit": "descriptors/s",
+                "ms_per_step": 1000.0 * s_elapsed / s_steps, "steps": s_steps, "warmup": s_warm,
+                "value": 2 * args.points_per_gpu / (s_elapsed / s_steps), "unit": "descriptors/s",
                 "speedup_vs_n1_needs": "the N = 1 line of the same build (ms_per_step there / ms_per_step here)",
                 "parity_ok": None if spar is None else spar["ok"],
                 "checksum": ssum,
