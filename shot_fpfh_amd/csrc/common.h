@@ -65,6 +65,7 @@ struct sf_ctx {
     // page-locked host words for the few scalars a step reads back (bounding box, list statistics): a copy into
     // pageable memory is staged and costs tens of microseconds of idle GPU each time
     void *pinned = nullptr; // SF_PINNED_BYTES
+    double *shot_coef = nullptr; // K5's polynomial coefficients in device memory (descriptors.hip::shot_coef_table)
     // one page-locked, device-visible word that kernels set when an index array handed in by the caller (a row selection,
     // a visiting order) holds a value out of range -- such an element is skipped, never dereferenced.  The host looks at
     // the word after every synchronisation it makes anyway (sf_ctx_check_flag) and turns it into SF_ERR_ARG.

@@ -93,6 +93,7 @@ extern "C" void sf_destroy(sf_ctx *ctx)
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->shot_coef) (void)hipFree(ctx->shot_coef);
     if (ctx->dev_flag) (void)hipHostFree((void *)ctx->dev_flag);
     sf_pool_trim(ctx);
     for (auto &kv : ctx->pool_size) (void)hipFree(kv.first); // blocks still held by live handles

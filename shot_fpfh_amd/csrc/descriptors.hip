@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
 {
     // skip_zero != 0: the support is the list minus its points at distance zero -- the serial compute_shot_descriptor
     // drops them BEFORE get_local_rf (shot.py:361-363), so neither their weight r nor their ">= 0" vote counts.
-    // raw != 0: stop after the eigen-decomposition and store the largest / smallest eigenvectors (x in slots
-    // 0..2, z in slots 3..5) as returned; the fused SHOT kernel does the sign votes from the neighbours it has
+    // raw != 0: stop after the eigen-decomposition and store the largest / smallest eigenvectors as returned, with their
+    // cross product, in the frame's layout (shot_finish_frame); the fused SHOT kernel does the sign votes from the neighbours it has
     // in registers anyway and completes the frame in place.
     const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
     const int64_t q0 = sf_uniform64((sf_xcd_block() * 4 + (threadIdx.x >> 6)) * 64);
@@ -409,9 +409,10 @@ __global__ __launch_bounds__(256) void k_shot_lrf(const double *__restrict__ rec
         if (lane < nq) {
             const int64_t q = q0 + lane;
             double *o = lrf + 9 * (qrow ? qrow[q] : q);
-            o[0] = x0; o[1] = x1; o[2] = x2;
-            o[3] = z0; o[4] = z1; o[5] = z2;
-            o[6] = 0.0; o[7] = 0.0; o[8] = 0.0;
+            // (the frame's final layout, unflipped, y = cross(z, x) of the unflipped axes: shot_finish_frame)
+            o[0] = x0; o[1] = z1 * x2 - z2 * x1; o[2] = z0;
+            o[3] = x1; o[4] = z2 * x0 - z0 * x2; o[5] = z1;
+            o[6] = x2; o[7] = z0 * x1 - z1 * x0; o[8] = z2;
         }
         return;
     }
@@ -555,10 +556,69 @@ __device__ inline void sf_sqrt_rsqrt(double x, double &root, double &inv)
     h = __builtin_fma(h, r, h);
     root = g;
     inv = h + h;
-    if (__ballot(!(x > 1e-290 && x < 1e290))) { // (wave-uniform, never taken for real clouds)
+    // (wave-uniform, never taken for real clouds; the test is on the exponent -- 2^-964 <= x < 2^963, i.e. 4.6e-291 .. 7.8e289,
+    // positive, finite, not NaN -- one integer subtraction and comparison with 32-bit literals instead of two comparisons
+    // against 64-bit constants that each cost two scalar moves)
+    if (__ballot(!((unsigned)__double2hiint(x) - 0x03b00000u < 0x7c200000u - 0x03b00000u))) {
         root = sqrt(x);
         inv = 1.0 / root;
     }
+}
+
+// The same pair for a WAVE-UNIFORM argument (the squared norm of a row: a sum of squares of weights, each 0 or >= 1e-19, so
+// either 0 or far inside the fast range): the range test is two scalar instructions on the exponent instead of two vector
+// comparisons against 64-bit literals (six vector instructions with their moves).
+__device__ inline void sf_sqrt_rsqrt_uniform(double x, double &root, double &inv)
+{
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
+    if (hi - 0x03b00000u < 0x7c200000u - 0x03b00000u) { // 2^-964 <= x < 2^963, positive, finite
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = 0.5 * y;
+        double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        r = __builtin_fma(-h, g, 0.5);
+        h = __builtin_fma(h, r, h);
+        root = g;
+        inv = h + h;
+    } else {
+        root = sqrt(x);
+        inv = 1.0 / root;
+    }
+}
+
+// ---- the frame of a fused SHOT kernel ---------------------------------------------------------------------------------
+// K4's raw mode leaves, in the frame's final row-major layout [x y z] per component, the largest / smallest eigenvectors as
+// returned (x, z) and y = cross(z, x) of THOSE.  The fused kernels count the sign votes (shot.py:40-45) from the neighbours they
+// have gathered anyway and flip: x and z by their own vote, y when exactly one of the two flipped (every product of the cross
+// product changes sign, so the rounded difference does too; a component that cancelled to zero stays +0, as -a + a does).  All of
+// it is wave-uniform: the nine numbers arrive by scalar loads and a flip is a scalar xor (y: plus one vector "+ 0").
+// (sign: 0 or the sign bit as a 64-bit mask, one scalar select per axis -- pinned, or the compiler distributes the select over
+// the components; a flip is then ONE 64-bit scalar xor per component)
+__device__ inline double shot_flip(double v, unsigned long long sign) { return __longlong_as_double(__double_as_longlong(v) ^ (long long)sign); }
+// raw: the nine raw numbers; E: the finished frame.  Returns whether anything changed (the caller writes E back if so).
+__device__ inline bool shot_finish_frame(const double (&raw)[9], int k, int xneg, int zneg, double (&E)[9])
+{
+    // coordinates are finite (checked at upload), so "not < 0" is ">= 0": flip when strictly more neighbours project negative
+    const bool fx = xneg > k - xneg, fz = zneg > k - zneg;
+    if (k == 0) { // shot.py:24-25
+        E[0] = 1.0; E[1] = 0.0; E[2] = 0.0; E[3] = 0.0; E[4] = 1.0; E[5] = 0.0; E[6] = 0.0; E[7] = 0.0; E[8] = 1.0;
+        return true;
+    }
+    unsigned long long sx = fx ? 0x8000000000000000ull : 0ull, sz = fz ? 0x8000000000000000ull : 0ull;
+    asm volatile("" : "+s"(sx), "+s"(sz));
+    const unsigned long long sy = sx ^ sz;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        E[3 * i + 0] = shot_flip(raw[3 * i + 0], sx);
+        E[3 * i + 1] = shot_flip(raw[3 * i + 1], sy) + 0.0; // (-a + a is +0: a component that cancelled stays +0 when y flips)
+        E[3 * i + 2] = shot_flip(raw[3 * i + 2], sz);
+    }
+    return fx | fz;
 }
 
 // Phase markers for tools/k5_phases.py (an ANALYSIS build only, -DSF_K5_MARK_BUILD: scheduling barriers + an assembler
@@ -605,59 +665,64 @@ __device__ inline double sf_sqrt_small(double x) // sqrt(x), 0 <= x <= 1/4, no d
     return x > 0.0 ? g : 0.0;
 }
 
-// Polynomial coefficients are pinned to SGPR pairs (empty asm): as plain immediates the compiler copies every
-// one of them into a VGPR pair first (2 v_mov per FMA); as SGPRs they are the FMA's scalar operand (s_mov only).
-__device__ inline double sf_sgpr(double c)
+
+// The two polynomials' coefficients live in device memory (a 26-double table the context owns, reached through a kernel argument)
+// and arrive by scalar loads -- sixteen dwords per instruction -- right where they are used.  As immediates every coefficient
+// costs two s_mov_b32 in front of its FMA (the instruction takes one scalar operand, and keeping 24 of them live across the
+// kernel is 48 scalar registers the kernel does not have): 96 scalar moves per keypoint, a quarter of its scalar instructions,
+// and the scalar stream is what holds the vector pipe back at seven waves per SIMD (tools/pmc_k5.sh: vector instructions
+// 783 -> 701 per keypoint bought nothing until the scalar ones followed).  (A __constant__ array with an initialiser is folded
+// back into immediates by the compiler.)
+#define SF_K_ATAN 1.2732395447351628  // 4 / pi
+#define SF_K_ACOS 0.6366197723675814  // 2 / pi
+#define SF_ATAN_TERMS 11
+#define SF_ACOS_TERMS 13
+#define SF_ACOS_AT 12 // (offset of the second table: both start on a 32-byte boundary)
+static const double SF_SHOT_COEF[SF_ACOS_AT + SF_ACOS_TERMS + 1] = {
+    // atan(t) / t / (pi/4) in s = t^2, highest power first
+    0.021102961440831885 * SF_K_ATAN, -0.04345403041920663 * SF_K_ATAN, 0.05687431322104835 * SF_K_ATAN, -0.06640058350060206 * SF_K_ATAN,
+    0.07689933264608774 * SF_K_ATAN,  -0.09090771637100807 * SF_K_ATAN, 0.11111106118508882 * SF_K_ATAN, -0.14285714179450393 * SF_K_ATAN,
+    0.19999999998836118 * SF_K_ATAN,  -0.33333333333328347 * SF_K_ATAN, SF_K_ATAN, 0.0,
+    // asin(r) / r / (pi/2) in s = r^2, highest power first
+    0.028169218060881414 * SF_K_ACOS, -0.010749050339697808 * SF_K_ACOS, 0.01603551434914882 * SF_K_ACOS, 0.0078029494773533175 * SF_K_ACOS,
+    0.011875494382636922 * SF_K_ACOS, 0.013929652902326633 * SF_K_ACOS,  0.017355259955786323 * SF_K_ACOS, 0.02237204763174451 * SF_K_ACOS,
+    0.03038194736709848 * SF_K_ACOS,  0.044642857103423646 * SF_K_ACOS,  0.07500000000020764 * SF_K_ACOS,  0.1666666666666665 * SF_K_ACOS,
+    SF_K_ACOS, 0.0};
+
+// atan(t) / (pi/4) for 0 <= t <= tan(pi/8) (1 + 1e-3): the minimax polynomial of tools/fit_poly.py with 4/pi folded into its
+// coefficients at compile time -- the azimuth weight is |dth| = angle / (pi/4), so the angle itself is never needed
+// (passing a loaded coefficient through an empty asm with a scalar-register constraint keeps it the FMA's scalar operand; left
+// alone the compiler selects the accumulate form v_fmac_f64, whose addend is the destination: two v_mov_b32 per coefficient)
+__device__ inline double sf_scalar_operand(double c)
 {
     asm("" : "+s"(c));
     return c;
 }
-#define SF_HORNER(p, s, c) p = __builtin_fma(p, s, sf_sgpr(c))
-
-// atan(t) / (pi/4) for 0 <= t <= tan(pi/8) (1 + 1e-3): the minimax polynomial of tools/fit_poly.py with 4/pi folded into its
-// coefficients at compile time -- the azimuth weight is |dth| = angle / (pi/4), so the angle itself is never needed
-__device__ inline double sf_atan_octant_fraction(double t)
+typedef const __attribute__((address_space(4))) double *sf_const_doubles; // (read through the scalar cache: never written by a kernel)
+__device__ inline double sf_atan_octant_fraction(double t, const double *__restrict__ coef_)
 {
-    constexpr double K = 1.2732395447351628; // 4 / pi
+    sf_const_doubles coef = (sf_const_doubles)coef_;
     const double s = t * t;
-    double p = sf_sgpr(0.021102961440831885 * K);
-    SF_HORNER(p, s, -0.04345403041920663 * K);
-    SF_HORNER(p, s, 0.05687431322104835 * K);
-    SF_HORNER(p, s, -0.06640058350060206 * K);
-    SF_HORNER(p, s, 0.07689933264608774 * K);
-    SF_HORNER(p, s, -0.09090771637100807 * K);
-    SF_HORNER(p, s, 0.11111106118508882 * K);
-    SF_HORNER(p, s, -0.14285714179450393 * K);
-    SF_HORNER(p, s, 0.19999999998836118 * K);
-    SF_HORNER(p, s, -0.33333333333328347 * K);
-    SF_HORNER(p, s, K);
+    double p = coef[0];
+#pragma unroll
+    for (int i = 1; i < SF_ATAN_TERMS; ++i) p = __builtin_fma(p, s, sf_scalar_operand(coef[i]));
     return t * p;
 }
 
 // acos(|z|) / (pi/2) for |z| <= 1 (result in [0, 1]; |z| = 0 gives exactly 1, |z| = 1 exactly 0): the asin-form minimax
 // polynomial with 2/pi folded into its coefficients.  The elevation weights are linear in phi / (pi/2) and symmetric about
 // the equator -- acos(-z) = pi - acos(z) -- so the angle of |z| is all they need (shot_weights).
-__device__ inline double sf_acos_abs_quadrants(double az)
+__device__ inline double sf_acos_abs_quadrants(double az, const double *__restrict__ coef_)
 {
-    constexpr double K = 0.6366197723675814; // 2 / pi
+    sf_const_doubles coef = (sf_const_doubles)coef_;
     const bool big = az > 0.5;
     const double xb = __builtin_fma(-0.5, az, 0.5), xs = az * az; // (1 - |z|) / 2 is exact
     const double rb = sf_sqrt_small(fmin(xb, 0.25));
     const double x = big ? xb : xs;
     const double r = big ? rb : az;
-    double p = sf_sgpr(0.028169218060881414 * K); // asin(r) = r + r s R(s), s = r^2 <= 1/4
-    SF_HORNER(p, x, -0.010749050339697808 * K);
-    SF_HORNER(p, x, 0.01603551434914882 * K);
-    SF_HORNER(p, x, 0.0078029494773533175 * K);
-    SF_HORNER(p, x, 0.011875494382636922 * K);
-    SF_HORNER(p, x, 0.013929652902326633 * K);
-    SF_HORNER(p, x, 0.017355259955786323 * K);
-    SF_HORNER(p, x, 0.02237204763174451 * K);
-    SF_HORNER(p, x, 0.03038194736709848 * K);
-    SF_HORNER(p, x, 0.044642857103423646 * K);
-    SF_HORNER(p, x, 0.07500000000020764 * K);
-    SF_HORNER(p, x, 0.1666666666666665 * K);
-    SF_HORNER(p, x, K);
+    double p = coef[SF_ACOS_AT]; // asin(r) = r + r s R(s), s = r^2 <= 1/4
+#pragma unroll
+    for (int i = 1; i < SF_ACOS_TERMS; ++i) p = __builtin_fma(p, x, sf_scalar_operand(coef[SF_ACOS_AT + i]));
     const double as = r * p; // asin(r) / (pi/2)
     // |z| <= 1/2: 1 - as ;  |z| > 1/2: 2 as
     return big ? as + as : 1.0 - as;
@@ -738,6 +803,7 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
 // computed in the kernel the wave-uniform division 1 / (r/2) was a 14-instruction vector sequence per chunk)
 struct shot_consts {
     double radius, half_r, q1, q3, inv_hr;
+    const double *coef; // SF_SHOT_COEF in device memory
 };
 
 // The interpolation weights of one neighbour (shot.py:73-171, 244-298), reduced to what the elections consume:
@@ -761,7 +827,7 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
     SF_K5_MARK(80, 0);
     const bool fwd = g.tdot > 0.0;
     const double tq = fmin(fabs(g.tcross) * sf_rcp(fwd ? g.tdot : 1.0), 0.4146);
-    const double at = fmin(sf_atan_octant_fraction(tq), 0.5);
+    const double at = fmin(sf_atan_octant_fraction(tq, k.coef), 0.5);
     adth = fwd ? at : 0.5;
     SF_K5_PIN(adth);
     // radial shells (interpolate_on_adjacent_husks): rho == r/2 belongs to neither and gets all three terms zero
@@ -782,7 +848,7 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
     //   current = 1 - |t - 1/2| ;  lower resp. upper = max(t - 1/2, 0), with the single exception the masks leave:
     //   a writer with z > 0 whose phi ROUNDS to pi/2 (t = 1 exactly) fails "phi < pi/2" and gets 0.
     SF_K5_MARK(82, 0);
-    double t = sf_acos_abs_quadrants(fmin(fabs(g.lzr), 1.0));
+    double t = sf_acos_abs_quadrants(fmin(fabs(g.lzr), 1.0), k.coef);
     SF_K5_PIN(t);
     SF_K5_MARK(83, 0);
     const double curv = 1.0 - fabs(t - 0.5);
@@ -847,36 +913,40 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         cz[c] = z - pz;
     }
     SF_K5_MARK(3, NCH);
+    // the lanes of each chunk that hold a list entry, as wave-uniform masks: votes and gate are mask arithmetic on the scalar
+    // unit (a ballot of a bare comparison is the comparison's own result register)
+    unsigned long long onm[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int rem = k - 64 * c;
+        onm[c] = rem >= 64 ? ~0ull : (rem > 0 ? (1ull << rem) - 1ull : 0ull);
+    }
     double E[9];
     if (FUSED) {
         double *lr = lrf + 9 * row;
-        double x0 = lr[0], x1 = lr[1], x2 = lr[2], z0 = lr[3], z1 = lr[4], z2 = lr[5];
-        int xneg = 0, xpos = 0, zneg = 0, zpos = 0;
+        double raw[9];
+        // Scalar loads, by reading the nine numbers through the constant address space: this wave is the only one that touches
+        // this frame, it reads it here and writes it below, so the scalar cache never holds a stale copy of it -- but the
+        // compiler, seeing stores to `lrf` in the same kernel, proves that for one of the two inlined bodies only and loads the
+        // other's frame into vector registers (every flip below then costs vector instructions).  The pin keeps all nine loads
+        // in front of the votes (left alone the scheduler sinks the y loads to their first use: a scalar-memory round trip of
+        // their own in the middle of the kernel).
+        const __attribute__((address_space(4))) double *clr = (const __attribute__((address_space(4))) double *)lr;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const bool on = c * 64 + lane < k; // the query itself (c = 0) votes ">= 0", as in the reference
-            const double xo = sf_dot3(cx[c], cy[c], cz[c], x0, x1, x2);
-            const double zo = sf_dot3(cx[c], cy[c], cz[c], z0, z1, z2);
-            xneg += __popcll(__ballot(on & (xo < 0.0)));
-            zneg += __popcll(__ballot(on & (zo < 0.0)));
-        }
-        xpos = k - xneg; // coordinates are finite (checked at upload), so "not < 0" is ">= 0"
-        zpos = k - zneg;
-        if (xneg > xpos) { x0 = -x0; x1 = -x1; x2 = -x2; }
-        if (zneg > zpos) { z0 = -z0; z1 = -z1; z2 = -z2; }
-        const double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0; // cross(z, x)
-        if (k == 0) { // shot.py:24-25
-            E[0] = 1.0; E[1] = 0.0; E[2] = 0.0; E[3] = 0.0; E[4] = 1.0; E[5] = 0.0; E[6] = 0.0; E[7] = 0.0; E[8] = 1.0;
-        } else {
-            E[0] = x0; E[1] = y0; E[2] = z0;
-            E[3] = x1; E[4] = y1; E[5] = z1;
-            E[6] = x2; E[7] = y2; E[8] = z2;
-        }
-        if (lane < 9) {
-            double v = E[0];
+        for (int i = 0; i < 9; ++i) raw[i] = clr[i];
 #pragma unroll
-            for (int i = 1; i < 9; ++i) v = lane == i ? E[i] : v;
-            lr[lane] = v;
+        for (int i = 0; i < 9; ++i) asm volatile("" : "+s"(raw[i]));
+        int xneg = 0, zneg = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { // the query itself (c = 0) votes ">= 0", as in the reference
+            const double xo = sf_dot3(cx[c], cy[c], cz[c], raw[0], raw[3], raw[6]);
+            const double zo = sf_dot3(cx[c], cy[c], cz[c], raw[2], raw[5], raw[8]);
+            xneg += __popcll(__ballot(xo < 0.0) & onm[c]);
+            zneg += __popcll(__ballot(zo < 0.0) & onm[c]);
+        }
+        if (shot_finish_frame(raw, k, xneg, zneg, E) && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) lr[i] = E[i];
         }
     } else {
 #pragma unroll
@@ -884,16 +954,17 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     }
 
     SF_K5_MARK(4, NCH);
-    // gate (shot.py:212): neighbours at non-zero distance; padding lanes get d2 = 0
+    // gate (shot.py:212): neighbours at non-zero distance, as one mask per chunk (padding lanes carry point 0's offset: masked)
     double d2[NCH];
+    unsigned long long posm[NCH];
     int npos = 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const double dd = (cx[c] * cx[c] + cy[c] * cy[c]) + cz[c] * cz[c];
-        d2[c] = c * 64 + lane < k ? dd : 0.0;
-        npos += __popcll(__ballot(d2[c] > 0.0));
+        d2[c] = (cx[c] * cx[c] + cy[c] * cy[c]) + cz[c] * cz[c];
+        posm[c] = __ballot(d2[c] > 0.0) & onm[c];
+        npos += __popcll(posm[c]);
     }
-    if (!((int64_t)npos > min_nb)) {
+    if (!(npos > (int)min_nb)) { // (launch_shot passes min_nb clamped into [-1, 2^31 - 1]: a scalar 32-bit comparison)
         for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
         return;
     }
@@ -919,7 +990,10 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     for (int c = 0; c < NCH; ++c) {
         g[c].bins1 = 0u;
         SF_K5_MARK(5, NCH);
-        if (d2[c] > 0.0) {
+        // (a branch per chunk on purpose: calling the geometry for all lanes puts the chunks' chains into one basic block, the
+        // scheduler interleaves them and the kernel needs 87 registers instead of 70 -- 5 waves per SIMD, 1.72 ms; capped at
+        // 72 / 80 registers it spills / runs 1.62 ms)
+        if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
             shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, K.half_r, g[c]);
             SF_K5_MARK(6, NCH);
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
@@ -931,7 +1005,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // who writes what (all reads of the keys come before the first winner replaces its key by a value)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (g[c].bins1 >> 31) {
+        if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             const unsigned iA = g[c].bins0 & 511u;
             const bool up = iA & 2u, odd = iA & 1u; // (bit 1: z > 0, bit 0: outer shell)
@@ -954,7 +1028,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         v_cd[c] = 0.0;
         v_ef[c] = 0.0;
         SF_K5_MARK(8, NCH);
-        if (g[c].bins1 >> 31) {
+        if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             const unsigned iA = g[c].bins0 & 511u;
             double vA, adth;
@@ -987,7 +1061,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         SF_SHOT_SYNC();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            if (g[c].bins1 >> 31) {
+            if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
                 const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
                 atomicMax(&sX[(g[c].bins0 >> (stmt ? 18 : 9)) & 511u], key);
             }
@@ -995,7 +1069,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         SF_SHOT_SYNC();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            if (g[c].bins1 >> 31) {
+            if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
                 const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
                 const unsigned iW = (g[c].bins0 >> (stmt ? 18 : 9)) & 511u;
                 const double val = stmt ? g[c].tdot : fabs(g[c].dc); // S1's range mask is always true for cf in 0..10
@@ -1005,23 +1079,24 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         SF_SHOT_SYNC();
     }
     SF_K5_MARK(12, NCH);
-    // every slot of the accumulator is +0 (nothing written) or minus the bin's value
+    // every slot of the accumulator is +0 (nothing written) or minus the bin's value: the row is acc * (-scale) + 0 (the sum
+    // of squares does not see the sign; the "+ 0" makes an empty slot +0 whatever the sign of the scale)
     double vals[6];
     double ss = 0.0;
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int b = lane + 64 * u;
-        const double v = b < 352 ? 0.0 - acc[b] : 0.0;
+        const double v = b < 352 ? acc[b] : 0.0;
         vals[u] = v;
         ss += v * v;
     }
     double nrm, inv_nrm; // (the short root / inverse-root pair: ~1 ulp each, a third of sqrt() followed by a division)
-    sf_sqrt_rsqrt(sf_wave_sum(ss), nrm, inv_nrm);
-    const double scale = nrm > 0.0 ? (normalize ? inv_nrm : 1.0) : 0.0; // shot.py:301-305
+    sf_sqrt_rsqrt_uniform(sf_wave_sum(ss), nrm, inv_nrm);
+    const double nscale = nrm > 0.0 ? (normalize ? -inv_nrm : -1.0) : -0.0; // shot.py:301-305
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int b = lane + 64 * u;
-        if (b < 352) o[b] = vals[u] * scale;
+        if (b < 352) o[b] = __builtin_fma(vals[u], nscale, 0.0);
     }
 }
 
@@ -1078,10 +1153,11 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
         unsigned long long *w = reinterpret_cast<unsigned long long *>(&L);
         for (int b = lane; b < (int)(sizeof(shot_long_lds) / 8); b += 64) w[b] = 0ull;
     }
-    double rx0 = 0, rx1 = 0, rx2 = 0, rz0 = 0, rz1 = 0, rz2 = 0;
+    double raw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (FUSED) {
         const double *lr = lrf + 9 * row;
-        rx0 = lr[0]; rx1 = lr[1]; rx2 = lr[2]; rz0 = lr[3]; rz1 = lr[4]; rz2 = lr[5];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) raw[i] = lr[i];
     }
     // ---- sweep V: gate (shot.py:212, 306) and the frame's sign votes (shot.py:40-45) ----
     int npos = 0, xneg = 0, zneg = 0;
@@ -1100,28 +1176,16 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
             const bool on = jj[u] >= 0;
             npos += __popcll(__ballot(on && ((cx * cx + cy * cy) + cz * cz) > 0.0));
             if (FUSED) {
-                xneg += __popcll(__ballot(on && sf_dot3(cx, cy, cz, rx0, rx1, rx2) < 0.0));
-                zneg += __popcll(__ballot(on && sf_dot3(cx, cy, cz, rz0, rz1, rz2) < 0.0));
+                xneg += __popcll(__ballot(on && sf_dot3(cx, cy, cz, raw[0], raw[3], raw[6]) < 0.0));
+                zneg += __popcll(__ballot(on && sf_dot3(cx, cy, cz, raw[2], raw[5], raw[8]) < 0.0));
             }
         }
     }
     double E[9];
     if (FUSED) { // (the frame is written whether or not the descriptor passes the gate, as in the cached form)
-        if (xneg > k - xneg) { rx0 = -rx0; rx1 = -rx1; rx2 = -rx2; }
-        if (zneg > k - zneg) { rz0 = -rz0; rz1 = -rz1; rz2 = -rz2; }
-        const double y0 = rz1 * rx2 - rz2 * rx1, y1 = rz2 * rx0 - rz0 * rx2, y2 = rz0 * rx1 - rz1 * rx0; // cross(z, x)
-        if (k == 0) { // shot.py:24-25
-            E[0] = 1.0; E[1] = 0.0; E[2] = 0.0; E[3] = 0.0; E[4] = 1.0; E[5] = 0.0; E[6] = 0.0; E[7] = 0.0; E[8] = 1.0;
-        } else {
-            E[0] = rx0; E[1] = y0; E[2] = rz0;
-            E[3] = rx1; E[4] = y1; E[5] = rz1;
-            E[6] = rx2; E[7] = y2; E[8] = rz2;
-        }
-        if (lane < 9) {
-            double v = E[0];
+        if (shot_finish_frame(raw, k, xneg, zneg, E) && lane == 0) {
 #pragma unroll
-            for (int i = 1; i < 9; ++i) v = lane == i ? E[i] : v;
-            lrf[9 * row + lane] = v;
+            for (int i = 0; i < 9; ++i) lrf[9 * row + i] = E[i];
         }
     } else {
 #pragma unroll
@@ -1424,10 +1488,16 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
 {
     const int64_t m = nb->m;
     if (!m) return SF_OK;
+    // (a list holds fewer than 2^31 points: clamped here, "more than min_nb neighbours" is a 32-bit comparison in the kernels)
+    min_nb = std::min<int64_t>(std::max<int64_t>(min_nb, -1), 2147483647LL);
     const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), block(64 * SF_SHOT_WPB), block_streaming(64 * SF_SHOT_LONG_WPB);
 #define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m
     const double r_ = nb->radius;
-    const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2)}; // the reference's own expressions (shot.py:95-117, 235)
+    if (!ctx->shot_coef) { // (once per context)
+        SF_HIP(hipMalloc(&ctx->shot_coef, sizeof(SF_SHOT_COEF)));
+        SF_HIP(hipMemcpy(ctx->shot_coef, SF_SHOT_COEF, sizeof(SF_SHOT_COEF), hipMemcpyHostToDevice));
+    }
+    const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2), ctx->shot_coef}; // the reference's own expressions (shot.py:95-117, 235)
     const sf_dispatch d = sf_nbrs_dispatch(nb);
 #define SF_SHOT_CASE(N)                                                                                              \
     if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); } \
@@ -1524,9 +1594,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const double *c = cov + 6 * q;
     const sf_eig::eig3 e = sf_eig::eigh3_lower(c[0], c[1], c[2], c[3], c[4], c[5]);
     double *o = lrf + 9 * q;
-    o[0] = e.v13; o[1] = e.v23; o[2] = e.v33; // eigenvectors[:, 2]
-    o[3] = e.v11; o[4] = e.v21; o[5] = e.v31; // eigenvectors[:, 0]
-    o[6] = 0.0; o[7] = 0.0; o[8] = 0.0;
+    const double x0 = e.v13, x1 = e.v23, x2 = e.v33; // eigenvectors[:, 2]
+    const double z0 = e.v11, z1 = e.v21, z2 = e.v31; // eigenvectors[:, 0]
+    // (the frame's final layout, unflipped, y = cross(z, x) of the unflipped axes: shot_finish_frame)
+    o[0] = x0; o[1] = z1 * x2 - z2 * x1; o[2] = z0;
+    o[3] = x1; o[4] = z2 * x0 - z0 * x2; o[5] = z1;
+    o[6] = x2; o[7] = z0 * x1 - z1 * x0; o[8] = z2;
 }
 
 } // namespace

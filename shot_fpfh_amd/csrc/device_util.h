@@ -43,19 +43,28 @@ __device__ inline int sf_prefix_count(unsigned long long mask)
 //   row_bcast15 (rows 1,3) -> row_bcast31 (rows 2,3)      : lane 63 holds the wave's sum -> v_readlane
 __device__ inline double sf_wave_sum(double v)
 {
+    // (the four in-row steps write every lane: __builtin_amdgcn_mov_dpp leaves the destination's old value undefined, so the
+    // compiler does not zero a register pair in front of each step -- two v_mov_b32 per step with update_dpp(0, ..))
+#define SF_DPP_ADD_ALL(ctrl)                                                                                    \
+    {                                                                                                           \
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);                       \
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);                       \
+        v += __hiloint2double(hi, lo);                                                                          \
+    }
 #define SF_DPP_ADD(ctrl, row_mask)                                                                              \
     {                                                                                                           \
         const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, row_mask, 0xf, false);           \
         const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, row_mask, 0xf, false);           \
         v += __hiloint2double(hi, lo);                                                                          \
     }
-    SF_DPP_ADD(0xB1, 0xf)  // quad_perm [1,0,3,2]
-    SF_DPP_ADD(0x4E, 0xf)  // quad_perm [2,3,0,1]
-    SF_DPP_ADD(0x141, 0xf) // row_half_mirror
-    SF_DPP_ADD(0x140, 0xf) // row_mirror
+    SF_DPP_ADD_ALL(0xB1)   // quad_perm [1,0,3,2]
+    SF_DPP_ADD_ALL(0x4E)   // quad_perm [2,3,0,1]
+    SF_DPP_ADD_ALL(0x141)  // row_half_mirror
+    SF_DPP_ADD_ALL(0x140)  // row_mirror
     SF_DPP_ADD(0x142, 0xa) // row_bcast15 into rows 1 and 3 (other rows add the old value 0)
     SF_DPP_ADD(0x143, 0xc) // row_bcast31 into rows 2 and 3
 #undef SF_DPP_ADD
+#undef SF_DPP_ADD_ALL
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
