@@ -195,6 +195,8 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
+    // (the keypoint's own counts of the two bins this lane writes, requested with the list: see the sparse form)
+    const unsigned own0 = counts[i * 128 + 16 * (4 * (kb >> 1) + 2 * (kb & 1)) + a], own1 = counts[i * 128 + 16 * (4 * (kb >> 1) + 2 * (kb & 1)) + a + 16];
     if (lane == 0) *reinterpret_cast<unsigned long long *>(abuf + 512) = 0ull; // the "limbs 8 .. 15" every A operand reads
     // A step covers 32 neighbours (v_mfma_i32_16x16x32_i8: 8 k per 16-lane group).  Transposing reads: in its group
     // (k block kb) lane 2 q + p supplies the address of row 8 kb + q, bytes 8 p .. + 7 of chunk bb (slot bb ^ f(row),
@@ -299,11 +301,10 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     {
         const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
         const int b0 = 16 * bb0 + a, b1 = b0 + 16;
-        const uint8_t *own = counts + i * 128;
         double *o = out + q * (int64_t)nb3;
         // count / k (the keypoint's own SPFH term, fpfh.py:88-90) through the reciprocal already at hand and one residual
         // step -- the closing step of a division: correctly rounded for these small integers at a tenth of the instructions
-        const double c0 = (double)((unsigned)own[b0] ^ 128u), c1 = (double)((unsigned)own[b1] ^ 128u);
+        const double c0 = (double)(own0 ^ 128u), c1 = (double)(own1 ^ 128u);
         double s0 = c0 * inv_k, s1 = c1 * inv_k;
         s0 = __builtin_fma(__builtin_fma(-s0, kd, c0), inv_k, s0);
         s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
@@ -345,6 +346,12 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(rows), 0, (int)rows_bytes, 0x00020000);
     const int a = lane & 15, kb = lane >> 4;
+    // the keypoint's own counts of the two bins this lane writes: requested HERE, with the list -- the "memory" clobbers of the
+    // DMA statements below pin a load where it is written, and at the end of the kernel (where the values are used) it was a
+    // memory round trip of its own on every wave's critical path
+    const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
+    const int o0 = 16 * bb0 + a, o1 = o0 + 16; // as in the full kernel
+    const unsigned own0 = counts[i * 128 + o0], own1 = counts[i * 128 + o1];
     if (lane == 0) *reinterpret_cast<unsigned long long *>(abuf + 512) = 0ull; // the "limbs 8 .. 15" every A operand reads
     // LDS image of a step: 64 pieces of 16 bytes, piece P = 32 (kb >> 1) + 16 u + 8 (kb & 1) + q holds chunk b_u of row
     // 8 kb + q -- the DMA writes its lanes' pieces back to back, so lane P fetches exactly that; the 32 pieces a
@@ -431,11 +438,8 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     sf_lane_swap<32>(mine, other); // lower half: mine = own (b0), other = b1's ; upper half: mine = b0's, other = own (b1)
     const double tot0 = mine, tot1 = other; // (after the swap `mine` is block b0's total in both halves, `other` b1's)
     {
-        const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
-        const int o0 = 16 * bb0 + a, o1 = o0 + 16; // the two bins this lane writes, as in the full kernel
-        const uint8_t *own = counts + i * 128;
         double *o = out + q * (int64_t)nb3;
-        const double c0 = (double)((unsigned)own[o0] ^ 128u), c1 = (double)((unsigned)own[o1] ^ 128u);
+        const double c0 = (double)(own0 ^ 128u), c1 = (double)(own1 ^ 128u);
         double s0 = c0 * inv_k, s1 = c1 * inv_k;
         s0 = __builtin_fma(__builtin_fma(-s0, kd, c0), inv_k, s0);
         s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
