@@ -1080,23 +1080,27 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     }
     SF_K5_MARK(12, NCH);
     // every slot of the accumulator is +0 (nothing written) or minus the bin's value: the row is acc * (-scale) + 0 (the sum
-    // of squares does not see the sign; the "+ 0" makes an empty slot +0 whatever the sign of the scale)
-    double vals[6];
+    // of squares does not see the sign; the "+ 0" makes an empty slot +0 whatever the sign of the scale).
+    // A lane takes PAIRS of adjacent bins -- (2 l, 2 l + 1) of each third of the row -- so that the row leaves in three
+    // 16-byte-per-lane store instructions instead of six 8-byte ones (and is read back in three LDS instructions): a wave's
+    // slot is held until its stores are acknowledged, and the row is issued at the very end of the wave's work -- leaving
+    // five of the six store instructions out (timing only) made the kernel 14 % faster, halving their number 1-1.5 %.
+    double2 vals[3];
     double ss = 0.0;
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int b = lane + 64 * u;
-        const double v = b < 352 ? acc[b] : 0.0;
-        vals[u] = v;
-        ss += v * v;
+    for (int u = 0; u < 3; ++u) {
+        const int b = 2 * lane + 128 * u;
+        vals[u] = b < 352 ? *reinterpret_cast<const double2 *>(acc + b) : make_double2(0.0, 0.0);
+        ss += vals[u].x * vals[u].x;
+        ss += vals[u].y * vals[u].y;
     }
     double nrm, inv_nrm; // (the short root / inverse-root pair: ~1 ulp each, a third of sqrt() followed by a division)
     sf_sqrt_rsqrt_uniform(sf_wave_sum(ss), nrm, inv_nrm);
     const double nscale = nrm > 0.0 ? (normalize ? -inv_nrm : -1.0) : -0.0; // shot.py:301-305
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int b = lane + 64 * u;
-        if (b < 352) o[b] = __builtin_fma(vals[u], nscale, 0.0);
+    for (int u = 0; u < 3; ++u) {
+        const int b = 2 * lane + 128 * u;
+        if (b < 352) *reinterpret_cast<double2 *>(o + b) = make_double2(__builtin_fma(vals[u].x, nscale, 0.0), __builtin_fma(vals[u].y, nscale, 0.0));
     }
 }
 
