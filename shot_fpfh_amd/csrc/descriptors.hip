@@ -904,7 +904,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int t = c * 64 + lane;
-        const int j = t < k ? idx[s + t] : -1;
+        const int j = t < k ? SF_LIST_LOAD(idx + s + t) : -1;
         const int jj = j < 0 ? 0 : j;
         double x, y, z;
         sf_load_pn(rec, jj, x, y, z, nx[c], ny[c], nz[c]);
@@ -946,7 +946,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         }
         if (shot_finish_frame(raw, k, xneg, zneg, E) && lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) lr[i] = E[i];
+            for (int i = 0; i < 9; ++i) lr[i] = E[i]; // (streamed past the L2 like the rows: no difference)
         }
     } else {
 #pragma unroll
@@ -1100,7 +1100,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int b = 2 * lane + 128 * u;
-        if (b < 352) *reinterpret_cast<double2 *>(o + b) = make_double2(__builtin_fma(vals[u].x, nscale, 0.0), __builtin_fma(vals[u].y, nscale, 0.0));
+        if (b < 352) sf_store_stream2(o + b, __builtin_fma(vals[u].x, nscale, 0.0), __builtin_fma(vals[u].y, nscale, 0.0));
     }
 }
 
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int b = lane + 64 * u;
-        if (b < 352) o[b] = vals[u] * scale;
+        if (b < 352) sf_store_stream(o + b, vals[u] * scale);
     }
 }
 

@@ -187,6 +187,23 @@ __device__ inline int sf_row16_sum(int v)
     return v;
 }
 
+// Stores of the descriptor rows (2.8 KB per SHOT row, 1 KB per FPFH row: 3.8 GB per pass at C3, never read again by the pass):
+// non-temporal, so that they stream through the L2 instead of evicting the records and table rows the gathers of the same
+// and of the next kernel live on (K5 1.52 -> 1.47 ms, the K6 that follows 0.81 -> 0.79: same-box A/B, tools/ab_libs.sh).
+__device__ inline void sf_store_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void sf_store_stream2(double *p, double a, double b)
+{
+    typedef double sf_d2 __attribute__((ext_vector_type(2)));
+    const sf_d2 v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<sf_d2 *>(p));
+}
+
+// A neighbour list is written once (K2) and read exactly once by every kernel that walks it (0.44 GB per kernel at C3): streamed
+// past the L2 both ways, like the descriptor rows.  Same-box A/B (tools/ab_libs.sh): the loads K5 -1 %, K7 -1.6 %; the stores
+// K2 -2.8 %, the K6 behind it -1 %.
+#define SF_LIST_LOAD(p) __builtin_nontemporal_load(p)
+#define SF_LIST_STORE(p, v) __builtin_nontemporal_store((int)(v), p)
+
 // XCD-aware block remap.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks
 // share an XCD / an L2).  Consecutive queries are spatial neighbours (cell-sorted order), so giving each
 // XCD ONE contiguous eighth of the queries makes the cells a query needs hot in that XCD's own 4 MB L2

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
         for (int c = 0; c < NC; ++c) {
             const int t = c * 64 + lane;
             jj[c] = -1;
-            if (c == 0 || c * 64 < ku) jj[c] = t < k ? idx[s + t] : -1;
+            if (c == 0 || c * 64 < ku) jj[c] = t < k ? SF_LIST_LOAD(idx + s + t) : -1;
         }
         double cx[NC], cy[NC], cz[NC], ax[NC], ay[NC], az[NC];
 #pragma unroll

@@ -61,7 +61,7 @@ __device__ __forceinline__ void fpfh_mc_list(const int32_t *__restrict__ idx, in
     for (int c = 0; c < NKS; ++c) {
         const int t = c * 64 + lane;
         jv[c] = -1;
-        if (c == 0 || c * 64 < k) jv[c] = t < k ? idx[s + t] : -1;
+        if (c == 0 || c * 64 < k) jv[c] = t < k ? SF_LIST_LOAD(idx + s + t) : -1;
     }
 }
 
@@ -310,8 +310,8 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
         s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
         double h0 = 0.0, h1 = 0.0;
         if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, b0, b1, h0, h1);
-        if (b0 < nb3) o[b0] = s0 + (HI ? vsel0 + h0 : vsel0) * inv_k;
-        if (b1 < nb3) o[b1] = s1 + (HI ? vsel1 + h1 : vsel1) * inv_k;
+        if (b0 < nb3) sf_store_stream(o + b0, s0 + (HI ? vsel0 + h0 : vsel0) * inv_k);
+        if (b1 < nb3) sf_store_stream(o + b1, s1 + (HI ? vsel1 + h1 : vsel1) * inv_k);
     }
 }
 
@@ -447,8 +447,8 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
         const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
         double h0 = 0.0, h1 = 0.0;
         if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, o0, o1, h0, h1);
-        if (o0 < nb3) o[o0] = s0 + (HI ? v0 + h0 : v0) * inv_k;
-        if (o1 < nb3) o[o1] = s1 + (HI ? v1 + h1 : v1) * inv_k;
+        if (o0 < nb3) sf_store_stream(o + o0, s0 + (HI ? v0 + h0 : v0) * inv_k);
+        if (o1 < nb3) sf_store_stream(o + o1, s1 + (HI ? v1 + h1 : v1) * inv_k);
     }
 }
 

@@ -208,9 +208,9 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
             const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
             if (MODE != 0) {
                 const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
-                if (hit0 && pos < room) idx[out + pos] = j;
+                if (hit0 && pos < room) SF_LIST_STORE(idx + out + pos, j);
                 const int pos1 = pos + (hit0 ? 1 : 0);
-                if (hit1 && pos1 < room) idx[out + pos1] = j + 1;
+                if (hit1 && pos1 < room) SF_LIST_STORE(idx + out + pos1, j + 1);
             }
             total += __popcll(m0) + __popcll(m1);
         }
