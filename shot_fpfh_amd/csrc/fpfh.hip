@@ -239,9 +239,11 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
     CT *row = counts + i * (int64_t)stride;
     if (live) { // uint8 table: 128 bins, two per lane; which 16-bin blocks of this row hold a count goes into the table-wide mask
         const unsigned v0 = lane < nb3 ? h[lane] : 0u, v1 = lane + 64 < nb3 ? h[lane + 64] : 0u; // (padding bins: count 0)
-        row[lane] = (CT)(v0 ^ bias); // (the uint8 table keeps count & 255; a point with more than 255 neighbours also has ...
-        row[lane + 64] = (CT)(v1 ^ bias);
-        if (hi && sf_uniform(k) > 255) { // ... count >> 8 in the table of high bytes)
+        // (the uint8 table keeps count & 255; a point with more than 255 neighbours also has count >> 8 in the table of high
+        // bytes.  Streamed past the L2 -- K7 gathers the PACKED rows; of this table it reads each keypoint's own row, once)
+        __builtin_nontemporal_store((CT)(v0 ^ bias), row + lane);
+        __builtin_nontemporal_store((CT)(v1 ^ bias), row + lane + 64);
+        if (hi && sf_uniform(k) > 255) {
             hi[i * 128 + lane] = (uint8_t)(v0 >> 8);
             hi[i * 128 + lane + 64] = (uint8_t)(v1 >> 8);
         }
