@@ -810,6 +810,28 @@ def main() -> int:
                 "what": "SF_K2_NO_HINT=1: every radius search first counts the lists of 2 048 sampled queries (one small launch, "
                         "8 KB read back) before it sizes its slots -- the cost of a first search on a cloud"}
 
+    # ---- the same step with the FPFH chain (K6, K7) and the SHOT chain (K4, K5) on two HIP streams: K7 waits on memory where
+    #      K5 waits on its vector pipe, side by side they fill each other's gaps.  NOT what `value` reports: the per-kernel
+    #      durations of the timed steps (the roofline's denominators) would then overlap ------------------------------------
+    if single and kinds == 2 and not args.overlap and not args.no_kernel_timers and args.sustained_seconds > 0:
+        job.overlap = True
+        try:
+            for _ in range(3):
+                job.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                job.step()
+            barrier()
+            t_two = (time.perf_counter() - t0) / args.steps
+        finally:
+            job.overlap = False
+        job.step()  # (what the parity block below reads is a step of the timed configuration)
+        eng.sync()
+        out["two_streams"] = {"ms_per_step": 1000.0 * t_two, "value": n_desc / t_two, "unit": "descriptors/s", "vs_timed_steps": 1000.0 * t_two / ms_per_step,
+                              "what": "DescriptorJob(overlap_chains=True) / bench.py --overlap: the FPFH and SHOT chains on the context's two HIP "
+                                      "streams; same rows bit for bit (tests/test_hip_parity.py::test_two_stream_overlap_gives_identical_results), kernels overlap in time"}
+
     # ---- parity of what the timed steps left in HBM ------------------------------------------------------------------
     if not args.no_parity:
         par = parity_sample(job, points, normals, radius, args.parity_rows)
