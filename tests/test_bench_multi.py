@@ -62,3 +62,16 @@ def test_emulated_rank_record_cannot_be_read_as_a_multi_gpu_result():
     assert d["emulated"] is True and d["emulated_rank"] == 3 and d["emulated_world"] == 8
     assert d["n_gpus"] == 1 and d["value"] is None and d["projected_value_upper_bound"] > 0
     assert d["parity"]["ok"]
+
+
+def test_secondary_keys_of_the_one_rank_record():
+    """The keys the default run adds behind the timed steps, at a small size: the sustained window, the slot-capacity line and
+    the two-stream step (same rows, the two chains side by side) -- and the parity block, read AFTER them, still holds."""
+    r = run_program([sys.executable, "bench.py", "--points-per-gpu", "60000", "--radius", "0.08", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline", "--sustained-seconds", "0.05", "--sustained-steps", "20", "--no-density", "--no-defaults",
+                     "--no-dropin", "--no-normals", "--no-match", "--parity-rows", "60"], timeout=900)
+    assert r["rc"] == 0, r["stderr"][-2000:]
+    d = json.loads([ln for ln in r["stdout"].splitlines() if ln.strip()][-1])
+    assert d["sustained"]["steps"] >= 20 and d["k2_slot_capacity"]["ms_per_step_with_a_sample_counted_in_every_search"] > 0
+    assert d["two_streams"]["ms_per_step"] > 0 and 0.5 < d["two_streams"]["vs_timed_steps"] < 1.5
+    assert d["parity"]["ok"]

@@ -483,3 +483,26 @@ def test_counting_build_gives_the_order_of_the_stable_sort(eng, kind, block):
         assert "k1_cell_settle" in names[0] and "k1_radix_sort" not in names[0], names[0]
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_layer_bounds_on_the_host_equal_the_device_search(eng):
+    """A block build looks the z-layers' first points up in a host copy of the sorted z coordinates (no launch, no
+    read-back); the wave-parallel device search it replaces stays for very large clouds: same table, same slab, same lists."""
+    p, _ = config1_cloud(50000, 8)
+    r, block = 0.035, (12000, 31000)
+    out = []
+    for device in (False, True):
+        if device:
+            os.environ["SF_K1_DEVICE_BOUNDS"] = "1"
+        try:
+            cloud = eng.cloud(p)
+            nb, rep = launches(eng, lambda: (cloud.build_grid(r, block=block, reach=1), cloud.radius_search_self(r, *block))[1])
+            off, idx = nb.export()
+            out.append((cloud.layer_table().copy(), cloud.perm()[block[0]:block[1]].copy(), off, idx, set(rep)))
+            nb.free()
+            cloud.free()
+        finally:
+            os.environ.pop("SF_K1_DEVICE_BOUNDS", None)
+    assert "k1_layer_bounds" not in out[0][4] and "k1_layer_bounds" in out[1][4]
+    for a, b in zip(out[0][:4], out[1][:4]):
+        assert np.array_equal(a, b)
