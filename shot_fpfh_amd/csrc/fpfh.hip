@@ -109,7 +109,9 @@ __device__ inline int theta_bin_fast(const fpfh_edges &ed, int nb, double a, dou
 // limit / SEL: dispatch by list length, per point (sf_nbrs_dispatch) -- the main launch leaves out the points whose own list
 // exceeds its form, a second launch (SEL, the streaming form) serves exactly those.
 template <typename CT, int NCH, int NB, bool SEL>
-__global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_eu(6))) void k_spfh(const double *__restrict__ rec,
+// (waves per SIMD: six for the forms of up to three chunks -- 80 registers; the four-chunk and the streaming form, asked for six,
+// spilled 52-140 bytes in their sweep: on the clustered cloud K6 1.09 + 0.34 ms, with five waves and no spill 0.81 + 0.27)
+__global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_eu((NCH == 0 || NCH >= 4) ? 5 : 6))) void k_spfh(const double *__restrict__ rec,
                                               const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ idx,
                                               int64_t m, int64_t self_begin, fpfh_edges ed, int nb_rt, int nb3, int stride,
@@ -472,8 +474,11 @@ __device__ inline void fpfh_mc_wrong_form(const unsigned *__restrict__ live, dou
 // for eight waves it fits 64 without spilling (the 4-chunk form spills five dwords), and the kernel -- which lives on the
 // number of waves that cover its LDS-DMA round trips -- runs 11 % faster at C3 (1.48 -> 1.31 ms).  LDS (4.6 KB per wave)
 // allows 8.5 waves per SIMD.  The same request made K5 and K6 spill and lose (2.13 / 0.98 ms instead of 1.70 / 0.82).
-// HI: some point of the table has more than 255 neighbours (sf_spfh::hi); the instantiation without it is the kernel of
-// rounds 1-3, instruction for instruction.
+// HI: some point of the table has more than 255 neighbours (sf_spfh::hi).  The FULL form is always launched in its HI
+// instantiation (without long neighbours its masks are zero and the correction executes nothing; `hi` may then be null): held
+// to 64 registers the 3-chunk instantiation WITHOUT it spills 360 bytes -- 24 ms per 1M keypoints instead of 1.46 (measured
+// late in round 4: SF_FPFH_DENSE=1; relaxed to 7 / 6 / 5 waves it runs 3.7 / 2.6 / 1.47 ms) -- while the one with it spills
+// 24.  A register-allocation accident, so tests/test_hip_round4.py holds the full form to a time, not just to its rows.
 template <int NKS, bool HI>
 __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
@@ -1331,7 +1336,7 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     const bool sparse = __builtin_popcount(sp->host_live[0] & 0xffu) <= 2;
 #define SF_MC_LAUNCH2(NAME, GRID, NKS, HI, LIMIT, SELP, NSEL)                                                         \
     if (sparse) { SF_LAUNCH(ctx, NAME, (k_fpfh_mc_sparse<NKS, HI>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); } \
-    else { SF_LAUNCH(ctx, NAME, (k_fpfh_mc<NKS, HI>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); }
+    else { SF_LAUNCH(ctx, NAME, (k_fpfh_mc<NKS, true>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); }
 #define SF_MC_LAUNCH(NKS)                                                                                            \
     if (hi) { SF_MC_LAUNCH2("k7_fpfh", grid, NKS, true, d.limit, (const int32_t *)nullptr, (int64_t)0) }             \
     else { SF_MC_LAUNCH2("k7_fpfh", grid, NKS, false, d.limit, (const int32_t *)nullptr, (int64_t)0) }

@@ -506,3 +506,39 @@ def test_layer_bounds_on_the_host_equal_the_device_search(eng):
     assert "k1_layer_bounds" not in out[0][4] and "k1_layer_bounds" in out[1][4]
     for a, b in zip(out[0][:4], out[1][:4]):
         assert np.array_equal(a, b)
+
+
+def test_full_form_of_k7_stays_within_reach_of_the_sparse_form(eng, monkeypatch):
+    """K7's full form (tables with more than two live 16-bin blocks: even bin counts, large radii, clouds in millimetres) and
+    its sparse-block form give the same rows; this holds the full form to a TIME as well: one of its instantiations, held to 64
+    registers, spilled 360 bytes and ran 24 ms per 1M keypoints instead of 1.5 -- for a whole round, with every row correct."""
+    p, nr, _ = synth_cloud(300000, 6)
+    r = 0.044  # ~ 105 neighbours, lists up to ~160: two chunks for most, the three-chunk instantiation for the launch
+    out = {}
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("SF_FPFH_DENSE", "1")
+        else:
+            monkeypatch.delenv("SF_FPFH_DENSE", raising=False)
+        cloud = eng.cloud(p, nr)
+        nb = cloud.radius_search_self(r)
+        spfh = eng.spfh(cloud, 5, nb.max_count)
+        spfh.compute(nb)
+        dst = eng.empty((cloud.n, 125))
+        spfh.fpfh(nb, None, out=dst)  # (first call: reads the block mask back)
+        _, rep = launches(eng, lambda: spfh.fpfh(nb, None, out=dst))
+        eng.sync()
+        eng.profile_reset()
+        eng.profile(True)
+        for _ in range(3):
+            spfh.fpfh(nb, None, out=dst)
+        eng.sync()
+        eng.profile(False)
+        ms = sum(v[1] for k, v in eng.profile_report().items() if k.startswith("k7_")) / 3
+        out[dense] = (ms, dst.rows_to_host(0, 2000).copy(), nb.max_count)
+        for o in (dst, spfh, nb, cloud):
+            o.free()
+    monkeypatch.delenv("SF_FPFH_DENSE", raising=False)
+    assert out[False][2] > 128  # (the launch is the three-chunk instantiation)
+    assert np.array_equal(out[False][1], out[True][1])
+    assert out[True][0] < 3.0 * out[False][0], (out[True][0], out[False][0])
