@@ -1591,7 +1591,7 @@ namespace {
 // It is meant to run on the side stream UNDER K7, which holds eight 64-register waves on every SIMD: a wave of this kernel
 // only ever finds room if it fits the hole ONE retiring K7 wave leaves (<= 64 VGPRs, single-wave workgroups) -- at 84
 // registers in 4-wave workgroups it was starved until K7's tail and ended after it (1.43 ms against K7's 1.33 ms).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lrf_from_cov(const double *__restrict__ cov, int64_t m, double *__restrict__ lrf)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lrf_from_cov(const double *__restrict__ cov, int64_t m, double *__restrict__ lrf)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= m) return;

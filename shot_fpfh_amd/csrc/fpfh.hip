@@ -470,17 +470,16 @@ __device__ inline void fpfh_mc_wrong_form(const unsigned *__restrict__ live, dou
     if (lane == 0) atomicOr(const_cast<unsigned *>(live) + 2, 1u);
 }
 
-// waves_per_eu(8, 8): left to itself the allocator gives the 3-chunk instantiation 74 registers (6 waves per SIMD); asked
-// for eight waves it fits 64 without spilling (the 4-chunk form spills five dwords), and the kernel -- which lives on the
-// number of waves that cover its LDS-DMA round trips -- runs 11 % faster at C3 (1.48 -> 1.31 ms).  LDS (4.6 KB per wave)
-// allows 8.5 waves per SIMD.  The same request made K5 and K6 spill and lose (2.13 / 0.98 ms instead of 1.70 / 0.82).
+// Occupancy: the full form keeps eight 4-register accumulators and wants 76 registers -- six waves per SIMD, no spill: 1.33 ms
+// per 1M keypoints at C3 (asked for seven waves: 8 bytes of scratch, 1.37 ms; for eight: 24 bytes, 1.45-1.54 ms).  LDS (4.6 KB
+// per wave) allows 8.5 waves per SIMD.
 // HI: some point of the table has more than 255 neighbours (sf_spfh::hi).  The FULL form is always launched in its HI
-// instantiation (without long neighbours its masks are zero and the correction executes nothing; `hi` may then be null): held
-// to 64 registers the 3-chunk instantiation WITHOUT it spills 360 bytes -- 24 ms per 1M keypoints instead of 1.46 (measured
-// late in round 4: SF_FPFH_DENSE=1; relaxed to 7 / 6 / 5 waves it runs 3.7 / 2.6 / 1.47 ms) -- while the one with it spills
-// 24.  A register-allocation accident, so tests/test_hip_round4.py holds the full form to a time, not just to its rows.
+// instantiation (without long neighbours its masks are zero and the correction executes nothing; `hi` may then be null): the
+// 3-chunk instantiation WITHOUT it wants 96 registers and, held to eight waves as this kernel was until late in round 4,
+// spilled 360 bytes into its step loop -- 24 ms per 1M keypoints, every row correct (SF_FPFH_DENSE=1 shows it; tools/check_spills.py
+// lists every kernel's private segment; tests/test_hip_round4.py holds the full form to a time as well as to its rows).
 template <int NKS, bool HI>
-__global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+__global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
                                                  int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
