@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     CT *row = counts + i * (int64_t)stride;
+    bool hi_empty = false;
     if (live) { // uint8 table: 128 bins, two per lane; which 16-bin blocks of this row hold a count goes into the table-wide mask
         const unsigned v0 = lane < nb3 ? h[lane] : 0u, v1 = lane + 64 < nb3 ? h[lane + 64] : 0u; // (padding bins: count 0)
         // (the uint8 table keeps count & 255; a point with more than 255 neighbours also has count >> 8 in the table of high
@@ -248,6 +249,10 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
         if (hi && sf_uniform(k) > 255) {
             hi[i * 128 + lane] = (uint8_t)(v0 >> 8);
             hi[i * 128 + lane + 64] = (uint8_t)(v1 >> 8);
+            // (a point with more than 255 neighbours whose counts all stay below 256 -- the rule unless its neighbourhood is a
+            // smooth surface with consistent normals -- has a row of zero high bytes: marked in its K7 record below, so that no
+            // keypoint that has it as a neighbour goes and reads that row)
+            hi_empty = __ballot(((v0 | v1) >> 8) != 0u) == 0ull;
         }
         if (packed && lane < 8) { // the host knows which two 16-bin blocks can be live (spfh_compute): the packed copy K7 gathers is
                                   // written here, straight from the LDS histogram, instead of by a kernel of its own re-reading the
@@ -276,7 +281,9 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
         if (p4) { // the per-neighbour record of the matrix-core K7
             double2 *o = reinterpret_cast<double2 *>(p4 + 4 * i);
             o[0] = make_double2(rec[6 * i + 0], rec[6 * i + 1]);
-            o[1] = make_double2(rec[6 * i + 2], (double)k);
+            // k as a double; NEGATIVE for a point with more than 255 neighbours and no high byte set: K7 squares it for the weight
+            // and asks "k > 255" to know whether the row of high bytes has anything to add
+            o[1] = make_double2(rec[6 * i + 2], hi_empty ? -(double)k : (double)k);
         }
     }
 }
