@@ -595,30 +595,54 @@ __global__ __launch_bounds__(256) void k_fpfh_tail(const double *__restrict__ re
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const int grp = lane / LPR, piece = lane % LPR;
     const int blk = SPARSE ? (piece ? b1 : b0) : piece; // the 16-bin block this lane accumulates
-    // weight of the lane's neighbour of the chunk starting at t0 (0 past the end and at distance 0, fpfh.py:110-114)
-    auto weight = [&](int t0, int &j, bool &lng) -> double {
-        const int t = t0 + lane;
-        j = 0;
-        lng = false;
-        if (t >= k) return 0.0;
-        j = idx[s + t];
-        const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)j);
-        const double2 u0 = pp[0], u1 = pp[1];
-        const double cx = u0.x - px, cy = u0.y - py, cz = u1.x - pz;
-        const double d2 = (cx * cx + cy * cy) + cz * cz;
-        const double kd = u1.y, xx = d2 * (kd * kd);
-        const double y0 = __builtin_amdgcn_rsq(xx);
-        const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
-        const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
-        lng = kd > 255.0;
-        return d2 > 0.0 ? y2 : 0.0;
+    // The list is walked in SUPER-CHUNKS of SC x 64 neighbours: the SC index loads of a super-chunk are issued together, then the
+    // SC record gathers, so that a super-chunk costs two memory round trips instead of 2 SC (the first version took a round trip
+    // per index load, per record gather and per row load of every 64 neighbours: 15 dependent trips for a list of 300, and that --
+    // not its 600 vector instructions -- was its time).  A list of at most SC x 64 = 512 points keeps its entries and weights in
+    // registers from the first pass (the largest weight) to the second (the sums).
+    constexpr int SC = 8;
+    // entries and weights of the super-chunk starting at `base` (weight 0 past the end and at distance 0, fpfh.py:110-114);
+    // bit c of `lng`: the lane's neighbour of chunk c has high bytes to add
+    auto load_super = [&](int base, int (&jv)[SC], double (&wv)[SC], unsigned &lng) {
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            const int t = base + 64 * c + lane;
+            jv[c] = (base + 64 * c < k && t < k) ? SF_LIST_LOAD(idx + s + t) : -1;
+        }
+        double2 u0[SC], u1[SC];
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            u0[c] = u1[c] = make_double2(0.0, 0.0);
+            if (base + 64 * c < k) { // (wave-uniform)
+                const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)(jv[c] < 0 ? 0 : jv[c]));
+                u0[c] = pp[0];
+                u1[c] = pp[1];
+            }
+        }
+        lng = 0u;
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            const double cx = u0[c].x - px, cy = u0[c].y - py, cz = u1[c].x - pz;
+            const double d2 = (cx * cx + cy * cy) + cz * cz;
+            const double kd = u1[c].y, xx = d2 * (kd * kd);
+            const double y0 = __builtin_amdgcn_rsq(xx);
+            const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+            const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+            const bool on = jv[c] >= 0;
+            wv[c] = (on && d2 > 0.0) ? y2 : 0.0;
+            lng |= (on && kd > 255.0) ? 1u << c : 0u;
+            jv[c] = on ? jv[c] : 0; // (past the end of the list the weight is 0 and row 0 is read)
+        }
     };
     // ---- pass 0: the largest weight -> the fixed-point exponent ----
+    int jv[SC];
+    double wv[SC];
+    unsigned lng = 0u;
     double wmax = 0.0;
-    for (int t0 = 0; t0 < k; t0 += 64) {
-        int j;
-        bool lng;
-        wmax = fmax(wmax, weight(t0, j, lng));
+    for (int base = 0; base < k; base += 64 * SC) {
+        load_super(base, jv, wv, lng);
+#pragma unroll
+        for (int c = 0; c < SC; ++c) wmax = fmax(wmax, wv[c]);
     }
     wmax = sf_wave_max_nonneg(wmax);
     const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
@@ -664,25 +688,31 @@ __global__ __launch_bounds__(256) void k_fpfh_tail(const double *__restrict__ re
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.0;
     };
-    for (int t0 = 0; t0 < k; t0 += 64) {
-        int j;
-        bool lng;
-        const double w = weight(t0, j, lng);
-        const double W = floor(ldexp(w, S)); // < 2^52, exact
-        const int n_here = min(64, k - t0);
-        for (int tt = 0; tt < n_here; tt += RPI) {
-            const int src = (tt + grp) & 63; // (past the end of the list the weight is 0 and row 0 is read)
-            const int jj = __shfl(j, src);
-            const double Ws = __shfl(W, src);
-            const bool ll = __shfl((int)lng, src) != 0;
-            const double w1 = floor(Ws * (1.0 / 67108864.0)), w0 = __builtin_fma(-w1, 67108864.0, Ws); // two 26-bit limbs
-            uint4 v = SPARSE ? *reinterpret_cast<const uint4 *>(packed + (size_t)jj * 32 + 16 * piece)
-                             : *reinterpret_cast<const uint4 *>(counts + (size_t)jj * 128 + 16 * piece);
-            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; // stored as count ^ 128
-            add_words(v, w0, w1);
-            if (ll) add_words(*reinterpret_cast<const uint4 *>(hi + (size_t)jj * 128 + 16 * blk), w0 * 256.0, w1 * 256.0);
+    for (int base = 0; base < k; base += 64 * SC) {
+        if (k > 64 * SC) load_super(base, jv, wv, lng); // (a list of one super-chunk still holds it from pass 0)
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            const int t0 = base + 64 * c;
+            if (t0 < k) { // (wave-uniform)
+                const double W = floor(ldexp(wv[c], S)); // < 2^52, exact
+                // every row group of the chunk, whatever the list's end (weight 0 and row 0 past it): a fixed trip count, so the
+                // row loads of a chunk are all in flight before the first of them is consumed
+#pragma unroll
+                for (int tt = 0; tt < 64; tt += RPI) {
+                    const int src = (tt + grp) & 63;
+                    const int jj = __shfl(jv[c], src);
+                    const double Ws = __shfl(W, src);
+                    const bool ll = ((unsigned)__shfl((int)lng, src) >> c) & 1u;
+                    const double w1 = floor(Ws * (1.0 / 67108864.0)), w0 = __builtin_fma(-w1, 67108864.0, Ws); // two 26-bit limbs
+                    uint4 v = SPARSE ? *reinterpret_cast<const uint4 *>(packed + (size_t)jj * 32 + 16 * piece)
+                                     : *reinterpret_cast<const uint4 *>(counts + (size_t)jj * 128 + 16 * piece);
+                    v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; // stored as count ^ 128
+                    add_words(v, w0, w1);
+                    if (ll) add_words(*reinterpret_cast<const uint4 *>(hi + (size_t)jj * 128 + 16 * blk), w0 * 256.0, w1 * 256.0);
+                }
+                if (((t0 + 64) & 1023) == 0 || t0 + 64 >= k) fold();
+            }
         }
-        if (((t0 + 64) & 1023) == 0 || t0 + 64 >= k) fold();
     }
     const double kd = (double)k;
     double inv_k = __builtin_amdgcn_rcp(kd);
