@@ -61,7 +61,7 @@ class ShotMultiprocessor:
                 f"Keeping a support of {keep.shape[0]} points out of {np.asarray(point_cloud).shape[0]} "
                 f"(voxel size: {voxel:.2f})"
             )
-        return Cloud(self._eng(), np.asarray(point_cloud)[keep], np.asarray(normals)[keep])
+        return Cloud(self._eng(), point_cloud, normals, subset=keep)  # (gathered on the device)
 
     # ---- pieces (names follow the reference's public methods) ----------------------------------------
     def compute_local_rf(self, keypoints, neighborhoods, support, radius):
@@ -155,7 +155,7 @@ class ShotMultiprocessor:
         if weights is None:
             weights = np.ones(n_scales)
         m = np.asarray(keypoints).shape[0]
-        stack = np.zeros((n_scales, m, 352))
+        stack = np.empty((n_scales, m, 352))  # (every row is assigned below: no 2.8 KB x M x scales of zeros first)
         lrf = None
         for s, radius in enumerate(radii):
             cloud = self._support_cloud(point_cloud, normals, None if voxel_sizes is None else voxel_sizes[s])
@@ -164,7 +164,11 @@ class ShotMultiprocessor:
                 try:
                     if lrf is None or not self.share_local_rfs:
                         lrf = nb.shot_lrf()
-                    stack[s] = nb.shot(lrf, self.normalize, self.min_neighborhood_size) * weights[s]
+                    d = nb.shot(lrf, self.normalize, self.min_neighborhood_size)
+                    if weights[s] == 1.0:
+                        stack[s] = d  # (one pass over the rows instead of a product into a temporary and a copy of that)
+                    else:
+                        np.multiply(d, weights[s], out=stack[s])
                 finally:
                     nb.free()
             finally:
