@@ -542,3 +542,27 @@ def test_full_form_of_k7_stays_within_reach_of_the_sparse_form(eng, monkeypatch)
     assert out[False][2] > 128  # (the launch is the three-chunk instantiation)
     assert np.array_equal(out[False][1], out[True][1])
     assert out[True][0] < 3.0 * out[False][0], (out[True][0], out[False][0])
+
+
+def test_cloud_of_a_subset_equals_the_cloud_of_the_gathered_rows(eng):
+    """Cloud(points, normals, subset=keep) -- the rows gathered on the device -- is the cloud of points[keep], normals[keep]:
+    same lists, same descriptors, bit for bit; an empty subset is an empty cloud; indices outside the array are refused."""
+    from shot_fpfh_amd.engine import Cloud
+
+    p, nr, _ = synth_cloud(30000, 9)
+    keep = np.random.default_rng(2).permutation(30000)[:17000].astype(np.int64)  # (any order, as grid_subsampling's)
+    kp = p[keep[:1500]]
+    outs = []
+    for cloud in (Cloud(eng, p[keep], nr[keep]), Cloud(eng, p, nr, subset=keep)):
+        nb = cloud.radius_search(kp, 0.06)
+        off, idx = nb.export()
+        outs.append((off, idx, nb.shot_single_scale(True, 5).copy()))
+        nb.free()
+        cloud.free()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    empty = Cloud(eng, p, nr, subset=np.zeros(0, dtype=np.int64))
+    assert empty.n == 0
+    empty.free()
+    with pytest.raises(ValueError):
+        Cloud(eng, p, nr, subset=np.array([0, 30000]))
