@@ -32,7 +32,8 @@ After the timed region the SAME process measures the rest of the path north_star
   * `parity`          -- 300 rows of the TIMED outputs against the CPU oracle (the timed path is the checked path);
   * `cpu_baseline`    -- (N = 1) the reference-shaped NumPy restatement (oracle/numpy_shaped.py, calibrated against
     the reference in the build container) and the scalar C port, on bounded samples, on this box's host cores.
-Prints ONE JSON line (rank 0).
+Prints ONE compact JSON line (rank 0, < 4 KB: the contract's keys, `roofline`, `cpu_baseline`, `sustained`, `parity`); every
+other block named above goes to the side file the line's `detail` key names (bench_detail.json) and to stderr.
 """
 from __future__ import annotations
 
@@ -69,6 +70,7 @@ ALG_BYTES = {
     "k1_cell_settle": 8 + 48 + 48 + 4 + 4,  # (index, cell) slot in, xyz + normal in, 48-byte record (+ SoA copy of xyz) out, both permutations
 }
 PER_PAIR = ("k2_radius_fill", "k2_radius_slots")
+PROFILE_TAG = "r05"  # profiles/<tag>_{traffic,k5_sq,sustained_clock}.json: counter files of THIS round's build (stamped)
 C4_EULER, C4_T = (0.3, -0.2, 0.5), (0.1, -0.3, 0.2)  # SURVEY 8d, config C4's rigid motion
 
 
@@ -261,6 +263,88 @@ class Control:
                 c.close()
             except OSError:
                 pass
+
+
+# ---- the record: ONE compact line on stdout, everything else in a side file -------------------------------------------------
+LINE_LIMIT = 4096  # bytes; the driver recovers the last stdout line as JSON -- round 4's 23.6 KB line came back unparsed
+DETAIL_FILE = "bench_detail.json"
+
+
+def _r(x, digits=6):
+    """Floats to `digits` significant digits (the line is a summary; bench_detail.json keeps full precision)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d[k] for k in keys if k in d}
+
+
+def compact_record(out: dict, detail_path: str | None) -> dict:
+    """The line the driver parses: the contract's keys + roofline + cpu_baseline + a few scalars, < LINE_LIMIT bytes.
+    Every other block of the run (`roofline_all`, `surface_cloud`, `reference_defaults`, `exchange_match`, ...) lives in the
+    side file `detail_path` names."""
+    cfg = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg.get("workload"), "sharding": cfg.get("sharding"), "library": cfg.get("library"),
+                      "exchange": (cfg.get("exchange") or "")[:80]}
+    line["roofline"] = _pick(out.get("roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                   "avg_launch_ms", "algorithmic_bytes_per_launch"))
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        cb = _pick(cb, ("value", "unit", "cores", "kind", "sample", "sample_wall_seconds"))
+        cb["sample"] = (cb.get("sample") or "")[:200]
+    line["cpu_baseline"] = cb
+    line["sustained"] = _pick(out.get("sustained"), ("ms_per_step_median", "ms_per_step_p95", "steps", "clock_mhz"))
+    par = out.get("parity")
+    if par is not None:
+        par = _pick(par, ("ok", "rows", "fpfh_max_abs_err", "shot_max_abs_err", "tolerance"))
+    line["parity"] = par
+    for k in ("rccl_ranks", "per_rank_ms_per_step", "exchange_ms", "emulated", "emulated_rank", "emulated_world",
+              "projected_value_upper_bound", "kernels_ms_per_step"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    ss = out.get("strong_scaling")
+    if ss is not None:
+        line["strong_scaling"] = _pick(ss, ("ms_per_step", "value", "parity_ok"))
+    em = out.get("exchange_match")
+    if em is not None:
+        line["end_to_end_config5_ms"] = out.get("end_to_end_config5_ms")
+    line["detail"] = detail_path
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:  # never the driver's problem: shed the optional blocks, longest first
+        for k in ("kernels_ms_per_step", "per_rank_ms_per_step", "strong_scaling", "sustained", "exchange_ms"):
+            line.pop(k, None)
+            if len(json.dumps(line, separators=(",", ":"))) < LINE_LIMIT:
+                break
+    return line
+
+
+def emit_record(json_fd: int, out: dict, detail_name: str = DETAIL_FILE) -> None:
+    """Full record -> side file (and stderr, for the log); compact line -> the saved stdout descriptor, LAST."""
+    path = None
+    try:
+        path = os.path.join(os.environ.get("SF_BENCH_DETAIL_DIR", ROOT), detail_name)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        path = os.path.relpath(path, ROOT)
+    except OSError as exc:
+        sys.stderr.write(f"bench.py: could not write {detail_name}: {exc}\n")
+        path = None
+    sys.stderr.write("bench.py detail record: " + json.dumps(out) + "\n")
+    sys.stderr.flush()
+    text = json.dumps(compact_record(out, path), separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    os.write(json_fd, (text + "\n").encode())
 
 
 # ---- CPU baselines (N = 1 only) -----------------------------------------------------------------------------------
@@ -661,7 +745,7 @@ def main() -> int:
     if args.sustained_seconds > 0 and not args.no_kernel_timers:
         sustained = sustained_window(job, eng, ms_per_step, args.sustained_seconds, args.sustained_steps, barrier, max_over_ranks)
         sustained["vs_timed_steps"] = sustained["ms_per_step_median"] / ms_per_step
-        ck, ck_src = load_stamped("r04_sustained_clock.json", build)
+        ck, ck_src = load_stamped(f"{PROFILE_TAG}_sustained_clock.json", build)
         sustained["clock_mhz"] = None if ck is None else ck.get("clock_mhz_time_weighted_hot_kernels")
         sustained["clock_source"] = ck_src if ck is None else ck.get("_source")
         if abs(sustained["vs_timed_steps"] - 1.0) > 0.02:
@@ -697,7 +781,7 @@ def main() -> int:
 
         alg_bytes = alg_bytes_of(dom)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        tj, traffic_src = load_stamped("r04_traffic.json", build)
+        tj, traffic_src = load_stamped(f"{PROFILE_TAG}_traffic.json", build)
         traffic = None if tj is None else tj.get(dom)
         # ---- every kernel of the step against both HBM ceilings (per STEP: a kernel launched in pieces counts once) ------------
         roof_all = {}
@@ -709,7 +793,7 @@ def main() -> int:
                            "launches_per_step": round(launches_per_step.get(k, 0), 2), "achieved_gbs": round(gbs, 1),
                            "frac_of_8000": round(gbs / HBM_PEAK_GBS, 4), "frac_of_6290": round(gbs / HBM_COPY_GBS, 4),
                            "hbm_bytes_measured": None if tj is None else tj.get(k)}
-        sq, sq_src = load_stamped("r04_k5_sq.json", build)
+        sq, sq_src = load_stamped(f"{PROFILE_TAG}_k5_sq.json", build)
         if sq is not None and "k5_shot" in roof_all:
             # float64 issue ceiling: a wave's vector instructions occupy its SIMD for SQ_ACTIVE_INST_VALU quad-cycles (x 4
             # cycles); one keypoint = one wave; 256 CUs x 4 SIMDs share the keypoints
@@ -1103,7 +1187,7 @@ def main() -> int:
             # (a ratio against a CPU says nothing about kernel quality -- the roofline fractions do; what it means in seconds:)
             out["cpu_baseline"]["implied_seconds_for_this_workload"] = n_desc / shaped["value"]
             out["cpu_baseline"]["gpu_seconds_for_this_workload"] = n_desc / value
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit_record(json_fd, out, DETAIL_FILE if not emulated else f"bench_detail_rank{rank}_of_{world}.json")
     os.close(json_fd)
     if ctl is not None:
         ctl.barrier()

@@ -349,3 +349,40 @@ def test_pinned_pool_finalizer_takes_no_lock_and_trim_releases():
     del b
     gc.collect()
     assert pool.trim() == 8192 and not lib.live
+
+
+# ---- bench.py's record: one short line for the driver, everything else in a side file ------------------------------------------
+def test_bench_line_is_compact_and_keeps_the_contract_keys(tmp_path, monkeypatch):
+    """Round 4's single 23.6 KB JSON line came back from the driver unparsed.  The line is now a summary of < 4 KB with the
+    contract's keys, `roofline` and `cpu_baseline`; the full record of a round-4 run (the largest shape there is) goes to the
+    side file."""
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench.json")))
+    assert len(json.dumps(full)) > 20000
+    monkeypatch.setenv("SF_BENCH_DETAIL_DIR", str(tmp_path))
+    r, w = os.pipe()
+    bench.emit_record(w, full)
+    os.close(w)
+    text = os.read(r, 1 << 16).decode()
+    os.close(r)
+    assert text.endswith("\n") and text.count("\n") == 1 and len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "sustained", "parity", "rccl_ranks", "per_rank_ms_per_step", "detail"):
+        assert k in line, k
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"]
+    assert json.load(open(tmp_path / "bench_detail.json")) == full
+    # the worst case the contract allows for -- 8 ranks, strong-scaling and exchange blocks present -- still fits
+    full.update(n_gpus=8, per_rank_ms_per_step=[3.123456] * 8, exchange_ms={"c_exchange": 0.123456, "c_allgather": 1.234567},
+                strong_scaling={"ms_per_step": 0.5, "value": 4e9, "parity_ok": True, "checksum": {"x": 1}}, end_to_end_config5_ms=12.5)
+    assert len(json.dumps(bench.compact_record(full, "bench_detail.json"), separators=(",", ":"))) < bench.LINE_LIMIT

@@ -2,7 +2,7 @@
 # Round-end evidence on ONE MI355X box (run through gpurun): everything profiles/ quotes for the library that is in place.
 #   tools/final_profiles.sh <tag>      e.g. r03
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
 mkdir -p gpurun_out
@@ -12,8 +12,9 @@ python tools/parse_rocprof.py ${TAG} > /dev/null 2>> gpurun_out/${TAG}_profile.l
 # 2. SQ counters of K5 -> profiles/<tag>_k5_sq.json (stamped)
 bash tools/pmc_k5.sh ${TAG} > gpurun_out/${TAG}_k5.log 2>&1
 # 3. the bench record itself (now quoting 1. and 2.), the emulated ranks of an 8-GPU job, config 4
-python bench.py > profiles/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-for r in 0 3 7; do python bench.py --gpus 8 --emulate-rank $r --no-strong > profiles/${TAG}_emulated_rank${r}_of_8.json 2>/dev/null; done
+python bench.py > profiles/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err   # the line the driver parses (ONE run: the first of this build)
+cp bench_detail.json profiles/${TAG}_bench_detail.json                            # every other block of that run
+for r in 0 3 7; do python bench.py --gpus 8 --emulate-rank $r --no-strong > profiles/${TAG}_emulated_rank${r}_of_8.json 2>/dev/null; cp bench_detail_rank${r}_of_8.json profiles/${TAG}_emulated_rank${r}_of_8_detail.json; done
 python tools/run_config4.py > profiles/${TAG}_config4.txt 2>&1
 python tools/show_bench.py profiles/${TAG}_bench.json profiles/${TAG}_emulated_rank0_of_8.json profiles/${TAG}_emulated_rank3_of_8.json profiles/${TAG}_emulated_rank7_of_8.json
 tail -12 profiles/${TAG}_config4.txt
