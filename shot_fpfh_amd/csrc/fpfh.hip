@@ -1138,6 +1138,31 @@ extern "C" int sf_spfh_allgather(sf_ctx *ctx, sf_spfh *sp, int64_t rows_per_rank
     }
     const size_t row_bytes = (size_t)sp->stride * sp->elem_bytes;
     char *base = (char *)sp->counts;
+    if (ctx->comm && ctx->nranks > 1) {
+        // Every rank must hold the same storage (element width, high-byte rows, packed rows): the number and size of the
+        // collectives below follow from it, and ranks that disagree would hang or scramble the table.  One 8-byte
+        // all-reduce(max) of (format, -format) in front of the gathers; min != max fails HERE, on every rank alike.
+        sf_pool_guard tmp(ctx);
+        int *fw = nullptr;
+        SF_CHECK(tmp.alloc(&fw, 2));
+        const int word = (int)sp->elem_bytes | (sp->hi ? 1 << 8 : 0) | (sp->p4 ? 1 << 9 : 0) | ((int)sp->stride << 12);
+        void *pin = nullptr;
+        SF_CHECK(sf_ctx_pinned(ctx, &pin));
+        int *hw = (int *)((char *)pin + SF_PINNED_BYTES - 16); // (the block's last words: nothing else lives there)
+        hw[0] = word;
+        hw[1] = -word;
+        SF_HIP(hipMemcpyAsync(fw, hw, 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        SF_CHECK(sf_comm_allreduce_max_i32(ctx, fw, fw, 2));
+        SF_HIP(hipMemcpyAsync(hw, fw, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        if (hw[0] != word || hw[1] != -word) {
+            sf_set_error("sf_spfh_allgather: the ranks hold SPFH tables of different storage (this rank: %d-byte counts%s%s, stride %d; "
+                         "format words over the ranks %#x .. %#x) -- size every rank's table by the longest list of ANY rank",
+                         sp->elem_bytes, sp->hi ? " + high-byte rows" : "", sp->p4 ? " + packed rows" : "", (int)sp->stride,
+                         (unsigned)-hw[1], (unsigned)hw[0]);
+            return SF_ERR_STATE;
+        }
+    }
     SF_CHECK(sf_comm_allgather(ctx, base + (size_t)ctx->rank * rows_per_rank * row_bytes, base,
                                (size_t)rows_per_rank * row_bytes));
     char *kb = (char *)sp->k;

@@ -277,14 +277,29 @@ class DescriptorJob:
             hb, he = cloud.halo_range(b, e)
         else:
             hb, he = b, e
-        nb: Neighbors = cloud.radius_search_self(self.radius, hb, he)
+        # spfh_exchange="allgather": the table rows of EVERY rank land in every rank's table, so all of them must hold the same
+        # storage (bytes / bytes + high-byte rows / 16 / 32 bits) -- sized by the longest list of ANY rank, as in
+        # _step_neighbor; "halo" recomputes what it needs and exchanges nothing, a rank-local size is right there
+        fold = self.plan.world > 1 and self.do_fpfh and self.exchange == "allgather"
+        if fold:
+            self.engine.collective_stats(True)
+        try:
+            nb: Neighbors = cloud.radius_search_self(self.radius, hb, he)
+        finally:
+            if fold:
+                self.engine.collective_stats(False)
         try:
             self.last_pairs = nb.total
             blk = nb if (hb, he) == (b, e) else nb.slice(b - hb, e - b)
             try:
                 two_streams = self.overlap and self.do_fpfh and self.do_shot
                 if self.do_fpfh:
-                    spfh = self._spfh_table(nb.max_count)  # (allocates on first use: before forking)
+                    longest = nb.max_count
+                    if fold:
+                        longest = max(nb.max_count_all, longest)
+                        if getattr(self.engine, "fold_max_count", None) is not None:
+                            longest = self.engine.fold_max_count(longest)  # (a transport without RCCL folds it itself)
+                    spfh = self._spfh_table(longest)  # (allocates on first use: before forking)
                 shared = self.share_sweep  # (any list length: the kernels dispatch per keypoint, sf_nbrs_dispatch)
                 if shared:
                     if self.moments is None or self.moments.shape[0] < nb.m:

@@ -112,6 +112,11 @@ def main():
     if mode == "reciprocal":
         return reciprocal_main(out_path, rank, world)
     p, nr, _ = synth_cloud(1500, 41)
+    if mode.endswith("_long"):  # one dense blob at low z: only the first rank sees lists of more than 255 points
+        from conftest import long_list_cloud
+
+        p, nr = long_list_cloud()
+        mode = mode[: -len("_long")]
     job = DescriptorJob(FakeEngine(), p, nr, 0.15, n_bins=5, normalize=True, min_neighborhood_size=5, world=world,
                         rank=rank, spfh_exchange=mode)
     job.step()

@@ -123,3 +123,14 @@ def family(name, n, rng):
 
 
 FAMILIES = ["uniform", "clustered", "lattice", "plane", "rough_plane", "line", "duplicates", "far_origin", "slab"]
+
+
+def long_list_cloud():
+    """1 500 uniform points + a 320-point blob of diameter 0.1 near z = 0.05: at radius 0.15 every blob point has more than 255
+    neighbours, and in a z-slab sharding only the first rank owns such a list."""
+    p, nr, _ = synth_cloud(1500, 41)
+    rng = np.random.default_rng(43)
+    blob = (np.array([0.5, 0.5, 0.06]) + (rng.random((320, 3), dtype=np.float32).astype(np.float64) - 0.5) * 0.1)
+    bn = rng.standard_normal((320, 3))
+    bn /= np.linalg.norm(bn, axis=1)[:, None]
+    return np.vstack([p, blob]), np.vstack([nr, bn])

@@ -46,6 +46,14 @@ class FakeNbrs:
         self.total = int(off[-1] - off[0])
         self.max_count = int(np.diff(off).max()) if self.m else 0
         self.max_count_all = self.max_count
+        eng = getattr(cloud, "engine", None)
+        if eng is not None and eng.stats_on:  # sf_comm_collective_stats: the longest list of ANY rank
+            import torch
+            import torch.distributed as dist
+
+            t = torch.tensor([self.max_count], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self.max_count_all = int(t[0])
 
     def slice(self, first, count):
         return FakeNbrs(self.cloud, self.radius, self.begin + first, self.off[first:first + count + 1], self.idx)
@@ -83,8 +91,10 @@ class FakeNbrs:
 
 
 class FakeSpfh:
-    def __init__(self, cloud, n_bins):
+    def __init__(self, cloud, n_bins, max_count=0):
         self.cloud, self.n_bins = cloud, n_bins
+        # the storage the device table would have (engine.Engine.spfh / sf_spfh_create): bytes, bytes + high-byte rows, 16, 32 bits
+        self.storage = (0 if max_count <= 255 else 3) if max_count <= 65535 and n_bins**3 <= 128 else (2 if max_count > 65535 else 1)
         self.table = np.full((cloud.n, n_bins**3), np.nan)
         self.k = np.zeros(cloud.n, dtype=np.int64)
         self._full = None
@@ -105,6 +115,10 @@ class FakeSpfh:
         import torch.distributed as dist
 
         world, rank = dist.get_world_size(), dist.get_rank()
+        kinds = [None] * world
+        dist.all_gather_object(kinds, self.storage)
+        if len(set(kinds)) != 1:  # sf_spfh_allgather's format word: ranks that disagree fail loudly (on the device they would hang)
+            raise RuntimeError(f"sf_spfh_allgather: the ranks hold SPFH tables of different storage {kinds}")
         pad = rows_per_rank * world
         buf = np.zeros((pad, self.table.shape[1]))
         buf[: self.cloud.n] = np.nan_to_num(self.table, nan=-7.0)
@@ -187,6 +201,8 @@ class FakeCloud:
 
 
 class FakeEngine:
+    stats_on = False
+
     # the two-stream interface of the device engine: the stand-in runs everything in program order
     def fork(self):
         pass
@@ -204,7 +220,9 @@ class FakeEngine:
         pass
 
     def cloud(self, points, normals=None):
-        return FakeCloud(points, normals)
+        c = FakeCloud(points, normals)
+        c.engine = self
+        return c
 
     def empty(self, shape, dtype=np.float64):
         return FakeArray(shape, dtype)
@@ -241,7 +259,7 @@ class FakeEngine:
         return out
 
     def collective_stats(self, on):
-        pass
+        self.stats_on = bool(on)
 
     def rows_gather_device(self, rows, sel, out):
         pick = sel.a.astype(np.int64)
@@ -263,4 +281,4 @@ class FakeEngine:
             dist.a[:m1] = d
 
     def spfh(self, cloud, n_bins, max_count):
-        return FakeSpfh(cloud, n_bins)
+        return FakeSpfh(cloud, n_bins, max_count)

@@ -53,6 +53,36 @@ def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode, world):
     assert np.abs(got["fpfh"] - fo).max() < 1e-9 and np.abs(got["shot"] - so).max() < 1e-12
 
 
+@pytest.mark.parametrize("mode", ["allgather_long", "neighbor_long"])
+def test_ranks_size_their_spfh_tables_by_the_longest_list_of_any_rank(tmp_path, mode):
+    """Only rank 0's slab holds lists of more than 255 points.  Ranks that exchange table rows must all hold the same storage
+    (bytes + high-byte rows here): DescriptorJob folds the longest list over the ranks before it creates the table -- in
+    step() (all-gather mode) as in _step_neighbor -- and the all-gather fails loudly when the storages differ (the stand-in's
+    check mirrors sf_spfh_allgather's format word)."""
+    from conftest import long_list_cloud
+    from fake_engine import FakeEngine
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    out = str(tmp_path / "stitched.npz")
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, mode], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    p, nr = long_list_cloud()
+    single = DescriptorJob(FakeEngine(), p, nr, 0.15, n_bins=5, normalize=True, min_neighborhood_size=5)
+    single.step()
+    assert single.spfh.storage == 3  # (the cloud does have lists above 255 points)
+    rows = single.block_original_indices()
+    f1, s1 = np.zeros((p.shape[0], 125)), np.zeros((p.shape[0], 352))
+    f1[rows], s1[rows] = single.fpfh_out.to_host(), single.shot_out.to_host()
+    assert (got["seen"] == 1).all() and np.array_equal(got["fpfh"], f1) and np.array_equal(got["shot"], s1)
+
+
 @pytest.mark.parametrize("world", [2, 3, 5, 8])
 def test_exchange_plan_covers_every_halo_and_pairs_up(world):
     """sharding.exchange_plan from a layer table alone: for every rank, block + received rows = its halo exactly; what
