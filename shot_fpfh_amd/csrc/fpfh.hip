@@ -556,6 +556,54 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// K7 for the keypoints whose own list exceeds 255 points, on the matrix cores (fpfh_mc.h: fpfh_mcl_body / _sparse): launched over
+// the selection of those keypoints (SEL) or over every keypoint (those of the main launch return at once).
+#ifndef SF_MCL_SC
+#define SF_MCL_SC 8 // chunks of 64 neighbours whose loads are in flight together (sparse form; the full form holds 4)
+#endif
+template <bool SEL, bool SPARSE>
+__global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mcl(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                                 const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                 int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
+                                                 int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
+                                                 const double *__restrict__ p4, const unsigned *__restrict__ live,
+                                                 const uint8_t *__restrict__ packed, unsigned packed_bytes,
+                                                 double *__restrict__ out, const uint8_t *__restrict__ hi, int limit,
+                                                 const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first)
+{
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf_all[SF_MC_WPB][32 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char abuf_all[SF_MC_WPB][9 * 64];
+    const int wv_id = threadIdx.x >> 6;
+    int64_t q = sf_uniform64(sf_xcd_block() * SF_MC_WPB + wv_id);
+    if (SEL) {
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
+    if (q >= m) return;
+    const unsigned mask = sf_uniform(*live) & 0xffu;
+    if ((__popc(mask) <= 2) != SPARSE) { // the host launched the wrong form: never leave the row unwritten
+        const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
+        if (sf_uniform(cnt[i - nbrs_begin]) > limit) fpfh_mc_wrong_form(live, out, q, nb3);
+        return;
+    }
+    if (SPARSE) {
+        const int b0 = mask ? __ffs(mask) - 1 : 0;
+        const unsigned rest = mask & (mask - 1u);
+        const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7; // (a lone live block is paired with an empty one)
+        if (sf_uniform(live[1]) == mask) {
+            fpfh_mcl_body_sparse<true, SF_MCL_SC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q, b0, b1,
+                                                  rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
+        } else {
+            fpfh_mcl_body_sparse<false, SF_MCL_SC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q, b0, b1,
+                                                   rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
+        }
+    } else {
+        fpfh_mcl_body<4>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id], abuf_all[wv_id], hi,
+                         limit);
+    }
+}
+
 // K7 for the keypoints whose own list exceeds the matrix-core form (more than 255 points): the vector ALU on the byte table,
 // with EXACT sums.  The weights 1 / (k_j d_j) become 52-bit fixed point scaled by the keypoint's largest weight (a first pass
 // over the list finds it) and are cut into two 26-bit limbs held as doubles; limb x count products (count = low byte +
@@ -1412,8 +1460,18 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     }
 #undef SF_MC_LAUNCH
 #undef SF_MC_LAUNCH2
-#undef SF_MC_ARGS
-    if (any_tail) {
+    if (any_tail && !getenv("SF_FPFH_TAIL_VECTOR")) {
+        // the lists above 255 points, on the matrix cores too (the vector-ALU form below stays as a cross-check: SF_FPFH_TAIL_VECTOR=1)
+#define SF_MCL_LAUNCH(SEL, GRID, SELP, NSEL, VF)                                                                       \
+        if (sparse) { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_mcl<SEL, true>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_MC_WPB))), block, SF_MC_ARGS, long_limit, SELP, NSEL, VF); } \
+        else { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_mcl<SEL, false>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_MC_WPB))), block, SF_MC_ARGS, long_limit, SELP, NSEL, VF); }
+        if (!kp_pos && d.n_tail) {
+            SF_MCL_LAUNCH(true, d.n_tail, d.tail_sel, d.n_tail, d.view_first)
+        } else { // keypoints by index (or lists without a selection): every keypoint is looked at
+            SF_MCL_LAUNCH(false, m, (const int32_t *)nullptr, (int64_t)0, (int64_t)0)
+        }
+#undef SF_MCL_LAUNCH
+    } else if (any_tail) {
         // (the packed 32-byte rows when the table has at most two live blocks and its packed copy is current: both forms sum
         // exactly, so which one runs changes no bit of a row)
         const unsigned m8 = sp->host_live[0] & 0xffu;
@@ -1434,6 +1492,7 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
 #undef SF_TAIL_LAUNCH
 #undef SF_TAIL_ARGS
     }
+#undef SF_MC_ARGS
     return SF_OK;
 }
 

@@ -454,3 +454,293 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
 
 #undef SF_MCS_DMA
 
+// --------------------------------------------------------------------------------------------------
+// The matrix-core contraction for lists of MORE than 255 points (round 5; until then the vector ALU served them at 3.4 x the
+// cost per pair: k_fpfh_tail).  Nothing in the arithmetic above is tied to 255 neighbours but the registers that hold a list
+// and the int32 recombination: |limb x (count - 128)| <= 2^14 per neighbour, so the int32 accumulators hold EXACT sums for any
+// list a byte table can have (k <= 65 535 -> < 2^30).  So: a first pass over the list finds the largest weight (the fixed-point
+// exponent), the second walks it in super-chunks of SC x 64 neighbours -- index loads, record gathers and weights of a
+// super-chunk at once, then its 2 SC steps of 32 neighbours through the same LDS-DMA / transposing reads / MFMAs -- and the
+// limb sums are recombined once, in float64 (the integer shift-adds of the short form would overflow; on a short list the
+// two give the same bits).  A list of at most SC x 64 points keeps entries and weights in registers between the passes.
+// High bytes of neighbours that have more than 255 neighbours of their own: fpfh_mc_hi per super-chunk, list order.
+// The sparse and the full form mirror each other operation by operation, as the short forms do: same bits.
+// --------------------------------------------------------------------------------------------------
+template <int SC>
+__device__ __forceinline__ void fpfh_mcl_load(const int32_t *__restrict__ idx, const double *__restrict__ p4, int64_t s, int k,
+                                              int base, int lane, double px, double py, double pz, int (&jv)[SC], double (&wv)[SC],
+                                              unsigned long long (&lm)[SC])
+{
+#pragma unroll
+    for (int c = 0; c < SC; ++c) {
+        const int t = base + 64 * c + lane;
+        jv[c] = (base + 64 * c < k && t < k) ? SF_LIST_LOAD(idx + s + t) : -1;
+    }
+    double2 u0[SC], u1[SC];
+#pragma unroll
+    for (int c = 0; c < SC; ++c) {
+        u0[c] = u1[c] = make_double2(0.0, 0.0);
+        if (base + 64 * c < k) { // (wave-uniform)
+            const double2 *pp = reinterpret_cast<const double2 *>(p4 + 4 * (size_t)(jv[c] < 0 ? 0 : jv[c]));
+            u0[c] = pp[0];
+            u1[c] = pp[1];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < SC; ++c) {
+        const double cx = u0[c].x - px, cy = u0[c].y - py, cz = u1[c].x - pz;
+        const double d2 = (cx * cx + cy * cy) + cz * cz;
+        const double kd = u1[c].y, xx = d2 * (kd * kd);
+        const double y0 = __builtin_amdgcn_rsq(xx);
+        const double y1 = __builtin_fma(0.5 * y0, __builtin_fma(-(xx * y0), y0, 1.0), y0);
+        const double y2 = __builtin_fma(0.5 * y1, __builtin_fma(-(xx * y1), y1, 1.0), y1);
+        const bool on = jv[c] >= 0;
+        wv[c] = (on && d2 > 0.0) ? y2 : 0.0; // (weight 0 past the end and at distance 0, fpfh.py:110-114: all limbs 0)
+        lm[c] = __ballot(wv[c] > 0.0 && kd > 255.0);
+        jv[c] = on ? jv[c] : 0; // (past the end of the list row 0 is fetched, under weight 0)
+    }
+}
+
+// limb sums -> float64, for one pair of accumulator registers against the padding column's
+__device__ __forceinline__ double fpfh_mcl_pair(int hi_limb, int lo_limb, int pad_hi, int pad_lo)
+{
+    return __builtin_fma((double)hi_limb - (double)pad_hi, 256.0, (double)lo_limb - (double)pad_lo); // exact: < 2^41
+}
+
+template <bool PACKED, int SC>
+__device__ __forceinline__ void fpfh_mcl_body_sparse(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                                     int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                                     const uint8_t *__restrict__ counts, const uint8_t *__restrict__ rows,
+                                                     unsigned rows_bytes, const double *__restrict__ p4,
+                                                     double *__restrict__ out, int64_t q, int b0, int b1,
+                                                     unsigned *rowbuf /* 4 KB: four steps of 1 KB */, unsigned char *abuf /* 576 B */,
+                                                     const uint8_t *__restrict__ hi, int limit)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
+    const int64_t slot = i - nbrs_begin;
+    const int k = sf_uniform(cnt[slot]);
+    if (k <= limit) return; // (the main launch's keypoint)
+    const int64_t s = offset[slot];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(rows), 0, (int)rows_bytes, 0x00020000);
+    const int a = lane & 15, kb = lane >> 4;
+    const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
+    const int o0 = 16 * bb0 + a, o1 = o0 + 16; // the two bins this lane writes, as in the short forms
+    unsigned own0 = (unsigned)counts[i * 128 + o0] ^ 128u, own1 = (unsigned)counts[i * 128 + o1] ^ 128u;
+    if (k > 255) { own0 += 256u * (unsigned)hi[i * 128 + o0]; own1 += 256u * (unsigned)hi[i * 128 + o1]; }
+    if (lane == 0) *reinterpret_cast<unsigned long long *>(abuf + 512) = 0ull; // the "limbs 8 .. 15" every A operand reads
+    // LDS image of a step and the DMA's lane mapping: fpfh_mc_body_sparse
+    const int d_u = (lane >> 4) & 1, d_row = 16 * (lane >> 5) + (lane & 15);
+    const unsigned dma_chunk16 = PACKED ? 16u * (unsigned)d_u : 16u * (unsigned)(d_u ? b1 : b0);
+    constexpr unsigned ROW_BYTES = PACKED ? 32u : 128u;
+    const int rd_piece = 32 * (kb >> 1) + 8 * (kb & 1) + (a >> 1);
+    const int rd0 = 16 * rd_piece + 8 * (a & 1), rd1 = rd0 + 256;
+    const unsigned lds_rows = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)rowbuf);
+#define SF_MCL_DMA(ST)                                                                                              \
+    {                                                                                                               \
+        const int jr = __shfl(jv[((ST) >> 1) < SC ? ((ST) >> 1) : 0], 32 * ((ST) & 1) + d_row);                     \
+        const unsigned voff = (unsigned)jr * ROW_BYTES + dma_chunk16;                                               \
+        unsigned keep_;                                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                         \
+                     "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"                                  \
+                     : "=&s"(keep_)                                                                                 \
+                     : "v"(voff), "s"(rsrc), "s"(lds_rows + 1024u * (unsigned)((ST) & 3))                           \
+                     : "memory");                                                                                   \
+    }
+    int jv[SC];
+    double wv[SC];
+    unsigned long long lm[SC];
+    // ---- pass 0: the largest weight -> the fixed-point exponent ----
+    double wmax = 0.0;
+    for (int base = 0; base < k; base += 64 * SC) {
+        fpfh_mcl_load<SC>(idx, p4, s, k, base, lane, px, py, pz, jv, wv, lm);
+#pragma unroll
+        for (int c = 0; c < SC; ++c) wmax = fmax(wmax, wv[c]);
+    }
+    wmax = sf_wave_max_nonneg(wmax);
+    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
+    const int S = 61 - e2; // W = floor(w 2^S) < 2^62
+
+    v4i acc0 = v4i{0, 0, 0, 0}, acc1 = v4i{0, 0, 0, 0}, accp = v4i{0, 0, 0, 0}; // blocks b0, b1, and the padding column
+    const long Bpad = (long)0x8080808080808080ull;
+    double h0 = 0.0, h1 = 0.0;
+    for (int base = 0; base < k; base += 64 * SC) {
+        if (k > 64 * SC) fpfh_mcl_load<SC>(idx, p4, s, k, base, lane, px, py, pz, jv, wv, lm); // (else: still held from pass 0)
+        const int left = k - base;
+        const int nst = left >= 64 * SC ? 2 * SC : (left + 31) >> 5; // steps of this super-chunk (wave-uniform)
+        // The 4 KB row buffer holds four steps: up to four are in flight, and a step's slot is refilled as soon as its reads
+        // have returned -- the loop waits for the OLDEST request only (vector-memory requests complete in order).
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            if (st < nst) SF_MCL_DMA(st)
+#pragma unroll
+        for (int st = 0; st < 2 * SC; ++st) {
+            if (st < nst) { // wave-uniform
+                if ((st & 1) == 0) fpfh_mc_limbs(abuf, lane, wv[st >> 1], S);
+                if (st + 3 < nst) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const long A = fpfh_mc_a_operand(abuf, a, kb, st);
+                const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
+                const v2i_t t0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd0 + 1024 * (st & 3)));
+                const v2i_t t1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + rd1 + 1024 * (st & 3)));
+                accp = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bpad, accp, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)(((unsigned long long)(unsigned)t0[1] << 32) | (unsigned)t0[0]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)(((unsigned long long)(unsigned)t1[1] << 32) | (unsigned)t1[0]), acc1, 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the slot is refilled
+                __builtin_amdgcn_wave_barrier();
+                if (st + 4 < nst) SF_MCL_DMA(st + 4)
+            }
+        }
+        fpfh_mc_hi<SC>(hi, jv, wv, lm, o0, o1, h0, h1);
+    }
+    // ---- recombination: fpfh_mc_body_sparse's, the limb pairs formed in float64 ----
+    const double p0 = ldexp(1.0, 32 * kb - S);
+    const double f0 = p0, f2 = p0 * 65536.0;
+    const double kd = (double)k;
+    double inv_k = __builtin_amdgcn_rcp(kd);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    double part0 = __builtin_fma(fpfh_mcl_pair(acc0[3], acc0[2], accp[3], accp[2]), f2, fpfh_mcl_pair(acc0[1], acc0[0], accp[1], accp[0]) * f0);
+    double part1 = __builtin_fma(fpfh_mcl_pair(acc1[3], acc1[2], accp[3], accp[2]), f2, fpfh_mcl_pair(acc1[1], acc1[0], accp[1], accp[0]) * f0);
+    sf_lane_swap<32>(part0, part1);
+    double v = part0 + part1;
+    double w = v;
+    sf_lane_swap<16>(v, w);
+    const double tot = v + w;
+    double mine = tot, other = tot;
+    sf_lane_swap<32>(mine, other);
+    const double tot0 = mine, tot1 = other;
+    {
+        double *o = out + q * (int64_t)nb3;
+        const double v0 = bb0 == b0 ? tot0 : (bb0 == b1 ? tot1 : 0.0);
+        const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
+        if (o0 < nb3) sf_store_stream(o + o0, (double)own0 / kd + (v0 + h0) * inv_k); // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
+        if (o1 < nb3) sf_store_stream(o + o1, (double)own1 / kd + (v1 + h1) * inv_k);
+    }
+#undef SF_MCL_DMA
+}
+
+// ... and on a table with more than two live blocks: whole 128-byte rows, one step (4 KB) in LDS at a time, eight MFMAs per step
+template <int SC>
+__device__ __forceinline__ void fpfh_mcl_body(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
+                                              int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                              const uint8_t *__restrict__ counts, unsigned table_bytes,
+                                              const double *__restrict__ p4, double *__restrict__ out, int64_t q,
+                                              unsigned *rowbuf /* 4 KB */, unsigned char *abuf /* 576 B */,
+                                              const uint8_t *__restrict__ hi, int limit)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
+    const int64_t slot = i - nbrs_begin;
+    const int k = sf_uniform(cnt[slot]);
+    if (k <= limit) return; // (the main launch's keypoint)
+    const int64_t s = offset[slot];
+    const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(counts), 0, (int)table_bytes, 0x00020000);
+    const int a = lane & 15, kb = lane >> 4;
+    const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
+    const int o0 = 16 * bb0 + a, o1 = o0 + 16;
+    unsigned own0 = (unsigned)counts[i * 128 + o0] ^ 128u, own1 = (unsigned)counts[i * 128 + o1] ^ 128u;
+    if (k > 255) { own0 += 256u * (unsigned)hi[i * 128 + o0]; own1 += 256u * (unsigned)hi[i * 128 + o1]; }
+    if (lane == 0) *reinterpret_cast<unsigned long long *>(abuf + 512) = 0ull;
+    const int frow = ((a >> 2) & 3) | ((kb & 1) << 2);
+    const int rd_base = (8 * kb + (a >> 1)) * 128 + 8 * (a & 1);
+    int xoff[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) xoff[bb] = rd_base + 16 * (bb ^ frow);
+    const int dma_chunk = (lane & 7) ^ ((lane >> 4) & 3);
+    const unsigned lds_rows = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)rowbuf);
+#define SF_MCLF_DMA(ST)                                                                                             \
+    {                                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                             \
+            const int jr = __shfl(jv[(ST) >> 1], 32 * ((ST) & 1) + 8 * u + (lane >> 3));                            \
+            const unsigned voff = (unsigned)jr * 128u + 16u * (unsigned)(dma_chunk ^ ((u & 1) << 2));              \
+            unsigned keep_;                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                     \
+                         "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"                              \
+                         : "=&s"(keep_)                                                                             \
+                         : "v"(voff), "s"(rsrc), "s"(lds_rows + 1024u * u)                                          \
+                         : "memory");                                                                               \
+        }                                                                                                           \
+    }
+    int jv[SC];
+    double wv[SC];
+    unsigned long long lm[SC];
+    double wmax = 0.0;
+    for (int base = 0; base < k; base += 64 * SC) {
+        fpfh_mcl_load<SC>(idx, p4, s, k, base, lane, px, py, pz, jv, wv, lm);
+#pragma unroll
+        for (int c = 0; c < SC; ++c) wmax = fmax(wmax, wv[c]);
+    }
+    wmax = sf_wave_max_nonneg(wmax);
+    const int e2 = wmax > 0.0 ? (int)((__double2hiint(wmax) >> 20) & 0x7ff) - 1023 : 0;
+    const int S = 61 - e2;
+    v4i acc[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) acc[bb] = v4i{0, 0, 0, 0};
+    double h0 = 0.0, h1 = 0.0;
+    for (int base = 0; base < k; base += 64 * SC) {
+        if (k > 64 * SC) fpfh_mcl_load<SC>(idx, p4, s, k, base, lane, px, py, pz, jv, wv, lm);
+        const int left = k - base;
+        const int nst = left >= 64 * SC ? 2 * SC : (left + 31) >> 5;
+#pragma unroll
+        for (int st = 0; st < 2 * SC; ++st) {
+            if (st < nst) { // wave-uniform
+                SF_MCLF_DMA(st)
+                if ((st & 1) == 0) fpfh_mc_limbs(abuf, lane, wv[st >> 1], S);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const long A = fpfh_mc_a_operand(abuf, a, kb, st);
+                const unsigned char *rb = reinterpret_cast<const unsigned char *>(rowbuf);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const v2i_t t = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i_t *)(rb + xoff[bb]));
+                    const long B = (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
+                    acc[bb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, B, acc[bb], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        fpfh_mc_hi<SC>(hi, jv, wv, lm, o0, o1, h0, h1);
+    }
+    // ---- recombination: fpfh_mc_body's, the limb pairs formed in float64 ----
+    int rpad[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // bin 127: the padding column
+    const double p0 = ldexp(1.0, 32 * kb - S);
+    const double f0 = p0, f2 = p0 * 65536.0;
+    const double kd = (double)k;
+    double inv_k = __builtin_amdgcn_rcp(kd);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    inv_k = __builtin_fma(inv_k, __builtin_fma(-kd, inv_k, 1.0), inv_k);
+    double part[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+        part[bb] = __builtin_fma(fpfh_mcl_pair(acc[bb][3], acc[bb][2], rpad[3], rpad[2]), f2, fpfh_mcl_pair(acc[bb][1], acc[bb][0], rpad[1], rpad[0]) * f0);
+    double keep[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double a_ = part[u], b_ = part[4 + u];
+        sf_lane_swap<32>(a_, b_);
+        keep[u] = a_ + b_;
+    }
+    double a0 = keep[0], b0_ = keep[2], a1 = keep[1], b1_ = keep[3];
+    sf_lane_swap<16>(a0, b0_);
+    sf_lane_swap<16>(a1, b1_);
+    const double vsel0 = a0 + b0_, vsel1 = a1 + b1_;
+    {
+        double *o = out + q * (int64_t)nb3;
+        if (o0 < nb3) sf_store_stream(o + o0, (double)own0 / kd + (vsel0 + h0) * inv_k);
+        if (o1 < nb3) sf_store_stream(o + o1, (double)own1 / kd + (vsel1 + h1) * inv_k);
+    }
+#undef SF_MCLF_DMA
+}

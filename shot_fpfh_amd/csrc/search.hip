@@ -85,6 +85,9 @@ struct __attribute__((aligned(8))) sf_dbl2 {
 // MODE 2: optimistic single pass -- query q owns the fixed slot [q*cap, (q+1)*cap) of idx; hits beyond cap
 //         are counted but not stored, and the host falls back to the exact two-pass scheme if any list
 //         overflowed (HBM is plentiful: slots cost cap*4 B per query).
+#ifndef SF_K2_STAGE
+#define SF_K2_STAGE 1 // list entries leave through an LDS ring, 64 positions (256 aligned bytes) per store
+#endif
 #ifndef SF_K2_WPB
 #define SF_K2_WPB 8 // waves per workgroup, four queries each (0.521 / 0.516 / 0.498 / 0.489 ms at C3 for 1 / 2 / 4 / 8)
 #endif
@@ -121,6 +124,9 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
     // 64 pairs, whichever runs they fall in.  Everything a lane needs to find its pair is vector work -- a DPP scan
     // gives the runs' first pair slots, the table goes to LDS -- because the scalar unit is shared by the whole CU.
     __shared__ int4 runs[SF_K2_WPB][4][12];
+#if SF_K2_STAGE
+    __shared__ int stages[MODE != 0 ? SF_K2_WPB : 1][256];
+#endif
     int4(*const tabs)[12] = runs[threadIdx.x >> 6];
     int first_slot = 0; // lane r < 9 of a row: first pair slot of run r; lane 9: the total
     {
@@ -182,6 +188,13 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
         int total = 0;
         const int64_t out = MODE == 1 ? offset[q] : q * (int64_t)cap;
         const int room = MODE == 2 ? cap : 0x7fffffff;
+#if SF_K2_STAGE
+        // Hits go to a 256-entry ring in LDS first and leave for HBM 64 list positions at a time: a sweep step finds ~14 hits
+        // of its 128 candidates, and 14 x 4 B stored past the L2 (`nt`) is a partial line each time -- the counters showed
+        // 2.2 x the lists' bytes written.  Whole, aligned 256-byte runs instead (slots start on 128-byte boundaries).
+        int *const stage = stages[threadIdx.x >> 6];
+        int flushed = 0; // list positions [0, flushed) are in HBM; a multiple of 64
+#endif
         for (int f0 = 0; f0 < nslots; f0 += 64) {
             const int f = f0 + lane;
             // run of slot f = last run whose first slot is <= f: a three-level binary search, the first level against a
@@ -208,12 +221,32 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_radius(sf_grid_desc g, const
             const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
             if (MODE != 0) {
                 const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
-                if (hit0 && pos < room) SF_LIST_STORE(idx + out + pos, j);
                 const int pos1 = pos + (hit0 ? 1 : 0);
+#if SF_K2_STAGE
+                if (hit0 && pos < room) stage[pos & 255] = j;
+                if (hit1 && pos1 < room) stage[pos1 & 255] = j + 1;
+#else
+                if (hit0 && pos < room) SF_LIST_STORE(idx + out + pos, j);
                 if (hit1 && pos1 < room) SF_LIST_STORE(idx + out + pos1, j + 1);
+#endif
             }
             total += __popcll(m0) + __popcll(m1);
+#if SF_K2_STAGE
+            if (MODE != 0) { // (at most 63 + 128 positions are pending here: the ring of 256 never wraps onto them)
+                const int have = total < room ? total : room;
+                while (have - flushed >= 64) {
+                    SF_LIST_STORE(idx + out + flushed + lane, stage[(flushed + lane) & 255]);
+                    flushed += 64;
+                }
+            }
+#endif
         }
+#if SF_K2_STAGE
+        if (MODE != 0) {
+            const int have = total < room ? total : room;
+            if (flushed + lane < have) SF_LIST_STORE(idx + out + flushed + lane, stage[(flushed + lane) & 255]);
+        }
+#endif
         if (lane == 0) {
             if (MODE != 1) {
                 count[SEL ? q0 + qi : q] = total;

@@ -1,5 +1,5 @@
 """The bench step (FPFH + SHOT, 1M uniform points) at other radii than BASELINE's: a quick look for cliffs between the forms
-(1 / 2 / 3 / 4 chunks, the long-list launches).  python tools/bench_radii.py"""
+(1 / 2 / 3 / 4 chunks, the long-list launches).  python tools/bench_radii.py [radius ...]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_cloud
@@ -8,7 +8,7 @@ from shot_fpfh_amd.sharding import DescriptorJob
 
 eng = Engine()
 pts, nrm = make_cloud(1_000_000, 3)
-for r in (0.015, 0.02, 0.025, 0.03, 0.035, 0.04, 0.045, 0.05):
+for r in ([float(a) for a in sys.argv[1:]] or (0.015, 0.02, 0.025, 0.03, 0.035, 0.04, 0.045, 0.05)):
     job = DescriptorJob(eng, pts, nrm, r, n_bins=5, normalize=True, min_neighborhood_size=10)
     for _ in range(3):
         job.step()
