@@ -130,6 +130,7 @@ class Control:
 
     def __init__(self, rank: int, world: int, timeout: float = 180.0):
         self.rank, self.world = rank, world
+        Control.establish_secret(rank, timeout)
         base = int(os.environ.get("MASTER_PORT", "29500"))
         first = base if os.environ.get("SF_BENCH_SELF_SPAWNED") else base + 1
         cands = [first + i for i in range(32)]
@@ -156,7 +157,10 @@ class Control:
                 c.settimeout(timeout)
                 c.sendall(hello)
                 try:
-                    got[int(self._recv(c))] = c
+                    r = int(self._recv(c))
+                    if not 1 <= r < world or r in got:
+                        raise ValueError(f"rank {r} out of range or already connected")
+                    got[r] = c
                 except (ConnectionError, ValueError, TypeError, OSError):
                     c.close()  # (not one of this job's ranks)
             srv.close()
@@ -192,14 +196,56 @@ class Control:
             buf += chunk
         return buf
 
+    _token = None  # the job's secret, once known
+    _token_file = None
+
+    @staticmethod
+    def _token_path() -> str:
+        import tempfile
+
+        return os.path.join(tempfile.gettempdir(), f"sfbench-{os.getuid()}-{os.environ.get('MASTER_PORT', '29500')}.token")
+
+    @classmethod
+    def establish_secret(cls, rank: int, timeout: float) -> None:
+        """Every message carries an HMAC-SHA256 under a key only the ranks of THIS job know, and a message that does not verify is
+        never unpickled.  The key: the random token spawn_ranks() put into its children's environment (SF_BENCH_TOKEN; a launcher
+        may set it too) -- or, under a launcher that sets none (torchrun's run id defaults to the public string "none"), 16
+        random bytes that rank 0 writes to a file only this user can read (mode 0600, created exclusively) and the other ranks
+        of the node read back.  Never an empty or guessable key: without a secret the control plane does not start."""
+        tok = os.environ.get("SF_BENCH_TOKEN")
+        if not tok:
+            path = cls._token_path()
+            if rank == 0:
+                try:
+                    os.unlink(path)  # (a stale file of an earlier run of this user on this port)
+                except FileNotFoundError:
+                    pass
+                fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+                tok = os.urandom(16).hex()
+                os.write(fd, tok.encode())
+                os.close(fd)
+                cls._token_file = path
+            else:
+                deadline = time.time() + timeout
+                while time.time() < deadline:
+                    try:
+                        st = os.stat(path)
+                        if st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0 and st.st_size == 32:
+                            with open(path) as f:
+                                tok = f.read().strip()
+                            break
+                    except FileNotFoundError:
+                        pass
+                    time.sleep(0.05)
+        if not tok or len(tok) < 16:
+            raise SystemExit("bench control plane: no job secret (set SF_BENCH_TOKEN to 16+ random characters, the same on every rank)")
+        cls._token = tok
+
     @staticmethod
     def _key() -> bytes:
-        """Every message carries an HMAC-SHA256 under a key only the ranks of THIS job know: the token spawn_ranks() put into
-        its children's environment, or -- under torchrun -- the launcher's run id (TORCHELASTIC_RUN_ID; the environment of a
-        process is readable by its own user only).  A message that does not verify is never unpickled: a stray local
-        process that connects to rank 0's port cannot hand the bench an object to execute."""
-        tok = os.environ.get("SF_BENCH_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
-        return ("sfbench|" + tok + "|" + os.environ.get("MASTER_PORT", "") + "|" + os.environ.get("WORLD_SIZE", "")).encode()
+        if not Control._token:
+            raise SystemExit("bench control plane: used before its secret was established")
+        return ("sfbench|" + Control._token + "|" + os.environ.get("MASTER_PORT", "") + "|" + os.environ.get("WORLD_SIZE", "")).encode()
 
     @staticmethod
     def _send(c, obj) -> None:
@@ -258,6 +304,12 @@ class Control:
         return self.allgather(obj)[0]
 
     def close(self) -> None:
+        if Control._token_file:
+            try:
+                os.unlink(Control._token_file)
+            except OSError:
+                pass
+            Control._token_file = None
         for c in self.peers + ([self.sock] if self.rank else []):
             try:
                 c.close()
@@ -591,6 +643,9 @@ def main() -> int:
     ap.add_argument("--oversubscribe", action="store_true",
                     help="FUNCTIONAL TEST ONLY: allow more ranks than GPUs; every exchange is then staged through host memory "
                          "and the control plane (RCCL refuses two ranks on one device) and no timing is a scaling result")
+    ap.add_argument("--allow-staged", action="store_true",
+                    help="N > 1: if the RCCL communicator cannot be built, run anyway with every exchange staged through host memory "
+                         "(a functional test; without this flag the run exits with code 3 and prints no record)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
                     help="length of the sustained window run after the K timed steps (0: skip)")
     ap.add_argument("--sustained-steps", type=int, default=500, help="... and its minimum number of steps")
@@ -707,8 +762,16 @@ def main() -> int:
             errs = ctl.allgather(err) if ctl else [err]
             if any(errs):
                 first = next(e for e in errs if e)
-                if ctl is None:
-                    raise SystemExit(f"RCCL communicator: {first}")
+                if ctl is None or not args.allow_staged:
+                    # a multi-GPU line measured over host memory would be read as an xGMI result: fail, loudly, on every rank
+                    # (all of them reach this point: the error strings were all-gathered over the control plane)
+                    if lead:
+                        sys.stderr.write(f"bench.py: the RCCL communicator of {world} rank(s) could not be built or failed its pre-flight "
+                                         f"({first[:400]}); no record is printed.  --allow-staged runs the same job with every exchange "
+                                         f"staged through host memory (a functional test, never a measurement).\n")
+                    if ctl is not None:
+                        ctl.close()
+                    return 3
                 exchange = stage_through_host(f"RCCL communicator failed ({first[:200]})")
             else:
                 exchange = f"RCCL over {world} rank(s): ncclSend/ncclRecv (SPFH rows), ncclAllGather (descriptor rows)"
@@ -966,6 +1029,11 @@ def main() -> int:
         ref_job.step()
         eng.sync()
         t_prep = time.perf_counter() - t_prep
+        barrier()
+        t0 = time.perf_counter()
+        ref_job.step()  # (the partner cloud's SHOT pass once more, warm: a term of end_to_end_config5_ms)
+        barrier()
+        t_ref_step = max_over_ranks(time.perf_counter() - t0)
         scan_orig = job.block_original_indices()            # scan rows of this rank -> scan point
         ref_label = perm[ref_job.block_original_indices()]  # ref rows of this rank -> the scan point they came from
         s_sel, r_sel = np.flatnonzero(scan_orig < total_rows), np.flatnonzero(ref_label < total_rows)
@@ -1035,7 +1103,12 @@ def main() -> int:
                 "match_pairs_allgather_s": t_pairs,
                 "registration_from_all_matches": reg,
                 "partner_cloud_descriptor_pass_s": t_prep,
+                "partner_cloud_shot_pass_ms": 1000.0 * t_ref_step,
             }
+            # BASELINE config 5 end to end on resident clouds: this cloud's FPFH + SHOT pass (the timed step), the partner cloud's
+            # SHOT pass, and the exchange + matching pass (subset gather, all-gather of rows and labels, sharded K8) -- a sum of three
+            # separately timed phases, each the maximum over the ranks
+            out["end_to_end_config5_ms"] = ms_per_step + 1000.0 * t_ref_step + 1000.0 * t_match
         sub.close()
         ref_job.close()
 

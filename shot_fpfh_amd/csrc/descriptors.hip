@@ -541,6 +541,19 @@ __device__ inline double sf_dot3(double a0, double a1, double a2, double b0, dou
 // minus its exponent pre/post-scaling, which only matters outside [1e-290, 1e290]: bit-identical to sqrt() there
 // (tools/ubench/sqrt_check.hip: 0 differences in 1.6e7 inputs), 10 instructions instead of 22; the half-inverse
 // the iteration carries along, refined once more, is 1/sqrt(x) to ~1 ulp for two more instructions.
+#ifndef SF_SHOT_KPW
+#define SF_SHOT_KPW 1 // keypoints a wave of the cached K5 serves one after the other (1: one wave per keypoint, as until round 4)
+#endif
+#ifndef SF_SHOT_OUTLINE
+#define SF_SHOT_OUTLINE (SF_SHOT_KPW > 1) // the libm fallbacks of the cached K5 as function calls
+#endif
+// (the libm forms behind the fast paths below, OUTLINED when the cached K5 loops over keypoints: see shot_centre_ray_side)
+__device__ __attribute__((noinline)) double2 sf_sqrt_rsqrt_slow(double x)
+{
+    const double root = sqrt(x);
+    return make_double2(root, 1.0 / root);
+}
+
 __device__ inline void sf_sqrt_rsqrt(double x, double &root, double &inv)
 {
     const double y = __builtin_amdgcn_rsq(x);
@@ -560,8 +573,14 @@ __device__ inline void sf_sqrt_rsqrt(double x, double &root, double &inv)
     // positive, finite, not NaN -- one integer subtraction and comparison with 32-bit literals instead of two comparisons
     // against 64-bit constants that each cost two scalar moves)
     if (__ballot(!((unsigned)__double2hiint(x) - 0x03b00000u < 0x7c200000u - 0x03b00000u))) {
-        root = sqrt(x);
-        inv = 1.0 / root;
+        if (SF_SHOT_OUTLINE) {
+            const double2 t = sf_sqrt_rsqrt_slow(x);
+            root = t.x;
+            inv = t.y;
+        } else {
+            root = sqrt(x);
+            inv = 1.0 / root;
+        }
     }
 }
 
@@ -585,6 +604,10 @@ __device__ inline void sf_sqrt_rsqrt_uniform(double x, double &root, double &inv
         h = __builtin_fma(h, r, h);
         root = g;
         inv = h + h;
+    } else if (SF_SHOT_OUTLINE) {
+        const double2 t = sf_sqrt_rsqrt_slow(x);
+        root = t.x;
+        inv = t.y;
     } else {
         root = sqrt(x);
         inv = 1.0 / root;
@@ -728,11 +751,12 @@ __device__ inline double sf_acos_abs_quadrants(double az, const double *__restri
     return big ? as + as : 1.0 - as;
 }
 
-// (`cosine_raw`: normals @ eigenvectors[:, 2], shot.py:215, before the clip -- a form that holds the neighbours' offsets in
-// registers across its passes keeps this one number per neighbour instead of the normal: k_shot_wide)
+// (`cosine_raw`: normals @ eigenvectors[:, 2], shot.py:215, before the clip)
 // The reference's own expression for the side of the octant's centre ray (shot.py:283-288), for the neighbours the cross
-// product cannot decide.  OUTLINED for the forms that loop over chunks: inlined into a loop, libm's atan2 has its two dozen
-// constants hoisted out of it as loop invariants -- live across the whole loop, they spill (k_shot_wide: 116 bytes of scratch).
+// product cannot decide.  OUTLINED for forms that LOOP (over chunks or keypoints): inlined into a loop, libm's atan2 has its two
+// dozen constants hoisted out of it as loop invariants -- live across the whole loop, they spill (a register-held form for lists
+// of 256 .. 512 points, built and dropped in round 5 -- per pair it ran no faster than k_shot_long -- went from 116 bytes of
+// scratch to none with this one attribute).
 __device__ __attribute__((noinline)) int shot_centre_ray_side(double lx, double ly, int ti)
 {
     const double tsz = 2 * SHOT_PI / 8;
@@ -817,7 +841,7 @@ __device__ inline void shot_geometry_core(double cx, double cy, double cz, doubl
 __device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
                                      const double *E, double half_r, shot_kept &o)
 {
-    shot_geometry_core<false>(cx, cy, cz, d2, sf_dot3(nx, ny, nz, E[2], E[5], E[8]), E, half_r, o);
+    shot_geometry_core<(bool)(SF_SHOT_OUTLINE)>(cx, cy, cz, d2, sf_dot3(nx, ny, nz, E[2], E[5], E[8]), E, half_r, o);
 }
 
 // Radius-derived constants of the interpolation, computed once on the host (as kernel arguments they live in SGPRs;
@@ -897,7 +921,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  const int32_t *__restrict__ qrow, const shot_consts &K,
                                                  double *__restrict__ lrf, int normalize, int64_t min_nb,
-                                                 double *__restrict__ out, int64_t q, unsigned long long *slot)
+                                                 double *__restrict__ out, int64_t q, unsigned long long *slot, int lane)
 {
     // FUSED: `lrf` holds the raw axes written by k_shot_lrf(raw = 1); the sign votes (shot.py:40-45) are taken
     // here from the gathered neighbours and the finished frame is written back before it is used.
@@ -909,7 +933,6 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
     SF_K5_MARK(1, NCH);
     unsigned long long *const sA = slot;
-    const int lane = threadIdx.x & 63;
     const int64_t s = offset[q];
     const int k = cnt[q];
     const int64_t row = qrow ? qrow[q] : q;
@@ -1156,7 +1179,7 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
                                              const int32_t *__restrict__ qrow,
                                              int64_t m, shot_consts K, double *__restrict__ lrf, int normalize,
                                              int64_t min_nb, double *__restrict__ out, const int32_t *__restrict__ sel,
-                                             int64_t nsel, int64_t view_first, int skip_upto)
+                                             int64_t nsel, int64_t view_first)
 {
     __shared__ __attribute__((aligned(16))) shot_long_lds lds_all[SF_SHOT_LONG_WPB];
     const int lane = threadIdx.x & 63;
@@ -1171,7 +1194,6 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
     if (q >= m) return;
     const int64_t s = offset[q];
     const int k = sf_uniform(cnt[q]);
-    if (k <= skip_upto) return; // (a list the register-held form serves: k_shot_wide, launch_shot)
     const int64_t row = qrow ? qrow[q] : q;
     double *o = out + (int64_t)SF_SHOT_LEN * row;
     const double px = qx[q], py = qy[q], pz = qz[q];
@@ -1310,204 +1332,6 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
     }
 }
 
-// --------------------------------------------------------------------------------------------------
-// K5 for lists of 256 .. 64 NCH points (NCH = 8: 512), round 5: k_shot_long's arithmetic and LDS tables, but the list is
-// fetched ONCE.  The streaming form walks index list and records three times, 128 neighbours per dependent round trip --
-// 24 round trips for a list of 430 points, and on keypoints scattered over a surface scan (the reference's default: a support
-// subsampled at radius / 10, a tenth of the points keypoints) those round trips are its time, not its instructions.  Here all
-// index chunks are requested together, then all records; what the passes need of a neighbour stays in registers -- its
-// offset from the keypoint (cx, cy, cz) and ONE number of its normal, the cosine against the frame's z axis (a sign flip of
-// the axis is an exact negation of that dot product) -- 8 VGPRs per chunk.  Votes, gate, the election pass and the
-// accumulation pass then run from registers.  The passes are LOOPS over the chunks whose body serves "chunk 0" and then
-// rotates the register arrays by one chunk (a few dozen moves against ~400 instructions of body): the code stays a fifth of
-// its unrolled size.  Rows are those of k_shot_long bit for bit (same functions, same LDS operations in the same order).
-// --------------------------------------------------------------------------------------------------
-#ifndef SF_SHOT_WIDE_WPB
-#define SF_SHOT_WIDE_WPB 2
-#endif
-#ifndef SF_SHOT_WIDE_GROUP
-#define SF_SHOT_WIDE_GROUP 4
-#endif
-template <int NCH>
-__device__ __forceinline__ void shot_rotate(double (&a)[NCH])
-{
-    const double t = a[0];
-#pragma unroll
-    for (int c = 0; c + 1 < NCH; ++c) a[c] = a[c + 1];
-    a[NCH - 1] = t;
-}
-template <int NCH>
-__device__ __forceinline__ void shot_rotate(unsigned long long (&a)[NCH])
-{
-    const unsigned long long t = a[0];
-#pragma unroll
-    for (int c = 0; c + 1 < NCH; ++c) a[c] = a[c + 1];
-    a[NCH - 1] = t;
-}
-
-template <int NCH, bool FUSED, bool SEL>
-__global__ __launch_bounds__(64 * SF_SHOT_WIDE_WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shot_wide(
-    const double *__restrict__ rec, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
-    const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ qrow, int64_t m, shot_consts K, double *__restrict__ lrf, int normalize, int64_t min_nb,
-    double *__restrict__ out, int lo_limit, const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first)
-{
-    __shared__ __attribute__((aligned(16))) shot_long_lds lds_all[SF_SHOT_WIDE_WPB];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    shot_long_lds &L = lds_all[wave];
-    int64_t q = sf_xcd_block() * SF_SHOT_WIDE_WPB + wave;
-    if (SEL) {
-        if (q >= nsel) return;
-        q = (int64_t)sf_uniform(sel[q]) - view_first;
-        if (q < 0) return;
-    }
-    if (q >= m) return;
-    const int k = sf_uniform(cnt[q]);
-    if (k <= lo_limit || k > 64 * NCH) return; // (the cached form's keypoint, resp. the streaming form's)
-    const int64_t s = offset[q];
-    const int64_t row = qrow ? qrow[q] : q;
-    double *o = out + (int64_t)SF_SHOT_LEN * row;
-    const double px = qx[q], py = qy[q], pz = qz[q];
-    {
-        ulonglong2 *w = reinterpret_cast<ulonglong2 *>(&L);
-        for (int b = lane; b < (int)(sizeof(shot_long_lds) / 16); b += 64) w[b] = make_ulonglong2(0ull, 0ull);
-    }
-    // the frame: raw axes (FUSED: completed below by the votes) or the finished frame, by scalar loads (see shot_cached_body)
-    double raw[9];
-    {
-        const __attribute__((address_space(4))) double *clr = (const __attribute__((address_space(4))) double *)(lrf + 9 * row);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) raw[i] = clr[i];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) asm volatile("" : "+s"(raw[i]));
-    }
-    // ---- the list, once: every index chunk requested, then every record ----
-    int jv[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int t = 64 * c + lane;
-        jv[c] = (64 * c < k && t < k) ? SF_LIST_LOAD(idx + s + t) : -1;
-    }
-    double cx[NCH], cy[NCH], cz[NCH], cs[NCH];
-    unsigned long long posm[NCH];
-    int npos = 0, xneg = 0, zneg = 0;
-    // (the records of SF_SHOT_WIDE_GROUP chunks are in flight together -- 6 registers per chunk until the normal has shrunk to
-    // its cosine; all NCH at once would need 48 more registers than the passes do)
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        cx[c] = cy[c] = cz[c] = cs[c] = 0.0;
-        posm[c] = 0ull;
-        if (c % SF_SHOT_WIDE_GROUP == 0 && c) __builtin_amdgcn_sched_barrier(0);
-        if (64 * c < k) { // (wave-uniform)
-            double x, y, z, nx, ny, nz;
-            sf_load_pn(rec, jv[c] < 0 ? 0 : jv[c], x, y, z, nx, ny, nz);
-            cx[c] = x - px; cy[c] = y - py; cz[c] = z - pz;
-            cs[c] = sf_dot3(nx, ny, nz, raw[2], raw[5], raw[8]); // against the UNFLIPPED z axis when FUSED: negated below if it flips
-            const int rem = k - 64 * c;
-            const unsigned long long onm = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
-            const double d2 = (cx[c] * cx[c] + cy[c] * cy[c]) + cz[c] * cz[c];
-            posm[c] = __ballot(d2 > 0.0) & onm; // gate (shot.py:212): neighbours at non-zero distance
-            npos += __popcll(posm[c]);
-            if (FUSED) { // sign votes (shot.py:40-45); the query itself votes ">= 0"
-                xneg += __popcll(__ballot(sf_dot3(cx[c], cy[c], cz[c], raw[0], raw[3], raw[6]) < 0.0) & onm);
-                zneg += __popcll(__ballot(sf_dot3(cx[c], cy[c], cz[c], raw[2], raw[5], raw[8]) < 0.0) & onm);
-            }
-        }
-    }
-    double E[9];
-    if (FUSED) { // (the frame is written whether or not the descriptor passes the gate, as in the other forms)
-        if (shot_finish_frame(raw, k, xneg, zneg, E) && lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) lrf[9 * row + i] = E[i];
-        }
-        if (zneg > k - zneg) { // z flipped: n . (-z) = -(n . z) exactly
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) cs[c] = -cs[c];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) E[i] = raw[i];
-    }
-    if (!((int64_t)npos > min_nb)) {
-        for (int b = lane; b < SF_SHOT_LEN; b += 64) o[b] = 0.0;
-        return;
-    }
-    SF_SHOT_SYNC(); // (the cleared tables)
-    // ---- pass 1: the three elections ----
-#pragma clang loop unroll(disable)
-    for (int it = 0; it < NCH; ++it) {
-        if (posm[0]) { // (wave-uniform: chunks past the list's end, or without a neighbour at non-zero distance)
-            shot_kept g;
-            g.bins1 = 0u;
-            if (__builtin_amdgcn_inverse_ballot_w64(posm[0])) {
-                const double d2 = (cx[0] * cx[0] + cy[0] * cy[0]) + cz[0] * cz[0];
-                shot_geometry_core<true>(cx[0], cy[0], cz[0], d2, cs[0], E, K.half_r, g);
-                const unsigned long long key = (unsigned long long)__double_as_longlong(g.rho);
-                atomicMax(&L.keyA[g.bins0 & 511u], key);
-                atomicMax(&L.keyB[(g.bins0 >> 9) & 511u], key);
-                atomicMax(&L.keyG[(g.bins0 >> 18) & 511u], key);
-            }
-        }
-        shot_rotate<NCH>(cx); shot_rotate<NCH>(cy); shot_rotate<NCH>(cz); shot_rotate<NCH>(cs); shot_rotate<NCH>(posm);
-    }
-    SF_SHOT_SYNC();
-    // ---- pass 2: every elected writer claims its slot and adds its value (k_shot_long's sweep 2) ----
-    auto claim = [&](int table, unsigned slot_) -> bool {
-        const unsigned bit = 1u << (slot_ & 31u);
-        return (atomicOr(&L.claim[table][slot_ >> 5], bit) & bit) == 0u;
-    };
-#pragma clang loop unroll(disable)
-    for (int it = 0; it < NCH; ++it) {
-        if (posm[0]) {
-            if (__builtin_amdgcn_inverse_ballot_w64(posm[0])) {
-                shot_kept g;
-                g.bins1 = 0u;
-                const double d2 = (cx[0] * cx[0] + cy[0] * cy[0]) + cz[0] * cz[0];
-                shot_geometry_core<true>(cx[0], cy[0], cz[0], d2, cs[0], E, K.half_r, g);
-                const unsigned long long key = (unsigned long long)__double_as_longlong(g.rho);
-                const unsigned iA = g.bins0 & 511u, iB = (g.bins0 >> 9) & 511u, iG = (g.bins0 >> 18) & 511u;
-                const bool up = iA & 2u, odd = iA & 1u; // (bit 1: z > 0, bit 0: outer shell)
-                const unsigned long long own = L.keyA[iA], other_shell = L.keyA[iA ^ 1u], other_half = L.keyA[iA ^ 2u];
-                const bool winB = L.keyB[iB] == key, winG = L.keyG[iG] == key;
-                double vA, v_cd, v_ef, adth;
-                // (the polynomial coefficients are scalar loads from K.coef: the pointer is re-defined in every trip, or the
-                // loop-invariant loads are hoisted out of the loop -- 24 coefficients live across it spill)
-                shot_consts Kl = K;
-                asm volatile("" : "+s"(Kl.coef));
-                shot_weights(g, Kl, vA, v_cd, v_ef, adth);
-                if (own == key && claim(0, iA)) {
-                    unsafeAtomicAdd(&L.acc[iA], vA);
-                    if ((odd || other_shell == 0ull) && v_cd != 0.0) unsafeAtomicAdd(&L.acc[iA ^ 1u], v_cd);
-                    if ((key > other_half || (key == other_half && up)) && v_ef != 0.0) unsafeAtomicAdd(&L.acc[iA ^ 2u], v_ef);
-                }
-                const double adc = fabs(g.dc);
-                if (winB && claim(1, iB) && adc != 0.0) unsafeAtomicAdd(&L.acc[iB], adc);
-                if (winG && claim(2, iG) && adth != 0.0) unsafeAtomicAdd(&L.acc[iG], adth);
-            }
-        }
-        shot_rotate<NCH>(cx); shot_rotate<NCH>(cy); shot_rotate<NCH>(cz); shot_rotate<NCH>(cs); shot_rotate<NCH>(posm);
-    }
-    SF_SHOT_SYNC();
-    double vals[6];
-    double ss = 0.0;
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int b = lane + 64 * u;
-        const double v = b < 352 ? L.acc[b] : 0.0;
-        vals[u] = v;
-        ss += v * v;
-    }
-    double nrm, inv_nrm;
-    sf_sqrt_rsqrt(sf_wave_sum(ss), nrm, inv_nrm);
-    const double scale = nrm > 0.0 ? (normalize ? inv_nrm : 1.0) : 0.0; // shot.py:301-305
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int b = lane + 64 * u;
-        if (b < 352) sf_store_stream(o + b, vals[u] * scale);
-    }
-}
-
 template <int NCH, bool FUSED>
 __global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *__restrict__ rec,
                                                     const double *__restrict__ qx, const double *__restrict__ qy,
@@ -1533,11 +1357,71 @@ __global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *
     // The kernel is instantiated for the LONGEST list of the launch (a 1M-point uniform cloud at 110 neighbours on average
     // has one of 160+), but nearly every keypoint fits one chunk less: a wave-uniform branch picks the body that
     // matches THIS keypoint, so the gather, votes and distance tests of an empty last chunk are never issued.
+    const int lane = threadIdx.x & 63;
     if (NCH >= 3 && sf_uniform(cnt[q]) <= 64 * (NCH - 1)) {
-        shot_cached_body<(NCH >= 3 ? NCH - 1 : NCH), FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
+        shot_cached_body<(NCH >= 3 ? NCH - 1 : NCH), FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot, lane);
         return;
     }
-    shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
+    shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot, lane);
+}
+
+// The same kernel with SF_SHOT_KPW consecutive keypoints per wave, one after the other (round 5).  A wave's slot is held until its
+// row stores are acknowledged, and they are issued at the very end of a keypoint's work (round 4: 14 % of the kernel with five of
+// the six stores left out); in a loop the NEXT keypoint's scalar loads, LDS clear and index load are under way while the row
+// drains.  Three things keep the loop at the straight-line kernel's registers (the first attempt needed 139):
+//   * the TU is compiled without machine-level loop-invariant code motion (Makefile: -disable-machine-licm for this object):
+//     it hoists every literal of the body -- the libm fallbacks' two dozen constants first -- into registers held across the loop;
+//   * the lane number is re-defined in every trip (an empty asm): everything derived from it is formed where it is used;
+//   * ALL arguments arrive as one struct and are re-read from the kernel-argument segment in every trip: each is then live from
+//     the trip's start to its last use, as in the straight-line kernel, instead of across the whole loop (43 scalars spilled).
+struct shot_cached_args {
+    const double *rec, *qx, *qy, *qz;
+    const int64_t *offset;
+    const int32_t *cnt, *idx, *qrow;
+    int64_t m;
+    shot_consts K;
+    double *lrf;
+    int normalize;
+    int64_t min_nb;
+    double *out;
+    int limit;
+    const int32_t *sel;
+    int64_t nsel, view_first;
+};
+template <int NCH, bool FUSED>
+__global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached_loop(shot_cached_args unused_by_name)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long slots[SF_SHOT_WPB][704];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long *const slot = slots[wave];
+    const int64_t first = (sf_xcd_block() * SF_SHOT_WPB + wave) * SF_SHOT_KPW;
+    typedef const __attribute__((address_space(4))) shot_cached_args *args_ptr;
+#pragma clang loop unroll(disable)
+    for (int kp = 0; kp < SF_SHOT_KPW; ++kp) {
+        args_ptr a = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr(); // (the struct is the only parameter: offset 0)
+        asm volatile("" : "+s"(a));
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        int64_t q = first + kp;
+        const int32_t *sel = a->sel;
+        if (sel) {
+            if (q >= a->nsel) return;
+            q = (int64_t)sf_uniform(sel[q]) - a->view_first;
+            if (q < 0) continue;
+        }
+        if (q >= a->m) return;
+        const int32_t *cnt = a->cnt;
+        const int kq = sf_uniform(cnt[q]);
+        if (kq > a->limit) continue;
+        const shot_consts K{a->K.radius, a->K.half_r, a->K.q1, a->K.q3, a->K.inv_hr, a->K.coef}; // (field by field: no copy constructor across address spaces)
+        if (NCH >= 3 && kq <= 64 * (NCH - 1)) {
+            shot_cached_body<(NCH >= 3 ? NCH - 1 : NCH), FUSED>(a->rec, a->qx, a->qy, a->qz, a->offset, cnt, a->idx, a->qrow, K, a->lrf, a->normalize,
+                                                                a->min_nb, a->out, q, slot, lane);
+            continue;
+        }
+        shot_cached_body<NCH, FUSED>(a->rec, a->qx, a->qy, a->qz, a->offset, cnt, a->idx, a->qrow, K, a->lrf, a->normalize, a->min_nb, a->out, q,
+                                     slot, lane);
+    }
 }
 
 } // namespace
@@ -1714,7 +1598,7 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     if (!m) return SF_OK;
     // (a list holds fewer than 2^31 points: clamped here, "more than min_nb neighbours" is a 32-bit comparison in the kernels)
     min_nb = std::min<int64_t>(std::max<int64_t>(min_nb, -1), 2147483647LL);
-    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), block(64 * SF_SHOT_WPB), block_streaming(64 * SF_SHOT_LONG_WPB);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB * SF_SHOT_KPW))), block(64 * SF_SHOT_WPB), block_streaming(64 * SF_SHOT_LONG_WPB);
 #define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m
     const double r_ = nb->radius;
     if (!ctx->shot_coef) { // (once per context)
@@ -1723,25 +1607,20 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     }
     const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2), ctx->shot_coef}; // the reference's own expressions (shot.py:95-117, 235)
     const sf_dispatch d = sf_nbrs_dispatch(nb);
+#if SF_SHOT_KPW > 1
+    const shot_cached_args A{c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, K, dlrf, normalize, min_nb, dout, d.limit,
+                             nullptr, 0, 0};
+#define SF_SHOT_CASE(N)                                                                                              \
+    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached_loop<N, true>), grid, block, A); }                          \
+    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached_loop<N, false>), grid, block, A); }
+#else
 #define SF_SHOT_CASE(N)                                                                                              \
     if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); } \
     else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); }
-    // lists above the cached form: up to 512 points held in registers (k_shot_wide), beyond that streamed (k_shot_long);
-    // SF_SHOT_NO_WIDE=1: everything streamed (the form of round 4, kept as a cross-check -- same rows bit for bit)
-    const char *nw = getenv("SF_SHOT_NO_WIDE");
-    const bool no_wide = nw && nw[0] == '1';
-    const int cached_upto = d.chunks >= 1 && d.chunks <= 4 ? d.limit : -1; // (what the cached main launch serves; -1: there is none)
-    const int wide_upto = no_wide ? cached_upto : 512;                     // lists of cached_upto + 1 .. wide_upto points: k_shot_wide
+#endif
 #define SF_SHOT_STREAM(NAME, SEL, GRID, SELP, NSEL)                                                                   \
-    if (wide_upto > cached_upto) {                                                                                    \
-        const dim3 gw(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_WIDE_WPB))), bw(64 * SF_SHOT_WIDE_WPB);                     \
-        if (fused) { SF_LAUNCH(ctx, NAME, (k_shot_wide<8, true, SEL>), gw, bw, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, cached_upto, SELP, NSEL, d.view_first); } \
-        else { SF_LAUNCH(ctx, NAME, (k_shot_wide<8, false, SEL>), gw, bw, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, cached_upto, SELP, NSEL, d.view_first); } \
-    }                                                                                                                 \
-    if (nb->max_count > wide_upto) {                                                                                  \
-        if (fused) { SF_LAUNCH(ctx, NAME "_long", (k_shot_long<true, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first, wide_upto); } \
-        else { SF_LAUNCH(ctx, NAME "_long", (k_shot_long<false, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first, wide_upto); } \
-    }
+    if (fused) { SF_LAUNCH(ctx, NAME, (k_shot_long<true, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); } \
+    else { SF_LAUNCH(ctx, NAME, (k_shot_long<false, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); }
     if (d.chunks == 1) { SF_SHOT_CASE(1) }
     else if (d.chunks == 2) { SF_SHOT_CASE(2) }
     else if (d.chunks == 3) { SF_SHOT_CASE(3) }

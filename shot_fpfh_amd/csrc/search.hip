@@ -606,6 +606,165 @@ __global__ __launch_bounds__(64) void k_knn(sf_grid_desc g, const int32_t *__res
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// k nearest neighbours for k <= 64 on K2's mapping (round 5; k_knn above -- one wave per query over the whole 27-cell stencil, the
+// k best pruned in LDS again and again -- took 3.7 ms per 1M queries at k = 30 against K2's 0.46 ms for lists of 110).
+// Set-up and sweep are k_radius's: four queries per wave, the run tables of all four built at once, runs clipped in x to what
+// the ball of radius R can reach, two candidates per lane and load.  The hits (d2 <= R^2) of a query go to an LDS list of
+// SF_KNN_CAP entries in scan order -- which is ascending POSITION order -- and ONE rank pass then orders them: entry e's rank
+// is the number of entries with a smaller d2 (every entry is broadcast from LDS once and compared by all lanes: two vector
+// instructions per entry and 64 lanes); entries of rank < k write themselves to slot `rank`.  Ties in d2 (duplicated points;
+// exact ties are otherwise one in millions) give equal ranks: a slot then stays empty, or k + 1 entries qualify -- both are
+// seen by one ballot, and the pass is repeated with the tie broken by position, KDTree.query's order here as in k_knn.
+// status: 0 answered, 1 fewer than k points within R (the host retries with a doubled R), 2 more than SF_KNN_CAP points within
+// R (the host hands the query to k_knn at the same R).
+// --------------------------------------------------------------------------------------------------
+#ifndef SF_KNN_CAP
+#define SF_KNN_CAP 256
+#endif
+template <int NT, bool TIES>
+__device__ __forceinline__ void knn_rank_pass(const double *kd, int total, int lane, int (&rank)[4])
+{
+    double d[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int e = lane + 64 * u;
+        d[u] = e < total ? kd[e] : INFINITY;
+        rank[u] = 0;
+    }
+#pragma unroll 4
+    for (int l = 0; l < total; ++l) {
+        const double b = kd[l]; // (one address for the whole wave: a broadcast read)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) rank[u] += TIES ? ((b < d[u]) || (b == d[u] && l < lane + 64 * u)) : (b < d[u]);
+    }
+}
+
+template <bool SEL>
+__global__ __launch_bounds__(64 * SF_K2_WPB) void k_knn4(sf_grid_desc g, const int32_t *__restrict__ cell_start,
+                                              const double *__restrict__ xs, const double *__restrict__ ys,
+                                              const double *__restrict__ zs, const double *__restrict__ qx,
+                                              const double *__restrict__ qy, const double *__restrict__ qz, int64_t m, double r2,
+                                              int k, const int32_t *__restrict__ perm, int32_t *__restrict__ idx_out,
+                                              int32_t *__restrict__ status, const int32_t *__restrict__ qsel)
+{
+    const int lane = threadIdx.x & 63, sl = lane & 15, rw = lane >> 4;
+    const int64_t q0 = sf_uniform64((sf_xcd_block() * SF_K2_WPB + (threadIdx.x >> 6)) * 4);
+    if (q0 >= m) return;
+    const int nq = (int)(m - q0 < 4 ? m - q0 : 4);
+    const int64_t qm0 = q0 + (rw < nq ? rw : 0);
+    const int64_t qm = SEL ? (int64_t)qsel[qm0] : qm0;
+    const double pxv = qx[qm], pyv = qy[qm], pzv = qz[qm]; // this row's query
+    int y0, y1, z0, z1;
+    stencil_bounds(pyv, g.lo[1], g.inv_cell, g.dim[1], y0, y1);
+    stencil_bounds(pzv, g.lo[2], g.inv_cell, g.dim[2], z0, z1);
+    __shared__ int4 runs[SF_K2_WPB][4][12];
+    __shared__ double kd_all[SF_K2_WPB][SF_KNN_CAP];
+    __shared__ int kj_all[SF_K2_WPB][SF_KNN_CAP];
+    __shared__ int ks_all[SF_K2_WPB][64];
+    int4(*const tabs)[12] = runs[threadIdx.x >> 6];
+    double *const kd = kd_all[threadIdx.x >> 6];
+    int *const kj = kj_all[threadIdx.x >> 6];
+    int *const ks = ks_all[threadIdx.x >> 6];
+    int first_slot = 0;
+    { // (the run tables: k_radius, which has the reasoning)
+        const int r = sl < 9 ? sl : 8;
+        const int cz = z0 + r / 3, cy = y0 + r % 3;
+        bool ok = sl < 9 && rw < nq && cz <= z1 && cy <= y1;
+        const int64_t row = ((int64_t)(ok ? cz : z0) * g.dim[1] + (ok ? cy : y0)) * g.dim[0];
+        const double pxr = pxv - g.lo[0], pyr = pyv - g.lo[1], pzr = pzv - g.lo[2];
+        const double by0 = (double)cy * g.cell, bz0 = (double)cz * g.cell;
+        const double slack_y = 1e-9 * g.cell + 1e-15 * (fabs(pyr) + by0 + g.cell);
+        const double slack_z = 1e-9 * g.cell + 1e-15 * (fabs(pzr) + bz0 + g.cell);
+        const double dy = fmax(fmax(by0 - pyr, pyr - (by0 + g.cell)) - slack_y, 0.0);
+        const double dz = fmax(fmax(bz0 - pzr, pzr - (bz0 + g.cell)) - slack_z, 0.0);
+        const double w2 = (r2 * (1.0 + 1e-9) - dy * dy) - dz * dz;
+        ok = ok && w2 >= 0.0;
+        const double w = sf_sqrt_fast(fmax(w2, 0.0)) * (1.0 + 1e-9) + 1e-9 * g.cell +
+                         1e-15 * (fabs(pxr) + (double)g.dim[0] * (g.cell / (double)g.xsub));
+        int s = 0, e = 0;
+        if (sl < 9) {
+            s = cell_start[row + sf_cell_coord(pxr - w, 0.0, g.inv_cell_x, g.dim[0])];
+            e = cell_start[row + sf_cell_coord(pxr + w, 0.0, g.inv_cell_x, g.dim[0]) + 1];
+        }
+        if (!ok) { s = 0; e = 0; }
+        const int base = s & ~1;
+        const int npairs = (e - base + 1) >> 1;
+        int inc = npairs;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);
+        first_slot = inc - npairs;
+        if (sl < 12) tabs[rw][sl] = make_int4(base - 2 * first_slot, s, e, first_slot);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int qi = 0; qi < nq; ++qi) {
+        const int64_t q = SEL ? (int64_t)sf_uniform(__shfl((int)qm, 16 * qi)) : q0 + qi;
+        const int4 *const tab = tabs[qi];
+        const double px = __shfl(pxv, 16 * qi), py = __shfl(pyv, 16 * qi), pz = __shfl(pzv, 16 * qi);
+        const int b4 = __shfl(first_slot, 16 * qi + 4), b8 = __shfl(first_slot, 16 * qi + 8);
+        const int nslots = sf_uniform(__shfl(first_slot, 16 * qi + 9));
+        int total = 0;
+        for (int f0 = 0; f0 < nslots; f0 += 64) {
+            const int f = f0 + lane;
+            int r = f >= b4 ? 4 : 0;
+            r += f >= tab[r + 2].w ? 2 : 0;
+            r += f >= tab[r + 1].w ? 1 : 0;
+            r = f >= b8 ? 8 : r;
+            const int4 t = tab[r];
+            const bool live = f < nslots;
+            const int j = live ? t.x + 2 * f : 0;
+            const bool in0 = live & (j >= t.y), in1 = live & (j + 1 < t.z);
+            const double2 X = *reinterpret_cast<const double2 *>(xs + j);
+            const double2 Y = *reinterpret_cast<const double2 *>(ys + j);
+            const double2 Z = *reinterpret_cast<const double2 *>(zs + j);
+            const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
+            const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
+            const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
+            const bool hit0 = in0 & (d2a <= r2);
+            const bool hit1 = in1 & (d2b <= r2);
+            const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+            const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
+            const int pos1 = pos + (hit0 ? 1 : 0);
+            if (hit0 && pos < SF_KNN_CAP) { kd[pos] = d2a; kj[pos] = j; }
+            if (hit1 && pos1 < SF_KNN_CAP) { kd[pos1] = d2b; kj[pos1] = j + 1; }
+            total += __popcll(m0) + __popcll(m1);
+        }
+        if (total < k || total > SF_KNN_CAP) { // (wave-uniform)
+            if (lane == 0) status[q] = total < k ? 1 : 2;
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier(); // (the list is written and read by this wave only; its LDS operations stay in order)
+        int rank[4] = {0, 0, 0, 0};
+        for (int attempt = 0; attempt < 2; ++attempt) { // 0: strict ranks; 1: ties broken by position (only if attempt 0 saw one)
+            if (attempt == 0) {
+                if (total <= 64) knn_rank_pass<1, false>(kd, total, lane, rank);
+                else if (total <= 128) knn_rank_pass<2, false>(kd, total, lane, rank);
+                else knn_rank_pass<4, false>(kd, total, lane, rank);
+            } else {
+                knn_rank_pass<4, true>(kd, total, lane, rank);
+            }
+            ks[lane] = -1;
+            __builtin_amdgcn_wave_barrier();
+            int nwin = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = lane + 64 * u;
+                const bool win = 64 * u < total && e < total && rank[u] < k;
+                if (win) ks[rank[u]] = e;
+                nwin += __popcll(__ballot(win));
+            }
+            __builtin_amdgcn_wave_barrier();
+            const bool hole = lane < k && ks[lane] < 0;
+            if (nwin == k && !__ballot(hole)) break;
+        }
+        if (lane < k) idx_out[q * (int64_t)k + lane] = perm[kj[ks[lane]]];
+        if (lane == 0) status[q] = 0;
+        __builtin_amdgcn_wave_barrier(); // (the next query's sweep overwrites the list)
+    }
+}
+
 // original index -> cell-sorted position of the FINAL grid, for every stored neighbour
 __global__ void k_knn_to_positions(int64_t total, const int32_t *__restrict__ inv_perm, int32_t *__restrict__ idx)
 {
@@ -1286,8 +1445,10 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
     if (!(emax > 0.0)) emax = 1.0; // all points coincide: any radius works
     double vol = 1.0;
     for (int a = 0; a < 3; ++a) vol *= std::max(ext[a], 1e-3 * emax);
-    // radius expected to hold ~3.5 k points at the mean density of the bounding box
-    double R = std::cbrt(3.5 * (double)k * vol / ((double)c->n * 4.18879020478639));
+    // radius expected to hold ~3.5 k points at the mean density of the bounding box (k_knn4 keeps the points within R in an LDS
+    // list of SF_KNN_CAP entries: at most 0.6 of that on average)
+    const double within_target = k <= 64 ? std::min(3.5 * (double)k, 0.6 * SF_KNN_CAP) : 3.5 * (double)k;
+    double R = std::cbrt(within_target * vol / ((double)c->n * 4.18879020478639));
     const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]) + emax * 1e-6 + 1e-300;
     sf_nbrs *nb = new sf_nbrs();
     nb->m = m;
@@ -1304,7 +1465,7 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
     // where count ~ R^3) and the grid is rebuilt.  Only the speed depends on R: queries that see fewer than k points within
     // it are retried with a doubled radius below.
     if (m >= 2 * SF_K2_SAMPLE && !large) {
-        const double target = 3.5 * (double)k;
+        const double target = within_target;
         for (int it = 0; it < 3; ++it) {
             sf_pool_guard stmp(ctx);
             int32_t *sel = nullptr, *cnt = nullptr;
@@ -1366,6 +1527,41 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         if (large) {
             if (knn_round_large(ctx, c, nb, g, sel, msel, k, R2, hstatus, subset ? &pending : nullptr) != SF_OK) {
                 return fail();
+            }
+        } else if (k <= 64 && !one_cell && !getenv("SF_KNN_OLD")) {
+            // K2's mapping (k_knn4); the few queries with more than SF_KNN_CAP points within R go to k_knn at the same R
+            const dim3 grid4(sf_xcd_grid(sf_div_up(msel, 4 * SF_K2_WPB))), block4(64 * SF_K2_WPB);
+            {
+                sf_launch_timer t_(ctx, "k2_knn");
+                if (sel) hipLaunchKernelGGL((k_knn4<true>), grid4, block4, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, msel, R2, k, c->perm, nb->idx, status, sel);
+                else hipLaunchKernelGGL((k_knn4<false>), grid4, block4, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, msel, R2, k, c->perm, nb->idx, status, sel);
+            }
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                sf_set_error("sf_knn_search: launch failed");
+                return fail();
+            }
+            std::vector<int32_t> crowded;
+            if (subset) { for (int32_t i : pending) if (hstatus[(size_t)i] == 2) crowded.push_back(i); }
+            else { for (int64_t i = 0; i < m; ++i) if (hstatus[(size_t)i] == 2) crowded.push_back((int32_t)i); }
+            if (!crowded.empty()) {
+                sf_pool_guard ctmp(ctx);
+                int32_t *csel = nullptr;
+                if (ctmp.alloc(&csel, crowded.size()) != SF_OK ||
+                    hipMemcpyAsync(csel, crowded.data(), crowded.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    return fail();
+                {
+                    sf_launch_timer t_(ctx, "k2_knn_crowded");
+                    hipLaunchKernelGGL(k_knn<2>, dim3(sf_xcd_grid((int64_t)crowded.size())), dim3(64), 0, ctx->stream, g, c->cell_start, c->xs, c->ys,
+                                       c->zs, nb->qx, nb->qy, nb->qz, (const int32_t *)csel, (int64_t)crowded.size(), k, R2, c->perm, nb->idx, status);
+                }
+                if (hipGetLastError() != hipSuccess ||
+                    hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                    sf_set_error("sf_knn_search: launch failed");
+                    return fail();
+                }
             }
         } else {
         sf_launch_timer *tm = new sf_launch_timer(ctx, "k2_knn");

@@ -99,53 +99,47 @@ def test_k2_lists_through_the_lds_ring(eng, O, monkeypatch, cap):
         cloud.free()
 
 
-# ---- K5 for lists of 256 .. 512 points held in registers (k_shot_wide) ---------------------------------------------------------
-@pytest.mark.parametrize("kind", ["uniform", "surface"])
-def test_k5_register_held_form_equals_the_streaming_form_bit_for_bit(eng, O, monkeypatch, kind):
-    """Lists of 256 .. 512 points: the form that fetches the list once and runs its passes from registers (k_shot_wide) against
-    the streaming form (SF_SHOT_NO_WIDE=1, k_shot_long) -- same functions, same LDS operations in the same order: equal bits --
-    and against the oracle; fused frame (single scale: votes in the kernel) and given frames (sf_shot); lists on both sides of
-    the 255 / 256 and 512 / 513 boundaries in one launch; a gate that zeroes some rows."""
+# ---- k-NN on K2's mapping (k_knn4) ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 8, 30, 64])
+@pytest.mark.parametrize("kind", ["uniform", "blob", "duplicates", "surface"])
+def test_knn_on_the_radius_search_mapping(eng, O, monkeypatch, kind, k):
+    """k <= 64: four queries per wave, the points within R ranked in ONE pass (k_knn4), against brute force and against the
+    one-wave-per-query kernel it replaces (SF_KNN_OLD=1): the same lists in the same (distance, position) order, so normals
+    computed from them are equal bit for bit.  Dense blob: queries with more than 256 points within R go to the old kernel at the
+    same R; duplicated points: exact distance ties, broken by position; queries far outside the cloud: radius doublings."""
     from conftest import config1_cloud
-    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+    from shot_fpfh_amd.descriptors import compute_normals
 
-    if kind == "uniform":
-        p, nr, _ = synth_cloud(40000, 31)
-        r = 0.145
-    else:
-        p, nr = config1_cloud(40000, 31)
-        r = 0.11
+    n, m = 30000, 4000
+    p, _, rng = synth_cloud(n, 61 + k)
+    if kind == "blob":
+        p[: n // 2] = 0.5 + 0.02 * (p[: n // 2] - 0.5)
+    elif kind == "duplicates":
+        p[1::3] = p[0:-1:3][: p[1::3].shape[0]]  # every third point sits on its predecessor
+    elif kind == "surface":
+        p, _ = config1_cloud(n, 61 + k)
+    q = np.vstack([p[rng.choice(n, m - 200, replace=False)], rng.random((200, 3)) * 3.0 - 1.0])
     cloud = eng.cloud(p)
-    nb = cloud.radius_search_self(r)
-    cnt = nb.counts()[np.argsort(cloud.perm())]
-    nb.free()
-    cloud.free()
-    assert cnt.min() < 256 and ((cnt > 255) & (cnt <= 512)).sum() > 2000 and cnt.max() > 512, (cnt.min(), cnt.max())
-    order = np.argsort(cnt)
-    picks = [order[:20], order[-40:]]
-    for edge in (255, 256, 257, 320, 384, 385, 448, 511, 512, 513):
-        lo = np.searchsorted(cnt[order], edge - 1)
-        picks.append(order[lo:lo + 10])
-    kp = np.unique(np.concatenate(picks + [np.random.default_rng(5).choice(p.shape[0], 300, replace=False)]))
-    res = {}
-    for mode in ("wide", "stream"):
-        if mode == "stream":
-            monkeypatch.setenv("SF_SHOT_NO_WIDE", "1")
-        else:
-            monkeypatch.delenv("SF_SHOT_NO_WIDE", raising=False)
-        with ShotMultiprocessor(normalize=True, min_neighborhood_size=300, verbose=False) as sm:
-            d = sm.compute_descriptor_single_scale(p, nr, p[kp], r)
-            lrf = sm.compute_local_rf(p[kp], None, p, r)
-            d2 = sm.compute_descriptor(p[kp], nr, None, lrf, p, r)
-            full = sm.compute_descriptor_single_scale(p, nr, p, r)
-        res[mode] = (d, d2, full)
-    monkeypatch.delenv("SF_SHOT_NO_WIDE", raising=False)
-    for a, b in zip(res["wide"], res["stream"]):
+    try:
+        monkeypatch.delenv("SF_KNN_OLD", raising=False)
+        nb = cloud.knn_search(q, k)
+        off, idx = nb.export()
+        monkeypatch.setenv("SF_KNN_OLD", "1")
+        off_old, idx_old = cloud.knn_search(q, k).export()
+        monkeypatch.delenv("SF_KNN_OLD", raising=False)
+    finally:
+        cloud.free()
+    assert np.array_equal(off, off_old) and np.array_equal(idx, idx_old)
+    sub = np.arange(0, m, 8)
+    off_o, idx_o = O.knn_lists(p, q[sub], k)
+    got, want = idx.reshape(m, k)[sub], np.sort(idx_o.reshape(sub.size, k), axis=1)
+    for i in np.flatnonzero(~(got == want).all(axis=1)):  # rows may differ only where the k-th and (k+1)-th are equidistant
+        d = np.sort(((p - q[sub[i]]) ** 2).sum(axis=1))
+        assert d[k - 1] == d[k], f"query {sub[i]}: different neighbour set without a distance tie"
+    if k >= 8 and kind != "duplicates":  # (normals of k-NN lists: the lists' ORDER enters the sums)
+        monkeypatch.delenv("SF_KNN_OLD", raising=False)
+        a = compute_normals(q[: m - 200], p, k=k)
+        monkeypatch.setenv("SF_KNN_OLD", "1")
+        b = compute_normals(q[: m - 200], p, k=k)
+        monkeypatch.delenv("SF_KNN_OLD", raising=False)
         assert np.array_equal(a, b)
-    d, d2, full = res["wide"]
-    assert np.array_equal(full[kp], d)  # all points keypoints (launch over the selection of long lists) == keypoint subset
-    assert (np.abs(d).sum(axis=1) == 0).any() and (np.abs(d).sum(axis=1) > 0).any()  # (the gate at 300 zeroes the short lists)
-    sub = np.arange(0, kp.size, max(1, kp.size // 100))
-    want = O.shot_single_scale(p, nr, p[kp[sub]], r, True, 300)
-    assert np.abs(d[sub] - want).max() < 1e-9, np.abs(d[sub] - want).max()
-    assert np.abs(d2 - d).max() < 1e-12

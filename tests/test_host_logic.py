@@ -310,6 +310,53 @@ def test_bench_control_plane_rendezvous_allgather_max_bcast(tmp_path, under_laun
         blocker.close()
 
 
+def test_bench_control_plane_drops_a_client_without_the_job_secret(tmp_path):
+    """No SF_BENCH_TOKEN and no launcher secret: rank 0 writes 16 random bytes to a file only this user can read and the other
+    ranks read it back; a local process that connects to rank 0's port and sends a well-formed message under a guessed key (the
+    public run id "none", the port, the world size) is dropped unread, and the job's own ranks still meet."""
+    import hashlib
+    import hmac
+    import os
+    import pickle
+    import socket
+    import struct
+    import subprocess
+    import sys
+    import time
+
+    from conftest import ROOT
+
+    s0 = socket.socket()
+    s0.bind(("127.0.0.1", 0))
+    port = s0.getsockname()[1]
+    s0.close()
+    script = tmp_path / "w.py"
+    script.write_text(_CTL_WORKER)
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SF_BENCH_SELF_SPAWNED="1", TORCHELASTIC_RUN_ID="none")
+    env.pop("SF_BENCH_TOKEN", None)
+    r0 = subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK="0"))
+    rogue = None
+    for _ in range(200):  # rank 0 listens on MASTER_PORT itself when the bench spawned its ranks
+        try:
+            rogue = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+            break
+        except OSError:
+            time.sleep(0.05)
+    assert rogue is not None
+    rogue.settimeout(10.0)
+    assert rogue.recv(64).startswith(b"SFBENCH")
+    data = pickle.dumps(1)
+    guessed = ("sfbench|none|" + str(port) + "|2").encode()
+    rogue.sendall(struct.pack("<Q", len(data)) + hmac.new(guessed, data, hashlib.sha256).digest() + data)
+    assert rogue.recv(16) == b""  # dropped: rank 0 closed the connection without unpickling
+    rogue.close()
+    r1 = subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK="1"))
+    assert r0.wait(timeout=120) == 0 and r1.wait(timeout=120) == 0
+    import tempfile
+
+    assert not os.path.exists(os.path.join(tempfile.gettempdir(), f"sfbench-{os.getuid()}-{port}.token"))  # (removed at close)
+
+
 def test_pinned_pool_finalizer_takes_no_lock_and_trim_releases():
     """engine._PinnedPool: a block returns through a weakref finalizer that may run at any allocation point, also inside
     array() while the pool's lock is held -- so the finalizer only appends to a deque.  Views keep a block alive; a

@@ -62,7 +62,7 @@ def _parity(got, want, rows):
     return {"rows": int(rows), "max_abs_err": float(err.max()), "ok": bool((err <= TOL * np.maximum(1.0, np.abs(want))).all())}
 
 
-def run(eng, points_1m, normals_1m, radius_1m, parity: bool = True) -> dict:
+def run(eng, points_1m, normals_1m, radius_1m, parity: bool = True, only: str | None = None) -> dict:
     from conftest import config1_cloud, synth_cloud
     from oracle import oracle as O
     from shot_fpfh_amd.core import grid_subsampling
@@ -104,6 +104,8 @@ def run(eng, points_1m, normals_1m, radius_1m, parity: bool = True) -> dict:
         out["shot_subsampled_support"][name] = line
         del d
 
+    if only == "shot_sub":  # (a quick look at the subsampled-support lines alone: python tools/bench_defaults.py shot_sub)
+        return out
     # ---- compute_normals(k = 30) ---------------------------------------------------------------------------------------
     out["normals_knn_k30"] = {}
     for name, pc in (("c2_100k", p2), ("uniform_1m", points_1m), ("surface_1m", ps)):
@@ -189,7 +191,7 @@ def main() -> int:
 
     eng = Engine()
     p, nr = make_cloud(1_000_000, 3)
-    print(json.dumps({"build": eng.lib.sf_version().decode(), "reference_defaults": run(eng, p, nr, 0.03)}, indent=1))
+    print(json.dumps({"build": eng.lib.sf_version().decode(), "reference_defaults": run(eng, p, nr, 0.03, only=sys.argv[1] if len(sys.argv) > 1 else None)}, indent=1))
     return 0
 
 
