@@ -541,19 +541,6 @@ __device__ inline double sf_dot3(double a0, double a1, double a2, double b0, dou
 // minus its exponent pre/post-scaling, which only matters outside [1e-290, 1e290]: bit-identical to sqrt() there
 // (tools/ubench/sqrt_check.hip: 0 differences in 1.6e7 inputs), 10 instructions instead of 22; the half-inverse
 // the iteration carries along, refined once more, is 1/sqrt(x) to ~1 ulp for two more instructions.
-#ifndef SF_SHOT_KPW
-#define SF_SHOT_KPW 1 // keypoints a wave of the cached K5 serves one after the other (1: one wave per keypoint, as until round 4)
-#endif
-#ifndef SF_SHOT_OUTLINE
-#define SF_SHOT_OUTLINE (SF_SHOT_KPW > 1) // the libm fallbacks of the cached K5 as function calls
-#endif
-// (the libm forms behind the fast paths below, OUTLINED when the cached K5 loops over keypoints: see shot_centre_ray_side)
-__device__ __attribute__((noinline)) double2 sf_sqrt_rsqrt_slow(double x)
-{
-    const double root = sqrt(x);
-    return make_double2(root, 1.0 / root);
-}
-
 __device__ inline void sf_sqrt_rsqrt(double x, double &root, double &inv)
 {
     const double y = __builtin_amdgcn_rsq(x);
@@ -573,14 +560,8 @@ __device__ inline void sf_sqrt_rsqrt(double x, double &root, double &inv)
     // positive, finite, not NaN -- one integer subtraction and comparison with 32-bit literals instead of two comparisons
     // against 64-bit constants that each cost two scalar moves)
     if (__ballot(!((unsigned)__double2hiint(x) - 0x03b00000u < 0x7c200000u - 0x03b00000u))) {
-        if (SF_SHOT_OUTLINE) {
-            const double2 t = sf_sqrt_rsqrt_slow(x);
-            root = t.x;
-            inv = t.y;
-        } else {
-            root = sqrt(x);
-            inv = 1.0 / root;
-        }
+        root = sqrt(x);
+        inv = 1.0 / root;
     }
 }
 
@@ -604,10 +585,6 @@ __device__ inline void sf_sqrt_rsqrt_uniform(double x, double &root, double &inv
         h = __builtin_fma(h, r, h);
         root = g;
         inv = h + h;
-    } else if (SF_SHOT_OUTLINE) {
-        const double2 t = sf_sqrt_rsqrt_slow(x);
-        root = t.x;
-        inv = t.y;
     } else {
         root = sqrt(x);
         inv = 1.0 / root;
@@ -751,23 +728,8 @@ __device__ inline double sf_acos_abs_quadrants(double az, const double *__restri
     return big ? as + as : 1.0 - as;
 }
 
-// (`cosine_raw`: normals @ eigenvectors[:, 2], shot.py:215, before the clip)
-// The reference's own expression for the side of the octant's centre ray (shot.py:283-288), for the neighbours the cross
-// product cannot decide.  OUTLINED for forms that LOOP (over chunks or keypoints): inlined into a loop, libm's atan2 has its two
-// dozen constants hoisted out of it as loop invariants -- live across the whole loop, they spill (a register-held form for lists
-// of 256 .. 512 points, built and dropped in round 5 -- per pair it ran no faster than k_shot_long -- went from 116 bytes of
-// scratch to none with this one attribute).
-__device__ __attribute__((noinline)) int shot_centre_ray_side(double lx, double ly, int ti)
-{
-    const double tsz = 2 * SHOT_PI / 8;
-    double dth = (atan2(ly, lx) - (-SHOT_PI + ti * tsz)) / tsz - 0.5;
-    dth = fmin(fmax(dth, -0.5), 0.5);
-    return (dth > 0.0) - (dth < 0.0);
-}
-
-template <bool OUTLINE = false>
-__device__ inline void shot_geometry_core(double cx, double cy, double cz, double d2, double cosine_raw,
-                                          const double *E, double half_r, shot_kept &o)
+__device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
+                                     const double *E, double half_r, shot_kept &o)
 {
     double rho, inv_rho;
     SF_K5_MARK(50, 0);
@@ -779,7 +741,8 @@ __device__ inline void shot_geometry_core(double cx, double cy, double cz, doubl
     const double lx = sf_dot3(cx, cy, cz, E[0], E[3], E[6]);
     const double ly = sf_dot3(cx, cy, cz, E[1], E[4], E[7]);
     const double lz = sf_dot3(cx, cy, cz, E[2], E[5], E[8]);
-    double cosine = fmin(fmax(cosine_raw, -1.0), 1.0);
+    double cosine = sf_dot3(nx, ny, nz, E[2], E[5], E[8]);
+    cosine = fmin(fmax(cosine, -1.0), 1.0);
     double lxp = lx, lyp = ly, lzp = lz;
     SF_K5_PIN(lxp); SF_K5_PIN(lyp); SF_K5_PIN(lzp); SF_K5_PIN(cosine);
     SF_K5_MARK(52, 0);
@@ -810,8 +773,6 @@ __device__ inline void shot_geometry_core(double cx, double cy, double cz, doubl
     int sth;
     if (fabs(cross) > 1e-9 * (fabs(lx) + fabs(ly))) {
         sth = cross > 0.0 ? 1 : -1;
-    } else if (OUTLINE) {
-        sth = shot_centre_ray_side(lx, ly, ti);
     } else { // on (or within rounding of) the centre ray, or lx = ly = 0: the reference's expression decides
         const double tsz = 2 * SHOT_PI / 8;
         double dth = (atan2(ly, lx) - (-SHOT_PI + ti * tsz)) / tsz - 0.5;
@@ -836,12 +797,6 @@ __device__ inline void shot_geometry_core(double cx, double cy, double cz, doubl
     o.rho = rho; o.dc = dc; o.tcross = cross; o.tdot = dot; o.lzr = lzr;
     o.bins0 = base | (bcos << 9) | (bth << 18);
     o.bins1 = 0x80000000u;
-}
-
-__device__ inline void shot_geometry(double cx, double cy, double cz, double d2, double nx, double ny, double nz,
-                                     const double *E, double half_r, shot_kept &o)
-{
-    shot_geometry_core<(bool)(SF_SHOT_OUTLINE)>(cx, cy, cz, d2, sf_dot3(nx, ny, nz, E[2], E[5], E[8]), E, half_r, o);
 }
 
 // Radius-derived constants of the interpolation, computed once on the host (as kernel arguments they live in SGPRs;
@@ -921,7 +876,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  const int32_t *__restrict__ qrow, const shot_consts &K,
                                                  double *__restrict__ lrf, int normalize, int64_t min_nb,
-                                                 double *__restrict__ out, int64_t q, unsigned long long *slot, int lane)
+                                                 double *__restrict__ out, int64_t q, unsigned long long *slot)
 {
     // FUSED: `lrf` holds the raw axes written by k_shot_lrf(raw = 1); the sign votes (shot.py:40-45) are taken
     // here from the gathered neighbours and the finished frame is written back before it is used.
@@ -933,6 +888,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
     // the winner's radial bin, and likewise S6/S7 by its elevation bin.
     SF_K5_MARK(1, NCH);
     unsigned long long *const sA = slot;
+    const int lane = threadIdx.x & 63;
     const int64_t s = offset[q];
     const int k = cnt[q];
     const int64_t row = qrow ? qrow[q] : q;
@@ -1357,71 +1313,11 @@ __global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *
     // The kernel is instantiated for the LONGEST list of the launch (a 1M-point uniform cloud at 110 neighbours on average
     // has one of 160+), but nearly every keypoint fits one chunk less: a wave-uniform branch picks the body that
     // matches THIS keypoint, so the gather, votes and distance tests of an empty last chunk are never issued.
-    const int lane = threadIdx.x & 63;
     if (NCH >= 3 && sf_uniform(cnt[q]) <= 64 * (NCH - 1)) {
-        shot_cached_body<(NCH >= 3 ? NCH - 1 : NCH), FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot, lane);
+        shot_cached_body<(NCH >= 3 ? NCH - 1 : NCH), FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
         return;
     }
-    shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot, lane);
-}
-
-// The same kernel with SF_SHOT_KPW consecutive keypoints per wave, one after the other (round 5).  A wave's slot is held until its
-// row stores are acknowledged, and they are issued at the very end of a keypoint's work (round 4: 14 % of the kernel with five of
-// the six stores left out); in a loop the NEXT keypoint's scalar loads, LDS clear and index load are under way while the row
-// drains.  Three things keep the loop at the straight-line kernel's registers (the first attempt needed 139):
-//   * the TU is compiled without machine-level loop-invariant code motion (Makefile: -disable-machine-licm for this object):
-//     it hoists every literal of the body -- the libm fallbacks' two dozen constants first -- into registers held across the loop;
-//   * the lane number is re-defined in every trip (an empty asm): everything derived from it is formed where it is used;
-//   * ALL arguments arrive as one struct and are re-read from the kernel-argument segment in every trip: each is then live from
-//     the trip's start to its last use, as in the straight-line kernel, instead of across the whole loop (43 scalars spilled).
-struct shot_cached_args {
-    const double *rec, *qx, *qy, *qz;
-    const int64_t *offset;
-    const int32_t *cnt, *idx, *qrow;
-    int64_t m;
-    shot_consts K;
-    double *lrf;
-    int normalize;
-    int64_t min_nb;
-    double *out;
-    int limit;
-    const int32_t *sel;
-    int64_t nsel, view_first;
-};
-template <int NCH, bool FUSED>
-__global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached_loop(shot_cached_args unused_by_name)
-{
-    __shared__ __attribute__((aligned(16))) unsigned long long slots[SF_SHOT_WPB][704];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned long long *const slot = slots[wave];
-    const int64_t first = (sf_xcd_block() * SF_SHOT_WPB + wave) * SF_SHOT_KPW;
-    typedef const __attribute__((address_space(4))) shot_cached_args *args_ptr;
-#pragma clang loop unroll(disable)
-    for (int kp = 0; kp < SF_SHOT_KPW; ++kp) {
-        args_ptr a = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr(); // (the struct is the only parameter: offset 0)
-        asm volatile("" : "+s"(a));
-        int lane = threadIdx.x & 63;
-        asm volatile("" : "+v"(lane));
-        int64_t q = first + kp;
-        const int32_t *sel = a->sel;
-        if (sel) {
-            if (q >= a->nsel) return;
-            q = (int64_t)sf_uniform(sel[q]) - a->view_first;
-            if (q < 0) continue;
-        }
-        if (q >= a->m) return;
-        const int32_t *cnt = a->cnt;
-        const int kq = sf_uniform(cnt[q]);
-        if (kq > a->limit) continue;
-        const shot_consts K{a->K.radius, a->K.half_r, a->K.q1, a->K.q3, a->K.inv_hr, a->K.coef}; // (field by field: no copy constructor across address spaces)
-        if (NCH >= 3 && kq <= 64 * (NCH - 1)) {
-            shot_cached_body<(NCH >= 3 ? NCH - 1 : NCH), FUSED>(a->rec, a->qx, a->qy, a->qz, a->offset, cnt, a->idx, a->qrow, K, a->lrf, a->normalize,
-                                                                a->min_nb, a->out, q, slot, lane);
-            continue;
-        }
-        shot_cached_body<NCH, FUSED>(a->rec, a->qx, a->qy, a->qz, a->offset, cnt, a->idx, a->qrow, K, a->lrf, a->normalize, a->min_nb, a->out, q,
-                                     slot, lane);
-    }
+    shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
 }
 
 } // namespace
@@ -1598,7 +1494,7 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     if (!m) return SF_OK;
     // (a list holds fewer than 2^31 points: clamped here, "more than min_nb neighbours" is a 32-bit comparison in the kernels)
     min_nb = std::min<int64_t>(std::max<int64_t>(min_nb, -1), 2147483647LL);
-    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB * SF_SHOT_KPW))), block(64 * SF_SHOT_WPB), block_streaming(64 * SF_SHOT_LONG_WPB);
+    const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SHOT_WPB))), block(64 * SF_SHOT_WPB), block_streaming(64 * SF_SHOT_LONG_WPB);
 #define SF_SHOT_ARGS c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m
     const double r_ = nb->radius;
     if (!ctx->shot_coef) { // (once per context)
@@ -1607,17 +1503,9 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
     }
     const shot_consts K{r_, r_ / 2, r_ / 4, r_ * 3 / 4, 1.0 / (r_ / 2), ctx->shot_coef}; // the reference's own expressions (shot.py:95-117, 235)
     const sf_dispatch d = sf_nbrs_dispatch(nb);
-#if SF_SHOT_KPW > 1
-    const shot_cached_args A{c->rec, nb->qx, nb->qy, nb->qz, nb->offset, nb->count, nb->idx, nb->qrow, m, K, dlrf, normalize, min_nb, dout, d.limit,
-                             nullptr, 0, 0};
-#define SF_SHOT_CASE(N)                                                                                              \
-    if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached_loop<N, true>), grid, block, A); }                          \
-    else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached_loop<N, false>), grid, block, A); }
-#else
 #define SF_SHOT_CASE(N)                                                                                              \
     if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); } \
     else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); }
-#endif
 #define SF_SHOT_STREAM(NAME, SEL, GRID, SELP, NSEL)                                                                   \
     if (fused) { SF_LAUNCH(ctx, NAME, (k_shot_long<true, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); } \
     else { SF_LAUNCH(ctx, NAME, (k_shot_long<false, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); }

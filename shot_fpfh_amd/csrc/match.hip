@@ -173,6 +173,31 @@ __global__ void k_match_merge(const double *__restrict__ pdist, const int64_t *_
     if (dist) dist[i] = bd;
 }
 
+// "Minimum over scales" (matching.py:77-136) from the per-scale row minima: min_j min_s d_s(i, j) = min_s min_j d_s(i, j), and the
+// first column that attains it is the lowest of the per-scale arg-mins at that distance.  The per-scale results come from the
+// matrix-core matcher with empty descriptors masked at +inf; the reference counts a pair with an empty side as `max_val`:
+//   * best == +inf: every pair of the row has an empty side at every scale -> a row of max_val, arg-min 0;
+//   * best <  max_val: the reference's answer (pairs at max_val lose against it);
+//   * max_val <= best < +inf (descriptors so far apart that "empty" pairs would win): counted in *n_hard -- the caller then
+//     runs the exact tile kernel on the whole problem (never seen on normalised rows, whose distances are at most 2).
+__global__ void k_match_scale_fold(const int64_t *__restrict__ idx_s, const double *__restrict__ dist_s, int n_scales, int64_t m1,
+                                   double max_val, int64_t *__restrict__ idx, double *__restrict__ dist, unsigned *__restrict__ n_hard)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m1) return;
+    double bd = INFINITY;
+    int64_t bj = 0;
+    for (int sc = 0; sc < n_scales; ++sc) {
+        const double d = dist_s[(int64_t)sc * m1 + i];
+        const int64_t j = idx_s[(int64_t)sc * m1 + i];
+        if (d < bd || (d == bd && d < INFINITY && j < bj)) { bd = d; bj = j; }
+    }
+    if (!(bd < INFINITY)) { bj = 0; bd = max_val; }
+    else if (!(bd < max_val)) atomicAdd(n_hard, 1u);
+    idx[i] = bj;
+    if (dist) dist[i] = bd;
+}
+
 // K9: inlier counts of all candidate transforms (ransac.py:60-67).  A workgroup keeps a tile of 256 x 8 matched
 // pairs in registers and walks over its range of draws; the 12 coefficients of a draw are wave-uniform (scalar
 // loads), the votes of a wave are a ballot + popcount, one LDS add per wave and draw, one global add per workgroup
@@ -377,6 +402,39 @@ extern "C" int sf_match_col_candidates(sf_ctx *ctx, const double *local_dist_dev
     return SF_OK;
 }
 
+// The 3-D branch through the FP16 pre-filter + exact float64 re-rank of the 2-D matcher, one scale after the other, and the fold
+// above (round 5; the exact tile kernel alone ran 2 x 10^4 x 10^4 x 352 in 12.6 ms = 11 TFLOP/s).  *done = false: not applicable
+// (small problem, SF_MATCH_EXACT=1) or a row needs the exact kernel -- the caller runs it.  Device pointers.
+static int match_multiscale_fast(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1, int64_t m2, int64_t d,
+                                 const unsigned char *a_ok, const unsigned char *b_ok, double max_val, int64_t *idx, double *dist,
+                                 bool *done)
+{
+    *done = false;
+    const char *fe = getenv("SF_MATCH_EXACT");
+    const double work = (double)m1 * (double)m2 * (double)d;
+    if ((fe && fe[0] == '1') || n_scales < 2 || work < 5e8 || m2 < 256 || !(max_val > 0.0) || std::isinf(max_val)) return SF_OK;
+    sf_pool_guard tmp(ctx);
+    int64_t *idx_s = nullptr;
+    double *dist_s = nullptr;
+    unsigned *n_hard = nullptr;
+    SF_CHECK(tmp.alloc(&idx_s, (size_t)n_scales * m1));
+    SF_CHECK(tmp.alloc(&dist_s, (size_t)n_scales * m1));
+    SF_CHECK(tmp.alloc(&n_hard, 1));
+    SF_HIP(hipMemsetAsync(n_hard, 0, sizeof(unsigned), ctx->stream));
+    for (int sc = 0; sc < n_scales; ++sc)
+        SF_CHECK(sf_match_gemm(ctx, a + (size_t)sc * m1 * d, m1, b + (size_t)sc * m2 * d, m2, d, idx_s + (size_t)sc * m1, dist_s + (size_t)sc * m1,
+                               "k8_match_gemm", nullptr, a_ok + (size_t)sc * m1, b_ok + (size_t)sc * m2));
+    SF_LAUNCH(ctx, "k8_match_merge", k_match_scale_fold, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), (const int64_t *)idx_s,
+              (const double *)dist_s, n_scales, m1, max_val, idx, dist, n_hard);
+    void *pin = nullptr;
+    SF_CHECK(sf_ctx_pinned(ctx, &pin));
+    unsigned *hw = (unsigned *)((char *)pin + SF_PINNED_BYTES - 32);
+    SF_HIP(hipMemcpyAsync(hw, n_hard, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    *done = *hw == 0u;
+    return SF_OK;
+}
+
 extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, int n_scales, int64_t m1,
                                           int64_t m2, int64_t d, const unsigned char *a_ok, const unsigned char *b_ok,
                                           double max_val, int64_t *idx, double *dist, int flags)
@@ -393,7 +451,9 @@ extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const do
         if (n_scales == 1 && std::isinf(max_val) && max_val > 0 && !force_exact && work >= 5e8 && m2 >= 256)
             // single scale, masked rows at +inf: the matrix-core path with ||b_j||^2 = +inf for masked reference rows
             return sf_match_gemm(ctx, a, m1, b, m2, d, idx, dist, "k8_match_gemm", nullptr, a_ok, b_ok);
-        SF_CHECK(match_one_way(ctx, a, m1, b, m2, d, idx, dist, "k8_match_tile_masked", n_scales, a_ok, b_ok, max_val));
+        bool done = false;
+        SF_CHECK(match_multiscale_fast(ctx, a, b, n_scales, m1, m2, d, a_ok, b_ok, max_val, idx, dist, &done));
+        if (!done) SF_CHECK(match_one_way(ctx, a, m1, b, m2, d, idx, dist, "k8_match_tile_masked", n_scales, a_ok, b_ok, max_val));
         return SF_OK;
     }
     if (flags != SF_HOST) { sf_set_error("sf_match_argmin_multiscale: flags must be SF_HOST or SF_IN_DEVICE|SF_OUT_DEVICE"); return SF_ERR_UNSUPPORTED; }
@@ -413,7 +473,9 @@ extern "C" int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const do
     if (m1) SF_HIP(hipMemcpyAsync(dao, a_ok, (size_t)n_scales * m1, hipMemcpyHostToDevice, ctx->stream));
     SF_HIP(hipMemcpyAsync(dbo, b_ok, (size_t)n_scales * m2, hipMemcpyHostToDevice, ctx->stream));
     if (m1) {
-        SF_CHECK(match_one_way(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_tile_multiscale", n_scales, dao, dbo, max_val));
+        bool done = false;
+        SF_CHECK(match_multiscale_fast(ctx, da, db, n_scales, m1, m2, d, dao, dbo, max_val, didx, ddist, &done));
+        if (!done) SF_CHECK(match_one_way(ctx, da, m1, db, m2, d, didx, ddist, "k8_match_tile_multiscale", n_scales, dao, dbo, max_val));
         SF_HIP(hipMemcpyAsync(idx, didx, (size_t)m1 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         if (dist) SF_HIP(hipMemcpyAsync(dist, ddist, (size_t)m1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }

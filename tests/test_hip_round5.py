@@ -143,3 +143,39 @@ def test_knn_on_the_radius_search_mapping(eng, O, monkeypatch, kind, k):
         b = compute_normals(q[: m - 200], p, k=k)
         monkeypatch.delenv("SF_KNN_OLD", raising=False)
         assert np.array_equal(a, b)
+
+
+# ---- 3-D matching ("minimum over scales") through the matrix-core matcher ---------------------------------------------------------
+@pytest.mark.parametrize("case", ["normalised", "empty_rows", "far_apart"])
+def test_multiscale_matching_through_the_prefilter_equals_the_exact_kernel(eng, O, monkeypatch, case):
+    """match_descriptors on (n_scales, n, 352) input: per scale the FP16 pre-filter + exact float64 re-rank, folded over the
+    scales, against the exact tile kernel (SF_MATCH_EXACT=1) and the NumPy restatement of matching.py:77-136.  Empty descriptors
+    at one scale or at all of them (a pair with an empty side counts as 1000); descriptors farther apart than 1000 (the fold
+    hands the whole problem back to the exact kernel)."""
+    from shot_fpfh_amd.matching import match_descriptors
+
+    rng = np.random.default_rng(77)
+    n1, n2, d, ns = 2600, 2300, 352, 3
+    a = rng.random((ns, n1, d)) * (rng.random((ns, n1, d)) < 0.3)
+    perm = rng.permutation(n1)[:n2]
+    b = a[:, perm] + 0.01 * rng.standard_normal((ns, n2, d)) * (a[:, perm] != 0)
+    if case != "far_apart":
+        a /= np.maximum(np.linalg.norm(a, axis=2, keepdims=True), 1e-300)
+        b /= np.maximum(np.linalg.norm(b, axis=2, keepdims=True), 1e-300)
+    else:
+        a[:, :40] *= 4000.0  # these rows are more than 1000 away from every reference row
+    if case != "normalised":
+        a[0, 5:60] = 0.0      # empty at one scale
+        a[:, 100:130] = 0.0   # empty at every scale
+        b[1, 10:200] = 0.0
+        b[:, 300:320] = 0.0
+    monkeypatch.delenv("SF_MATCH_EXACT", raising=False)
+    got = match_descriptors(a, b, verbose=False, engine=eng)
+    monkeypatch.setenv("SF_MATCH_EXACT", "1")
+    exact = match_descriptors(a, b, verbose=False, engine=eng)
+    monkeypatch.delenv("SF_MATCH_EXACT", raising=False)
+    assert np.array_equal(got[0], exact[0]) and np.array_equal(got[1], exact[1])
+    want = O.match_descriptors_multiscale(a, b)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    if case == "normalised":
+        assert (perm[got[1]] == got[0]).mean() > 0.99  # (and it does find the partners)
