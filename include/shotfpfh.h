@@ -209,6 +209,16 @@ int sf_shot_serial(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int64_t min_neig
  * mask back (8 bytes, once per sf_spfh_compute: it waits for K6 on the context's stream) and, when at most two of the
  * eight blocks do, multiplies only those -- same results, bit for bit. */
 sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_count);
+/* The table for a KNOWN search radius (the `radius` argument of compute_fpfh_descriptor, fpfh.py:19).  alpha = (c x u) . n_j
+ * with v not normalised (fpfh.py:60) never exceeds radius * max|n|^2: when that stays inside the one or two central bins of
+ * the alpha histogram (an even n_bins has an edge at 0), only those bins' n_bins^2 (2 n_bins^2) slots of a row can ever hold a
+ * count.  For n_bins = 6, 7, 8 -- 72 of 216, 49 of 343, 128 of 512 bins -- the table then keeps exactly that window of bins,
+ * one byte each, and the whole byte-table path (packed rows, high bytes, K7 on the matrix cores, the wire image of the
+ * exchange) serves these bin counts too; sf_fpfh writes zeros for the bins outside the window.  Without a usable window
+ * (radius <= 0, no normals, a larger reach, other bin counts) this IS sf_spfh_create.  sf_spfh_compute fails with
+ * SF_ERR_STATE when it is run with a radius that reaches beyond the table's window.  sf_spfh_elem_bytes: 1, 2 or 4. */
+sf_spfh *sf_spfh_create_for_radius(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_count, double radius);
+int sf_spfh_elem_bytes(const sf_spfh *spfh);
 int sf_spfh_compute(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *self_nbrs, sf_spfh *spfh, const double *edges);
 /* Extension for callers that want FPFH and SHOT from the SAME self-search lists (both descriptors of config 3 / 5):
  * sf_spfh_compute_moments is sf_spfh_compute that also leaves, per query of `self_nbrs`, the weighted covariance of

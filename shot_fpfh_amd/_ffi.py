@@ -72,6 +72,8 @@ SIGNATURES = {
     "sf_azimuth_idx": (_int, [_vp, _vp, _vp, _i64, _vp, _int]),
     "sf_shot_serial": (_int, [_vp, _vp, _vp, _i64, _vp, _int]),
     "sf_spfh_create": (_vp, [_vp, _vp, _int, _i64]),
+    "sf_spfh_create_for_radius": (_vp, [_vp, _vp, _int, _i64, C.c_double]),
+    "sf_spfh_elem_bytes": (_int, [_vp]),
     "sf_spfh_compute": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "sf_spfh_compute_moments": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sf_shot_from_moments": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),

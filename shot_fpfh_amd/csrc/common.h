@@ -268,6 +268,9 @@ struct sf_spfh {
     int stride = 0;      // elements per row (padded)
     int elem_bytes = 2;  // 1 = biased uint8 counts (matrix-core K7), 2 = uint16 counts, 4 = uint32 counts
     int bias = 0;        // stored value = count ^ bias (128 for the uint8 table: the byte read as int8 is count - 128)
+    int win_lo = 0;      // uint8 table: column c of a row holds bin win_lo + c, for c < win_len (the other bins of the nb3 are
+    int win_len = 0;     // structurally empty: alpha pinned to its one or two central bins -- sf_spfh_create_for_radius);
+                         // win_lo = 0, win_len = nb3 for every table of at most 128 bins
     void *counts = nullptr; // n x stride, by sorted position
     int32_t *k = nullptr;   // n, neighbourhood size (self included), by sorted position
     double *p4 = nullptr;   // uint8 table only: n x {x, y, z, (double)k} -- all the matrix-core K7 gathers per neighbour

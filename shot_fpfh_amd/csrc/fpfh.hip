@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
                                               unsigned *__restrict__ live, int alpha_bin, double nrm_max,
                                               uint8_t *__restrict__ packed, int pack_b0, int pack_b1,
                                               uint8_t *__restrict__ hi, int limit, const int32_t *__restrict__ sel,
-                                              int64_t nsel, int64_t view_first)
+                                              int64_t nsel, int64_t view_first, int alpha_pair, int win_lo, int win_len)
 {
     const int nb = NB > 0 ? NB : nb_rt;
     __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
@@ -165,16 +165,23 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
             // is longer than 1, so with the radius below the smallest |edge| of the alpha histogram every sample is in the
             // bin around 0 -- the host passes that bin (alpha_bin >= 0, wave-uniform) and alpha is never formed.  Then v and
             // w = u x v are not needed either unless theta's cheap form cannot decide (theta_bin_fast).
+            // (an EVEN bin count has an edge at 0: alpha then falls into one of the TWO central bins, alpha_pair and alpha_pair + 1,
+            // and only its side of that one edge has to be found -- the reference's own alpha, compared as searchsorted does)
             int ba = alpha_bin, bt = -2;
-            if (alpha_bin >= 0) {
+            if (alpha_bin >= 0 || alpha_pair >= 0) {
                 const double nc = (njx * cx + njy * cy) + njz * cz;
                 bt = theta_bin_fast(ed, nb, nc * uu - b * num, b, e_per_dist * (d2 * y1) * 1.01);
             }
-            if (bt == -2) { // the reference's own expressions (fpfh.py:58-66)
+            if (bt == -2 || alpha_bin < 0) { // the reference's own expressions (fpfh.py:58-66)
                 const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
-                const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
-                bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, b);
-                if (alpha_bin < 0) ba = hist_bin(ed.a, nb, (vx * njx + vy * njy) + vz * njz);
+                if (bt == -2) {
+                    const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
+                    bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, b);
+                }
+                if (alpha_bin < 0) {
+                    const double alpha = (vx * njx + vy * njy) + vz * njz;
+                    ba = alpha_pair >= 0 ? alpha_pair + (alpha >= ed.a[alpha_pair + 1] ? 1 : 0) : hist_bin(ed.a, nb, alpha);
+                }
             }
             const int bp = hist_bin(ed.p, nb, phi);
             if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt], 1u);
@@ -241,7 +248,8 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
     CT *row = counts + i * (int64_t)stride;
     bool hi_empty = false;
     if (live) { // uint8 table: 128 bins, two per lane; which 16-bin blocks of this row hold a count goes into the table-wide mask
-        const unsigned v0 = lane < nb3 ? h[lane] : 0u, v1 = lane + 64 < nb3 ? h[lane + 64] : 0u; // (padding bins: count 0)
+        // (column c of the row = bin win_lo + c; columns past the window are padding: count 0)
+        const unsigned v0 = lane < win_len ? h[win_lo + lane] : 0u, v1 = lane + 64 < win_len ? h[win_lo + lane + 64] : 0u;
         // (the uint8 table keeps count & 255; a point with more than 255 neighbours also has count >> 8 in the table of high
         // bytes.  Streamed past the L2 -- K7 gathers the PACKED rows; of this table it reads each keypoint's own row, once)
         __builtin_nontemporal_store((CT)(v0 ^ bias), row + lane);
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
             const int first = 16 * (lane < 4 ? pack_b0 : pack_b1) + 4 * (lane & 3);
             unsigned w = 0u;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) w |= (((first + t < nb3 ? h[first + t] : 0u) ^ bias) & 0xffu) << (8 * t);
+            for (int t = 0; t < 4; ++t) w |= (((first + t < win_len ? h[win_lo + first + t] : 0u) ^ bias) & 0xffu) << (8 * t);
             reinterpret_cast<unsigned *>(packed + i * 32)[lane] = w;
         }
         const unsigned long long n0 = __ballot(v0 != 0u), n1 = __ballot(v1 != 0u);
@@ -485,11 +493,11 @@ __device__ inline void fpfh_mc_wrong_form(const unsigned *__restrict__ live, dou
 // 3-chunk instantiation WITHOUT it wants 96 registers and, held to eight waves as this kernel was until late in round 4,
 // spilled 360 bytes into its step loop -- 24 ms per 1M keypoints, every row correct (SF_FPFH_DENSE=1 shows it; tools/check_spills.py
 // lists every kernel's private segment; tests/test_hip_round4.py holds the full form to a time as well as to its rows).
-template <int NKS, bool HI>
-__global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
+template <int NKS, bool HI, bool PADC = false>
+__global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(PADC ? 5 : 6, 8))) void k_fpfh_mc(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
-                                                 int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
+                                                 sf_bin_window W, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const double *__restrict__ p4, const unsigned *__restrict__ live,
                                                  const uint8_t *__restrict__ packed, unsigned packed_bytes,
                                                  double *__restrict__ out, const uint8_t *__restrict__ hi, int limit,
@@ -509,10 +517,10 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     // instead of 1.29 ms on a table with all eight blocks live -- and the host launches the one the table-wide block mask
     // asks for; the check here only guards against a stale host copy)
     if (__popc(sf_uniform(*live) & 0xffu) <= 2) { // the host launched the wrong form: never leave the row unwritten
-        fpfh_mc_wrong_form(live, out, q, nb3);
+        fpfh_mc_wrong_form(live, out, q, W.nb3);
         return;
     }
-    fpfh_mc_body<NKS, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
+    fpfh_mc_body<NKS, HI, PADC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, W, counts, table_bytes, p4, out, q, rowbuf_all[wv_id],
                           abuf_all[wv_id], hi, limit);
 }
 
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
 template <int NKS, bool HI>
 __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fpfh_mc_sparse(
     const double *__restrict__ rec, const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
-    const int32_t *__restrict__ idx, int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m, int nb3,
+    const int32_t *__restrict__ idx, int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m, sf_bin_window W,
     const uint8_t *__restrict__ counts, unsigned table_bytes, const double *__restrict__ p4, const unsigned *__restrict__ live,
     const uint8_t *__restrict__ packed, unsigned packed_bytes, double *__restrict__ out, const uint8_t *__restrict__ hi, int limit,
     const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first)
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     if (q >= m) return;
     const unsigned mask = sf_uniform(*live) & 0xffu;
     if (__popc(mask) > 2) { // the full kernel's case
-        fpfh_mc_wrong_form(live, out, q, nb3);
+        fpfh_mc_wrong_form(live, out, q, W.nb3);
         return;
     }
     const int b0 = mask ? __ffs(mask) - 1 : 0;
@@ -548,10 +556,10 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
     // ... from the packed copy (32 bytes per row: four rows per cache line) when every row of it was written under this
     // very mask, else from the table itself
     if (sf_uniform(live[1]) == mask) {
-        fpfh_mc_body_sparse<NKS, true, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q,
+        fpfh_mc_body_sparse<NKS, true, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, W, counts, packed, packed_bytes, p4, out, q,
                                            b0, b1, rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
     } else {
-        fpfh_mc_body_sparse<NKS, false, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q,
+        fpfh_mc_body_sparse<NKS, false, HI>(rec, offset, cnt, idx, nbrs_begin, kp_pos, W, counts, counts, table_bytes, p4, out, q,
                                             b0, b1, rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
     }
 }
@@ -561,11 +569,11 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) __attribute__((amdgpu_waves_per_eu(
 #ifndef SF_MCL_SC
 #define SF_MCL_SC 8 // chunks of 64 neighbours whose loads are in flight together (sparse form; the full form holds 4)
 #endif
-template <bool SEL, bool SPARSE>
+template <bool SEL, bool SPARSE, bool PADC = false>
 __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mcl(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
                                                  int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int64_t m,
-                                                 int nb3, const uint8_t *__restrict__ counts, unsigned table_bytes,
+                                                 sf_bin_window W, const uint8_t *__restrict__ counts, unsigned table_bytes,
                                                  const double *__restrict__ p4, const unsigned *__restrict__ live,
                                                  const uint8_t *__restrict__ packed, unsigned packed_bytes,
                                                  double *__restrict__ out, const uint8_t *__restrict__ hi, int limit,
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mcl(const double *__res
     const unsigned mask = sf_uniform(*live) & 0xffu;
     if ((__popc(mask) <= 2) != SPARSE) { // the host launched the wrong form: never leave the row unwritten
         const int64_t i = kp_pos ? (int64_t)kp_pos[q] : nbrs_begin + q;
-        if (sf_uniform(cnt[i - nbrs_begin]) > limit) fpfh_mc_wrong_form(live, out, q, nb3);
+        if (sf_uniform(cnt[i - nbrs_begin]) > limit) fpfh_mc_wrong_form(live, out, q, W.nb3);
         return;
     }
     if (SPARSE) {
@@ -592,14 +600,14 @@ __global__ __launch_bounds__(64 * SF_MC_WPB) void k_fpfh_mcl(const double *__res
         const unsigned rest = mask & (mask - 1u);
         const int b1 = rest ? __ffs(rest) - 1 : (b0 + 1) & 7; // (a lone live block is paired with an empty one)
         if (sf_uniform(live[1]) == mask) {
-            fpfh_mcl_body_sparse<true, SF_MCL_SC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, packed, packed_bytes, p4, out, q, b0, b1,
+            fpfh_mcl_body_sparse<true, SF_MCL_SC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, W, counts, packed, packed_bytes, p4, out, q, b0, b1,
                                                   rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
         } else {
-            fpfh_mcl_body_sparse<false, SF_MCL_SC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, counts, table_bytes, p4, out, q, b0, b1,
+            fpfh_mcl_body_sparse<false, SF_MCL_SC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, W, counts, counts, table_bytes, p4, out, q, b0, b1,
                                                    rowbuf_all[wv_id], abuf_all[wv_id], hi, limit);
         }
     } else {
-        fpfh_mcl_body<4>(rec, offset, cnt, idx, nbrs_begin, kp_pos, nb3, counts, table_bytes, p4, out, q, rowbuf_all[wv_id], abuf_all[wv_id], hi,
+        fpfh_mcl_body<4, PADC>(rec, offset, cnt, idx, nbrs_begin, kp_pos, W, counts, table_bytes, p4, out, q, rowbuf_all[wv_id], abuf_all[wv_id], hi,
                          limit);
     }
 }
@@ -834,14 +842,18 @@ __global__ void k_spfh_pack_done(unsigned *__restrict__ live)
 template <typename CT>
 __global__ void k_spfh_export(const CT *__restrict__ counts, const int32_t *__restrict__ kk,
                               const int32_t *__restrict__ perm, int64_t n, int nb3, int stride, unsigned bias,
-                              double *__restrict__ out, const uint8_t *__restrict__ hi)
+                              double *__restrict__ out, const uint8_t *__restrict__ hi, int win_lo, int win_len)
 {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n * nb3) return;
     int64_t i = g / nb3;
     int b = (int)(g - i * nb3);
-    unsigned cnt = (unsigned)counts[i * stride + b] ^ bias;
-    if (hi && kk[i] > 255) cnt += 256u * (unsigned)hi[i * stride + b]; // (byte table: a long point's high bytes)
+    const int col = b - win_lo; // (a bin outside the table's window: structurally empty)
+    unsigned cnt = 0u;
+    if (col >= 0 && col < win_len) {
+        cnt = (unsigned)counts[i * stride + col] ^ bias;
+        if (hi && kk[i] > 255) cnt += 256u * (unsigned)hi[i * stride + col]; // (byte table: a long point's high bytes)
+    }
     out[(int64_t)perm[i] * nb3 + b] = (double)cnt / (double)kk[i];
 }
 
@@ -956,7 +968,44 @@ __global__ void k_map_positions(const int64_t *__restrict__ kp_idx, const int32_
 
 } // namespace
 
+// The alpha bins a radius can reach: |alpha| <= |c| |u| |n_j| <= radius * max|n|^2 (alpha = (c x u) . n_j with v NOT normalised,
+// fpfh.py:60).  first .. last: the bins of -reach and +reach under np.histogramdd's rule; false when the reach leaves the histogram.
+static bool alpha_bins_within_reach(const double *edges_a, int nb, double reach, int *first, int *last)
+{
+    if (!(reach >= 0.0) || !std::isfinite(reach) || !(-reach > edges_a[0]) || !(reach < edges_a[nb])) return false;
+    int lo = 0, hi = 0;
+    for (int i = 1; i < nb; ++i) { // searchsorted(edges, x, 'right') - 1
+        if (edges_a[i] <= -reach) lo = i;
+        if (edges_a[i] <= reach) hi = i;
+    }
+    *first = lo;
+    *last = hi;
+    return true;
+}
+
+static sf_spfh *spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t max_count, double radius);
+
 extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t max_count)
+{
+    return spfh_create(ctx, c, n_bins, max_count, 0.0);
+}
+
+// The table for a KNOWN search radius.  With more than 128 bins (n_bins 6, 7, 8) a row no longer fits the 128-byte row of the
+// matrix-core K7 -- unless most of it is structurally empty: when radius * max|n|^2 stays inside the one or two central bins of
+// the alpha histogram (an even bin count has an edge at 0), only those bins' n_bins^2 (2 n_bins^2) slots can ever receive a
+// count: 72 of 216, 49 of 343, 128 of 512.  The table then keeps exactly that WINDOW of bins, one byte each, and everything
+// downstream -- K6's row, the packed rows, the high bytes, K7 on the matrix cores, the exchange's wire image -- is the 5-bin
+// path; K7 writes zeros for the bins outside the window.  (Until round 5 these bin counts took a 16-bit table and the
+// vector K7: 3.5 ms per 1M keypoints at 6 bins, 7.3 ms at 8, against 0.85 ms at 5.)  sf_spfh_compute checks that the radius it
+// is then run with keeps alpha inside the window.
+extern "C" sf_spfh *sf_spfh_create_for_radius(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t max_count, double radius)
+{
+    return spfh_create(ctx, c, n_bins, max_count, radius);
+}
+
+extern "C" int sf_spfh_elem_bytes(const sf_spfh *sp) { return sp ? sp->elem_bytes : 0; }
+
+static sf_spfh *spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t max_count, double radius)
 {
     if (!ctx || !c) { sf_set_error("sf_spfh_create: null argument"); return nullptr; }
     if (n_bins < 1 || n_bins > SF_MAX_FPFH_BINS) {
@@ -972,13 +1021,27 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
     // matrix-core K7 consumes as int8); else uint16, uint32 beyond 65535
     // (lists longer than 255 points: the byte table keeps count & 255 and the long points' rows get a table of high bytes
     // beside it -- one long list does not move every point's row to 16 bits and every keypoint to the vector K7)
-    sp->elem_bytes = (max_count <= 65535 && sp->nb3 <= 128) ? 1 : (max_count > 65535 ? 4 : 2);
+    sp->win_lo = 0;
+    sp->win_len = sp->nb3;
+    bool window = false;
+    if (sp->nb3 > 128 && n_bins <= SF_FAST_FPFH_BINS && max_count <= 65535 && radius > 0.0 && c->nrm_orig && !getenv("SF_FPFH_NO_WINDOW")) {
+        double n2 = 0.0, ea[SF_FAST_FPFH_BINS + 1];
+        if (sf_cloud_normals_max2(ctx, c, &n2) != SF_OK) { delete sp; return nullptr; }
+        for (int i = 0; i <= n_bins; ++i) ea[i] = -1.0 + 2.0 * (double)i / (double)n_bins; // (np.linspace(-1, 1, n + 1) up to an ulp:
+        int a0 = 0, a1 = 0;                                                                 // sf_spfh_compute checks the real edges)
+        if (alpha_bins_within_reach(ea, n_bins, radius * n2 * (1.0 + 1e-6), &a0, &a1) && (a1 - a0 + 1) * n_bins * n_bins <= 128) {
+            window = true;
+            sp->win_lo = a0 * n_bins * n_bins;
+            sp->win_len = (a1 - a0 + 1) * n_bins * n_bins;
+        }
+    }
+    sp->elem_bytes = (max_count <= 65535 && (sp->nb3 <= 128 || window)) ? 1 : (max_count > 65535 ? 4 : 2);
     if (n_bins > SF_FAST_FPFH_BINS) sp->elem_bytes = 4; // the generic kernels keep 32-bit counts
     sp->bias = sp->elem_bytes == 1 ? 128 : 0;
     // rows padded to a multiple of 128 elements: lane l of a wave owns elements 2l, 2l+1 of each 128-element
     // slice, so no lane of the K7 row loads ever falls outside its row (256 B rows for 125 uint16 bins)
     sp->stride = 128; // ... and to a power of two, so that a row is 256 B, 512 B, 1 KiB or 2 KiB (the K7 row shapes)
-    while (sp->stride < sp->nb3) sp->stride *= 2;
+    while (sp->stride < (window ? sp->win_len : sp->nb3)) sp->stride *= 2;
     if (n_bins > SF_FAST_FPFH_BINS) sp->stride = (sp->nb3 + 3) & ~3; // generic kernels: no shape constraint
     // room for ceil(n / nranks) rows per rank so the table can be all-gathered in place
     const int64_t nr = ctx->nranks > 0 ? ctx->nranks : 1;
@@ -989,16 +1052,18 @@ extern "C" sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t
         delete sp;
         return nullptr;
     }
-    if (hipMalloc(&sp->counts, nn * sp->stride * sp->elem_bytes) != hipSuccess ||
-        hipMalloc(&sp->k, nn * sizeof(int32_t)) != hipSuccess ||
-        (sp->elem_bytes == 1 && hipMalloc(&sp->p4, nn * 4 * sizeof(double)) != hipSuccess) ||
-        (sp->elem_bytes == 1 && max_count > 255 && hipMalloc(&sp->hi, nn * 128) != hipSuccess) ||
-        (sp->elem_bytes == 1 && (hipMalloc(&sp->live, 4 * sizeof(unsigned)) != hipSuccess ||
-                                 hipMalloc(&sp->packed, nn * 32) != hipSuccess ||
-                                 hipMemset(sp->live, 0, 4 * sizeof(unsigned)) != hipSuccess ||
-                                 // SF_FPFH_DENSE=1: every block counts as live from the start (K7 always takes its full form)
-                                 hipMemset(sp->live, getenv("SF_FPFH_DENSE") ? 0xff : 0, sizeof(unsigned)) != hipSuccess ||
-                                 hipMemset(sp->live + 1, 0xff, sizeof(unsigned)) != hipSuccess))) {
+    // (every block from the context's stream-ordered pool: a drop-in call creates a table and frees it again)
+    const bool bytes_tab = sp->elem_bytes == 1;
+    bool ok = sf_pool_alloc(ctx, nn * sp->stride * sp->elem_bytes, &sp->counts) == SF_OK && sf_pool_alloc(ctx, nn * sizeof(int32_t), (void **)&sp->k) == SF_OK;
+    if (ok && bytes_tab) ok = sf_pool_alloc(ctx, nn * 4 * sizeof(double), (void **)&sp->p4) == SF_OK;
+    if (ok && bytes_tab && max_count > 255) ok = sf_pool_alloc(ctx, nn * 128, (void **)&sp->hi) == SF_OK;
+    if (ok && bytes_tab)
+        ok = sf_pool_alloc(ctx, 4 * sizeof(unsigned), (void **)&sp->live) == SF_OK && sf_pool_alloc(ctx, nn * 32, (void **)&sp->packed) == SF_OK &&
+             hipMemsetAsync(sp->live, 0, 4 * sizeof(unsigned), ctx->stream) == hipSuccess &&
+             // SF_FPFH_DENSE=1: every block counts as live from the start (K7 always takes its full form)
+             hipMemsetAsync(sp->live, getenv("SF_FPFH_DENSE") ? 0xff : 0, sizeof(unsigned), ctx->stream) == hipSuccess &&
+             hipMemsetAsync(sp->live + 1, 0xff, sizeof(unsigned), ctx->stream) == hipSuccess;
+    if (!ok) {
         sf_set_error("sf_spfh_create: out of device memory");
         sf_spfh_free(ctx, sp);
         return nullptr;
@@ -1014,12 +1079,8 @@ extern "C" void sf_spfh_free(sf_ctx *ctx, sf_spfh *sp)
 {
     if (!sp) return;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    if (sp->counts) (void)hipFree(sp->counts);
-    if (sp->k) (void)hipFree(sp->k);
-    if (sp->p4) (void)hipFree(sp->p4);
-    if (sp->live) (void)hipFree(sp->live);
-    if (sp->packed) (void)hipFree(sp->packed);
-    if (sp->hi) (void)hipFree(sp->hi);
+    for (void *p : {(void *)sp->counts, (void *)sp->k, (void *)sp->p4, (void *)sp->live, (void *)sp->packed, (void *)sp->hi})
+        if (p) { if (ctx) sf_pool_release(ctx, p); else (void)hipFree(p); }
     delete sp;
 }
 
@@ -1066,7 +1127,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     if (!m) return SF_OK;
     // alpha's bin is known beforehand when every |alpha| <= radius * max|n|^2 stays clear of the histogram's edges (see
     // k_spfh): the bin that holds 0, if 0 is strictly inside one
-    int alpha_bin = -1;
+    int alpha_bin = -1, alpha_pair = -1; // alpha pinned to ONE bin / to one of TWO adjacent bins (an even count: an edge at 0)
     double nrm_max = 1.0;
     {
         double n2 = 0.0;
@@ -1078,7 +1139,20 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
         if (std::isfinite(reach) && reach < nearest)
             for (int i = 0; i < nbn; ++i)
                 if (ed.a[i] < 0.0 && 0.0 < ed.a[i + 1]) alpha_bin = i;
-        if (getenv("SF_FPFH_NO_ALPHA_SHORTCUT")) alpha_bin = -1;
+        int a0 = 0, a1 = 0;
+        const bool within = alpha_bins_within_reach(ed.a, nbn, reach, &a0, &a1);
+        if (alpha_bin < 0 && within && a1 == a0 + 1) alpha_pair = a0;
+        if (getenv("SF_FPFH_NO_ALPHA_SHORTCUT")) alpha_bin = alpha_pair = -1;
+        if (sp->elem_bytes == 1 && sp->win_len != sp->nb3) {
+            // a table that keeps a WINDOW of the bins (sf_spfh_create_for_radius): every alpha this radius can produce must
+            // fall into it, or counts would be lost without a trace
+            if (!within || a0 * nbn * nbn < sp->win_lo || (a1 + 1) * nbn * nbn > sp->win_lo + sp->win_len) {
+                sf_set_error("sf_spfh_compute: the table keeps bins %d .. %d of %d (created for a smaller radius); a search radius of %g "
+                             "reaches other alpha bins -- create the table for this radius", sp->win_lo, sp->win_lo + sp->win_len - 1,
+                             sp->nb3, nb->radius);
+                return SF_ERR_STATE;
+            }
+        }
     }
     const dim3 grid(sf_xcd_grid(sf_div_up(m, SF_SPFH_WPB))), block(64 * SF_SPFH_WPB);
     const sf_dispatch dsp = sf_nbrs_dispatch(nb);
@@ -1089,7 +1163,8 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     SF_LAUNCH(ctx, NAME, (k_spfh<CT, NCH, NB, SEL>), GRID, block, c->rec, nb->offset, nb->count, nb->idx, m,            \
               nb->self_begin, ed, nbn, sp->nb3, sp->stride, (CT *)sp->counts, sp->k, (unsigned)sp->bias, sp->p4, nb->radius, cov, \
               sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max, fused_packed, fused_b0, fused_b1,   \
-              hi_rows, dsp.limit, SELP, NSEL, dsp.view_first)
+              hi_rows, dsp.limit, SELP, NSEL, dsp.view_first, alpha_pair, sizeof(CT) == 1 ? sp->win_lo : 0,                \
+              sizeof(CT) == 1 ? sp->win_len : sp->nb3)
 #define SF_SPFH_LAUNCH(NAME, GRID, CT, NCH, SEL, SELP, NSEL)                                                            \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(NAME, GRID, CT, NCH, 1, SEL, SELP, NSEL); } break;                                            \
@@ -1117,9 +1192,11 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     int fused_b0 = -1, fused_b1 = -1;
     if (sp->elem_bytes == 1) {
         // alpha pinned to one bin => only the 16-bin blocks that hold that bin's n_bins^2 slots can receive a count
+        // (blocks of table COLUMNS: bin b sits in column b - win_lo)
         unsigned det = 0u;
-        if (alpha_bin >= 0)
-            for (int blk = (alpha_bin * nbn * nbn) / 16; blk <= ((alpha_bin + 1) * nbn * nbn - 1) / 16; ++blk) det |= 1u << blk;
+        const int pin0 = alpha_bin >= 0 ? alpha_bin : alpha_pair, pin1 = alpha_bin >= 0 ? alpha_bin : alpha_pair + 1;
+        if (pin0 >= 0)
+            for (int blk = (pin0 * nbn * nbn - sp->win_lo) / 16; blk <= ((pin1 + 1) * nbn * nbn - 1 - sp->win_lo) / 16; ++blk) det |= 1u << blk;
         // Steady state of a resident table (every pass after the first with the same parameters): the device's mask already
         // holds `det`, it names at most two blocks and the packed copy was written under it -- and the host KNOWS all that
         // (host_live mirrors live[] exactly while mask_known).  Then K6 writes the packed rows itself and none of the four
@@ -1344,13 +1421,13 @@ extern "C" int sf_spfh_export(sf_ctx *ctx, sf_cloud *c, sf_spfh *sp, double *out
         const dim3 grid((unsigned)sf_div_up(tot, 256)), block(256);
         if (sp->elem_bytes == 1) {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint8_t>, grid, block, (const uint8_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, (unsigned)sp->bias, dout, (const uint8_t *)sp->hi);
+                      c->perm, n, sp->nb3, sp->stride, (unsigned)sp->bias, dout, (const uint8_t *)sp->hi, sp->win_lo, sp->win_len);
         } else if (sp->elem_bytes == 2) {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint16_t>, grid, block, (const uint16_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, 0u, dout, (const uint8_t *)nullptr);
+                      c->perm, n, sp->nb3, sp->stride, 0u, dout, (const uint8_t *)nullptr, 0, sp->nb3);
         } else {
             SF_LAUNCH(ctx, "k6_spfh_export", k_spfh_export<uint32_t>, grid, block, (const uint32_t *)sp->counts, sp->k,
-                      c->perm, n, sp->nb3, sp->stride, 0u, dout, (const uint8_t *)nullptr);
+                      c->perm, n, sp->nb3, sp->stride, 0u, dout, (const uint8_t *)nullptr, 0, sp->nb3);
         }
     }
     if (owned) {
@@ -1421,10 +1498,19 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
         d.limit = 255;
         d.n_mid = 0;
     }
+    if (sp->win_len > 127) {
+        // (a window of 128 real bins runs the full form's 4-chunk instantiation with its padding column from a constant operand:
+        // one launch for every list of at most 255 points)
+        d.chunks = 4;
+        d.limit = 255;
+        d.n_mid = 0;
+    }
     const int long_limit = 255; // lists above it: k_fpfh_tail
     const bool any_tail = nb->max_count > long_limit;
     const uint8_t *hi = sp->hi;
-#define SF_MC_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, sp->nb3, (const uint8_t *)sp->counts,       \
+    const sf_bin_window W{sp->nb3, sp->win_lo, sp->win_len};
+    const bool padc = sp->win_len > 127; // (a window of 128 real bins: no padding column in the table)
+#define SF_MC_ARGS c->rec, nb->offset, nb->count, nb->idx, nb->self_begin, kp_pos, m, W, (const uint8_t *)sp->counts,       \
                    (unsigned)tb, (const double *)sp->p4, (const unsigned *)sp->live, (const uint8_t *)sp->packed,                \
                    (unsigned)((size_t)sp->rows_alloc * 32), dout, hi
     // Which form runs is decided here, on the table-wide block mask -- read back once per K6 (8 bytes; the one host
@@ -1445,6 +1531,7 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     const bool sparse = __builtin_popcount(sp->host_live[0] & 0xffu) <= 2;
 #define SF_MC_LAUNCH2(NAME, GRID, NKS, HI, LIMIT, SELP, NSEL)                                                         \
     if (sparse) { SF_LAUNCH(ctx, NAME, (k_fpfh_mc_sparse<NKS, HI>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); } \
+    else if (padc) { SF_LAUNCH(ctx, NAME, (k_fpfh_mc<4, true, true>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); } \
     else { SF_LAUNCH(ctx, NAME, (k_fpfh_mc<NKS, true>), GRID, block, SF_MC_ARGS, LIMIT, SELP, NSEL, d.view_first); }
 #define SF_MC_LAUNCH(NKS)                                                                                            \
     if (hi) { SF_MC_LAUNCH2("k7_fpfh", grid, NKS, true, d.limit, (const int32_t *)nullptr, (int64_t)0) }             \
@@ -1460,10 +1547,11 @@ static int launch_fpfh_mc(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, co
     }
 #undef SF_MC_LAUNCH
 #undef SF_MC_LAUNCH2
-    if (any_tail && !getenv("SF_FPFH_TAIL_VECTOR")) {
+    if (any_tail && (!getenv("SF_FPFH_TAIL_VECTOR") || sp->win_len != sp->nb3)) {
         // the lists above 255 points, on the matrix cores too (the vector-ALU form below stays as a cross-check: SF_FPFH_TAIL_VECTOR=1)
 #define SF_MCL_LAUNCH(SEL, GRID, SELP, NSEL, VF)                                                                       \
         if (sparse) { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_mcl<SEL, true>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_MC_WPB))), block, SF_MC_ARGS, long_limit, SELP, NSEL, VF); } \
+        else if (padc) { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_mcl<SEL, false, true>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_MC_WPB))), block, SF_MC_ARGS, long_limit, SELP, NSEL, VF); } \
         else { SF_LAUNCH(ctx, "k7_fpfh_tail", (k_fpfh_mcl<SEL, false>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_MC_WPB))), block, SF_MC_ARGS, long_limit, SELP, NSEL, VF); }
         if (!kp_pos && d.n_tail) {
             SF_MCL_LAUNCH(true, d.n_tail, d.tail_sel, d.n_tail, d.view_first)

@@ -29,6 +29,17 @@
 // --------------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// Which bins of the descriptor the table's 128 columns are: column c = bin win_lo + c for c < win_len; the other bins of the
+// nb3 are structurally empty (sf_spfh::win_lo) and the keypoint's row gets zeros there.  win_lo = 0, win_len = nb3 for tables
+// of at most 128 bins.
+struct sf_bin_window { int nb3, win_lo, win_len; };
+__device__ __forceinline__ void fpfh_mc_zero_outside(double *__restrict__ o, const sf_bin_window &W, int lane)
+{
+    if (W.win_len != W.nb3) // (wave-uniform)
+        for (int b = lane; b < W.nb3; b += 64)
+            if (b < W.win_lo || b >= W.win_lo + W.win_len) sf_store_stream(o + b, 0.0);
+}
+
 // Staged rows: 128 B each, no padding -- the image is written by LDS-DMA (buffer_load_dwordx4 ... lds: a wave
 // instruction writes its 64 lanes' 16-byte chunks back to back), so the bank spread comes from the SOURCE side:
 // slot s of row r holds chunk s ^ f(r), f(r) = (r >> 1) & 7.  A transposing read of one 32-lane half (8 rows x 16
@@ -177,10 +188,12 @@ __device__ __forceinline__ long fpfh_mc_a_operand(const unsigned char *abuf, int
     return (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
 }
 
-template <int NKS, bool HI>
+// PADC: the padding column that removes the -128 bias comes from an MFMA against a constant operand (as in the sparse form)
+// instead of column 127 of the table -- for a window of 128 real bins (n_bins = 8), which leaves no padding column.
+template <int NKS, bool HI, bool PADC = false>
 __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                              const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-                                             int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                             int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, sf_bin_window W,
                                              const uint8_t *__restrict__ counts, unsigned table_bytes,
                                              const double *__restrict__ p4, double *__restrict__ out, int64_t q,
                                              unsigned *rowbuf /* 4 KB */, unsigned char *abuf /* 576 B */,
@@ -236,6 +249,7 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     v4i acc[8]; // acc[bb]: column a = bin 16 bb + a, rows = limbs 4 kb .. 4 kb + 3
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) acc[bb] = v4i{0, 0, 0, 0};
+    v4i accp = v4i{0, 0, 0, 0};
 
 #pragma unroll
     for (int st = 0; st < 2 * NKS; ++st) {
@@ -253,6 +267,7 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
                 const long B = (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
                 acc[bb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, B, acc[bb], 0, 0, 0);
             }
+            if (PADC) accp = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)0x8080808080808080ull, accp, 0, 0, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next step's DMA overwrites the rows
             __builtin_amdgcn_wave_barrier();
         }
@@ -260,7 +275,7 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     // ---- recombination: lane (a, g) holds rows (limbs) 4g .. 4g+3 of column a of acc[bb]; bin = 16 bb + a ----
     int rpad[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of bb = 7: bin 127
+    for (int r = 0; r < 4; ++r) rpad[r] = PADC ? accp[r] : __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // column 15 of bb = 7: bin 127
     // A lane's four limb rows are combined in INTEGER arithmetic first: |R| <= 128 * 128 * 255 < 2^22, so
     // (R[r+1] << 8) + R[r] and the same combination of the padding column stay below 2^30.01, and their difference --
     // (sum_j d_j c_jb of limb r + 1) 2^8 + (that of limb r), each at most 128 * 255 * 255 -- is below 2^31: it fits an
@@ -301,7 +316,9 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
     {
         const int bb0 = 4 * (kb >> 1) + 2 * (kb & 1);
         const int b0 = 16 * bb0 + a, b1 = b0 + 16;
-        double *o = out + q * (int64_t)nb3;
+        double *o = out + q * (int64_t)W.nb3;
+        fpfh_mc_zero_outside(o, W, lane);
+        o += W.win_lo;
         // count / k (the keypoint's own SPFH term, fpfh.py:88-90) through the reciprocal already at hand and one residual
         // step -- the closing step of a division: correctly rounded for these small integers at a tenth of the instructions
         const double c0 = (double)(own0 ^ 128u), c1 = (double)(own1 ^ 128u);
@@ -310,8 +327,8 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
         s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
         double h0 = 0.0, h1 = 0.0;
         if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, b0, b1, h0, h1);
-        if (b0 < nb3) sf_store_stream(o + b0, s0 + (HI ? vsel0 + h0 : vsel0) * inv_k);
-        if (b1 < nb3) sf_store_stream(o + b1, s1 + (HI ? vsel1 + h1 : vsel1) * inv_k);
+        if (b0 < W.win_len) sf_store_stream(o + b0, s0 + (HI ? vsel0 + h0 : vsel0) * inv_k);
+        if (b1 < W.win_len) sf_store_stream(o + b1, s1 + (HI ? vsel1 + h1 : vsel1) * inv_k);
     }
 }
 
@@ -330,7 +347,7 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
 template <int NKS, bool PACKED, bool HI>
 __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-                                                    int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                                    int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, sf_bin_window W,
                                                     const uint8_t *__restrict__ counts, const uint8_t *__restrict__ rows,
                                                     unsigned rows_bytes, const double *__restrict__ p4,
                                                     double *__restrict__ out, int64_t q, int b0, int b1,
@@ -438,7 +455,9 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
     sf_lane_swap<32>(mine, other); // lower half: mine = own (b0), other = b1's ; upper half: mine = b0's, other = own (b1)
     const double tot0 = mine, tot1 = other; // (after the swap `mine` is block b0's total in both halves, `other` b1's)
     {
-        double *o = out + q * (int64_t)nb3;
+        double *o = out + q * (int64_t)W.nb3;
+        fpfh_mc_zero_outside(o, W, lane);
+        o += W.win_lo;
         const double c0 = (double)(own0 ^ 128u), c1 = (double)(own1 ^ 128u);
         double s0 = c0 * inv_k, s1 = c1 * inv_k;
         s0 = __builtin_fma(__builtin_fma(-s0, kd, c0), inv_k, s0);
@@ -447,8 +466,8 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
         const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
         double h0 = 0.0, h1 = 0.0;
         if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, o0, o1, h0, h1);
-        if (o0 < nb3) sf_store_stream(o + o0, s0 + (HI ? v0 + h0 : v0) * inv_k);
-        if (o1 < nb3) sf_store_stream(o + o1, s1 + (HI ? v1 + h1 : v1) * inv_k);
+        if (o0 < W.win_len) sf_store_stream(o + o0, s0 + (HI ? v0 + h0 : v0) * inv_k);
+        if (o1 < W.win_len) sf_store_stream(o + o1, s1 + (HI ? v1 + h1 : v1) * inv_k);
     }
 }
 
@@ -510,7 +529,7 @@ __device__ __forceinline__ double fpfh_mcl_pair(int hi_limb, int lo_limb, int pa
 template <bool PACKED, int SC>
 __device__ __forceinline__ void fpfh_mcl_body_sparse(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                                      const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-                                                     int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                                     int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, sf_bin_window W,
                                                      const uint8_t *__restrict__ counts, const uint8_t *__restrict__ rows,
                                                      unsigned rows_bytes, const double *__restrict__ p4,
                                                      double *__restrict__ out, int64_t q, int b0, int b1,
@@ -617,20 +636,22 @@ __device__ __forceinline__ void fpfh_mcl_body_sparse(const double *__restrict__ 
     sf_lane_swap<32>(mine, other);
     const double tot0 = mine, tot1 = other;
     {
-        double *o = out + q * (int64_t)nb3;
+        double *o = out + q * (int64_t)W.nb3;
+        fpfh_mc_zero_outside(o, W, lane);
+        o += W.win_lo;
         const double v0 = bb0 == b0 ? tot0 : (bb0 == b1 ? tot1 : 0.0);
         const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
-        if (o0 < nb3) sf_store_stream(o + o0, (double)own0 / kd + (v0 + h0) * inv_k); // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
-        if (o1 < nb3) sf_store_stream(o + o1, (double)own1 / kd + (v1 + h1) * inv_k);
+        if (o0 < W.win_len) sf_store_stream(o + o0, (double)own0 / kd + (v0 + h0) * inv_k); // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
+        if (o1 < W.win_len) sf_store_stream(o + o1, (double)own1 / kd + (v1 + h1) * inv_k);
     }
 #undef SF_MCL_DMA
 }
 
 // ... and on a table with more than two live blocks: whole 128-byte rows, one step (4 KB) in LDS at a time, eight MFMAs per step
-template <int SC>
+template <int SC, bool PADC = false>
 __device__ __forceinline__ void fpfh_mcl_body(const double *__restrict__ rec, const int64_t *__restrict__ offset,
                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ idx,
-                                              int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, int nb3,
+                                              int64_t nbrs_begin, const int32_t *__restrict__ kp_pos, sf_bin_window W,
                                               const uint8_t *__restrict__ counts, unsigned table_bytes,
                                               const double *__restrict__ p4, double *__restrict__ out, int64_t q,
                                               unsigned *rowbuf /* 4 KB */, unsigned char *abuf /* 576 B */,
@@ -686,6 +707,7 @@ __device__ __forceinline__ void fpfh_mcl_body(const double *__restrict__ rec, co
     v4i acc[8];
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) acc[bb] = v4i{0, 0, 0, 0};
+    v4i accp = v4i{0, 0, 0, 0};
     double h0 = 0.0, h1 = 0.0;
     for (int base = 0; base < k; base += 64 * SC) {
         if (k > 64 * SC) fpfh_mcl_load<SC>(idx, p4, s, k, base, lane, px, py, pz, jv, wv, lm);
@@ -706,6 +728,7 @@ __device__ __forceinline__ void fpfh_mcl_body(const double *__restrict__ rec, co
                     const long B = (long)(((unsigned long long)(unsigned)t[1] << 32) | (unsigned)t[0]);
                     acc[bb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, B, acc[bb], 0, 0, 0);
                 }
+                if (PADC) accp = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, (long)0x8080808080808080ull, accp, 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -715,7 +738,7 @@ __device__ __forceinline__ void fpfh_mcl_body(const double *__restrict__ rec, co
     // ---- recombination: fpfh_mc_body's, the limb pairs formed in float64 ----
     int rpad[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rpad[r] = __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // bin 127: the padding column
+    for (int r = 0; r < 4; ++r) rpad[r] = PADC ? accp[r] : __builtin_amdgcn_update_dpp(0, acc[7][r], 0x150 + 15, 0xf, 0xf, false); // bin 127: the padding column
     const double p0 = ldexp(1.0, 32 * kb - S);
     const double f0 = p0, f2 = p0 * 65536.0;
     const double kd = (double)k;
@@ -738,9 +761,11 @@ __device__ __forceinline__ void fpfh_mcl_body(const double *__restrict__ rec, co
     sf_lane_swap<16>(a1, b1_);
     const double vsel0 = a0 + b0_, vsel1 = a1 + b1_;
     {
-        double *o = out + q * (int64_t)nb3;
-        if (o0 < nb3) sf_store_stream(o + o0, (double)own0 / kd + (vsel0 + h0) * inv_k);
-        if (o1 < nb3) sf_store_stream(o + o1, (double)own1 / kd + (vsel1 + h1) * inv_k);
+        double *o = out + q * (int64_t)W.nb3;
+        fpfh_mc_zero_outside(o, W, lane);
+        o += W.win_lo;
+        if (o0 < W.win_len) sf_store_stream(o + o0, (double)own0 / kd + (vsel0 + h0) * inv_k);
+        if (o1 < W.win_len) sf_store_stream(o + o1, (double)own1 / kd + (vsel1 + h1) * inv_k);
     }
 #undef SF_MCLF_DMA
 }

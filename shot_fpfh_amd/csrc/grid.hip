@@ -456,9 +456,11 @@ static int cloud_upload(sf_ctx *ctx, sf_cloud *c, const double *xyz, const doubl
 {
     const int64_t n = c->n;
     const size_t bytes = (size_t)(n ? n : 1) * 3 * sizeof(double);
-    SF_HIP(hipMalloc(&c->xyz_orig, bytes));
-    SF_HIP(hipMalloc(&c->zperm, (size_t)(n ? n : 1) * sizeof(int32_t)));
-    SF_HIP(hipMalloc(&c->z_orig, (size_t)(n + 2) * sizeof(double)));
+    // (from the context's stream-ordered pool, like every other block of a cloud: a drop-in call uploads a cloud and frees it
+    // again, and hipMalloc / hipFree -- the latter a device-wide synchronisation -- cost it about a millisecond each way)
+    SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->xyz_orig));
+    SF_CHECK(sf_pool_alloc(ctx, (size_t)(n ? n : 1) * sizeof(int32_t), (void **)&c->zperm));
+    SF_CHECK(sf_pool_alloc(ctx, (size_t)(n + 2) * sizeof(double), (void **)&c->z_orig));
     if (n) {
         // ---- the z-sorted internal order: sort (z, caller index) once, stable ----
         sf_pool_guard tmp(ctx);
@@ -487,7 +489,7 @@ static int cloud_upload(sf_ctx *ctx, sf_cloud *c, const double *xyz, const doubl
         SF_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (normals) {
-        SF_HIP(hipMalloc(&c->nrm_orig, bytes));
+        SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nrm_orig));
         SF_CHECK(upload_in_zorder(ctx, c, normals, flags, c->nrm_orig));
     }
     return SF_OK;
@@ -514,7 +516,7 @@ extern "C" int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *c, const double *norm
     if (!ctx || !c || !normals) { sf_set_error("sf_cloud_set_normals: null argument"); return SF_ERR_ARG; }
     SF_HIP(hipSetDevice(ctx->device));
     size_t bytes = (size_t)(c->n ? c->n : 1) * 24;
-    if (!c->nrm_orig) SF_HIP(hipMalloc(&c->nrm_orig, bytes));
+    if (!c->nrm_orig) SF_CHECK(sf_pool_alloc(ctx, bytes, (void **)&c->nrm_orig));
     SF_CHECK(upload_in_zorder(ctx, c, normals, flags, c->nrm_orig));
     c->normals_sorted = false;
     c->nrm_max2 = -1.0;
@@ -782,10 +784,10 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         int32_t *start_rel = c->cell_start + cid_base;
         if (c->cell_count_cap < slab_cells || c->count_dirty) { // (first build of this cloud with a slab this large)
             if (c->cell_count_cap < slab_cells) {
-                if (c->cell_count) (void)hipFree(c->cell_count);
+                if (c->cell_count) sf_pool_release(ctx, c->cell_count);
                 c->cell_count = nullptr;
                 c->cell_count_cap = 0;
-                SF_HIP(hipMalloc(&c->cell_count, (size_t)slab_cells * sizeof(int32_t)));
+                SF_CHECK(sf_pool_alloc(ctx, (size_t)slab_cells * sizeof(int32_t), (void **)&c->cell_count));
                 c->cell_count_cap = slab_cells;
             }
             sf_launch_timer t_(ctx, "k1_cell_zero");
@@ -930,10 +932,7 @@ extern "C" void sf_cloud_free(sf_ctx *ctx, sf_cloud *c)
     if (!c) return;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     cloud_release_grid(ctx, c);
-    if (c->xyz_orig) (void)hipFree(c->xyz_orig);
-    if (c->nrm_orig) (void)hipFree(c->nrm_orig);
-    if (c->z_orig) (void)hipFree(c->z_orig);
-    if (c->cell_count) (void)hipFree(c->cell_count);
-    if (c->zperm) (void)hipFree(c->zperm);
+    for (void *p : {(void *)c->xyz_orig, (void *)c->nrm_orig, (void *)c->z_orig, (void *)c->cell_count, (void *)c->zperm})
+        if (p) { if (ctx) sf_pool_release(ctx, p); else (void)hipFree(p); }
     delete c;
 }

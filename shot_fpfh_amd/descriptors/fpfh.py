@@ -54,7 +54,7 @@ def compute_fpfh_descriptor(
             return (out, np.zeros((0, int(n_bins) ** 3))) if return_spfh else out
         nbrs = cloud.radius_search_self(radius)
         try:
-            spfh = Spfh(cloud, n_bins, nbrs.max_count)
+            spfh = Spfh(cloud, n_bins, nbrs.max_count, radius)
             try:
                 spfh.compute(nbrs)
                 if verbose:

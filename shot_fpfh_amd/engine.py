@@ -261,8 +261,8 @@ class Engine:
     def cloud(self, points, normals=None) -> "Cloud":
         return Cloud(self, points, normals)
 
-    def spfh(self, cloud: "Cloud", n_bins: int, max_count: int) -> "Spfh":
-        return Spfh(cloud, n_bins, max_count)
+    def spfh(self, cloud: "Cloud", n_bins: int, max_count: int, radius: Optional[float] = None) -> "Spfh":
+        return Spfh(cloud, n_bins, max_count, radius)
 
     def azimuth_idx(self, x, y) -> np.ndarray:
         """get_azimuth_idx (shot.py:51-70) evaluated by the device function K5 bins with."""
@@ -658,7 +658,10 @@ class Neighbors:
         _ffi.check(self.engine.lib.sf_shot_lrf(self.engine.h, self.cloud.h, self.h, _ptr(lrf), SF_HOST), "sf_shot_lrf")
         return lrf
 
-    def shot(self, lrf, normalize: bool = True, min_neighborhood_size: int = 100, out: Optional[DeviceArray] = None):
+    def shot(self, lrf, normalize: bool = True, min_neighborhood_size: int = 100, out: Optional[DeviceArray] = None,
+             host_out: Optional[np.ndarray] = None):
+        """host_out: a C-contiguous float64 array of (m, 352) that receives the rows (a slice of a larger result, e.g. one
+        scale of compute_descriptor_multiscale's stack: the device-to-host copy lands where the rows are wanted)."""
         if isinstance(lrf, DeviceArray):
             if out is None:
                 raise ValueError("device-resident LRFs need a device output")
@@ -671,7 +674,12 @@ class Neighbors:
         lrf = _f64(lrf).reshape(-1, 9)
         if lrf.shape[0] != self.m:
             raise ValueError("one local reference frame per keypoint expected")
-        res = self.engine.host_empty((self.m, _ffi.SHOT_LEN))
+        if host_out is not None:
+            if host_out.shape != (self.m, _ffi.SHOT_LEN) or host_out.dtype != np.float64 or not host_out.flags.c_contiguous:
+                raise ValueError("host_out must be a C-contiguous float64 array of shape (m, 352)")
+            res = host_out
+        else:
+            res = self.engine.host_empty((self.m, _ffi.SHOT_LEN))
         _ffi.check(
             self.engine.lib.sf_shot(self.engine.h, self.cloud.h, self.h, _ptr(lrf), int(bool(normalize)),
                                     int(min_neighborhood_size), _ptr(res), SF_HOST),
@@ -751,12 +759,20 @@ class Neighbors:
 class Spfh:
     """Device-resident SPFH table (integer bin counts + neighbourhood sizes) of a whole cloud."""
 
-    def __init__(self, cloud: Cloud, n_bins: int, max_count: int):
+    def __init__(self, cloud: Cloud, n_bins: int, max_count: int, radius: Optional[float] = None):
+        """radius: the search radius the table will be computed with -- lets bin counts 6, 7 and 8 keep the window of bins a
+        neighbourhood of that radius can fill in the byte table of the matrix-core path (sf_spfh_create_for_radius)."""
         self.cloud, self.engine, self.n_bins = cloud, cloud.engine, int(n_bins)
         self.edges = fpfh_edges(self.n_bins)
-        self.h = _ffi.check_handle(
-            self.engine.lib.sf_spfh_create(self.engine.h, cloud.h, self.n_bins, int(max_count)), "sf_spfh_create"
-        )
+        if radius is not None and radius > 0:
+            self.h = _ffi.check_handle(
+                self.engine.lib.sf_spfh_create_for_radius(self.engine.h, cloud.h, self.n_bins, int(max_count), float(radius)),
+                "sf_spfh_create_for_radius")
+        else:
+            self.h = _ffi.check_handle(
+                self.engine.lib.sf_spfh_create(self.engine.h, cloud.h, self.n_bins, int(max_count)), "sf_spfh_create"
+            )
+        self.elem_bytes = int(self.engine.lib.sf_spfh_elem_bytes(self.h))  # 1: byte table (matrix-core K7), 2 / 4: wider counts
 
     def compute(self, self_nbrs: Neighbors, moments_out: Optional[DeviceArray] = None) -> "Spfh":
         """K6 for the queries of `self_nbrs`.  moments_out ((m, 6) device array): also leave the weighted covariance of

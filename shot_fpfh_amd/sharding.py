@@ -161,8 +161,11 @@ class DescriptorJob:
         self.last_pairs = 0
 
     def _spfh_table(self, max_count: int) -> Spfh:
-        # table kind: bytes (3: with the high-byte rows of the points that have more than 255 neighbours), 16 or 32 bits
-        if max_count <= 65535 and self.n_bins**3 <= 128:
+        # table kind: bytes (3: with the high-byte rows of the points that have more than 255 neighbours), 16 or 32 bits.  Bytes
+        # for at most 128 bins -- and for 6, 7, 8 bins when the radius keeps alpha in its central bins (the table then holds that
+        # window of the bins, Spfh(radius=...)): known from the table once one has been created
+        byte_capable = self.n_bins**3 <= 128 or getattr(self, "_spfh_bytes", False)
+        if max_count <= 65535 and byte_capable:
             wide = 0 if max_count <= 255 else 3
         else:
             wide = 2 if max_count > 65535 else 1
@@ -171,7 +174,13 @@ class DescriptorJob:
         if self.spfh is None or wide != self._spfh_wide:
             if self.spfh is not None:
                 self.spfh.free()
-            self.spfh = self.engine.spfh(self.cloud, self.n_bins, max_count)
+            try:
+                self.spfh = self.engine.spfh(self.cloud, self.n_bins, max_count, self.radius)
+            except TypeError:  # (an engine stand-in without the radius argument)
+                self.spfh = self.engine.spfh(self.cloud, self.n_bins, max_count)
+            self._spfh_bytes = getattr(self.spfh, "elem_bytes", 0) == 1
+            if self._spfh_bytes and max_count <= 65535:
+                wide = 3 if (max_count > 255 or wide == 3) else 0
             self._spfh_wide = wide
         return self.spfh
 
