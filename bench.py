@@ -804,7 +804,8 @@ def main() -> int:
     # ---- sustained: the same step for >= 2 s (>= 500 steps), no per-kernel events; if it disagrees with the K-step figure by
     #      more than 2 % the sustained figure is the one `value` reports (and the record says so) ------------------------------
     sustained = None
-    value_source = f"the {args.steps} timed steps"
+    value_source = (f"the {args.steps} timed steps (every step repeats the search of the same range: planned from the previous "
+                    f"search's record, no read-back -- `k2_slot_capacity` in the detail file has the step without it)")
     if args.sustained_seconds > 0 and not args.no_kernel_timers:
         sustained = sustained_window(job, eng, ms_per_step, args.sustained_seconds, args.sustained_steps, barrier, max_over_ranks)
         sustained["vs_timed_steps"] = sustained["ms_per_step_median"] / ms_per_step
@@ -951,11 +952,15 @@ def main() -> int:
             del os.environ["SF_K2_NO_HINT"]
         if lead:
             out["k2_slot_capacity"] = {
-                "timed_steps_use": "mean and maximum list length of the previous search with this radius on this cloud (sf_cloud::list_stats)",
+                "timed_steps_use": "the record of the previous search of this range with this radius on this cloud (sf_cloud::search_records: "
+                                   "total, longest list, histogram of the lengths, slot size) -- the lists of a self search are a function "
+                                   "of (cloud, radius, range), so a repeated step launches its sweep and plans every later launch without a "
+                                   "statistics pass or a read-back",
                 "ms_per_step_with_a_sample_counted_in_every_search": 1000.0 * t_nohint,
                 "ms_per_step_timed": ms_per_step,
                 "what": "SF_K2_NO_HINT=1: every radius search first counts the lists of 2 048 sampled queries (one small launch, "
-                        "8 KB read back) before it sizes its slots -- the cost of a first search on a cloud"}
+                        "8 KB read back) before it sizes its slots, and ends with the statistics pass and its read-back -- the cost "
+                        "of a FIRST search of a range (what a one-off drop-in call pays)"}
 
     # ---- the same step with the FPFH chain (K6, K7) and the SHOT chain (K4, K5) on two HIP streams: K7 waits on memory where
     #      K5 waits on its vector pipe, side by side they fill each other's gaps.  NOT what `value` reports: the per-kernel

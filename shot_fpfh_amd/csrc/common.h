@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -219,7 +220,18 @@ struct sf_cloud {
     // mean and maximum list length of the last radius search on this cloud, per radius: what the NEXT search with that
     // radius sizes its slots from instead of counting a sample first (search.hip::run_search).  A capacity hint, nothing
     // more: a list that outgrows its slot is re-done exactly whatever the slot size was.
-    std::map<double, std::pair<double, int64_t>> list_stats;
+    std::map<std::pair<double, bool>, std::pair<double, int64_t>> list_stats; // (radius, self search?) -> (mean, longest list)
+    // The lists of a SELF search are a function of (cloud, radius, query range) alone -- the points never change after the upload
+    // and every grid build of one radius gives the same cell-sorted order -- so the host-side numbers a search ends with (total,
+    // longest list, histogram of the lengths, how many lists overflowed their slot at which slot size) are remembered per
+    // (radius, first position, count): the next search of that range launches its sweep and plans every later launch from the
+    // record, without the step's one read-back (round 5; SF_K2_NO_HINT=1 turns it off, SF_K2_CHECK_RECORD=1 re-counts and compares).
+    struct search_record {
+        int64_t total = 0, n_overflow = 0, ovf_total = 0, cap = 0, hist[5] = {0, 0, 0, 0, 0};
+        int32_t max_count = 0, max_count_all = 0;
+        bool folded = false; // max_count_all is the maximum over every rank (sf_comm_collective_stats was on)
+    };
+    std::map<std::tuple<double, int64_t, int64_t>, search_record> search_records;
 };
 
 struct sf_nbrs {

@@ -616,8 +616,13 @@ __global__ __launch_bounds__(64) void k_knn(sf_grid_desc g, const int32_t *__res
 // instructions per entry and 64 lanes); entries of rank < k write themselves to slot `rank`.  Ties in d2 (duplicated points;
 // exact ties are otherwise one in millions) give equal ranks: a slot then stays empty, or k + 1 entries qualify -- both are
 // seen by one ballot, and the pass is repeated with the tie broken by position, KDTree.query's order here as in k_knn.
+// Two cuts in front of the rank pass: (a) a list of more than 80 entries is first reduced to the entries at or below an UPPER
+// BOUND of the k-th smallest d2 -- the largest of the k smallest of a 64-entry subset (every stride-th entry, ranked among
+// themselves): 64 compare steps buy a rank pass over ~ k x length / 64 entries instead of `length` x 2 tiers; (b) a query with
+// more than SF_KNN_CAP points within R (a dense spot; a retry at a doubled radius) takes its bound from the part of the list
+// that was kept and sweeps ONCE MORE with that bound as its radius.
 // status: 0 answered, 1 fewer than k points within R (the host retries with a doubled R), 2 more than SF_KNN_CAP points within
-// R (the host hands the query to k_knn at the same R).
+// the bound of (b) (the host hands the query to k_knn at the same R).
 // --------------------------------------------------------------------------------------------------
 #ifndef SF_KNN_CAP
 #define SF_KNN_CAP 256
@@ -705,37 +710,99 @@ __global__ __launch_bounds__(64 * SF_K2_WPB) void k_knn4(sf_grid_desc g, const i
         const double px = __shfl(pxv, 16 * qi), py = __shfl(pyv, 16 * qi), pz = __shfl(pzv, 16 * qi);
         const int b4 = __shfl(first_slot, 16 * qi + 4), b8 = __shfl(first_slot, 16 * qi + 8);
         const int nslots = sf_uniform(__shfl(first_slot, 16 * qi + 9));
-        int total = 0;
-        for (int f0 = 0; f0 < nslots; f0 += 64) {
-            const int f = f0 + lane;
-            int r = f >= b4 ? 4 : 0;
-            r += f >= tab[r + 2].w ? 2 : 0;
-            r += f >= tab[r + 1].w ? 1 : 0;
-            r = f >= b8 ? 8 : r;
-            const int4 t = tab[r];
-            const bool live = f < nslots;
-            const int j = live ? t.x + 2 * f : 0;
-            const bool in0 = live & (j >= t.y), in1 = live & (j + 1 < t.z);
-            const double2 X = *reinterpret_cast<const double2 *>(xs + j);
-            const double2 Y = *reinterpret_cast<const double2 *>(ys + j);
-            const double2 Z = *reinterpret_cast<const double2 *>(zs + j);
-            const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
-            const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
-            const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
-            const bool hit0 = in0 & (d2a <= r2);
-            const bool hit1 = in1 & (d2b <= r2);
-            const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-            const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
-            const int pos1 = pos + (hit0 ? 1 : 0);
-            if (hit0 && pos < SF_KNN_CAP) { kd[pos] = d2a; kj[pos] = j; }
-            if (hit1 && pos1 < SF_KNN_CAP) { kd[pos1] = d2b; kj[pos1] = j + 1; }
-            total += __popcll(m0) + __popcll(m1);
-        }
-        if (total < k || total > SF_KNN_CAP) { // (wave-uniform)
-            if (lane == 0) status[q] = total < k ? 1 : 2;
+        // one sweep of the query's candidate pairs: the points with d2 <= thr2 go to the LDS list in scan order (= ascending
+        // position); returns how many there are (the list keeps the first SF_KNN_CAP)
+        auto sweep = [&](double thr2) -> int {
+            int total = 0;
+            for (int f0 = 0; f0 < nslots; f0 += 64) {
+                const int f = f0 + lane;
+                int r = f >= b4 ? 4 : 0;
+                r += f >= tab[r + 2].w ? 2 : 0;
+                r += f >= tab[r + 1].w ? 1 : 0;
+                r = f >= b8 ? 8 : r;
+                const int4 t = tab[r];
+                const bool live = f < nslots;
+                const int j = live ? t.x + 2 * f : 0;
+                const bool in0 = live & (j >= t.y), in1 = live & (j + 1 < t.z);
+                const double2 X = *reinterpret_cast<const double2 *>(xs + j);
+                const double2 Y = *reinterpret_cast<const double2 *>(ys + j);
+                const double2 Z = *reinterpret_cast<const double2 *>(zs + j);
+                const double dxa = X.x - px, dya = Y.x - py, dza = Z.x - pz;
+                const double dxb = X.y - px, dyb = Y.y - py, dzb = Z.y - pz;
+                const double d2a = (dxa * dxa + dya * dya) + dza * dza, d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
+                const bool hit0 = in0 & (d2a <= thr2);
+                const bool hit1 = in1 & (d2b <= thr2);
+                const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+                const int pos = total + sf_prefix_count(m0) + sf_prefix_count(m1);
+                const int pos1 = pos + (hit0 ? 1 : 0);
+                if (hit0 && pos < SF_KNN_CAP) { kd[pos] = d2a; kj[pos] = j; }
+                if (hit1 && pos1 < SF_KNN_CAP) { kd[pos1] = d2b; kj[pos1] = j + 1; }
+                total += __popcll(m0) + __popcll(m1);
+            }
+            __builtin_amdgcn_wave_barrier(); // (the list is written and read by this wave only; its LDS operations stay in order)
+            return total;
+        };
+        // An upper bound of the k-th smallest d2 from a SUBSET of the list: at most 64 entries, every `stride`-th (scan order walks
+        // the stencil layer by layer, so a stride spreads the subset over the ball), ranked among themselves; the largest of
+        // the subset's k smallest has at least k list entries at or below it.  +inf when the subset is smaller than k.
+        auto bound_from_subset = [&](int have, int stride) -> double {
+            const int ns = (have + stride - 1) / stride; // <= 64
+            if (ns < k) return INFINITY;
+            const double ds = lane < ns ? kd[lane * stride] : INFINITY;
+            int rk = 0;
+#pragma unroll 4
+            for (int l = 0; l < ns; ++l) rk += kd[l * stride] < ds;
+            return sf_wave_max_nonneg(lane < ns && rk < k ? ds : 0.0);
+        };
+        int total = sweep(r2);
+        if (total < k) { // (wave-uniform) fewer than k points within R: the host retries with a doubled radius
+            if (lane == 0) status[q] = 1;
             continue;
         }
-        __builtin_amdgcn_wave_barrier(); // (the list is written and read by this wave only; its LDS operations stay in order)
+        if (total > SF_KNN_CAP) {
+            // more points within R than the list holds (a dense spot, or a retry at a doubled radius): a bound from the part
+            // of the list that was kept, and the sweep once more with that bound as its radius
+            const double tau = bound_from_subset(SF_KNN_CAP, SF_KNN_CAP / 64);
+            __builtin_amdgcn_wave_barrier();
+            total = tau < r2 ? sweep(tau) : total;
+            if (total > SF_KNN_CAP) { // (still too many: k_knn at the same R, sf_knn_search)
+                if (lane == 0) status[q] = 2;
+                continue;
+            }
+        }
+        // lists of more than 80 entries: drop what cannot be among the k nearest before the rank pass (a rank pass costs the
+        // list's length x its number of 64-entry tiers; the bound costs 64 and the pass after it ~ k x length / 64 entries)
+        if (total > 80) {
+            const int stride = (total + 63) >> 6;
+            const double tau = bound_from_subset(total, stride);
+            if (tau < INFINITY) { // (wave-uniform) compaction in place, order kept: every tier is read before any is written
+                double dv[4];
+                int jv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = lane + 64 * u;
+                    dv[u] = e < total ? kd[e] : INFINITY;
+                    jv[u] = e < total ? kj[e] : 0;
+                }
+                __builtin_amdgcn_wave_barrier();
+                int kept = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (64 * u < total) { // (wave-uniform)
+                        const bool keep = dv[u] <= tau;
+                        const unsigned long long mk = __ballot(keep);
+                        if (keep) {
+                            const int pos = kept + sf_prefix_count(mk);
+                            kd[pos] = dv[u];
+                            kj[pos] = jv[u];
+                        }
+                        kept += __popcll(mk);
+                    }
+                }
+                total = kept; // (>= k: the subset's k smallest are among the kept)
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         int rank[4] = {0, 0, 0, 0};
         for (int attempt = 0; attempt < 2; ++attempt) { // 0: strict ranks; 1: ties broken by position (only if attempt 0 saw one)
             if (attempt == 0) {
@@ -1018,7 +1085,7 @@ static int plan_dispatch(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     const int64_t m = nb->m;
     if (m >= SF_K2_SAMPLE) {
         if (c->list_stats.size() > 64) c->list_stats.clear();
-        c->list_stats[nb->radius] = {(double)nb->total / (double)m, nb->max_count};
+        c->list_stats[{nb->radius, nb->self}] = {(double)nb->total / (double)m, nb->max_count};
     }
     // WHICH form serves a keypoint depends on its own list alone -- longer than 255 points: the second launch -- so that a
     // keypoint gets the same bits whatever else is in the launch (another block of a sharded job, a slice, a subset); the
@@ -1143,7 +1210,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     if (optimistic) {
         // the lists of the previous search with this radius on this cloud say how long this one's will be (same cloud, same
         // radius: the same lists, or a sub-range of them); the first search counts a sample instead.  SF_K2_NO_HINT=1: always.
-        auto hint = c->list_stats.find(nb->radius);
+        auto hint = c->list_stats.find({nb->radius, nb->self});
         if (hint != c->list_stats.end() && !getenv("SF_K2_NO_HINT")) cap = capacity_from(c, hint->second.first, hint->second.second);
         else SF_CHECK(sample_capacity(ctx, c, nb, g, r2, &cap));
         // slots of at most 24 GiB: a cloud whose longest list is far above its mean keeps the slots of the mean and re-does
@@ -1160,12 +1227,45 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
         SF_CHECK(exact_scan_fill(ctx, c, nb, g, grid, block, r2));
         return plan_dispatch(ctx, c, nb);
     }
+    // a self search of a range that has been searched before with this radius: its record (sf_cloud::search_records)
+    const std::tuple<double, int64_t, int64_t> rkey{nb->radius, nb->self_begin, m};
+    const sf_cloud::search_record *rec = nullptr;
+    if (nb->self && !getenv("SF_K2_NO_HINT")) {
+        auto it = c->search_records.find(rkey);
+        if (it != c->search_records.end() && (it->second.folded || !(ctx->collective_stats && ctx->comm))) rec = &it->second;
+    }
+    if (rec) cap = rec->cap;
     SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)(cap * m) + 4)); // +4: consumers read indices 16 B at a time
     nb->cap = cap;
     SF_LAUNCH(ctx, "k2_radius_slots", (k_radius<2, false>), grid, block, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
               nb->qz, m, r2, (int)cap, nb->count, nb->offset, nb->idx, (const int32_t *)nullptr);
     int64_t ovf_total = 0;
-    SF_CHECK(count_stats(ctx, nb, (int)cap, &ovf_total));
+    if (rec && !getenv("SF_K2_CHECK_RECORD")) { // no statistics pass, no read-back: the step's launches follow without a wait
+        nb->total = rec->total;
+        nb->max_count = rec->max_count;
+        nb->max_count_all = rec->max_count_all;
+        nb->n_overflow = rec->n_overflow;
+        for (int h = 0; h < 5; ++h) nb->hist[h] = rec->hist[h];
+        ovf_total = rec->ovf_total;
+    } else {
+        SF_CHECK(count_stats(ctx, nb, (int)cap, &ovf_total));
+        if (rec && (nb->total != rec->total || nb->max_count != rec->max_count || nb->n_overflow != rec->n_overflow ||
+                    ovf_total != rec->ovf_total || nb->hist[4] != rec->hist[4] || nb->hist[0] != rec->hist[0])) {
+            sf_set_error("sf_radius_search_self: the lists of positions %lld .. + %lld at radius %g differ from the record of the previous "
+                         "search of that range (total %lld / %lld)", (long long)nb->self_begin, (long long)m, nb->radius,
+                         (long long)nb->total, (long long)rec->total);
+            return SF_ERR_STATE;
+        }
+        if (nb->self && nb->n_overflow * 2 <= m) {
+            if (c->search_records.size() > 256) c->search_records.clear();
+            sf_cloud::search_record r;
+            r.total = nb->total; r.n_overflow = nb->n_overflow; r.ovf_total = ovf_total; r.cap = cap;
+            for (int h = 0; h < 5; ++h) r.hist[h] = nb->hist[h];
+            r.max_count = nb->max_count; r.max_count_all = nb->max_count_all;
+            r.folded = ctx->collective_stats && ctx->comm;
+            c->search_records[rkey] = r;
+        }
+    }
     if (nb->n_overflow * 2 > m) { // the sample misjudged the cloud as a whole: redo exactly
         sf_pool_release(ctx, nb->idx);
         nb->idx = nullptr;

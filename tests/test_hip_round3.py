@@ -77,13 +77,15 @@ def test_allreduce_min_u64_on_a_one_rank_communicator(comm_engine):
     d.free()
 
 
-@pytest.mark.parametrize("n_bins,expect_row_bytes", [(5, 64), (4, 64), (2, 160), (7, 1028)])
-def test_spfh_rows_travel_in_the_format_k7_reads(comm_engine, n_bins, expect_row_bytes):
+@pytest.mark.parametrize("n_bins,expect_row_bytes,dense", [(5, 64, False), (4, 64, False), (4, 160, True), (7, 1028, False)])
+def test_spfh_rows_travel_in_the_format_k7_reads(comm_engine, monkeypatch, n_bins, expect_row_bytes, dense):
     """sf_spfh_exchange_rows through ncclSend / ncclRecv (self exchange): the image of the receiving rows afterwards is
     the image of the sent rows before.  5 bins: alpha is pinned, two live blocks, packed rows (64 B); 4 bins: an edge at
-    alpha = 0, alpha in one of the two central bins (round 5) -- bins 16 .. 47, again two live blocks (64 B); 2 bins: no alpha
-    bin excluded, whole rows (160 B); 7 bins: 343 bins per row, the 16-bit table when created without a radius (1024 B + k)."""
+    alpha = 0, alpha in one of the two central bins (round 5) -- bins 16 .. 47, again two live blocks (64 B); a table whose
+    every block counts as live (SF_FPFH_DENSE=1): whole rows (160 B); 7 bins: 343 bins per row, the 16-bit table when created without a radius (1024 B + k)."""
     e = comm_engine
+    if dense:
+        monkeypatch.setenv("SF_FPFH_DENSE", "1")
     p, nr, _ = synth_cloud(6000, 12)
     cloud = e.cloud(p, nr)
     cloud.build_grid(0.1)

@@ -228,3 +228,62 @@ def test_fpfh_six_to_eight_bins_keep_a_window_of_the_bins_in_the_byte_table(eng,
         got[job.block_original_indices()] = job.fpfh_out.to_host()
         job.close()
     assert np.array_equal(got, one)
+
+
+# ---- a self search of a range that was searched before: planned from its record, no read-back --------------------------------------
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+def test_repeated_self_search_is_planned_from_its_record(eng, O, monkeypatch, kind):
+    """The lists of a self search are a function of (cloud, radius, range): the second search of a range launches its sweep and
+    every selection from the record of the first -- no statistics kernel, no read-back -- and leaves the same lists; a block of
+    the cloud has a record of its own; SF_K2_CHECK_RECORD=1 re-counts and compares; descriptors of a repeated DescriptorJob
+    step are bit-identical to the first step's.  Clustered cloud: lists that overflow their slot and lists above 255 points."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    if kind == "uniform":
+        p, nr, _ = synth_cloud(40000, 71)
+        r = 0.06
+    else:
+        p, nr, _, _ = family("clustered", 40000, np.random.default_rng(71))
+        r = 0.05
+    cloud = eng.cloud(p, nr)
+    try:
+        cloud.build_grid(r)
+
+        def search(b=0, e=None):
+            eng.sync(); eng.profile_reset(); eng.profile(True)
+            nb = cloud.radius_search_self(r, b, e)
+            eng.sync(); eng.profile(False)
+            names = {k for k, v in eng.profile_report().items() if v[0]}
+            out = (nb.total, nb.max_count, nb.export())
+            nb.free()
+            return out, names
+
+        first, n1 = search()
+        again, n2 = search()
+        assert "k2_reduce" in n1 and "k2_reduce" not in n2 and "k2_sample" not in n2
+        assert first[0] == again[0] and first[1] == again[1]
+        assert np.array_equal(first[2][0], again[2][0]) and np.array_equal(first[2][1], again[2][1])
+        blk, nb1 = search(5000, 21000)
+        blk2, nb2 = search(5000, 21000)
+        assert "k2_reduce" in nb1 and "k2_reduce" not in nb2 and np.array_equal(blk[2][1], blk2[2][1]) and blk[0] == blk2[0]
+        monkeypatch.setenv("SF_K2_CHECK_RECORD", "1")
+        chk, n3 = search()
+        monkeypatch.delenv("SF_K2_CHECK_RECORD", raising=False)
+        assert "k2_reduce" in n3 and chk[0] == first[0]
+    finally:
+        cloud.free()
+    job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=5)
+    try:
+        job.step()
+        f1, s1 = job.fpfh_out.to_host(), job.shot_out.to_host()
+        eng.sync(); eng.profile_reset(); eng.profile(True)
+        job.step()
+        eng.sync(); eng.profile(False)
+        assert "k2_reduce" not in {k for k, v in eng.profile_report().items() if v[0]}
+        assert np.array_equal(job.fpfh_out.to_host(), f1) and np.array_equal(job.shot_out.to_host(), s1)
+        rows = job.block_original_indices()
+        pick = np.arange(0, p.shape[0], 400)
+        fo = O.compute_fpfh_descriptor(rows[pick], p, nr, r, 5)
+        assert np.abs(f1[pick] - fo).max() < 1e-9
+    finally:
+        job.close()

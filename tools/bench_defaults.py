@@ -87,6 +87,30 @@ def run(eng, points_1m, normals_1m, radius_1m, parity: bool = True, only: str | 
         with ShotMultiprocessor(**sm_kw) as sm:
             return sm.compute_descriptor_single_scale(pc, nr, kp, r, subsampling_voxel_size=r / 10.0)
 
+    # ---- BASELINE config 2 exactly as written: 100k-point uniform cloud, 10k keypoints, SHOT + FPFH, radius 0.05, no support
+    #      subsampling (fpfh.py:16, shot_parallelization.py:135): the two drop-in calls back to back, host to host ---------------
+    from shot_fpfh_amd.descriptors import compute_fpfh_descriptor
+
+    def config2():
+        f = compute_fpfh_descriptor(kp2_idx, p2, n2, 0.05, 5, verbose=False, engine=eng)
+        with ShotMultiprocessor(**sm_kw) as sm:
+            d = sm.compute_descriptor_single_scale(p2, n2, kp2, 0.05)
+        return f, d
+
+    (f2, d2), wall, kern = _timed(eng, config2)
+    par = None
+    if parity:
+        rows = np.sort(rng.choice(kp2.shape[0], 150, replace=False))
+        pf = _parity(f2[rows], O.compute_fpfh_descriptor(kp2_idx[rows], p2, n2, 0.05, 5), rows.size)
+        ps_ = _parity(d2[rows], O.shot_single_scale(p2, n2, kp2[rows], 0.05, True, MIN_NB), rows.size)
+        par = {"rows": int(rows.size), "fpfh_max_abs_err": pf["max_abs_err"], "shot_max_abs_err": ps_["max_abs_err"], "ok": pf["ok"] and ps_["ok"]}
+    out["config2_as_written"] = _line("compute_fpfh_descriptor(10 000 keypoint indices, 100 000 points, r=0.05, 5 bins) + ShotMultiprocessor("
+                                      "min_neighborhood_size=10).compute_descriptor_single_scale(same cloud and keypoints, r=0.05), no subsampling",
+                                      2 * kp2.shape[0], wall, kern, par)
+    del f2, d2
+    if only == "config2":
+        return out
+
     cases = [("c2_100k_10k_keypoints", p2, n2, kp2, 0.05), ("uniform_1m_all_keypoints", points_1m, normals_1m, points_1m, radius_1m),
              ("surface_1m_100k_keypoints", ps, ns, kps, r_s)]
     out["shot_subsampled_support"] = {}
@@ -100,6 +124,19 @@ def run(eng, points_1m, normals_1m, radius_1m, parity: bool = True, only: str | 
         line = _line(f"ShotMultiprocessor(min_neighborhood_size=10).compute_descriptor_single_scale(subsampling_voxel_size=r/10), "
                      f"{pc.shape[0]} points, {kp.shape[0]} keypoints, r={r}", kp.shape[0], wall, kern, par)
         line["support_points"] = int(keep.shape[0])
+        c_ = eng.cloud(pc[keep])
+        try:
+            sub_ = kp[:: max(1, kp.shape[0] // 20000)]
+            nb_ = c_.radius_search(sub_, r)
+            line["mean_support_points_per_ball"] = nb_.total / max(nb_.m, 1)
+            line["longest_list"] = int(nb_.max_count)
+            nb_.free()
+        finally:
+            c_.free()
+        if kern:
+            pairs = line["mean_support_points_per_ball"] * kp.shape[0]
+            k5 = sum(v for k_, v in kern.items() if k_.startswith("k5_"))
+            line["k5_ns_per_pair"] = 1e6 * k5 / pairs if pairs else None
         line["non_zero_rows"] = int(np.any(d, axis=1).sum())
         out["shot_subsampled_support"][name] = line
         del d
