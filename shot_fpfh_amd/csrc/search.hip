@@ -1263,6 +1263,11 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
             for (int h = 0; h < 5; ++h) r.hist[h] = nb->hist[h];
             r.max_count = nb->max_count; r.max_count_all = nb->max_count_all;
             r.folded = ctx->collective_stats && ctx->comm;
+            if (r.n_overflow) { // lists outgrew their slots this time: the next search of the range takes slots that hold the longest
+                const int64_t most = std::max<int64_t>(((((int64_t)24 << 30) / (4 * m)) / 32) * 32, 32);
+                const int64_t cap2 = capacity_from(c, (double)nb->total / (double)m, nb->max_count);
+                if (cap2 >= nb->max_count && cap2 <= most) { r.cap = cap2; r.n_overflow = 0; r.ovf_total = 0; }
+            }
             c->search_records[rkey] = r;
         }
     }

@@ -263,8 +263,8 @@ def test_repeated_self_search_is_planned_from_its_record(eng, O, monkeypatch, ki
         assert "k2_reduce" in n1 and "k2_reduce" not in n2 and "k2_sample" not in n2
         assert first[0] == again[0] and first[1] == again[1]
         assert np.array_equal(first[2][0], again[2][0]) and np.array_equal(first[2][1], again[2][1])
-        blk, nb1 = search(5000, 21000)
-        blk2, nb2 = search(5000, 21000)
+        blk, nb1 = search(5000, 30000)  # (at least 16 384 queries: the single sweep into slots, which is what keeps a record)
+        blk2, nb2 = search(5000, 30000)
         assert "k2_reduce" in nb1 and "k2_reduce" not in nb2 and np.array_equal(blk[2][1], blk2[2][1]) and blk[0] == blk2[0]
         monkeypatch.setenv("SF_K2_CHECK_RECORD", "1")
         chk, n3 = search()

@@ -9,6 +9,7 @@ mkdir -p gpurun_out
 # 1. kernel trace + HBM counters of the bench command -> profiles/<tag>_summary.md, profiles/<tag>_traffic.json (stamped)
 bash tools/profile_gpu.sh ${TAG} --no-match --no-normals > gpurun_out/${TAG}_profile.log 2>&1
 python tools/parse_rocprof.py ${TAG} > /dev/null 2>> gpurun_out/${TAG}_profile.log
+python tools/trace_gaps.py $(find gpurun_out/prof_${TAG}/trace -name '*kernel_trace.csv' | head -1) auto 20 > profiles/${TAG}_trace_gaps.txt 2>&1
 # 2. SQ counters of K5 -> profiles/<tag>_k5_sq.json (stamped)
 bash tools/pmc_k5.sh ${TAG} > gpurun_out/${TAG}_k5.log 2>&1
 # 3. the bench record itself (now quoting 1. and 2.), the emulated ranks of an 8-GPU job, config 4
