@@ -167,12 +167,22 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
             // w = u x v are not needed either unless theta's cheap form cannot decide (theta_bin_fast).
             // (an EVEN bin count has an edge at 0: alpha then falls into one of the TWO central bins, alpha_pair and alpha_pair + 1,
             // and only its side of that one edge has to be found -- the reference's own alpha, compared as searchsorted does)
+            // (np.linspace(-1, 1, n + 1) has an edge at 0 exactly when n is even: the pair form exists for even bin counts only, and
+            // the odd ones -- 5 bins, the headline -- compile to the code they had before it)
+            constexpr bool EVEN = NB > 0 && NB % 2 == 0;
             int ba = alpha_bin, bt = -2;
-            if (alpha_bin >= 0 || alpha_pair >= 0) {
+            if (alpha_bin >= 0 || (EVEN && alpha_pair >= 0)) {
                 const double nc = (njx * cx + njy * cy) + njz * cz;
                 bt = theta_bin_fast(ed, nb, nc * uu - b * num, b, e_per_dist * (d2 * y1) * 1.01);
             }
-            if (bt == -2 || alpha_bin < 0) { // the reference's own expressions (fpfh.py:58-66)
+            if (!EVEN) {
+                if (bt == -2) { // the reference's own expressions (fpfh.py:58-66)
+                    const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
+                    const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)
+                    bt = theta_bin(ed, nb, (njx * wx + njy * wy) + njz * wz, b);
+                    if (alpha_bin < 0) ba = hist_bin(ed.a, nb, (vx * njx + vy * njy) + vz * njz);
+                }
+            } else if (bt == -2 || alpha_bin < 0) {
                 const double vx = cy * uz - cz * uy, vy = cz * ux - cx * uz, vz = cx * uy - cy * ux; // cross(c, u)
                 if (bt == -2) {
                     const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx; // cross(u, v)

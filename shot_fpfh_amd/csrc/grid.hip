@@ -770,7 +770,9 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
     // issued before it, so this flag needs no event of its own -- unlike the lazy gather of sf_cloud_ensure_sorted_normals)
     c->normals_sorted = c->nrm_orig != nullptr;
     const bool force_radix = getenv("SF_K1_RADIX") != nullptr; // (read at every build: the tests compare the two paths in one process)
-    if (ns > 0 && !force_radix && slab_cells <= SF_COUNT_CELLS_PER_POINT * ns) {
+    // (the counting build ranks every point among the points of its cell, pop compares per point: grids with a handful of points per
+    // cell only -- a mean population above 64 goes to the sort, whose cost does not depend on how the points pile up)
+    if (ns > 0 && !force_radix && slab_cells <= SF_COUNT_CELLS_PER_POINT * ns && ns <= 64 * slab_cells) {
         // ---- the counting build (see k_cell_count): fill, count, scan, place, settle ----
         const int64_t slab_tiles = sf_div_up(slab_cells, (int64_t)SF_SCAN_TILE), n_status = slab_tiles + 1;
         const int64_t fill_blocks = sf_div_up(ncell + 1 - slab_cells, (int64_t)SF_SCAN_TILE);
@@ -782,6 +784,9 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
         SF_CHECK(tmp.alloc(&slot, (size_t)ns));
         SF_CHECK(tmp.alloc(&status, (size_t)n_status));
         int32_t *start_rel = c->cell_start + cid_base;
+        // (the counters are zero between builds: k_cell_scan writes them back.  A build that did not get as far as its scan --
+        // a launch that failed, an error left on the device by whatever ran before -- leaves them as they are: zeroed again)
+        if (hipPeekAtLastError() != hipSuccess) c->count_dirty = true;
         if (c->cell_count_cap < slab_cells || c->count_dirty) { // (first build of this cloud with a slab this large)
             if (c->cell_count_cap < slab_cells) {
                 if (c->cell_count) sf_pool_release(ctx, c->cell_count);
