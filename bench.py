@@ -366,7 +366,7 @@ def compact_record(out: dict, detail_path: str | None) -> dict:
             line[k] = out[k]
     ss = out.get("strong_scaling")
     if ss is not None:
-        line["strong_scaling"] = _pick(ss, ("ms_per_step", "value", "parity_ok"))
+        line["strong_scaling"] = _pick(ss, ("ms_per_step", "graph_ms_per_step", "value", "parity_ok"))
     em = out.get("exchange_match")
     if em is not None:
         line["end_to_end_config5_ms"] = out.get("end_to_end_config5_ms")
@@ -984,6 +984,25 @@ def main() -> int:
                               "what": "DescriptorJob(overlap_chains=True) / bench.py --overlap: the FPFH and SHOT chains on the context's two HIP "
                                       "streams; same rows bit for bit (tests/test_hip_parity.py::test_two_stream_overlap_gives_identical_results), kernels overlap in time"}
 
+    # ---- the same step replayed as ONE launch (HIP graph: DescriptorJob.step_replay).  Same launches, same rows; what it saves
+    #      is host time, so it shows on small steps (strong scaling below), not on this one.  Secondary: `value` is the eager step ----
+    if (single or emulated) and not args.no_kernel_timers and args.sustained_seconds > 0:
+        try:
+            for _ in range(4):  # (two eager steps, the capture, one replay)
+                job.step_replay()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                job.step_replay()
+            barrier()
+            t_g = (time.perf_counter() - t0) / args.steps
+            out["graph_replay"] = {"ms_per_step": 1000.0 * t_g, "vs_timed_steps": 1000.0 * t_g / ms_per_step,
+                                   "captured": getattr(job, "_graph", None) is not None, "not_captured_because": getattr(job, "_graph_failed", None),
+                                   "what": "DescriptorJob.step_replay(): the step captured once into a HIP graph (sf_graph_begin / sf_graph_end) "
+                                           "and replayed with one call per step; rows bit-identical (tests/test_hip_round5.py)"}
+        except Exception as exc:  # noqa: BLE001 -- a secondary line must not take the record down
+            out["graph_replay"] = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---- parity of what the timed steps left in HBM ------------------------------------------------------------------
     if not args.no_parity:
         par = parity_sample(job, points, normals, radius, args.parity_rows)
@@ -1004,6 +1023,19 @@ def main() -> int:
         # number of descriptors as the weak line, so the two are timed at the same clocks)
         s_steps, s_warm = args.steps * world, max(args.warmup, 1) * world
         s_elapsed, _, _, _, _ = time_steps(sjob, eng, s_steps, s_warm, barrier, max_over_ranks, False)
+        s_graph = None
+        if emulated or ctl is None:  # (with real peers the exchange's RCCL calls would have to be captured: step_replay runs step())
+            try:
+                for _ in range(4):
+                    sjob.step_replay()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(s_steps):
+                    sjob.step_replay()
+                barrier()
+                s_graph = (time.perf_counter() - t0) / s_steps if getattr(sjob, "_graph", None) is not None else None
+            except Exception:  # noqa: BLE001
+                s_graph = None
         spar = None if args.no_parity else parity_sample(sjob, sp_pts, sp_nrm, args.radius, min(args.parity_rows, 100))
         if ctl is not None and spar is not None:
             spar = {"ok": all(p["ok"] for p in ctl.allgather(spar))}
@@ -1017,6 +1049,7 @@ def main() -> int:
                 "what": f"the {args.points_per_gpu}-point cloud of N = 1 (radius {args.radius}) cut into {world} blocks of "
                         f"{-(-args.points_per_gpu // world)} keypoints: total work fixed",
                 "ms_per_step": 1000.0 * s_elapsed / s_steps, "steps": s_steps, "warmup": s_warm,
+                "graph_ms_per_step": None if s_graph is None else 1000.0 * s_graph,
                 "value": 2 * args.points_per_gpu / (s_elapsed / s_steps), "unit": "descriptors/s",
                 "speedup_vs_n1_needs": "the N = 1 line of the same build (ms_per_step there / ms_per_step here)",
                 "parity_ok": None if spar is None else spar["ok"],

@@ -191,6 +191,22 @@ int sf_azimuth_idx(sf_ctx *ctx, const double *x, const double *y, int64_t n, int
 int sf_shot_serial(sf_ctx *ctx, sf_cloud *cloud, sf_nbrs *nbrs, int64_t min_neighborhood_size, double *out /* m x 352 */,
                    int flags);
 
+/* ---- a repeated step as ONE launch (HIP graph) -------------------------------------------------------------------------
+ * sf_graph_begin .. sf_graph_end capture every device operation the calls in between issue on the context's streams (nothing
+ * runs yet) into an executable graph; sf_graph_launch replays it on the main stream.  What is captured must not synchronise with
+ * the device: a REPEATED step of the path qualifies (same cloud, radius and buffers: every launch is planned from the previous
+ * search's record), a first one does not -- run the step once eagerly and capture only if sf_sync_count() did not move (a
+ * capture that hits a wait is invalidated by the runtime: sf_graph_end then returns NULL with its reason).  The arguments of the
+ * captured calls (device buffers, sizes) are part of the graph: replay only while they are alive and unchanged.  Launch timers
+ * (sf_profile) must be off.  Not part of the reference's API: a host-overhead lever for small, repeated steps (a rank's share
+ * of a strong-scaled job). */
+typedef struct sf_graph sf_graph;
+unsigned long long sf_sync_count(void); /* host waits on a stream made by the library so far, in this process */
+int sf_graph_begin(sf_ctx *ctx);
+sf_graph *sf_graph_end(sf_ctx *ctx);
+int sf_graph_launch(sf_ctx *ctx, sf_graph *graph);
+void sf_graph_free(sf_ctx *ctx, sf_graph *graph);
+
 /* ---- FPFH: compute_fpfh_descriptor (fpfh.py:16-117, decorrelated=False) -------------------
  * sf_spfh_create allocates the table for all n cloud points; sf_spfh_compute (K6) fills the rows of
  * the queries of `self_nbrs` (a sf_radius_search_self result); edges = 3 x (n_bins+1) histogram

@@ -71,6 +71,11 @@ SIGNATURES = {
     "sf_shot_single_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _int]),
     "sf_azimuth_idx": (_int, [_vp, _vp, _vp, _i64, _vp, _int]),
     "sf_shot_serial": (_int, [_vp, _vp, _vp, _i64, _vp, _int]),
+    "sf_sync_count": (C.c_ulonglong, []),
+    "sf_graph_begin": (_int, [_vp]),
+    "sf_graph_end": (_vp, [_vp]),
+    "sf_graph_launch": (_int, [_vp, _vp]),
+    "sf_graph_free": (None, [_vp, _vp]),
     "sf_spfh_create": (_vp, [_vp, _vp, _int, _i64]),
     "sf_spfh_create_for_radius": (_vp, [_vp, _vp, _int, _i64, C.c_double]),
     "sf_spfh_elem_bytes": (_int, [_vp]),

@@ -13,6 +13,16 @@
 
 #include "../../include/shotfpfh.h"
 
+// Every host wait on a stream goes through this counter (sf_sync_count): a step that is to be captured into a HIP graph must not
+// wait for the device, and whether it does is checked on an eager run of the same step first (Engine.capture's callers).
+extern unsigned long long g_sf_sync_count; // context.hip
+static inline hipError_t sf_counted_stream_sync(hipStream_t s)
+{
+    ++g_sf_sync_count;
+    return hipStreamSynchronize(s);
+}
+#define hipStreamSynchronize(s) sf_counted_stream_sync(s)
+
 #define SF_WAVE 64
 
 void sf_set_error(const char *fmt, ...);
@@ -47,6 +57,14 @@ struct sf_prof_entry {
     double total_ms = 0.0;
 };
 
+// A captured step (sf_graph_begin / sf_graph_end): the HIP graph of everything issued between the two calls, and the pool blocks
+// released meanwhile -- a replay writes into them again, so they stay out of the pool for as long as the graph lives.
+struct sf_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<void *> held;
+};
+
 struct sf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // the stream calls are issued on (one of streams[])
@@ -76,6 +94,7 @@ struct sf_ctx {
     std::multimap<size_t, void *> pool_free;
     std::map<void *, size_t> pool_size;
     size_t pool_cached = 0;
+    sf_graph *capture = nullptr; // non-null between sf_graph_begin and sf_graph_end
 };
 
 int sf_pool_alloc(sf_ctx *ctx, size_t bytes, void **out);

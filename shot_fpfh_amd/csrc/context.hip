@@ -161,6 +161,67 @@ extern "C" int sf_wait_mark(sf_ctx *ctx)
 
 extern "C" void *sf_stream(sf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// ---- a step as a HIP graph ------------------------------------------------------------------------------------------------
+// A repeated step of the path -- same cloud, same radius, same buffers -- issues the same launches with the same arguments
+// (round 5: no read-back left in it, every launch is planned from the previous search's record).  Small steps are then bound
+// by the host: a rank's eighth of the 1M-point cloud is 0.5 ms of GPU work behind some thirty library calls and a dozen
+// launches.  sf_graph_begin puts the context's main stream into capture (the side stream joins through the fork / join
+// events), sf_graph_end turns what was issued into an executable graph, sf_graph_launch replays it with ONE call.  While
+// capturing, nothing may synchronise with the device (a call that would -- a first search of a range, a table whose block
+// mask the host does not know -- fails with the runtime's error and the capture is abandoned by sf_graph_end); pool blocks
+// released during the capture stay with the graph, which writes into them at every replay, until sf_graph_free.
+unsigned long long g_sf_sync_count = 0;
+extern "C" unsigned long long sf_sync_count(void) { return g_sf_sync_count; }
+
+extern "C" int sf_graph_begin(sf_ctx *ctx)
+{
+    if (!ctx) { sf_set_error("null ctx"); return SF_ERR_ARG; }
+    if (ctx->capture) { sf_set_error("sf_graph_begin: already capturing"); return SF_ERR_STATE; }
+    if (ctx->stream != ctx->streams[0]) { sf_set_error("sf_graph_begin: forked (sf_join first)"); return SF_ERR_STATE; }
+    if (ctx->profiling) { sf_set_error("sf_graph_begin: launch timers are on (sf_profile(0) first)"); return SF_ERR_STATE; }
+    SF_HIP(hipSetDevice(ctx->device));
+    SF_HIP(hipStreamSynchronize(ctx->streams[0]));
+    SF_HIP(hipStreamSynchronize(ctx->streams[1]));
+    SF_HIP(hipStreamBeginCapture(ctx->streams[0], hipStreamCaptureModeRelaxed));
+    ctx->capture = new sf_graph();
+    return SF_OK;
+}
+
+extern "C" sf_graph *sf_graph_end(sf_ctx *ctx)
+{
+    if (!ctx || !ctx->capture) { sf_set_error("sf_graph_end: not capturing"); return nullptr; }
+    sf_graph *g = ctx->capture;
+    ctx->capture = nullptr;
+    ctx->stream = ctx->streams[0];
+    hipError_t e = hipStreamEndCapture(ctx->streams[0], &g->graph);
+    if (e == hipSuccess && g->graph) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess || !g->exec) {
+        sf_set_error("sf_graph_end: the step could not be captured (%s)", hipGetErrorString(e));
+        (void)hipGetLastError();
+        sf_graph_free(ctx, g);
+        return nullptr;
+    }
+    return g;
+}
+
+extern "C" int sf_graph_launch(sf_ctx *ctx, sf_graph *g)
+{
+    if (!ctx || !g || !g->exec) { sf_set_error("sf_graph_launch: bad argument"); return SF_ERR_ARG; }
+    if (ctx->capture) { sf_set_error("sf_graph_launch: capturing"); return SF_ERR_STATE; }
+    SF_HIP(hipGraphLaunch(g->exec, ctx->streams[0]));
+    return SF_OK;
+}
+
+extern "C" void sf_graph_free(sf_ctx *ctx, sf_graph *g)
+{
+    if (!g) return;
+    if (ctx) { (void)hipStreamSynchronize(ctx->streams[0]); (void)hipStreamSynchronize(ctx->streams[1]); }
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    for (void *p : g->held) { if (ctx) sf_pool_release(ctx, p); else (void)hipFree(p); }
+    delete g;
+}
+
 extern "C" void *sf_dev_alloc(sf_ctx *ctx, size_t bytes)
 {
     if (!ctx) { sf_set_error("null ctx"); return nullptr; }
@@ -281,6 +342,7 @@ void sf_pool_release(sf_ctx *ctx, void *p)
     if (!p) return;
     auto it = ctx->pool_size.find(p);
     if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
+    if (ctx->capture) { ctx->capture->held.push_back(p); return; } // (a captured launch refers to it: the graph keeps it)
     ctx->pool_free.emplace(it->second, p);
     ctx->pool_cached += it->second;
     if (ctx->pool_cached > ((size_t)96 << 30)) sf_pool_trim(ctx);

@@ -184,6 +184,27 @@ class _PinnedPool:
             self.lib.sf_host_free(None, addr)
 
 
+class StepGraph:
+    """An executable HIP graph of a captured step (Engine.capture): launch() replays it on the engine's main stream."""
+
+    def __init__(self, engine: "Engine", handle):
+        self.engine, self.h = engine, handle
+
+    def launch(self) -> None:
+        _ffi.check(self.engine.lib.sf_graph_launch(self.engine.h, self.h), "sf_graph_launch")
+
+    def free(self) -> None:
+        if getattr(self, "h", None) and self.engine.h:
+            self.engine.lib.sf_graph_free(self.engine.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Engine:
     """One GPU: a libshotfpfh context with its own HIP stream.  Fails loudly when the native library
     or the GPU is missing -- there is no CPU path."""
@@ -253,6 +274,21 @@ class Engine:
     def join(self) -> None:
         """Back on the main stream, ordered after the side stream."""
         _ffi.check(self.lib.sf_join(self.h), "sf_join")
+
+    # ---- a repeated step as one launch (HIP graph; include/shotfpfh.h "a repeated step as ONE launch") -----------------------
+    def capture(self, fn) -> "StepGraph":
+        """Run fn() with the context's streams in capture mode: nothing executes, every device operation fn issues becomes a
+        node of the returned graph.  fn must not synchronise with the device (a repeated DescriptorJob.step() does not; a first
+        one does) -- the capture is then abandoned and ShotFpfhError raised."""
+        _ffi.check(self.lib.sf_graph_begin(self.h), "sf_graph_begin")
+        try:
+            fn()
+        except BaseException:
+            g = self.lib.sf_graph_end(self.h)  # (leave capture mode whatever happened)
+            if g:
+                self.lib.sf_graph_free(self.h, g)
+            raise
+        return StepGraph(self, _ffi.check_handle(self.lib.sf_graph_end(self.h), "sf_graph_end"))
 
     def empty(self, shape, dtype=np.float64) -> DeviceArray:
         return DeviceArray(self, shape, dtype)

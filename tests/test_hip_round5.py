@@ -287,3 +287,37 @@ def test_repeated_self_search_is_planned_from_its_record(eng, O, monkeypatch, ki
         assert np.abs(f1[pick] - fo).max() < 1e-9
     finally:
         job.close()
+
+
+# ---- a repeated step as one launch (HIP graph) ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["whole", "rank3_of_8", "clustered"])
+def test_step_replayed_as_a_hip_graph_gives_the_same_rows(eng, mode):
+    """DescriptorJob.step_replay(): two eager steps, the third captured (Engine.capture: sf_graph_begin / sf_graph_end), later
+    calls replay the graph with one launch -- rows bit-identical to step()'s, also for one rank's share of an 8-rank job (block
+    build, halo rows of the emulated peers) and on a clustered cloud (second launches over selections, lists above 255 points);
+    buffers written between replays are overwritten again; close() gives the graph's blocks back."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    if mode == "clustered":
+        p, nr, _, _ = family("clustered", 60000, np.random.default_rng(81))
+        kw, r = {}, 0.04
+    else:
+        p, nr, _ = synth_cloud(60000, 81)
+        kw, r = ({} if mode == "whole" else dict(world=8, rank=3, emulate_peers=True)), 0.05
+    job = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=5, **kw)
+    try:
+        job.step()
+        f0, s0 = job.fpfh_out.to_host(), job.shot_out.to_host()
+        for i in range(5):
+            if i == 3:  # scribble over the outputs: the next replay must write every row again
+                job.fpfh_out.from_host(np.full(job.fpfh_out.shape, np.nan))
+                job.shot_out.from_host(np.full(job.shot_out.shape, np.nan))
+            job.step_replay()
+        eng.sync()
+        assert getattr(job, "_graph_failed", None) is None and getattr(job, "_graph", None) is not None
+        assert np.array_equal(job.fpfh_out.to_host(), f0) and np.array_equal(job.shot_out.to_host(), s0)
+        job.step()  # (an eager step after replays: the pool still hands out sound blocks)
+        eng.sync()
+        assert np.array_equal(job.fpfh_out.to_host(), f0) and np.array_equal(job.shot_out.to_host(), s0)
+    finally:
+        job.close()

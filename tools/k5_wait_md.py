@@ -35,6 +35,10 @@ def main():
     a, _ = per_dispatch(out_dir, "a")
     c, nc = per_dispatch(out_dir, "c")
     d, nd = per_dispatch(out_dir, "d")
+    for sub in ("e", "f"):  # (the texture cache's counters come two per pass)
+        more, _ = per_dispatch(out_dir, sub)
+        for k, v in more.items():
+            d.setdefault(k, v)
     lines = [f"# K5 (`k_shot_cached`): what its waves wait for ({tag}, build {build})", "",
              "`tools/pmc_k5.sh` (rocprofv3 --pmc, separate passes, SHOT chain alone at C3: one wave per keypoint), per wave "
              "(= per keypoint); SQ cycle counters are in units of 4 cycles.", ""]
