@@ -29,7 +29,7 @@ else:
 dur, gap, cnt = defaultdict(float), defaultdict(float), defaultdict(int)
 prev_end = rows[0][0]
 for s, e, name in rows:
-    short = re.sub(r"^void ", "", name)
+    short = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     short = re.sub(r"\(.*$", "", short)[:70]
     dur[short] += e - s
     gap[short] += max(0, s - prev_end)
@@ -39,7 +39,7 @@ span = prev_end - rows[0][0]
 big, pe = (0, ""), rows[0][0]
 for s_, e_, name in rows:
     if s_ - pe > big[0]:
-        big = (s_ - pe, re.sub(r"\(.*$", "", re.sub(r"^void ", "", name))[:60])
+        big = (s_ - pe, re.sub(r"\(.*$", "", re.sub(r"^void ", "", name).replace("(anonymous namespace)::", ""))[:60])
     pe = max(pe, e_)
 print(f"largest idle gap inside the steps: {big[0] / 1e3:.2f} us, in front of {big[1]}")
 print(f"span per step {span / steps / 1e3:.1f} us; busy {sum(dur.values()) / steps / 1e3:.1f} us; idle {sum(gap.values()) / steps / 1e3:.1f} us")
