@@ -228,7 +228,8 @@ sf_spfh *sf_spfh_create(sf_ctx *ctx, sf_cloud *cloud, int n_bins, int64_t max_co
 /* The table for a KNOWN search radius (the `radius` argument of compute_fpfh_descriptor, fpfh.py:19).  alpha = (c x u) . n_j
  * with v not normalised (fpfh.py:60) never exceeds radius * max|n|^2: when that stays inside the one or two central bins of
  * the alpha histogram (an even n_bins has an edge at 0), only those bins' n_bins^2 (2 n_bins^2) slots of a row can ever hold a
- * count.  For n_bins = 6, 7, 8 -- 72 of 216, 49 of 343, 128 of 512 bins -- the table then keeps exactly that window of bins,
+ * count.  For n_bins = 6, 7, 8, 9, 11 -- 72 of 216, 49 of 343, 128 of 512, 81 of 729, 121 of 1331 bins: every count whose
+ * window fits the 128 columns of a byte row -- the table then keeps exactly that window of bins,
  * one byte each, and the whole byte-table path (packed rows, high bytes, K7 on the matrix cores, the wire image of the
  * exchange) serves these bin counts too; sf_fpfh writes zeros for the bins outside the window.  Without a usable window
  * (radius <= 0, no normals, a larger reach, other bin counts) this IS sf_spfh_create.  sf_spfh_compute fails with

@@ -25,9 +25,13 @@
 
 namespace {
 
+// Bin counts above SF_FAST_FPFH_BINS that the fast K6 still serves: the ODD ones whose central alpha bin's n^2 slots fit the
+// 128-column byte row -- 9 (81 bins) and 11 (121) -- when the radius pins alpha to that bin (a windowed table, see
+// sf_spfh_create_for_radius).  Without a window these counts take the generic kernels.
+#define SF_WIN_FPFH_BINS 11
 struct fpfh_edges {
-    double a[SF_FAST_FPFH_BINS + 1], p[SF_FAST_FPFH_BINS + 1], t[SF_FAST_FPFH_BINS + 1];
-    double tan_t[SF_FAST_FPFH_BINS + 1]; // tan of the interior theta edges (index 1..nb-1)
+    double a[SF_WIN_FPFH_BINS + 1], p[SF_WIN_FPFH_BINS + 1], t[SF_WIN_FPFH_BINS + 1];
+    double tan_t[SF_WIN_FPFH_BINS + 1]; // tan of the interior theta edges (index 1..nb-1)
 };
 
 // np.histogramdd bin of x: searchsorted(edges, x, 'right') - 1, x == last edge -> last bin, out of
@@ -37,7 +41,7 @@ __device__ inline int hist_bin(const double *e, int nb, double x)
     if (!(x >= e[0]) || x > e[nb]) return -1;
     int b = 0;
 #pragma unroll
-    for (int i = 1; i < SF_FAST_FPFH_BINS; ++i)
+    for (int i = 1; i < SF_WIN_FPFH_BINS; ++i)
         if (i < nb && x >= e[i]) b = i;
     return b;
 }
@@ -54,7 +58,7 @@ __device__ inline int theta_bin(const fpfh_edges &ed, int nb, double a, double b
         int bin = 0;
         double gap = 1.0e300; // smallest |a - tan(e_i) b| over the interior edges
 #pragma unroll
-        for (int i = 1; i < SF_FAST_FPFH_BINS; ++i)
+        for (int i = 1; i < SF_WIN_FPFH_BINS; ++i)
             if (i < nb) {
                 // a - tan(e_i) b with ONE rounding: its sign is that of the exact difference, and whenever that differs
                 // from the rounded product's verdict the gap is within an ulp, far inside the band the fallback owns
@@ -84,7 +88,7 @@ __device__ inline int theta_bin_fast(const fpfh_edges &ed, int nb, double a, dou
         int bin = 0;
         double gap = 1.0e300;
 #pragma unroll
-        for (int i = 1; i < SF_FAST_FPFH_BINS; ++i)
+        for (int i = 1; i < SF_WIN_FPFH_BINS; ++i)
             if (i < nb) {
                 const double di = __builtin_fma(-ed.tan_t[i], b, a);
                 bin += di >= 0.0 ? 1 : 0;
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
                                               int64_t nsel, int64_t view_first, int alpha_pair, int win_lo, int win_len)
 {
     const int nb = NB > 0 ? NB : nb_rt;
+    // (the wave's histogram holds the table's WINDOW of the bins: all n_bins^3 of at most 512 for the unwindowed tables)
     __shared__ unsigned int hist[SF_SPFH_WPB][SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS * SF_FAST_FPFH_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t q = sf_uniform64(sf_xcd_block() * SF_SPFH_WPB + wave);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
     }
     if (q >= m) return; // whole wave exits together; no block-wide barrier below
     unsigned int *h = hist[wave];
-    for (int b = lane; b < nb3; b += 64) h[b] = 0;
+    for (int b = lane; b < win_len; b += 64) h[b] = 0;
     const int64_t i = self_begin + q; // cell-sorted position of this point
     const int64_t s = offset[q];
     const int k = cnt[q];
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
                 }
             }
             const int bp = hist_bin(ed.p, nb, phi);
-            if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt], 1u);
+            if ((ba | bp | bt) >= 0) atomicAdd(&h[(ba * nb + bp) * nb + bt - win_lo], 1u);
         }
     };
     // Optional by-product (cov != NULL): the weighted covariance of the SHOT frame (shot.py:27-35, w = r - ||c||, the
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
     bool hi_empty = false;
     if (live) { // uint8 table: 128 bins, two per lane; which 16-bin blocks of this row hold a count goes into the table-wide mask
         // (column c of the row = bin win_lo + c; columns past the window are padding: count 0)
-        const unsigned v0 = lane < win_len ? h[win_lo + lane] : 0u, v1 = lane + 64 < win_len ? h[win_lo + lane + 64] : 0u;
+        const unsigned v0 = lane < win_len ? h[lane] : 0u, v1 = lane + 64 < win_len ? h[lane + 64] : 0u;
         // (the uint8 table keeps count & 255; a point with more than 255 neighbours also has count >> 8 in the table of high
         // bytes.  Streamed past the L2 -- K7 gathers the PACKED rows; of this table it reads each keypoint's own row, once)
         __builtin_nontemporal_store((CT)(v0 ^ bias), row + lane);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
             const int first = 16 * (lane < 4 ? pack_b0 : pack_b1) + 4 * (lane & 3);
             unsigned w = 0u;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) w |= (((first + t < win_len ? h[win_lo + first + t] : 0u) ^ bias) & 0xffu) << (8 * t);
+            for (int t = 0; t < 4; ++t) w |= (((first + t < win_len ? h[first + t] : 0u) ^ bias) & 0xffu) << (8 * t);
             reinterpret_cast<unsigned *>(packed + i * 32)[lane] = w;
         }
         const unsigned long long n0 = __ballot(v0 != 0u), n1 = __ballot(v1 != 0u);
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
         // the table-wide mask is still growing)
         if (lane == 0 && (mask & ~*live)) atomicOr(live, mask);
     } else {
-        for (int b = lane; b < stride; b += 64) row[b] = (CT)((b < nb3 ? h[b] : 0u) ^ bias); // (padding bins: count 0)
+        for (int b = lane; b < stride; b += 64) row[b] = (CT)((b < nb3 ? h[b] : 0u) ^ bias); // (padding bins: count 0; win_lo = 0 here)
     }
     if (lane == 0) {
         kout[i] = k;
@@ -1034,8 +1039,8 @@ static sf_spfh *spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t max_co
     sp->win_lo = 0;
     sp->win_len = sp->nb3;
     bool window = false;
-    if (sp->nb3 > 128 && n_bins <= SF_FAST_FPFH_BINS && max_count <= 65535 && radius > 0.0 && c->nrm_orig && !getenv("SF_FPFH_NO_WINDOW")) {
-        double n2 = 0.0, ea[SF_FAST_FPFH_BINS + 1];
+    if (sp->nb3 > 128 && n_bins <= SF_WIN_FPFH_BINS && max_count <= 65535 && radius > 0.0 && c->nrm_orig && !getenv("SF_FPFH_NO_WINDOW")) {
+        double n2 = 0.0, ea[SF_WIN_FPFH_BINS + 1];
         if (sf_cloud_normals_max2(ctx, c, &n2) != SF_OK) { delete sp; return nullptr; }
         for (int i = 0; i <= n_bins; ++i) ea[i] = -1.0 + 2.0 * (double)i / (double)n_bins; // (np.linspace(-1, 1, n + 1) up to an ulp:
         int a0 = 0, a1 = 0;                                                                 // sf_spfh_compute checks the real edges)
@@ -1046,13 +1051,13 @@ static sf_spfh *spfh_create(sf_ctx *ctx, sf_cloud *c, int n_bins, int64_t max_co
         }
     }
     sp->elem_bytes = (max_count <= 65535 && (sp->nb3 <= 128 || window)) ? 1 : (max_count > 65535 ? 4 : 2);
-    if (n_bins > SF_FAST_FPFH_BINS) sp->elem_bytes = 4; // the generic kernels keep 32-bit counts
+    if (n_bins > SF_FAST_FPFH_BINS && !window) sp->elem_bytes = 4; // the generic kernels keep 32-bit counts
     sp->bias = sp->elem_bytes == 1 ? 128 : 0;
     // rows padded to a multiple of 128 elements: lane l of a wave owns elements 2l, 2l+1 of each 128-element
     // slice, so no lane of the K7 row loads ever falls outside its row (256 B rows for 125 uint16 bins)
     sp->stride = 128; // ... and to a power of two, so that a row is 256 B, 512 B, 1 KiB or 2 KiB (the K7 row shapes)
     while (sp->stride < (window ? sp->win_len : sp->nb3)) sp->stride *= 2;
-    if (n_bins > SF_FAST_FPFH_BINS) sp->stride = (sp->nb3 + 3) & ~3; // generic kernels: no shape constraint
+    if (n_bins > SF_FAST_FPFH_BINS && !window) sp->stride = (sp->nb3 + 3) & ~3; // generic kernels: no shape constraint
     // room for ceil(n / nranks) rows per rank so the table can be all-gathered in place
     const int64_t nr = ctx->nranks > 0 ? ctx->nranks : 1;
     sp->rows_alloc = std::max<int64_t>(sf_div_up(c->n, nr) * nr, 1);
@@ -1111,7 +1116,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     }
     SF_HIP(hipSetDevice(ctx->device));
     SF_CHECK(sf_cloud_ensure_sorted_normals(ctx, c));
-    if (sp->n_bins > SF_FAST_FPFH_BINS) {
+    if (sp->n_bins > SF_FAST_FPFH_BINS && sp->elem_bytes != 1) {
         if (cov) { sf_set_error("sf_spfh_compute_moments: n_bins=%d has no shared-sweep form (use sf_spfh_compute)", sp->n_bins); return SF_ERR_UNSUPPORTED; }
         const int64_t mg = nb->m;
         if (!mg) return SF_OK;
@@ -1127,7 +1132,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     }
     fpfh_edges ed;
     const int nbn = sp->n_bins;
-    for (int i = 0; i <= SF_FAST_FPFH_BINS; ++i) {
+    for (int i = 0; i <= SF_WIN_FPFH_BINS; ++i) {
         ed.a[i] = edges[i <= nbn ? i : nbn];
         ed.p[i] = edges[(nbn + 1) + (i <= nbn ? i : nbn)];
         ed.t[i] = edges[2 * (nbn + 1) + (i <= nbn ? i : nbn)];
@@ -1175,7 +1180,14 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
               sizeof(CT) == 1 ? sp->live : (unsigned *)nullptr, alpha_bin, nrm_max, fused_packed, fused_b0, fused_b1,   \
               hi_rows, dsp.limit, SELP, NSEL, dsp.view_first, alpha_pair, sizeof(CT) == 1 ? sp->win_lo : 0,                \
               sizeof(CT) == 1 ? sp->win_len : sp->nb3)
-#define SF_SPFH_LAUNCH(NAME, GRID, CT, NCH, SEL, SELP, NSEL)                                                            \
+    // (9 and 11 bins: byte tables with a window only -- instantiated for that element type alone: WIDE = 1)
+#define SF_SPFH_WIDE_1(NAME, GRID, CT, NCH, SEL, SELP, NSEL)                                                            \
+    if (nbn == 9) { SF_SPFH_NB(NAME, GRID, CT, NCH, 9, SEL, SELP, NSEL); }                                              \
+    else if (nbn == 11) { SF_SPFH_NB(NAME, GRID, CT, NCH, 11, SEL, SELP, NSEL); }                                       \
+    else { sf_set_error("sf_spfh_compute: no fast kernel for %d bins", nbn); return SF_ERR_UNSUPPORTED; }
+#define SF_SPFH_WIDE_0(NAME, GRID, CT, NCH, SEL, SELP, NSEL)                                                            \
+    { sf_set_error("sf_spfh_compute: no fast kernel for %d bins on this table", nbn); return SF_ERR_UNSUPPORTED; }
+#define SF_SPFH_LAUNCH(NAME, GRID, CT, NCH, SEL, SELP, NSEL, WIDE)                                                            \
     switch (nbn) { /* every supported bin count gets its own instantiation: no spilled edge table */                   \
     case 1: { SF_SPFH_NB(NAME, GRID, CT, NCH, 1, SEL, SELP, NSEL); } break;                                            \
     case 2: { SF_SPFH_NB(NAME, GRID, CT, NCH, 2, SEL, SELP, NSEL); } break;                                            \
@@ -1184,20 +1196,21 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
     case 5: { SF_SPFH_NB(NAME, GRID, CT, NCH, 5, SEL, SELP, NSEL); } break;                                            \
     case 6: { SF_SPFH_NB(NAME, GRID, CT, NCH, 6, SEL, SELP, NSEL); } break;                                            \
     case 7: { SF_SPFH_NB(NAME, GRID, CT, NCH, 7, SEL, SELP, NSEL); } break;                                            \
-    default: { SF_SPFH_NB(NAME, GRID, CT, NCH, 8, SEL, SELP, NSEL); } break;                                           \
+    case 8: { SF_SPFH_NB(NAME, GRID, CT, NCH, 8, SEL, SELP, NSEL); } break;                                            \
+    default: { SF_SPFH_WIDE_##WIDE(NAME, GRID, CT, NCH, SEL, SELP, NSEL); } break;                                       \
     }
     // the main launch in the register-cached form the bulk of the lists calls for; the few lists that need more chunks in the
     // 4-chunk instantiation of the same form; the points with more than 255 neighbours in the streaming form
-#define SF_SPFH_DISPATCH(CT)                                                                        \
+#define SF_SPFH_DISPATCH(CT, WIDE)                                                                        \
     switch (dsp.chunks) {                                                                           \
-    case 1: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 1, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
-    case 2: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 2, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
-    case 3: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 3, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
-    case 4: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 4, false, (const int32_t *)nullptr, (int64_t)0); } break;                \
-    default: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 0, false, (const int32_t *)nullptr, (int64_t)0); } break;               \
+    case 1: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 1, false, (const int32_t *)nullptr, (int64_t)0, WIDE); } break;                \
+    case 2: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 2, false, (const int32_t *)nullptr, (int64_t)0, WIDE); } break;                \
+    case 3: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 3, false, (const int32_t *)nullptr, (int64_t)0, WIDE); } break;                \
+    case 4: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 4, false, (const int32_t *)nullptr, (int64_t)0, WIDE); } break;                \
+    default: { SF_SPFH_LAUNCH("k6_spfh", grid, CT, 0, false, (const int32_t *)nullptr, (int64_t)0, WIDE); } break;               \
     }                                                                                               \
-    if (dsp.n_mid) { SF_SPFH_LAUNCH("k6_spfh_mid", grid_mid, CT, 4, true, dsp.mid_sel, dsp.n_mid); } \
-    if (dsp.n_tail) { SF_SPFH_LAUNCH("k6_spfh_tail", grid_tail, CT, 0, true, dsp.tail_sel, dsp.n_tail); }
+    if (dsp.n_mid) { SF_SPFH_LAUNCH("k6_spfh_mid", grid_mid, CT, 4, true, dsp.mid_sel, dsp.n_mid, WIDE); } \
+    if (dsp.n_tail) { SF_SPFH_LAUNCH("k6_spfh_tail", grid_tail, CT, 0, true, dsp.tail_sel, dsp.n_tail, WIDE); }
     uint8_t *fused_packed = nullptr;
     int fused_b0 = -1, fused_b1 = -1;
     if (sp->elem_bytes == 1) {
@@ -1217,11 +1230,11 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
             fused_b0 = m8 ? __builtin_ffs((int)m8) - 1 : 0;
             const unsigned rest = m8 & (m8 - 1u);
             fused_b1 = rest ? __builtin_ffs((int)rest) - 1 : (fused_b0 + 1) & 7; // (same pairing as spfh_pack_row)
-            SF_SPFH_DISPATCH(uint8_t)
+            SF_SPFH_DISPATCH(uint8_t, 1)
             return SF_OK;
         }
         if (det) SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_live_or, dim3(1), dim3(1), sp->live, det);
-        SF_SPFH_DISPATCH(uint8_t)
+        SF_SPFH_DISPATCH(uint8_t, 1)
         // rows [self_begin, self_begin + m) are new: pack their live blocks (a no-op on the device when more than two are)
         SF_LAUNCH(ctx, "k6_spfh_pack", k_spfh_pack, dim3((unsigned)sf_div_up(m, 256)), dim3(256), (const uint8_t *)sp->counts,
                   nb->self_begin, nb->self_begin + m, (const unsigned *)sp->live, sp->packed);
@@ -1238,11 +1251,13 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
             sp->host_live_valid = false;
         }
     } else if (sp->elem_bytes == 2) {
-        SF_SPFH_DISPATCH(uint16_t)
+        SF_SPFH_DISPATCH(uint16_t, 0)
     } else {
-        SF_SPFH_DISPATCH(uint32_t)
+        SF_SPFH_DISPATCH(uint32_t, 0)
     }
 #undef SF_SPFH_DISPATCH
+#undef SF_SPFH_WIDE_1
+#undef SF_SPFH_WIDE_0
 #undef SF_SPFH_LAUNCH
 #undef SF_SPFH_NB
     return SF_OK;
@@ -1637,7 +1652,7 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
         dout = owned;
     }
     int rc = SF_OK;
-    if (m && sp->n_bins > SF_FAST_FPFH_BINS) {
+    if (m && sp->n_bins > SF_FAST_FPFH_BINS && sp->elem_bytes != 1) {
         if (m > 2147483000LL) { sf_set_error("sf_fpfh: too many keypoints for one launch"); return SF_ERR_UNSUPPORTED; }
         SF_LAUNCH(ctx, "k7_fpfh", k_fpfh_generic, dim3((unsigned)m), dim3(256), c->rec, nb->offset, nb->count, nb->idx,
                   nb->self_begin, (const int32_t *)pos, m, sp->nb3, sp->stride, (const unsigned *)sp->counts, sp->k, dout);

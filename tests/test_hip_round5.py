@@ -182,9 +182,10 @@ def test_multiscale_matching_through_the_prefilter_equals_the_exact_kernel(eng, 
 
 
 # ---- FPFH with 6, 7, 8 bins on the byte table (a window of the bins) and the matrix cores ---------------------------------------
-@pytest.mark.parametrize("n_bins", [6, 7, 8])
+@pytest.mark.parametrize("n_bins", [6, 7, 8, 9, 11])
 def test_fpfh_six_to_eight_bins_keep_a_window_of_the_bins_in_the_byte_table(eng, O, monkeypatch, n_bins):
-    """radius * max|n|^2 inside the central alpha bin(s): the table keeps 72 / 49 / 128 of the 216 / 343 / 512 bins as bytes
+    """(... and 9 and 11 bins: 81 of 729, 121 of 1331 -- the odd counts whose central alpha bin fits the 128-column row.)
+    radius * max|n|^2 inside the central alpha bin(s): the table keeps 72 / 49 / 128 of the 216 / 343 / 512 bins as bytes
     (sf_spfh_create_for_radius) and K7 runs on the matrix cores.  Against the oracle (SPFH bit-exact), against the 16-bit table
     + vector K7 these bin counts took until round 5 (SF_FPFH_NO_WINDOW=1), sparse-block form == full form, lists above 255
     points (high bytes, the long-list form), keypoints by index and all points, and the sharded job in two blocks."""
@@ -195,8 +196,9 @@ def test_fpfh_six_to_eight_bins_keep_a_window_of_the_bins_in_the_byte_table(eng,
     p, nr, rng = synth_cloud(20000, 40 + n_bins)
     cloud = eng.cloud(p, nr)
     try:
-        assert Spfh(cloud, n_bins, 100, 0.05).elem_bytes == 1 and Spfh(cloud, n_bins, 100).elem_bytes == 2
-        assert Spfh(cloud, n_bins, 100, 0.9).elem_bytes == 2  # (a radius that reaches other alpha bins: no window)
+        wide = 2 if n_bins <= 8 else 4  # (without a window: 16-bit counts up to 8 bins, the generic kernels' 32-bit beyond)
+        assert Spfh(cloud, n_bins, 100, 0.05).elem_bytes == 1 and Spfh(cloud, n_bins, 100).elem_bytes == wide
+        assert Spfh(cloud, n_bins, 100, 0.9).elem_bytes == wide  # (a radius that reaches other alpha bins: no window)
     finally:
         cloud.free()
     for r, nkp in ((0.05, 1500), (0.17, 400)):  # ~10 and ~400 neighbours per ball (lists above 255 points at the second radius)

@@ -6,7 +6,7 @@ from shot_fpfh_amd.engine import Engine
 from shot_fpfh_amd.sharding import DescriptorJob
 eng = Engine()
 pts, nrm = make_cloud(1_000_000, 3)
-for nb in (3, 4, 5, 6, 8, 11):
+for nb in (3, 4, 5, 6, 7, 8, 9, 11, 10):
     job = DescriptorJob(eng, pts, nrm, 0.03, n_bins=nb, normalize=True, min_neighborhood_size=10, do_shot=False)
     for _ in range(3): job.step()
     eng.sync(); eng.profile_reset(); eng.profile(True)
