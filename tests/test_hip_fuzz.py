@@ -92,7 +92,7 @@ def test_fpfh_vs_oracle(eng, O, name, seed):
     p, nr, _, _ = family(name, 3000, rng)
     n = p.shape[0]
     for trial in range(3):
-        n_bins = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 11]))
+        n_bins = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11]))
         r = _radius_for(p, rng, int(rng.choice([12, 40, 120])))
         if name == "lattice":
             r = float(np.sqrt(rng.choice([3, 5, 6])) / 16.0)
