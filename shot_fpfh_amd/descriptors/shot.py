@@ -17,6 +17,7 @@ import numpy as np
 import numpy.typing as npt
 
 from ..core import grid_subsampling
+from ..core.geometry import grid_subsampling_many
 from ..engine import Cloud, Engine, default_engine
 
 __all__ = ["ShotMultiprocessor", "compute_shot_descriptor", "get_azimuth_idx"]
@@ -50,12 +51,13 @@ class ShotMultiprocessor:
             raise AttributeError("ShotMultiprocessor must be used as a context manager (`with ShotMultiprocessor(...) as sm:`)")
         return eng
 
-    def _support_cloud(self, point_cloud, normals, voxel) -> Cloud:
+    def _support_cloud(self, point_cloud, normals, voxel, keep=None) -> Cloud:
         """The support the descriptors are computed on: the whole cloud or its voxel-subsampled subset
-        (shot_parallelization.py:157-166)."""
+        (shot_parallelization.py:157-166).  keep: the subset's indices when the caller has them already."""
         if voxel is None:
             return Cloud(self._eng(), point_cloud, normals)
-        keep = grid_subsampling(np.asarray(point_cloud), voxel, engine=self._eng())
+        if keep is None:
+            keep = grid_subsampling(np.asarray(point_cloud), voxel, engine=self._eng())
         if self.verbose:
             logging.info(
                 f"Keeping a support of {keep.shape[0]} points out of {np.asarray(point_cloud).shape[0]} "
@@ -159,8 +161,11 @@ class ShotMultiprocessor:
         # place in it: a pageable np.empty + one host copy per scale cost 38 of the 87 ms of a two-radius call on 100 000 keypoints)
         stack = self._eng().host_empty((n_scales, m, 352))
         lrf = None
+        # (the supports of all scales at once: their host-side sorts run side by side, core.geometry.grid_subsampling_many)
+        keeps = None if voxel_sizes is None else grid_subsampling_many(np.asarray(point_cloud), list(voxel_sizes)[:n_scales], engine=self._eng())
         for s, radius in enumerate(radii):
-            cloud = self._support_cloud(point_cloud, normals, None if voxel_sizes is None else voxel_sizes[s])
+            cloud = self._support_cloud(point_cloud, normals, None if voxel_sizes is None else voxel_sizes[s],
+                                        None if keeps is None else keeps[s])
             try:
                 nb = cloud.radius_search(keypoints, radius)
                 try:
