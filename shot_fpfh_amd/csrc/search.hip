@@ -1492,6 +1492,29 @@ int sf_cloud_bbox(sf_ctx *ctx, sf_cloud *c, double lo[3], double hi[3]); // grid
 // One round of the large-k path for the selected queries (sel == NULL: all m): count the points within R, and for the
 // queries that have at least k of them write, sort and take.  hstatus[q] = 0 answered / 1 retry with a larger R.
 // Queries are processed in batches whose candidate lists stay within ~1.5e8 entries (3 GB of scratch).
+namespace {
+// [0]: queries not answered yet (status != 0), [1]: of those the crowded ones (status == 2)
+__global__ __launch_bounds__(256) void k_knn_status_counts(const int32_t *__restrict__ status, int64_t m, unsigned *__restrict__ out)
+{
+    unsigned a = 0, b = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = status[i];
+        a += v != 0;
+        b += v == 2;
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(out, a);
+        if (b) atomicAdd(out + 1, b);
+    }
+}
+struct knn_status_is {
+    const int32_t *status;
+    bool crowded_only;
+    __host__ __device__ bool operator()(int32_t q) const { return crowded_only ? status[q] == 2 : status[q] != 0; }
+};
+} // namespace
+
 static int knn_round_large(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const sf_grid_desc &g, const int32_t *sel, int64_t msel, int k,
                            double R2, std::vector<int32_t> &hstatus, const std::vector<int32_t> *sel_host)
 {
@@ -1571,9 +1594,15 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
     if (!(emax > 0.0)) emax = 1.0; // all points coincide: any radius works
     double vol = 1.0;
     for (int a = 0; a < 3; ++a) vol *= std::max(ext[a], 1e-3 * emax);
-    // radius expected to hold ~3.5 k points at the mean density of the bounding box (k_knn4 keeps the points within R in an LDS
-    // list of SF_KNN_CAP entries: at most 0.6 of that on average)
-    const double within_target = k <= 64 ? std::min(3.5 * (double)k, 0.6 * SF_KNN_CAP) : 3.5 * (double)k;
+    // radius expected to hold ~2 k (k <= 64) / ~3.5 k points at the mean density of the bounding box (k_knn4 keeps the points within
+    // R in an LDS list of SF_KNN_CAP entries: at most 0.6 of that on average)
+    // (k <= 64, k_knn4: 2 k, at least k + 6 -- a retry costs little there: the unanswered queries are counted and selected on the
+    // device, and a query crowded at the doubled radius sweeps again inside its bound; `tools/knn_target_ab.py`: 1M queries at
+    // k = 30, search + normals, 2.88 ms wall at 3.5 k against 2.46 at 2 k on the uniform cloud, 3.58 against 3.46 on the surface.
+    // The one-wave-per-query kernel of larger k keeps 3.5 k.)
+    double per_k = k <= 64 ? 2.0 : 3.5;
+    if (const char *e = getenv("SF_KNN_TARGET")) { const double v = atof(e); if (v >= 1.2 && v <= 8.0) per_k = v; } // (experiments)
+    const double within_target = k <= 64 ? std::min(std::max(per_k * (double)k, (double)k + 6.0), 0.6 * SF_KNN_CAP) : per_k * (double)k;
     double R = std::cbrt(within_target * vol / ((double)c->n * 4.18879020478639));
     const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]) + emax * 1e-6 + 1e-300;
     sf_nbrs *nb = new sf_nbrs();
@@ -1634,16 +1663,46 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
     }
     if (!m) return nb;
     sf_pool_guard ktmp(ctx); // status / qsel go back to the pool on every exit of this function
-    int32_t *status = nullptr, *qsel = nullptr;
-    if (ktmp.alloc(&status, (size_t)m) != SF_OK || ktmp.alloc(&qsel, (size_t)m) != SF_OK) return fail();
-    std::vector<int32_t> hstatus((size_t)m), pending;
+    int32_t *status = nullptr, *qsel = nullptr, *qsel2 = nullptr;
+    unsigned *dcounts = nullptr;
+    if (ktmp.alloc(&status, (size_t)m) != SF_OK || ktmp.alloc(&qsel, (size_t)m) != SF_OK || ktmp.alloc(&qsel2, (size_t)m) != SF_OK ||
+        ktmp.alloc(&dcounts, 2) != SF_OK)
+        return fail();
+    std::vector<int32_t> hstatus, pending; // (the count / fill / sort scheme of k > 1984 keeps its bookkeeping on the host)
+    if (large) hstatus.assign((size_t)m, 0);
     int64_t msel = m;
     bool subset = false;
+    void *pinv = nullptr;
+    if (sf_ctx_pinned(ctx, &pinv) != SF_OK) return fail();
+    unsigned *hcounts = (unsigned *)((char *)pinv + SF_PINNED_BYTES - 64);
+    // how many queries are unanswered (status != 0) and how many of them are crowded (status == 2): 8 bytes read back per
+    // round instead of the m status words and a host loop over them (round 5: 3 ms of host time per 1M queries and round)
+    auto count_statuses = [&]() -> int {
+        SF_HIP(hipMemsetAsync(dcounts, 0, 2 * sizeof(unsigned), ctx->stream));
+        SF_LAUNCH(ctx, "k2_knn_status", k_knn_status_counts, dim3(256), dim3(256), (const int32_t *)status, m, dcounts);
+        SF_HIP(hipMemcpyAsync(hcounts, dcounts, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        return SF_OK;
+    };
+    auto select_status = [&](bool crowded_only, int32_t *out) -> int { // the queries with status == 2 / != 0, ascending
+        rocprim::counting_iterator<int32_t> first(0);
+        size_t tb = 0, *dnum = nullptr;
+        sf_pool_guard st(ctx);
+        SF_CHECK(st.alloc(&dnum, 1));
+        const knn_status_is pred{status, crowded_only};
+        SF_HIP(rocprim::select(nullptr, tb, first, out, dnum, (size_t)m, pred, ctx->stream));
+        char *scratch = nullptr;
+        SF_CHECK(st.alloc(&scratch, tb ? tb : 8));
+        sf_launch_timer t_(ctx, "k2_knn_status");
+        SF_HIP(rocprim::select(scratch, tb, first, out, dnum, (size_t)m, pred, ctx->stream));
+        return SF_OK;
+    };
     // Each round answers the queries that have k points within R; the others are retried with R doubled on a coarser
     // grid.  A query far outside the cloud's bounding box (KDTree.query answers those too: ICP feeds it scans that are
     // not yet aligned) stays pending until the grid has shrunk to ONE cell; that round drops the radius test, so every
     // cloud point is a candidate and, k being at most n, every remaining query is answered.
     bool resolved = false;
+    int64_t n_pending = 0;
     for (int round = 0; round < 2200 && !resolved; ++round) { // R doubles: a double overflows long before 2200 rounds
         sf_grid_desc g = sf_make_grid_desc(c);
         const bool one_cell = g.dim[0] == g.xsub && g.dim[1] == 1 && g.dim[2] == 1;
@@ -1654,74 +1713,58 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
             if (knn_round_large(ctx, c, nb, g, sel, msel, k, R2, hstatus, subset ? &pending : nullptr) != SF_OK) {
                 return fail();
             }
-        } else if (k <= 64 && !one_cell && !getenv("SF_KNN_OLD")) {
-            // K2's mapping (k_knn4); the few queries with more than SF_KNN_CAP points within R go to k_knn at the same R
-            const dim3 grid4(sf_xcd_grid(sf_div_up(msel, 4 * SF_K2_WPB))), block4(64 * SF_K2_WPB);
-            {
-                sf_launch_timer t_(ctx, "k2_knn");
-                if (sel) hipLaunchKernelGGL((k_knn4<true>), grid4, block4, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, msel, R2, k, c->perm, nb->idx, status, sel);
-                else hipLaunchKernelGGL((k_knn4<false>), grid4, block4, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, msel, R2, k, c->perm, nb->idx, status, sel);
-            }
-            if (hipGetLastError() != hipSuccess ||
-                hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                sf_set_error("sf_knn_search: launch failed");
-                return fail();
-            }
-            std::vector<int32_t> crowded;
-            if (subset) { for (int32_t i : pending) if (hstatus[(size_t)i] == 2) crowded.push_back(i); }
-            else { for (int64_t i = 0; i < m; ++i) if (hstatus[(size_t)i] == 2) crowded.push_back((int32_t)i); }
-            if (!crowded.empty()) {
-                sf_pool_guard ctmp(ctx);
-                int32_t *csel = nullptr;
-                if (ctmp.alloc(&csel, crowded.size()) != SF_OK ||
-                    hipMemcpyAsync(csel, crowded.data(), crowded.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-                    return fail();
-                {
-                    sf_launch_timer t_(ctx, "k2_knn_crowded");
-                    hipLaunchKernelGGL(k_knn<2>, dim3(sf_xcd_grid((int64_t)crowded.size())), dim3(64), 0, ctx->stream, g, c->cell_start, c->xs, c->ys,
-                                       c->zs, nb->qx, nb->qy, nb->qz, (const int32_t *)csel, (int64_t)crowded.size(), k, R2, c->perm, nb->idx, status);
-                }
-                if (hipGetLastError() != hipSuccess ||
-                    hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                    sf_set_error("sf_knn_search: launch failed");
-                    return fail();
-                }
-            }
+            pending.clear();
+            for (int64_t i = 0; i < m; ++i)
+                if (hstatus[(size_t)i] != 0) pending.push_back((int32_t)i);
+            n_pending = (int64_t)pending.size();
         } else {
-        sf_launch_timer *tm = new sf_launch_timer(ctx, "k2_knn");
+            if (k <= 64 && !one_cell && !getenv("SF_KNN_OLD")) {
+                // K2's mapping (k_knn4); the few queries with more than SF_KNN_CAP points within their bound go to k_knn at the same R
+                const dim3 grid4(sf_xcd_grid(sf_div_up(msel, 4 * SF_K2_WPB))), block4(64 * SF_K2_WPB);
+                {
+                    sf_launch_timer t_(ctx, "k2_knn");
+                    if (sel) hipLaunchKernelGGL((k_knn4<true>), grid4, block4, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, msel, R2, k, c->perm, nb->idx, status, sel);
+                    else hipLaunchKernelGGL((k_knn4<false>), grid4, block4, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, msel, R2, k, c->perm, nb->idx, status, sel);
+                }
+                if (hipGetLastError() != hipSuccess || count_statuses() != SF_OK) { sf_set_error("sf_knn_search: launch failed"); return fail(); }
+                if (hcounts[1]) {
+                    const int64_t nc = hcounts[1];
+                    if (select_status(true, qsel2) != SF_OK) return fail();
+                    sf_launch_timer t_(ctx, "k2_knn_crowded");
+                    hipLaunchKernelGGL(k_knn<2>, dim3(sf_xcd_grid(nc)), dim3(64), 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy,
+                                       nb->qz, (const int32_t *)qsel2, nc, k, R2, c->perm, nb->idx, status);
+                }
+            } else {
+                sf_launch_timer tm(ctx, "k2_knn");
 #define SF_KNN_LAUNCH(EPL) hipLaunchKernelGGL(k_knn<EPL>, grid, block, 0, ctx->stream, g, c->cell_start, c->xs, c->ys, c->zs, nb->qx, nb->qy, nb->qz, sel, msel, k, R2, c->perm, nb->idx, status)
-        if (k <= 64) SF_KNN_LAUNCH(2);         // buffer of 64 * EPL candidates >= k + 64
-        else if (k <= 192) SF_KNN_LAUNCH(4);
-        else if (k <= 448) SF_KNN_LAUNCH(8);
-        else if (k <= 960) SF_KNN_LAUNCH(16);
-        else SF_KNN_LAUNCH(32);
+                if (k <= 64) SF_KNN_LAUNCH(2);         // buffer of 64 * EPL candidates >= k + 64
+                else if (k <= 192) SF_KNN_LAUNCH(4);
+                else if (k <= 448) SF_KNN_LAUNCH(8);
+                else if (k <= 960) SF_KNN_LAUNCH(16);
+                else SF_KNN_LAUNCH(32);
 #undef SF_KNN_LAUNCH
-        delete tm;
-        if (hipGetLastError() != hipSuccess ||
-            hipMemcpyAsync(hstatus.data(), status, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            sf_set_error("sf_knn_search: launch failed");
-            return fail();
+            }
+            if (hipGetLastError() != hipSuccess || count_statuses() != SF_OK) { sf_set_error("sf_knn_search: launch failed"); return fail(); }
+            n_pending = hcounts[0];
         }
-        }
-        pending.clear();
-        for (int64_t i = 0; i < m; ++i)
-            if (hstatus[(size_t)i] != 0) pending.push_back((int32_t)i);
-        if (pending.empty()) { resolved = true; break; }
+        if (!n_pending) { resolved = true; break; }
         if (one_cell) break; // cannot happen for k <= n (reported below)
         R = std::max(2.0 * R, std::min(diag, 1e300) * 1e-6); // sparse regions: retry only the unresolved queries on a coarser grid
-        if (sf_cloud_build_grid(ctx, c, R) != SF_OK ||
-            hipMemcpyAsync(qsel, pending.data(), pending.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            return fail();
+        if (large) {
+            if (sf_cloud_build_grid(ctx, c, R) != SF_OK ||
+                hipMemcpyAsync(qsel, pending.data(), pending.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                return fail();
+        } else {
+            if (select_status(false, qsel2) != SF_OK) return fail(); // (before the grid is rebuilt: stream order keeps it behind the round's kernels)
+            std::swap(qsel, qsel2);
+            if (sf_cloud_build_grid(ctx, c, R) != SF_OK) return fail();
         }
-        msel = (int64_t)pending.size();
+        msel = n_pending;
         subset = true;
     }
     if (!resolved) { // never return lists with unwritten rows
-        sf_set_error("sf_knn_search: internal error, %zu queries unresolved", pending.size());
+        sf_set_error("sf_knn_search: internal error, %lld queries unresolved", (long long)n_pending);
         return fail();
     }
     if (sf_cloud_ensure_inv_perm(ctx, c) != SF_OK) return fail();
