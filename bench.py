@@ -349,7 +349,7 @@ def compact_record(out: dict, detail_path: str | None) -> dict:
     line["config"] = {"workload": cfg.get("workload"), "sharding": cfg.get("sharding"), "library": cfg.get("library"),
                       "exchange": (cfg.get("exchange") or "")[:80]}
     line["roofline"] = _pick(out.get("roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                   "avg_launch_ms", "algorithmic_bytes_per_launch"))
+                                                   "avg_launch_ms", "algorithmic_bytes_per_launch", "valu_issue_frac"))
     cb = out.get("cpu_baseline")
     if cb is not None:
         cb = _pick(cb, ("value", "unit", "cores", "kind", "sample", "sample_wall_seconds"))
@@ -926,6 +926,9 @@ def main() -> int:
                 f"per-launch HBM bytes from separate rocprofv3 --pmc passes on THIS build ({build}), {traffic_src}",
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                # share of the kernel's time its SIMDs spend issuing float64 vector instructions (counters of this build,
+                # roofline_all.k5_shot.valu_issue): what actually bounds the kernel
+                "valu_issue_frac": (roof_all.get(dom) or {}).get("valu_issue", {}).get("ceiling_over_measured"),
                 "note": ("the kernel is float64-VALU-issue bound, not HBM bound (roofline_all.k5_shot.valu_issue); the HBM fraction is "
                          "reported because the contract asks for it") if dom == "k5_shot" else None,
             },

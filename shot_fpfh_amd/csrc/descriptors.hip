@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
                                              const int32_t *__restrict__ qrow,
                                              int64_t m, shot_consts K, double *__restrict__ lrf, int normalize,
                                              int64_t min_nb, double *__restrict__ out, const int32_t *__restrict__ sel,
-                                             int64_t nsel, int64_t view_first)
+                                             int64_t nsel, int64_t view_first, int lo)
 {
     __shared__ __attribute__((aligned(16))) shot_long_lds lds_all[SF_SHOT_LONG_WPB];
     const int lane = threadIdx.x & 63;
@@ -1150,6 +1150,7 @@ __global__ __launch_bounds__(64 * SF_SHOT_LONG_WPB) void k_shot_long(const doubl
     if (q >= m) return;
     const int64_t s = offset[q];
     const int k = sf_uniform(cnt[q]);
+    if (k <= lo) return; // (a list the team form of another launch holds: launch_shot)
     const int64_t row = qrow ? qrow[q] : q;
     double *o = out + (int64_t)SF_SHOT_LEN * row;
     const double px = qx[q], py = qy[q], pz = qz[q];
@@ -1318,6 +1319,222 @@ __global__ __launch_bounds__(64 * SF_SHOT_WPB) void k_shot_cached(const double *
         return;
     }
     shot_cached_body<NCH, FUSED>(rec, qx, qy, qz, offset, cnt, idx, qrow, K, lrf, normalize, min_nb, out, q, slot);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K5 for lists of 256 .. 64 NCH NW points (round 5): a TEAM of waves -- one workgroup -- per keypoint.  The register-cached
+// form's work, spread over waves: a list of n chunks is served by a = ceil(n / NCH) waves (the workgroup's other waves end at
+// once; a barrier waits for the surviving waves only), wave w holding the chunks w, w + a, w + 2a of the list in registers:
+// ONE gather, the geometry evaluated ONCE (the streaming form evaluates it twice, once to elect and once to add, because no
+// single wave can keep 12 registers per chunk for a list of any length), the election tables are the workgroup's.  All three
+// elections (S2.., S1, S9) run in one phase on three key tables; the winners then replace their key by their value (one
+// compare-and-swap claims the slot and stores: duplicated points hold the same key) and the S3/S4 and S6/S7 writers store
+// into a value table of their own (two addends per slot at most: commutative), so the row is the sum of the four tables in a
+// fixed order -- every bit of it independent of how the waves were scheduled and of the team's size.  Four
+// workgroup barriers per keypoint.  LDS: 4 x 352 x 8 B + 256 B = 11.3 KB per team.
+// --------------------------------------------------------------------------------------------------
+#ifndef SF_TEAM_NCH
+#define SF_TEAM_NCH 3 // 70 registers: seven waves per SIMD (tools/ab_long.sh: 2 / 3 / 4 chunks per wave)
+#endif
+struct shot_team_lds {
+    unsigned long long keyA[352], keyB[352], keyG[352]; // keys (rho's bit pattern), then tagged values: S2+S5+S8+S10, S1, S9
+    double vx[352];                                      // S3/S4 + S6/S7 by destination bin (two addends at most: see below)
+    __attribute__((aligned(16))) int red[16][4];         // per wave: gate count and the two sign votes
+};
+
+__device__ inline double shot_untag(unsigned long long x) { return fmax(-__longlong_as_double((long long)x), 0.0); }
+
+template <int NCH, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW) void k_shot_team(const double *__restrict__ rec, const double *__restrict__ qx,
+                                                       const double *__restrict__ qy, const double *__restrict__ qz,
+                                                       const int64_t *__restrict__ offset, const int32_t *__restrict__ cnt,
+                                                       const int32_t *__restrict__ idx, const int32_t *__restrict__ qrow,
+                                                       int64_t m, shot_consts K, double *__restrict__ lrf, int normalize,
+                                                       int64_t min_nb, double *__restrict__ out,
+                                                       const int32_t *__restrict__ sel, int64_t nsel, int64_t view_first,
+                                                       int lo)
+{
+    __shared__ __attribute__((aligned(16))) shot_team_lds L;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t q = sf_xcd_block();
+    if (sel) {
+        if (q >= nsel) return;
+        q = (int64_t)sf_uniform(sel[q]) - view_first;
+        if (q < 0) return;
+    }
+    if (q >= m) return;
+    const int k = sf_uniform(cnt[q]);
+    if (k <= lo || k > 64 * NCH * NW) return; // (another launch's list: launch_shot)
+    const int nact = (((k + 63) >> 6) + NCH - 1) / NCH; // waves that hold a part of this list
+    if (wave >= nact) return;
+    const int nthr = 64 * nact;
+    const int64_t s = offset[q];
+    const int64_t row = qrow ? qrow[q] : q;
+    double *o = out + (int64_t)SF_SHOT_LEN * row;
+    const double px = qx[q], py = qy[q], pz = qz[q];
+    {
+        ulonglong2 *w = reinterpret_cast<ulonglong2 *>(&L);
+        for (int b = threadIdx.x; b < 704; b += nthr) w[b] = make_ulonglong2(0ull, 0ull);
+    }
+    // this wave's chunks of the list: chunk w + a c of the list is its chunk c
+    double cx[NCH], cy[NCH], cz[NCH], nx[NCH], ny[NCH], nz[NCH];
+    unsigned long long onm[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int first = 64 * (wave + nact * c);
+        cx[c] = cy[c] = cz[c] = nx[c] = ny[c] = nz[c] = 0.0;
+        onm[c] = 0ull;
+        if (first < k) { // (wave-uniform)
+            const int t = first + lane;
+            const int j = t < k ? SF_LIST_LOAD(idx + s + t) : -1;
+            double x, y, z;
+            sf_load_pn(rec, j < 0 ? 0 : j, x, y, z, nx[c], ny[c], nz[c]);
+            cx[c] = x - px;
+            cy[c] = y - py;
+            cz[c] = z - pz;
+            const int rem = k - first;
+            onm[c] = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+        }
+    }
+    double raw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int xneg = 0, zneg = 0;
+    if (FUSED) { // (read by every wave of the team before the barriers below, written back by one lane after them)
+        const __attribute__((address_space(4))) double *clr = (const __attribute__((address_space(4))) double *)(lrf + 9 * row);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) raw[i] = clr[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) asm volatile("" : "+s"(raw[i]));
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (onm[c]) {
+                const double xo = sf_dot3(cx[c], cy[c], cz[c], raw[0], raw[3], raw[6]);
+                const double zo = sf_dot3(cx[c], cy[c], cz[c], raw[2], raw[5], raw[8]);
+                xneg += __popcll(__ballot(xo < 0.0) & onm[c]);
+                zneg += __popcll(__ballot(zo < 0.0) & onm[c]);
+            }
+        }
+    }
+    double d2[NCH];
+    unsigned long long posm[NCH];
+    int npos = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        d2[c] = (cx[c] * cx[c] + cy[c] * cy[c]) + cz[c] * cz[c];
+        posm[c] = __ballot(d2[c] > 0.0) & onm[c];
+        npos += __popcll(posm[c]);
+    }
+    if (lane == 0) {
+        L.red[wave][0] = npos;
+        L.red[wave][1] = xneg;
+        L.red[wave][2] = zneg;
+    }
+    __syncthreads(); // the cleared tables, the waves' counts
+    npos = xneg = zneg = 0;
+    for (int w = 0; w < nact; ++w) {
+        const int4 part = *reinterpret_cast<const int4 *>(L.red[w]);
+        npos += sf_uniform(part.x);
+        xneg += sf_uniform(part.y);
+        zneg += sf_uniform(part.z);
+    }
+    double E[9];
+    if (FUSED) {
+        if (shot_finish_frame(raw, k, xneg, zneg, E) && threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) lrf[9 * row + i] = E[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E[i] = lrf[9 * row + i];
+    }
+    if (!(npos > (int)min_nb)) { // (the same for every wave of the team)
+        for (int b = threadIdx.x; b < SF_SHOT_LEN; b += nthr) o[b] = 0.0;
+        return;
+    }
+    constexpr unsigned WON_B = 1u << 26, WON_G = 1u << 27, WON_A = 1u << 28, WON_CD = 1u << 29, WON_EF = 1u << 30;
+    // ---- the three elections ----
+    shot_kept g[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        g[c].bins1 = 0u;
+        if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
+            shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, K.half_r, g[c]);
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            atomicMax(&L.keyA[g[c].bins0 & 511u], key);
+            atomicMax(&L.keyB[(g[c].bins0 >> 9) & 511u], key);
+            atomicMax(&L.keyG[(g[c].bins0 >> 18) & 511u], key);
+        }
+    }
+    __syncthreads();
+    // ---- who writes what: every key is read before the first winner replaces one by its value ----
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            const unsigned iA = g[c].bins0 & 511u;
+            const bool up = iA & 2u, odd = iA & 1u; // (bit 1: z > 0, bit 0: outer shell)
+            const unsigned long long own = L.keyA[iA], other_shell = L.keyA[iA ^ 1u], other_half = L.keyA[iA ^ 2u];
+            unsigned f = 0u;
+            if (own == key) {
+                f = WON_A;
+                if (odd || other_shell == 0ull) f |= WON_CD; // (as in the cached form: shot_cached_body)
+                if (key > other_half || (key == other_half && up)) f |= WON_EF;
+            }
+            if (L.keyB[(g[c].bins0 >> 9) & 511u] == key) f |= WON_B;
+            if (L.keyG[(g[c].bins0 >> 18) & 511u] == key) f |= WON_G;
+            g[c].bins1 |= f;
+        }
+    }
+    __syncthreads();
+    // ---- the winners' values: one claimed writer per slot ----
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
+            const unsigned iA = g[c].bins0 & 511u;
+            double vA, v_cd, v_ef, adth;
+            shot_weights(g[c], K, vA, v_cd, v_ef, adth);
+            const unsigned f = g[c].bins1;
+            if ((f & WON_A) && atomicCAS(&L.keyA[iA], key, tag_value(vA)) == key) {
+                // (a bin receives at most one S3/S4 value -- from the winner of bin ^ 1 -- and one S6/S7 value -- from the winner
+                // of bin ^ 2: two addends into a slot that starts at +0 give the same sum in either order)
+                if ((f & WON_CD) && v_cd != 0.0) unsafeAtomicAdd(&L.vx[iA ^ 1u], v_cd);
+                if ((f & WON_EF) && v_ef != 0.0) unsafeAtomicAdd(&L.vx[iA ^ 2u], v_ef);
+            }
+            if (f & WON_B) atomicCAS(&L.keyB[(g[c].bins0 >> 9) & 511u], key, tag_value(fabs(g[c].dc)));
+            if (f & WON_G) atomicCAS(&L.keyG[(g[c].bins0 >> 18) & 511u], key, tag_value(adth));
+        }
+    }
+    __syncthreads();
+    // ---- the row: wave 0 sums the four tables in a fixed order, takes the norm, scales and stores (the other waves are done:
+    //      with three writers, each repeating the sums and the norm for a third of the stores, the launch took 6 % longer --
+    //      the team is bound by the vector instructions it issues, like the cached form) ----
+    if (wave != 0) return;
+    double2 vals[3];
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int b = 2 * lane + 128 * u;
+        vals[u] = make_double2(0.0, 0.0);
+        if (b < 352) {
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(L.keyA + b);
+            const ulonglong2 bb = *reinterpret_cast<const ulonglong2 *>(L.keyB + b);
+            const ulonglong2 gg = *reinterpret_cast<const ulonglong2 *>(L.keyG + b);
+            const double2 vx = *reinterpret_cast<const double2 *>(L.vx + b);
+            vals[u].x = ((shot_untag(a.x) + vx.x) + shot_untag(bb.x)) + shot_untag(gg.x);
+            vals[u].y = ((shot_untag(a.y) + vx.y) + shot_untag(bb.y)) + shot_untag(gg.y);
+        }
+        ss += vals[u].x * vals[u].x;
+        ss += vals[u].y * vals[u].y;
+    }
+    double nrm, inv_nrm;
+    sf_sqrt_rsqrt_uniform(sf_wave_sum(ss), nrm, inv_nrm);
+    const double scale = nrm > 0.0 ? (normalize ? inv_nrm : 1.0) : 0.0; // shot.py:301-305
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int b = 2 * lane + 128 * u;
+        if (b < 352) sf_store_stream2(o + b, vals[u].x * scale, vals[u].y * scale);
+    }
 }
 
 } // namespace
@@ -1506,20 +1723,43 @@ static int launch_shot(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, double *dlrf, int 
 #define SF_SHOT_CASE(N)                                                                                              \
     if (fused) { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, true>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); } \
     else { SF_LAUNCH(ctx, "k5_shot", (k_shot_cached<N, false>), grid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.limit, (const int32_t *)nullptr, (int64_t)0, (int64_t)0); }
-#define SF_SHOT_STREAM(NAME, SEL, GRID, SELP, NSEL)                                                                   \
-    if (fused) { SF_LAUNCH(ctx, NAME, (k_shot_long<true, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); } \
-    else { SF_LAUNCH(ctx, NAME, (k_shot_long<false, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first); }
+#define SF_SHOT_STREAM(NAME, SEL, GRID, SELP, NSEL, LO)                                                               \
+    if (fused) { SF_LAUNCH(ctx, NAME, (k_shot_long<true, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first, LO); } \
+    else { SF_LAUNCH(ctx, NAME, (k_shot_long<false, SEL>), dim3(sf_xcd_grid(sf_div_up(GRID, SF_SHOT_LONG_WPB))), block_streaming, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, SELP, NSEL, d.view_first, LO); }
+    // the team form (k_shot_team): one workgroup of NW waves per selected keypoint, lists of 256 .. 64 NCH NW points
+#define SF_SHOT_TEAM(NCH, NW)                                                                                         \
+    if (fused) { SF_LAUNCH(ctx, "k5_shot_tail", (k_shot_team<NCH, NW, true>), dim3(sf_xcd_grid(d.n_tail)), dim3(64 * NW), SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.tail_sel, d.n_tail, d.view_first, 255); } \
+    else { SF_LAUNCH(ctx, "k5_shot_tail", (k_shot_team<NCH, NW, false>), dim3(sf_xcd_grid(d.n_tail)), dim3(64 * NW), SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, d.tail_sel, d.n_tail, d.view_first, 255); }
     if (d.chunks == 1) { SF_SHOT_CASE(1) }
     else if (d.chunks == 2) { SF_SHOT_CASE(2) }
     else if (d.chunks == 3) { SF_SHOT_CASE(3) }
     else if (d.chunks == 4) { SF_SHOT_CASE(4) }
-    else { SF_SHOT_STREAM("k5_shot", false, m, (const int32_t *)nullptr, (int64_t)0) }
+    else { SF_SHOT_STREAM("k5_shot", false, m, (const int32_t *)nullptr, (int64_t)0, 0) }
     if (d.n_mid) { // the few lists that need more chunks than the bulk: the same form, four chunks
         const dim3 grid_mid(sf_xcd_grid(sf_div_up(d.n_mid, SF_SHOT_WPB)));
         if (fused) { SF_LAUNCH(ctx, "k5_shot_mid", (k_shot_cached<4, true>), grid_mid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, 255, d.mid_sel, d.n_mid, d.view_first); }
         else { SF_LAUNCH(ctx, "k5_shot_mid", (k_shot_cached<4, false>), grid_mid, block, SF_SHOT_ARGS, K, dlrf, normalize, min_nb, dout, 255, d.mid_sel, d.n_mid, d.view_first); }
     }
-    if (d.n_tail) { SF_SHOT_STREAM("k5_shot_tail", true, d.n_tail, d.tail_sel, d.n_tail) }
+    if (d.n_tail) {
+        // Lists above 255 points: a team of waves per keypoint while the list fits the team's registers (the longest list of
+        // the search decides which team sizes are launched at all; every launch walks the selection and takes its own lengths),
+        // the streaming form beyond.  SF_SHOT_NO_TEAM=1: the streaming form for all of them (A/B, tools/ab_long.sh).
+        // team size: the smallest that holds the longest list of the search (a shorter list uses as many of the team's waves as
+        // it needs); SF_SHOT_NO_TEAM=1: the streaming form for every long list (A/B)
+        const bool no_team = getenv("SF_SHOT_NO_TEAM") != nullptr;
+        const int64_t longest = nb->max_count > 255 ? nb->max_count : INT64_MAX; // (unknown: every form is launched)
+        if (no_team) {
+            SF_SHOT_STREAM("k5_shot_tail", true, d.n_tail, d.tail_sel, d.n_tail, 0)
+        } else {
+            constexpr int TN = SF_TEAM_NCH; // chunks a wave of the team holds
+            int64_t covered;
+            if (longest <= 64 * TN * 4) { SF_SHOT_TEAM(TN, 4) covered = 64 * TN * 4; }
+            else if (longest <= 64 * TN * 8) { SF_SHOT_TEAM(TN, 8) covered = 64 * TN * 8; }
+            else { SF_SHOT_TEAM(TN, 16) covered = 64 * TN * 16; }
+            if (longest > covered) { SF_SHOT_STREAM("k5_shot_tail_stream", true, d.n_tail, d.tail_sel, d.n_tail, (int)covered) }
+        }
+    }
+#undef SF_SHOT_TEAM
 #undef SF_SHOT_STREAM
 #undef SF_SHOT_CASE
 #undef SF_SHOT_ARGS

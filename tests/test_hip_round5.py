@@ -323,3 +323,61 @@ def test_step_replayed_as_a_hip_graph_gives_the_same_rows(eng, mode):
         assert np.array_equal(job.fpfh_out.to_host(), f0) and np.array_equal(job.shot_out.to_host(), s0)
     finally:
         job.close()
+
+
+def _shot_launches(eng, fn):
+    eng.profile_reset()
+    eng.profile(True)
+    try:
+        out = fn()
+    finally:
+        eng.profile(False)
+    return out, {k: v[0] for k, v in eng.profile_report().items() if v[0]}
+
+
+@pytest.mark.parametrize("mean_k", [380, 800, 1500, 3300])
+def test_k5_team_of_waves_for_long_lists(eng, O, monkeypatch, mean_k):
+    """K5 for lists above 255 points: a team of waves per keypoint holds the list in registers (k_shot_team: three chunks per
+    wave, as many waves as the list needs out of a workgroup of 4 / 8 / 16 -- lists up to 768 / 1 536 / 3 072 points), the
+    streaming form takes what is longer.  Rows against the oracle at every boundary of the wave count, bit-identical from run
+    to run (one writer per slot, fixed order of the five tables), and against the streaming form (SF_SHOT_NO_TEAM=1), which
+    adds the same values in list order."""
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    n = 14000
+    p, nr, _ = synth_cloud(n, 60 + mean_k)
+    p = p.astype(np.float64)
+    ext = p.max(0) - p.min(0)
+    r = float((mean_k * ext.prod() / n / (4.0 / 3.0 * np.pi)) ** (1.0 / 3.0)) * 1.08  # (+ the share of a ball outside the cloud)
+    cloud = eng.cloud(p)
+    nb = cloud.radius_search_self(r)
+    cnt = nb.counts()[np.argsort(cloud.perm())]
+    nb.free()
+    cloud.free()
+    assert cnt.max() > mean_k and cnt.max() > 256, cnt.max()
+    order = np.argsort(cnt)
+    picks = [order[-25:], order[:5], np.random.default_rng(mean_k).choice(n, 40, replace=False)]
+    for edge in (255, 256, 257, 320, 384, 385, 576, 577, 767, 768, 769, 960, 1152, 1153, 1535, 1536, 1537, 2048, 3071, 3072, 3073):
+        lo = np.searchsorted(cnt[order], edge)
+        picks.append(order[max(lo - 2, 0):lo + 3])
+    kp = np.unique(np.concatenate(picks))
+    monkeypatch.delenv("SF_SHOT_NO_TEAM", raising=False)
+    rows = {}
+    for normalize, min_nb in ((True, 100), (False, 300)):
+        with ShotMultiprocessor(min_neighborhood_size=min_nb, normalize=normalize, verbose=False) as sm:
+            # every point a keypoint: the search plans its launches, the long lists are a selection of their own
+            full, rep = _shot_launches(eng, lambda: sm.compute_descriptor_single_scale(p, nr, p, r))
+            again = sm.compute_descriptor_single_scale(p, nr, p, r)
+        assert np.array_equal(full, again)
+        assert rep.get("k5_shot_tail") == 1, rep
+        assert ("k5_shot_tail_stream" in rep) == (cnt.max() > 3072), (rep, cnt.max())
+        want = O.shot_single_scale(p, nr, p[kp], r, normalize, min_nb)
+        assert np.abs(full[kp] - want).max() < 1e-9, (normalize, np.abs(full[kp] - want).max())
+        assert (np.abs(want).sum(1) > 0).sum() > kp.size // 2  # (the gate lets the long lists through)
+        rows[normalize] = full
+    monkeypatch.setenv("SF_SHOT_NO_TEAM", "1")
+    with ShotMultiprocessor(min_neighborhood_size=100, normalize=True, verbose=False) as sm:
+        stream, rep = _shot_launches(eng, lambda: sm.compute_descriptor_single_scale(p, nr, p, r))
+    monkeypatch.delenv("SF_SHOT_NO_TEAM", raising=False)
+    assert "k5_shot_tail_stream" not in rep and rep.get("k5_shot_tail") == 1, rep
+    assert np.abs(stream - rows[True]).max() < 1e-13, np.abs(stream - rows[True]).max()

@@ -38,7 +38,7 @@ SHORT = [
 SHORT_RE = [
     (r"radix_sort", "rocprim_radix_sort"), (r"k_radius<2, ", "k2_radius_slots"), (r"k_radius<1, true>", "k2_radius_refill"), (r"k_radius<1, false>", "k2_radius_fill"),
     (r"k_radius<0, true>", "k2_sample"), (r"k_radius<0, false>", "k2_radius_count"), (r"k_iota_stride", "k2_sample"),
-    (r"k_patch_offsets", "k2_select"), (r"select|partition", "rocprim_select"), (r"k_shot_long", "k5_shot_tail"), (r"k_fpfh_mcl", "k7_fpfh_tail"),
+    (r"k_patch_offsets", "k2_select"), (r"select|partition", "rocprim_select"), (r"k_shot_long|k_shot_team", "k5_shot_tail"), (r"k_fpfh_mcl", "k7_fpfh_tail"),
     (r"k_fpfh_tail", "k7_fpfh_tail"), (r"k_spfh<[^>]*, true>", "k6_spfh_tail"), (r"k_pca_cov<0, true>", "k3_normals_tail"),
     (r"k_cell_fill_long", "k1_cell_start"), (r"k_cell_count", "k1_cell_count"), (r"k_cell_scan", "k1_cell_scan"), (r"k_cell_place", "k1_cell_place"),
     (r"k_cell_settle", "k1_cell_settle"),

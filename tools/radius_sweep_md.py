@@ -33,7 +33,7 @@ for ln in open(radii):
     k = ast.literal_eval(m.group(5))
     k2 = sum(v for n, v in k.items() if n.startswith("k2_"))
     out.append(f"| {m.group(1)} | {m.group(2)} | {float(m.group(3)):.2f} | {m.group(4)} | {k2:.2f} | {pair(k, 'k6_spfh', 'k6_spfh_tail', 'k6_spfh_mid')} | "
-               f"{pair(k, 'k7_fpfh', 'k7_fpfh_tail', 'k7_fpfh_mid')} | {pair(k, 'k5_shot', 'k5_shot_tail', 'k5_shot_mid')} |")
+               f"{pair(k, 'k7_fpfh', 'k7_fpfh_tail', 'k7_fpfh_mid')} | {pair(k, 'k5_shot', 'k5_shot_tail', 'k5_shot_tail_stream', 'k5_shot_mid')} |")
 out += ["", "`python tools/bench_nbins.py` -- FPFH alone, radius 0.03, by bin count (ms per step; K6 + K7):", "",
         "| n_bins | bins | ms / step | K6 (+ pack) | K7 |", "|---|---|---|---|---|"]
 for ln in open(nbins):
