@@ -365,7 +365,11 @@ __global__ __launch_bounds__(512, 1) void k_match_half(const _Float16 *__restric
 #undef SF_H_FRAG
 }
 
-// Step 3: the reference's arithmetic on the surviving candidates (one lane per row; scipy's loop order).
+// Step 3: the reference's arithmetic on the surviving candidates (scipy's loop order: every distance is one lane's sequential
+// sum).  LPR lanes share a scan row -- lane u takes the candidates u, u + LPR, ... of every split's list -- and fold their
+// (distance, column) pairs with the reference's tie rule (smaller column); with one lane per row a launch of 10^4 rows is 40
+// workgroups of serial 352-term sums.
+template <int LPR>
 __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const double *__restrict__ b, int64_t d,
                              const unsigned char *__restrict__ a_ok, const int *__restrict__ cnt,
                              const int32_t *__restrict__ cand_j, const float *__restrict__ cand_k,
@@ -374,12 +378,16 @@ __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const dou
                              int64_t *__restrict__ idx,
                              double *__restrict__ dist, int *__restrict__ flag, int *__restrict__ n_flagged)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m1) return;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (i >= m1) return; // (whole groups of LPR lanes: LPR divides the wave)
     if (a_ok && !a_ok[i]) { // masked scan row: +inf from everything, first column (shotfpfh.h, sf_match_argmin_multiscale)
-        idx[i] = 0;
-        if (dist) dist[i] = INFINITY;
-        flag[i] = 0;
+        if (sub == 0) {
+            idx[i] = 0;
+            if (dist) dist[i] = INFINITY;
+            flag[i] = 0;
+        }
         return;
     }
     // final threshold: the smallest over the column splits (each = that split's smallest key + W_i)
@@ -400,7 +408,7 @@ __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const dou
         for (int s = 0; s < nsplit; ++s) {
             const int64_t base = ((int64_t)s * m1_pad + i) * HCAP;
             const int n = min(cnt[(int64_t)s * m1_pad + i], HCAP);
-            for (int c = 0; c < n; ++c) {
+            for (int c = sub; c < n; c += LPR) {
                 if (!(cand_k[base + c] <= t)) continue;
                 const int64_t j = cand_j[base + c];
                 const double *bjp = b + j * d;
@@ -421,6 +429,18 @@ __global__ void k_half_final(const double *__restrict__ a, int64_t m1, const dou
             }
         }
     }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) { // (minimum with the smaller column on ties: the order of the fold does not matter)
+        const double ob = __shfl_xor(best, off);
+        const int64_t oj = __shfl_xor(bj, off);
+        const int om = __shfl_xor((int)model_ok, off);
+        if (oj >= 0 && (bj < 0 || ob < best || (ob == best && oj < bj))) {
+            best = ob;
+            bj = oj;
+        }
+        model_ok = model_ok && om;
+    }
+    if (sub != 0) return;
     const bool decided = bj >= 0 && model_ok;
     idx[i] = decided ? bj : 0;
     if (dist) dist[i] = best;
@@ -566,10 +586,16 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
                       ms, (const _Float16 *)bh, m2p, (const float *)nbf, (const float *)win, tiles_per_split, msp, row_blocks, nsplit,
                       seed ? tbest : (float *)nullptr, cnt, candj, candk, thr);
         }
-        SF_LAUNCH(ctx, "k8_half_final", k_half_final, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), da + r0 * d, ms, db, d,
-                  a_ok ? a_ok + r0 : a_ok, (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr,
-                  (const float *)win, (const double *)(na2 + r0), unit, (int)nsplit, msp, didx + r0, ddist ? ddist + r0 : ddist,
+#define SF_HALF_FINAL(LPR)                                                                                            \
+        SF_LAUNCH(ctx, "k8_half_final", k_half_final<LPR>, dim3((unsigned)sf_div_up(ms * LPR, 256)), dim3(256), da + r0 * d, ms, db, d, \
+                  a_ok ? a_ok + r0 : a_ok, (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, \
+                  (const float *)win, (const double *)(na2 + r0), unit, (int)nsplit, msp, didx + r0, ddist ? ddist + r0 : ddist, \
                   flag + r0, nflag);
+        static const int lpr_env = [] { const char *e = getenv("SF_MATCH_FINAL_LPR"); return e ? atoi(e) : 0; }(); // (A/B)
+        // (10^4 rows: 1.53 / 0.48 / 0.26 ms with 1 / 4 / 16 lanes per row; 262 144 rows: 3.9 / 4.5 / 5.5 ms -- the chip is full with one)
+        const int lpr = lpr_env ? lpr_env : (ms <= 65536 ? 16 : 1);
+        if (lpr == 1) { SF_HALF_FINAL(1) } else if (lpr == 4) { SF_HALF_FINAL(4) } else { SF_HALF_FINAL(16) }
+#undef SF_HALF_FINAL
     }
     int nf = 0;
     SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -75,7 +75,7 @@ def test_hot_kernels_do_not_spill():
                 res[cur][m.group(1).strip()] = int(m.group(2))
     assert len(res) > 100
     names = subprocess.run(["c++filt", *res], capture_output=True, text=True).stdout.splitlines()
-    hot = re.compile(r"k_shot_cached<|k_fpfh_mc<|k_fpfh_mc_sparse<|k_radius<|k_radius_cov|k_spfh<unsigned char, [123], |k_lrf_from_cov|"
+    hot = re.compile(r"k_shot_cached<|k_shot_team<|k_fpfh_mcl<|k_knn4<|k_fpfh_mc<|k_fpfh_mc_sparse<|k_radius<|k_radius_cov|k_spfh<unsigned char, [123], |k_lrf_from_cov|"
                      r"k_cell_(count|scan|place|settle)|k_pca_cov<|k_count_stats")
     seen_hot = 0
     for (_, r), name in zip(res.items(), names):
