@@ -110,7 +110,7 @@ class _PinnedPool:
     including inside `array()` of the same thread.  The finalizer therefore takes no lock at all: it appends to a deque
     (atomic in CPython), and `array()` / `trim()` move the returned blocks into the free list under the lock."""
 
-    THRESHOLD = 32 << 20      # smaller results use ordinary NumPy memory
+    THRESHOLD = int(float(os.environ.get("SF_PINNED_THRESHOLD_MB", "32")) * (1 << 20))  # smaller results use ordinary NumPy memory
     KEEP_BYTES = 4 << 30      # cached (unused) blocks beyond this are unpinned; Engine.trim_host_cache() drops them all
 
     def __init__(self, lib, ctx):
