@@ -375,6 +375,14 @@ def test_k5_team_of_waves_for_long_lists(eng, O, monkeypatch, mean_k):
         assert np.abs(full[kp] - want).max() < 1e-9, (normalize, np.abs(full[kp] - want).max())
         assert (np.abs(want).sum(1) > 0).sum() > kp.size // 2  # (the gate lets the long lists through)
         rows[normalize] = full
+    # frames computed first, descriptors from given frames (sf_shot_lrf + sf_shot: the team form without the fused sign votes)
+    cloud = eng.cloud(p, nr)
+    nb = cloud.radius_search(p[kp], r)
+    lrf = nb.shot_lrf()
+    unfused = nb.shot(lrf, True, 100)
+    nb.free()
+    cloud.free()
+    assert np.abs(unfused - rows[True][kp]).max() < 1e-13, np.abs(unfused - rows[True][kp]).max()
     monkeypatch.setenv("SF_SHOT_NO_TEAM", "1")
     with ShotMultiprocessor(min_neighborhood_size=100, normalize=True, verbose=False) as sm:
         stream, rep = _shot_launches(eng, lambda: sm.compute_descriptor_single_scale(p, nr, p, r))
