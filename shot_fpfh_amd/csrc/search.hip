@@ -1104,10 +1104,10 @@ static int plan_dispatch(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
         int64_t within = 0;
         for (int c = 0; c < need; ++c) {
             within += nb->hist[c];
-            // (the FOUR-chunk instantiations run at five waves per SIMD instead of seven: when up to an eighth of the lists
-            // need the fourth chunk it still pays to keep them out of the bulk -- clustered cloud 5.08 -> 4.93 ms, uniform cloud
-            // at 174 neighbours 5.17 -> 5.10; with most lists there, 213 neighbours, 6.06 -> 6.73)
-            const int64_t share = (c + 1 == 3 && need == 4) ? 8 : 50;
+            // (the FOUR-chunk instantiations run at five waves per SIMD instead of seven: when up to a fifth of the lists
+            // need the fourth chunk it still pays to keep them out of the bulk -- clustered cloud, 13 % of them: 5.08 -> 4.93 ms;
+            // uniform cloud at 159 / 174 / 181 neighbours, 3 / 17 / 30 %: 5.04 -> 4.92, 5.17 -> 5.10, 5.52 -> 5.56)
+            const int64_t share = (c + 1 == 3 && need == 4) ? 5 : 50;
             if ((fit - within) * share <= fit) { chunks = c + 1; break; }
         }
         if (getenv("SF_NO_MID_LAUNCH")) chunks = need;
