@@ -505,9 +505,14 @@ def fold_checksums(parts: list) -> dict:
     return {k: format(sum(p[k] for p in parts) % 2**64, "016x") for k in parts[0]}
 
 
+COUNTERS_APPLY = True  # (main(): False for a workload other than the one the counter passes ran -- 1M points per GPU, radius 0.03)
+
+
 def load_stamped(name: str, build: str):
     """A measurement kept under profiles/ (HBM traffic per launch, SQ counters) -- but only if it was taken on the very
-    build that is loaded now (tools/parse_rocprof.py stamps the file with sf_version())."""
+    build that is loaded now (tools/parse_rocprof.py stamps the file with sf_version()) and on this workload."""
+    if not COUNTERS_APPLY:
+        return None, f"profiles/{name} holds counters of the default workload (1M points per GPU, radius 0.03): not quoted for this one"
     path = os.path.join(ROOT, "profiles", name)
     try:
         d = json.load(open(path))
@@ -655,6 +660,8 @@ def main() -> int:
                     help="single process, no rendezvous: run rank R's share of a --gpus N descriptor pass on this GPU (the rows "
                          "the adjacent ranks would send are computed once beforehand; the exchange call itself is skipped)")
     args = ap.parse_args()
+    global COUNTERS_APPLY
+    COUNTERS_APPLY = args.points_per_gpu == 1_000_000 and abs(args.radius - 0.03) < 1e-12
 
     emulated = args.emulate_rank is not None
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not emulated:
