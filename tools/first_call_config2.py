@@ -1,5 +1,10 @@
+"""First calls of a process and the steady state of BASELINE config 2 as written (100k points, 10k keypoints, r = 0.05:
+compute_fpfh_descriptor + ShotMultiprocessor.compute_descriptor_single_scale), with the results of the last two rounds kept
+alive as a caller would.  SF_PINNED_THRESHOLD_MB sets the size from which results live in page-locked memory (default 32).
+python tools/first_call_config2.py"""
 import sys, time, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import synth_cloud
 import shot_fpfh_amd as s
