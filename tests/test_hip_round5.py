@@ -389,3 +389,54 @@ def test_k5_team_of_waves_for_long_lists(eng, O, monkeypatch, mean_k):
     monkeypatch.delenv("SF_SHOT_NO_TEAM", raising=False)
     assert "k5_shot_tail_stream" not in rep and rep.get("k5_shot_tail") == 1, rep
     assert np.abs(stream - rows[True]).max() < 1e-13, np.abs(stream - rows[True]).max()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+def test_point_order_leaves_every_row_unchanged_at_full_size(eng, kind):
+    """BASELINE config 3 at full size, all 2 x 10^6 rows (the oracle checks 300 of each, test_hip_round2.py): the same cloud
+    handed over with its points in another order.  The cell-sorted positions of the points of a cell, every neighbour list's
+    order and which lane holds which neighbour all change; no descriptor may.  FPFH rows are sums of integers and of
+    fixed-point weights: bit-identical (the clustered cloud's long neighbours add their high bytes in float64, in list order:
+    1e-12 there).  SHOT rows add their (at most five) contributions per bin in list order, and the frame's moments are float64
+    sums in list order: 1e-12.  The clustered cloud (the bench's: 13 % of its lists above 255 points) takes every second
+    launch -- K5's team form, K7's long form, the high-byte rows."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    n = 1_000_000
+    if kind == "uniform":
+        r = 0.03
+        p, nr, rng = synth_cloud(n, 3)
+    else:
+        r = 0.004454284480470688  # (tools/bench_density.py: the radius that gives this cloud the headline's 110 neighbours)
+        rng = np.random.default_rng(3)
+        p, nr, _, _ = family("clustered", n, rng)
+    shuffle = rng.permutation(n)
+    a = DescriptorJob(eng, p, nr, r, n_bins=5, normalize=True, min_neighborhood_size=10)
+    b = DescriptorJob(eng, p[shuffle], nr[shuffle], r, n_bins=5, normalize=True, min_neighborhood_size=10)
+    try:
+        a.step()
+        b.step()
+        assert a.last_pairs == b.last_pairs
+        where_a = np.empty(n, np.int64)  # row of job a's outputs that belongs to point i
+        where_a[a.block_original_indices()] = np.arange(n)
+        point_b = shuffle[b.block_original_indices()]  # point (numbering of the cloud as given) of job b's row j
+        fa = a.fpfh_out.to_host()
+        worst_f = worst_s = 0.0
+        nonzero = 0
+        for j0 in range(0, n, 125_000):
+            rows = where_a[point_b[j0:j0 + 125_000]]
+            fb = b.fpfh_out.rows_to_host(j0, min(125_000, n - j0))
+            worst_f = max(worst_f, float(np.abs(fb - fa[rows]).max()))
+        del fa
+        sa = a.shot_out.to_host()
+        for j0 in range(0, n, 125_000):
+            rows = where_a[point_b[j0:j0 + 125_000]]
+            sb = b.shot_out.rows_to_host(j0, min(125_000, n - j0))
+            worst_s = max(worst_s, float(np.abs(sb - sa[rows]).max()))
+            nonzero += int(np.any(sb, axis=1).sum())
+        assert worst_f == 0.0 if kind == "uniform" else worst_f < 1e-12, worst_f
+        assert worst_s < 1e-12, worst_s
+        assert nonzero > (0.99 if kind == "uniform" else 0.5) * n
+    finally:
+        a.close()
+        b.close()
