@@ -440,3 +440,67 @@ def test_point_order_leaves_every_row_unchanged_at_full_size(eng, kind):
     finally:
         a.close()
         b.close()
+
+
+def _rows_by_point(job, arr, n):
+    where = np.empty(n, np.int64)
+    where[job.block_original_indices()] = np.arange(n)
+    return arr.to_host()[where]
+
+
+@pytest.mark.parametrize("with_fpfh", [True, False])
+def test_a_power_of_two_scale_changes_no_bit_of_a_shot_row_at_full_size(eng, with_fpfh):
+    """BASELINE config 3 at full size, every row: coordinates and radius multiplied by 4 (exact in floating point).  Every
+    decision of SHOT is a comparison of quantities that scale together -- distances against the radius and its half, the
+    frame's votes, the bins from ratios -- and every weight is a ratio, so all 10^6 frames and rows must come out bit for bit:
+    no absolute threshold anywhere on the path.  (FPFH is not scale-invariant in the reference either: its weights are 1 / d
+    and alpha = ((p_j - p_i) x n_i) . n_j is not normalised, fpfh.py:60.)"""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    n, r = 1_000_000, 0.03
+    p, nr, _ = synth_cloud(n, 3)
+    out = []
+    for scale in (1.0, 4.0):
+        # (with FPFH the frames' moments come out of K6's sweep and K5 is fused; without, k_shot_lrf forms them)
+        job = DescriptorJob(eng, scale * p, nr, scale * r, n_bins=5, normalize=True, min_neighborhood_size=10, do_fpfh=with_fpfh)
+        job.step()
+        out.append((_rows_by_point(job, job.lrf_out, n), _rows_by_point(job, job.shot_out, n), job.last_pairs))
+        job.close()
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.any(out[0][1], axis=1).mean() > 0.99
+
+
+def test_rigid_motion_of_the_cloud_at_full_size(eng):
+    """BASELINE config 3 at full size, every row: the cloud and its normals rotated and translated.  FPFH is built from angles
+    and distances: all 10^6 rows within 1e-9.  SHOT's frame is defined up to the signs its votes settle (shot.py:40-45) --
+    a tied vote, 7 % of the lists of 110 points per axis, keeps the sign the eigen-solver returned, in the reference too --
+    so: every frame equals the rotated frame up to the signs of its columns, and wherever the signs agree the rows agree."""
+    from shot_fpfh_amd.sharding import DescriptorJob
+
+    n, r = 1_000_000, 0.03
+    p, nr, rng = synth_cloud(n, 3)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    t = rng.standard_normal(3)
+    out = []
+    for pp, nn in ((p, nr), (p @ q.T + t, nr @ q.T)):
+        job = DescriptorJob(eng, pp, nn, r, n_bins=5, normalize=True, min_neighborhood_size=10)
+        job.step()
+        out.append((_rows_by_point(job, job.fpfh_out, n), _rows_by_point(job, job.lrf_out, n).reshape(n, 3, 3),
+                    _rows_by_point(job, job.shot_out, n), job.last_pairs))
+        job.close()
+    (fa, ea, sa, pa), (fb, eb, sb, pb) = out
+    assert pa == pb  # (no pair at a distance within rounding of the radius)
+    assert np.abs(fb - fa).max() < 1e-9, np.abs(fb - fa).max()
+    # columns of a frame are its axes x, y, z: (Q E_a)^T E_b must be diag(+-1)
+    c = np.einsum("nij,nik->njk", q @ ea, eb)
+    diag = np.stack([c[:, 0, 0], c[:, 1, 1], c[:, 2, 2]], axis=1)
+    assert (np.abs(np.abs(diag) - 1.0) < 1e-6).all(axis=1).mean() > 0.9999  # (the rest: two eigenvalues within rounding of each other)
+    same = (diag > 0.999999).all(axis=1)
+    assert same.mean() > 0.8, same.mean()
+    err = np.abs(sb - sa).max(axis=1)
+    # (a neighbour within rounding of a bin boundary may change bins under the rotation: a handful of rows in 10^6)
+    assert (err[same] > 1e-9).sum() <= 20, ((err[same] > 1e-9).sum(), err[same].max())
