@@ -504,3 +504,48 @@ def test_rigid_motion_of_the_cloud_at_full_size(eng):
     err = np.abs(sb - sa).max(axis=1)
     # (a neighbour within rounding of a bin boundary may change bins under the rotation: a handful of rows in 10^6)
     assert (err[same] > 1e-9).sum() <= 20, ((err[same] > 1e-9).sum(), err[same].max())
+
+
+def test_radius_search_is_symmetric_at_full_size(eng):
+    """K2 at BASELINE config 3's size, all 110 M pairs: j is in the list of i exactly when i is in the list of j (the squared
+    distance is the same float64 either way, so an asymmetric pair is a candidate a sweep missed or one it invented), every
+    point is in its own list, lists are ascending and duplicate-free."""
+    n, r = 1_000_000, 0.03
+    p, _, _ = synth_cloud(n, 3)
+    cloud = eng.cloud(p)
+    nb = cloud.radius_search(p, r)
+    off, idx = nb.export()
+    nb.free()
+    cloud.free()
+    cnt = np.diff(off)
+    assert off[-1] == idx.size and 100 < idx.size / n < 120
+    rows = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    fwd = rows * n + idx
+    assert (np.diff(fwd) > 0).all()  # ascending inside a list, no duplicates
+    assert int((rows == idx).sum()) == n
+    bwd = idx.astype(np.int64) * n + rows
+    del rows, idx
+    bwd.sort()
+    assert np.array_equal(fwd, bwd)
+
+
+def test_knn_lists_agree_with_the_radius_search_at_full_size(eng):
+    """k-NN (k = 30, the CLI's default for normals) for all 10^6 points of config 3's cloud against K2, an independent kernel:
+    the k nearest points hold every point within r0 when there are at most k of them, and only such points otherwise --
+    #{entries with d <= r0} == min(#{points within r0}, k) for every query; the point itself is in its list."""
+    n, k, r0 = 1_000_000, 30, 0.02
+    p, _, _ = synth_cloud(n, 3)
+    cloud = eng.cloud(p)
+    nbk = cloud.knn_search(p, k)
+    off, idx, dist = nbk.export(True)
+    nbk.free()
+    nb = cloud.radius_search(p, r0)
+    within = nb.counts()
+    nb.free()
+    cloud.free()
+    assert np.array_equal(np.diff(off), np.full(n, k))
+    dist, idx = dist.reshape(n, k), idx.reshape(n, k)
+    assert (np.diff(idx, axis=1) > 0).all()  # (the export's canonical form: ascending indices, no duplicates)
+    assert ((idx == np.arange(n)[:, None]) & (dist == 0)).any(axis=1).all()  # the point itself, at distance 0
+    assert 0.2 < (within < k).mean() < 0.8  # (both cases of the minimum are exercised)
+    assert np.array_equal((dist <= r0).sum(axis=1), np.minimum(within, k))
