@@ -549,3 +549,53 @@ def test_knn_lists_agree_with_the_radius_search_at_full_size(eng):
     assert ((idx == np.arange(n)[:, None]) & (dist == 0)).any(axis=1).all()  # the point itself, at distance 0
     assert 0.2 < (within < k).mean() < 0.8  # (both cases of the minimum are exercised)
     assert np.array_equal((dist <= r0).sum(axis=1), np.minimum(within, k))
+
+
+def test_ransac_scores_at_full_size(eng, O):
+    """K9 at BASELINE config 4's size -- 10^4 candidate transforms x 10^6 matches in one launch: the inlier counts of 32 draws
+    spread over the launch (and of the best one) equal the oracle's, count for count; an infinite threshold counts every
+    match for every draw, a negative one none."""
+    from shot_fpfh_amd.core.geometry import solver_point_to_point_batched
+
+    n, draws = 1_000_000, 10_000
+    rng = np.random.default_rng(11)
+    scan = rng.random((n, 3))
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    ref = scan @ q.T + np.array([0.3, -0.2, 0.1]) + 2e-3 * rng.standard_normal((n, 3))
+    wrong = rng.random(n) < 0.3  # (30 % of the matches are wrong)
+    ref[wrong] = rng.random((int(wrong.sum()), 3))
+    pick = rng.integers(0, n, size=(draws, 4))
+    rot, tr = solver_point_to_point_batched(scan[pick], ref[pick])
+    rt = np.concatenate([rot.reshape(draws, 9), tr], axis=1)
+    thr = 0.01
+    got = eng.ransac_score(scan, ref, rt, thr)
+    assert got.max() > 0.5 * n  # (a draw of four correct matches exists among 10^4)
+    check = np.unique(np.concatenate([np.linspace(0, draws - 1, 32).astype(int), [int(np.argmax(got))]]))
+    want = O.ransac_score(scan, ref, rt[check], thr)
+    assert np.array_equal(got[check], want), (got[check], want)
+    assert np.array_equal(eng.ransac_score(scan, ref, rt[check], np.inf), np.full(check.size, n))
+    assert not eng.ransac_score(scan, ref, rt[check], -1.0).any()
+
+
+def test_normals_under_scale_and_rigid_motion_at_full_size(eng):
+    """compute_normals(radius) (K3, the fused sweep) for all 10^6 points of config 3's cloud: unit vectors; coordinates and radius
+    x 4 change no bit; under a rigid motion every normal is the rotated normal up to its sign (the eigen-solver's, with no
+    pre-computed normals to orient it) -- the direction within 1e-9 for all but the points whose two smallest eigenvalues meet."""
+    n, r = 1_000_000, 0.03
+    p, _, rng = synth_cloud(n, 3)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    t = rng.standard_normal(3)
+    res = []
+    for pts, rad in ((p, r), (4.0 * p, 4.0 * r), (p @ q.T + t, r)):
+        cloud = eng.cloud(pts)
+        res.append(cloud.normals_radius(pts, rad))
+        cloud.free()
+    na, ns, nr = res
+    assert np.abs(np.linalg.norm(na, axis=1) - 1.0).max() < 1e-12
+    assert np.array_equal(na, ns)
+    cosine = np.abs(np.einsum("ij,ij->i", nr, na @ q.T))
+    assert (cosine < 1.0 - 1e-9).mean() < 1e-4, ((cosine < 1.0 - 1e-9).sum(), cosine.min())
