@@ -15,6 +15,8 @@ bash tools/pmc_k5.sh ${TAG} > gpurun_out/${TAG}_k5.log 2>&1
 # 2b. the same for K5's team form beside the cached form at a radius with lists on both sides of 255 -> profiles/<tag>_k5_team.md
 bash tools/pmc_team.sh ${TAG} 0.04 > gpurun_out/${TAG}_k5_team.log 2>&1
 python tools/team_sq_md.py gpurun_out/pmc_team_${TAG} ${TAG} 0.04 >> gpurun_out/${TAG}_k5_team.log 2>&1
+# 2c. what the SIMDs do during every kernel of the step -> profiles/<tag>_step_sq.md
+bash tools/pmc_step.sh ${TAG} > gpurun_out/${TAG}_step_sq.log 2>&1
 # 3. the bench record itself (now quoting 1. and 2.), the emulated ranks of an 8-GPU job, config 4
 python bench.py > profiles/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err   # the line the driver parses (ONE run: the first of this build)
 cp bench_detail.json profiles/${TAG}_bench_detail.json                            # every other block of that run
