@@ -87,3 +87,26 @@ def test_hot_kernels_do_not_spill():
             assert spill <= 4, (name, r)
         assert spill <= 24, (name, r)
     assert seen_hot >= 20
+
+
+def test_the_header_compiles_as_c_and_a_c_caller_links():
+    """include/shotfpfh.h is plain C99 (what cgo / JNI / ctypes bind) and examples/c_abi_demo.c -- a caller that is not Python --
+    compiles against it and links against the library: every function it uses is exported with that signature's name."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "shotfpfh.h")
+    for lang, std in (("c", "-std=c99"), ("c++", "-std=c++11")):
+        r = subprocess.run(["gcc", std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", lang, hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    lib_dir = os.path.join(ROOT, "shot_fpfh_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libshotfpfh.so")):
+        pytest.skip("library not built")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", lib_dir, "-lshotfpfh", "-lm",
+                            "-Wl,-rpath," + lib_dir, "-o", os.path.join(tmp, "c_abi_demo")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import family, synth_cloud
+from conftest import family, run_program, synth_cloud
 
 pytestmark = pytest.mark.gpu
 
@@ -599,3 +599,42 @@ def test_normals_under_scale_and_rigid_motion_at_full_size(eng):
     assert np.array_equal(na, ns)
     cosine = np.abs(np.einsum("ij,ij->i", nr, na @ q.T))
     assert (cosine < 1.0 - 1e-9).mean() < 1e-4, ((cosine < 1.0 - 1e-9).sum(), cosine.min())
+
+
+def test_a_c_program_gets_the_rows_the_python_drop_ins_return(eng, tmp_path):
+    """examples/c_abi_demo.c, compiled with gcc against include/shotfpfh.h: FPFH and SHOT rows of 1 500 keypoints of a 30 000-point
+    cloud computed by a C caller equal the rows of compute_fpfh_descriptor / compute_descriptor_single_scale bit for bit -- the
+    Python layer adds nothing to the boundary."""
+    import shutil
+    import subprocess
+
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "shot_fpfh_amd")
+    exe = str(tmp_path / "c_abi_demo")
+    r = subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"),
+                        "-L", lib_dir, "-lshotfpfh", "-lm", "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n, radius = 30_000, 0.05
+    p, nr, rng = synth_cloud(n, 77)
+    kp = np.sort(rng.choice(n, 1_500, replace=False)).astype(np.int64)
+    with open(tmp_path / "cloud.bin", "wb") as f:
+        np.array([n, kp.size], np.int64).tofile(f)
+        np.ascontiguousarray(p, np.float64).tofile(f)
+        np.ascontiguousarray(nr, np.float64).tofile(f)
+        kp.tofile(f)
+    # (the helper process of conftest starts programs that use the GPU: this process already holds a context)
+    res = run_program([exe, str(tmp_path / "cloud.bin"), str(tmp_path / "rows.bin"), repr(radius)], timeout=300)
+    assert res["rc"] == 0, res
+    rows = np.fromfile(tmp_path / "rows.bin", dtype=np.float64)
+    fpfh_c, shot_c = rows[: kp.size * 125].reshape(kp.size, 125), rows[kp.size * 125:].reshape(kp.size, 352)
+    fpfh_py = s.compute_fpfh_descriptor(kp, p, nr, radius, 5, verbose=False)
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+        shot_py = sm.compute_descriptor_single_scale(p, nr, p[kp], radius)
+    assert np.array_equal(fpfh_c, fpfh_py)
+    assert np.array_equal(shot_c, shot_py)
+    assert np.any(shot_c, axis=1).mean() > 0.5 and np.any(fpfh_c, axis=1).all()  # (a corner point's list may fail SHOT's gate)
