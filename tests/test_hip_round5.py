@@ -638,3 +638,26 @@ def test_a_c_program_gets_the_rows_the_python_drop_ins_return(eng, tmp_path):
     assert np.array_equal(fpfh_c, fpfh_py)
     assert np.array_equal(shot_c, shot_py)
     assert np.any(shot_c, axis=1).mean() > 0.5 and np.any(fpfh_c, axis=1).all()  # (a corner point's list may fail SHOT's gate)
+
+
+def test_reciprocity_filter_at_scale_keeps_exactly_the_true_pairs(eng):
+    """match_descriptors(filter_nonreciprocal=True) on 200 000 x 150 000 x 352 (the FP16 pre-filter's size): the reference set is
+    a noisy copy of 150 000 of the scan rows in another order.  A scan row whose copy is there must keep it; one whose copy is
+    not finds some other row's copy, which is closer to its own original -- the column arg-min rejects it.  What is left is
+    exactly the set of true pairs."""
+    from shot_fpfh_amd.matching import match_descriptors
+
+    rng = np.random.default_rng(505)
+    m, mr, d = 200_000, 150_000, 352
+    a = rng.random((m, d), dtype=np.float32).astype(np.float64)
+    a *= rng.random((m, d), dtype=np.float32) < 0.3  # SHOT-like sparsity
+    a /= np.maximum(np.linalg.norm(a, axis=1)[:, None], 1e-300)
+    src = rng.permutation(m)[:mr]  # ref row j is a copy of scan row src[j]
+    b = a[src] + 1e-6 * rng.standard_normal((mr, d)).astype(np.float32)
+    si, ri = match_descriptors(a, b, filter_nonreciprocal=True, verbose=False, engine=eng)
+    order = np.argsort(si)
+    want_scan = np.sort(src)
+    assert np.array_equal(si[order], want_scan)
+    back = np.empty(m, np.int64)
+    back[src] = np.arange(mr)
+    assert np.array_equal(ri[order], back[want_scan])
