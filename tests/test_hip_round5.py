@@ -661,3 +661,29 @@ def test_reciprocity_filter_at_scale_keeps_exactly_the_true_pairs(eng):
     back = np.empty(m, np.int64)
     back[src] = np.arange(mr)
     assert np.array_equal(ri[order], back[want_scan])
+
+
+def test_icp_recovers_a_planted_motion_on_a_large_scan(eng):
+    """Point-to-point ICP at a size its golden does not reach: 150 000 points of a 600 000-point surface scan moved
+    by a known small rigid motion.  Every scan point has its exact partner in the reference, so the planted motion is a fixed
+    point of the iteration with zero residual: the inverse motion must come back.  (Point-to-plane on this cloud -- a sphere
+    with radial normals -- cannot see a rotation about the centre; its golden is a plane-rich scene, test_hip_parity.py.)"""
+    from conftest import config1_cloud
+    from shot_fpfh_amd.core import RigidTransform
+    from shot_fpfh_amd.icp import icp_point_to_point
+
+    n, m = 600_000, 150_000
+    ref, _ = config1_cloud(n, 21)
+    rng = np.random.default_rng(22)
+    axis = rng.standard_normal(3)
+    axis /= np.linalg.norm(axis)
+    ang = np.deg2rad(0.6)
+    kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    rot = np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * kx @ kx
+    t = np.array([0.002, -0.001, 0.0015])
+    scan = ref[rng.choice(n, m, replace=False)] @ rot.T + t
+    tf, rms, ok = icp_point_to_point(scan, ref, RigidTransform(np.eye(3), np.zeros(3)), d_max=0.02, voxel_size=0.002, max_iter=80,
+                                     rms_threshold=1e-7, disable_progress_bar=True)
+    assert ok, rms
+    assert np.abs(tf.rotation @ rot - np.eye(3)).max() < 1e-7, np.abs(tf.rotation @ rot - np.eye(3)).max()
+    assert np.abs(tf.rotation @ t + tf.translation).max() < 1e-7
