@@ -615,7 +615,12 @@ __device__ inline bool shot_finish_frame(const double (&raw)[9], int k, int xneg
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         E[3 * i + 0] = shot_flip(raw[3 * i + 0], sx);
-        E[3 * i + 1] = shot_flip(raw[3 * i + 1], sy) + 0.0; // (-a + a is +0: a component that cancelled stays +0 when y flips)
+        // (-a + a is +0: a component of y that cancelled stays +0 when y flips -- what "flipped + 0.0" would do, as integer
+        // operations on the scalar unit: the vector add put y's three components into six vector registers for the whole
+        // kernel, the difference between five and six waves per SIMD for the fused four-chunk form)
+        unsigned long long yb = (unsigned long long)__double_as_longlong(raw[3 * i + 1]) ^ sy;
+        yb = (yb << 1) ? yb : 0ull;
+        E[3 * i + 1] = __longlong_as_double((long long)yb);
         E[3 * i + 2] = shot_flip(raw[3 * i + 2], sz);
     }
     return fx | fz;
