@@ -92,7 +92,9 @@ int sf_d2d(sf_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* st
  * sf_cloud_upload copies xyz (n x 3) and normals (n x 3, nullable) to the GPU.
  * sf_cloud_build_grid (kernel K1) bins the points into cells of edge >= `cell`, sorts them by cell
  * and keeps cell-sorted SoA copies of xyz / normals; it must be called with cell >= the largest
- * radius later searched (re-callable; a search with a larger radius rebuilds automatically). */
+ * radius later searched (re-callable; a search with a larger radius -- or one below half the cell, for speed -- and every
+ * k-NN search rebuild automatically).  Every build re-sorts into fresh arrays: list sets (sf_nbrs) made on an earlier build
+ * are refused by their consumers with SF_ERR_STATE from then on -- use a search's lists before the next rebuild. */
 sf_cloud *sf_cloud_upload(sf_ctx *ctx, const double *xyz, const double *normals, int64_t n, int flags);
 int sf_cloud_set_normals(sf_ctx *ctx, sf_cloud *cloud, const double *normals, int flags);
 int sf_cloud_build_grid(sf_ctx *ctx, sf_cloud *cloud, double cell);
@@ -136,6 +138,17 @@ sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *cloud, double radius, int6
  * Every list has exactly k entries, nearest first (ties: lower cell-sorted position).  1 <= k <= n (k <= 1984: the k best
  * are kept in LDS during one sweep; beyond: count / fill / segmented sort through global memory). */
 sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, int k, int flags);
+/* Caller-supplied neighbourhoods: ShotMultiprocessor.compute_local_rf / compute_descriptor work on the lists they are HANDED --
+ * support[neighborhoods[i]], shot_parallelization.py:46-84, 86-133 -- whatever made them (KDTree.query_radius of another radius,
+ * KDTree.query, a selection of the caller's).  sf_nbrs_import makes a list set of them that sf_shot_lrf / sf_shot / sf_normals /
+ * sf_pca consume like a search result.  queries: m x 3 (row i = keypoint i); offsets: m + 1 ascending from 0; idx:
+ * offsets[m] point indices in the numbering of sf_cloud_upload (each in 0 .. n-1, else SF_ERR_ARG through NULL + sf_last_error);
+ * radius: the value get_local_rf / compute_single_shot_descriptor are called with (shot.py:16-48, 175-306) -- it enters their
+ * formulas and filters nothing.  flags: SF_HOST, or SF_IN_DEVICE with all three arrays on the device.  Like every list set, the
+ * result is bound to the cloud's current grid: use it before the next search with another radius (consumers return
+ * SF_ERR_STATE otherwise). */
+sf_nbrs *sf_nbrs_import(sf_ctx *ctx, sf_cloud *cloud, const double *queries, int64_t m, const int64_t *offsets,
+                        const int64_t *idx, double radius, int flags);
 /* non-owning view of queries [first, first+count) of `nbrs` (free it before the parent) */
 sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nbrs, int64_t first, int64_t count);
 int64_t sf_nbrs_num_queries(const sf_nbrs *nbrs);

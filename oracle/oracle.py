@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
         L.orc_shot.argtypes = [_f64p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_double, _f64p, C.c_int, C.c_int64, _f64p]
         L.orc_azimuth_idx.restype = C.c_int
         L.orc_azimuth_idx.argtypes = [C.c_double, C.c_double]
+        L.orc_lrf_single.restype = None
+        L.orc_lrf_single.argtypes = [_f64p, _f64p, _i32p, C.c_int64, C.c_double, _f64p]
         L.orc_shot_single.restype = None
         L.orc_shot_single.argtypes = [_f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_double, _f64p, C.c_int, C.c_int64, _f64p]
         L.orc_shot_serial.restype = C.c_int
@@ -231,6 +233,33 @@ def shot_single(point, neighbors, normals, radius, lrf, normalize=True, min_neig
     out = np.zeros(352)
     lib().orc_shot_single(_f64(point), nbh, nrm, np.arange(nbh.shape[0], dtype=np.int32), nbh.shape[0], float(radius),
                           _f64(lrf).reshape(9), int(bool(normalize)), int(min_neighborhood_size), out)
+    return out
+
+
+def shot_lrf_lists(cloud, keypoints, offsets, idx, radius):
+    """ShotMultiprocessor.compute_local_rf on the caller's lists (shot_parallelization.py:46-84): keypoint i's
+    neighbourhood is cloud[idx[offsets[i]:offsets[i+1]]]."""
+    p, q = _f64(cloud), _f64(keypoints)
+    idx32 = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.zeros((q.shape[0], 3, 3))
+    L = lib()
+    for i in range(q.shape[0]):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        L.orc_lrf_single(q[i], p, idx32[a:b] if b > a else np.zeros(1, np.int32), b - a, float(radius), out[i].reshape(9))
+    return out
+
+
+def shot_lists(cloud, normals, keypoints, offsets, idx, radius, lrf, normalize=True, min_neighborhood_size=100):
+    """ShotMultiprocessor.compute_descriptor on the caller's lists (shot_parallelization.py:86-133)."""
+    p, nrm, q = _f64(cloud), _f64(normals), _f64(keypoints)
+    lrf = _f64(lrf).reshape(-1, 9)
+    idx32 = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.zeros((q.shape[0], 352))
+    L = lib()
+    for i in range(q.shape[0]):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        L.orc_shot_single(q[i], p, nrm, idx32[a:b] if b > a else np.zeros(1, np.int32), b - a, float(radius), lrf[i],
+                          int(bool(normalize)), int(min_neighborhood_size), out[i])
     return out
 
 

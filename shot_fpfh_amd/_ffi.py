@@ -56,6 +56,7 @@ SIGNATURES = {
     "sf_radius_search": (_vp, [_vp, _vp, _vp, _i64, _f64, _int]),
     "sf_radius_search_self": (_vp, [_vp, _vp, _f64, _i64, _i64]),
     "sf_knn_search": (_vp, [_vp, _vp, _vp, _i64, _int, _int]),
+    "sf_nbrs_import": (_vp, [_vp, _vp, _vp, _i64, _vp, _vp, _f64, _int]),
     "sf_nbrs_slice": (_vp, [_vp, _vp, _i64, _i64]),
     "sf_nbrs_num_queries": (_i64, [_vp]),
     "sf_nbrs_total": (_i64, [_vp]),

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -15,10 +16,10 @@
 
 // Every host wait on a stream goes through this counter (sf_sync_count): a step that is to be captured into a HIP graph must not
 // wait for the device, and whether it does is checked on an eager run of the same step first (Engine.capture's callers).
-extern unsigned long long g_sf_sync_count; // context.hip
+extern std::atomic<unsigned long long> g_sf_sync_count; // context.hip
 static inline hipError_t sf_counted_stream_sync(hipStream_t s)
 {
-    ++g_sf_sync_count;
+    g_sf_sync_count.fetch_add(1, std::memory_order_relaxed);
     return hipStreamSynchronize(s);
 }
 #define hipStreamSynchronize(s) sf_counted_stream_sync(s)
@@ -200,6 +201,7 @@ struct sf_cloud {
     bool bbox_known = false;
     double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
     // grid
+    uint64_t grid_gen = 0;          // counts the builds of the grid (every build re-allocates the sorted arrays): sf_nbrs::grid_gen
     double cell = 0.0;              // actual cell edge used
     double inv_cell = 0.0;
     double lo[3] = {0, 0, 0};
@@ -240,17 +242,21 @@ struct sf_cloud {
     // radius sizes its slots from instead of counting a sample first (search.hip::run_search).  A capacity hint, nothing
     // more: a list that outgrows its slot is re-done exactly whatever the slot size was.
     std::map<std::pair<double, bool>, std::pair<double, int64_t>> list_stats; // (radius, self search?) -> (mean, longest list)
-    // The lists of a SELF search are a function of (cloud, radius, query range) alone -- the points never change after the upload
-    // and every grid build of one radius gives the same cell-sorted order -- so the host-side numbers a search ends with (total,
-    // longest list, histogram of the lengths, how many lists overflowed their slot at which slot size) are remembered per
-    // (radius, first position, count): the next search of that range launches its sweep and plans every later launch from the
-    // record, without the step's one read-back (round 5; SF_K2_NO_HINT=1 turns it off, SF_K2_CHECK_RECORD=1 re-counts and compares).
+    // The lists of a SELF search are a function of (cloud, radius, GRID, query range) alone -- the points never change after the
+    // upload and every build of one grid (cell edge, x subdivision) gives the same cell-sorted order -- so the host-side numbers a
+    // search ends with (total, longest list, histogram of the lengths, how many lists overflowed their slot at which slot size)
+    // are remembered per (radius, cell edge, xsub, first position, count): the next search of that range ON THAT GRID launches
+    // its sweep and plans every later launch from the record, without the step's one read-back (round 5; SF_K2_NO_HINT=1 turns
+    // it off, SF_K2_CHECK_RECORD=1 re-counts and compares).  The grid is part of the key (round 6, advisor): ensure_grid serves
+    // a radius from any grid with cell in [r, 2r], and positions [begin, begin + m) of a sub-range name other points on another
+    // grid -- a record of the 0.05-grid must not size the index array of the same range on the 0.03-grid.
     struct search_record {
         int64_t total = 0, n_overflow = 0, ovf_total = 0, cap = 0, hist[5] = {0, 0, 0, 0, 0};
         int32_t max_count = 0, max_count_all = 0;
         bool folded = false; // max_count_all is the maximum over every rank (sf_comm_collective_stats was on)
     };
-    std::map<std::tuple<double, int64_t, int64_t>, search_record> search_records;
+    typedef std::tuple<double, double, int, int64_t, int64_t> search_key; // radius, cell edge, xsub, first position, +-count
+    std::map<search_key, search_record> search_records;
 };
 
 struct sf_nbrs {
@@ -289,7 +295,23 @@ struct sf_nbrs {
     int32_t *mid_sel = nullptr;
     int64_t n_mid = 0;
     int64_t view_first = 0;        // a view's first slot in the owner's numbering (tail_sel entries are owner slots)
+    // `idx` holds cell-sorted positions of ONE build of the cloud's grid, and a self search's qx / qy / qz point INTO that build's
+    // arrays: a later search with another radius, a k-NN search or an explicit sf_cloud_build_grid rebuilds the grid -- other
+    // cells, or the same cells in freshly allocated arrays -- and the lists then name other points or read released memory.
+    // Every list set is stamped with the build it was made on (sf_cloud::grid_gen) and every consumer checks the stamp
+    // (sf_nbrs_on_grid): SF_ERR_STATE instead of rows computed from the wrong points (round 6).
+    uint64_t grid_gen = 0;
 };
+
+static inline void sf_nbrs_stamp(sf_nbrs *nb, const sf_cloud *c) { nb->grid_gen = c->grid_gen; }
+static inline int sf_nbrs_on_grid(const sf_nbrs *nb, const sf_cloud *c, const char *who)
+{
+    if (nb->grid_gen == c->grid_gen) return SF_OK;
+    sf_set_error("%s: the neighbour lists were made on another grid of this cloud (build %llu, now %llu): a search with another "
+                 "radius, a k-NN search or sf_cloud_build_grid rebuilt it -- search again, or use the lists before the next rebuild",
+                 who, (unsigned long long)nb->grid_gen, (unsigned long long)c->grid_gen);
+    return SF_ERR_STATE;
+}
 
 struct sf_spfh {
     int64_t n = 0;

@@ -170,8 +170,8 @@ extern "C" void *sf_stream(sf_ctx *ctx) { return ctx ? (void *)ctx->stream : nul
 // capturing, nothing may synchronise with the device (a call that would -- a first search of a range, a table whose block
 // mask the host does not know -- fails with the runtime's error and the capture is abandoned by sf_graph_end); pool blocks
 // released during the capture stay with the graph, which writes into them at every replay, until sf_graph_free.
-unsigned long long g_sf_sync_count = 0;
-extern "C" unsigned long long sf_sync_count(void) { return g_sf_sync_count; }
+std::atomic<unsigned long long> g_sf_sync_count{0};
+extern "C" unsigned long long sf_sync_count(void) { return g_sf_sync_count.load(std::memory_order_relaxed); }
 
 extern "C" int sf_graph_begin(sf_ctx *ctx)
 {
@@ -182,7 +182,11 @@ extern "C" int sf_graph_begin(sf_ctx *ctx)
     SF_HIP(hipSetDevice(ctx->device));
     SF_HIP(hipStreamSynchronize(ctx->streams[0]));
     SF_HIP(hipStreamSynchronize(ctx->streams[1]));
-    SF_HIP(hipStreamBeginCapture(ctx->streams[0], hipStreamCaptureModeRelaxed));
+    // (thread-local mode, not relaxed -- advisor, round 5: a synchronous hipMemcpy, hipMalloc / hipFree or event wait issued by this
+    // thread while capturing then FAILS and invalidates the capture -- sf_graph_end reports it and the caller runs the step eagerly --
+    // instead of executing at once against buffers the captured kernels have not written yet and being baked into the graph as a
+    // host-side decision.  The eager step that precedes every capture has warmed the pool: a captured step allocates nothing.)
+    SF_HIP(hipStreamBeginCapture(ctx->streams[0], hipStreamCaptureModeThreadLocal));
     ctx->capture = new sf_graph();
     return SF_OK;
 }
@@ -323,11 +327,16 @@ int sf_pool_alloc(sf_ctx *ctx, size_t bytes, void **out)
         return SF_OK;
     }
     void *p = nullptr;
+    // (while a step is being captured -- thread-local mode -- the allocation, and only it, runs with the thread's capture mode
+    // relaxed: a fresh block has no pending work, so allocating it eagerly is safe; every other eager call stays forbidden)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (ctx->capture) (void)hipThreadExchangeStreamCaptureMode(&mode);
     hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) { // give cached blocks back and retry once
+    if (e != hipSuccess && !ctx->capture) { // give cached blocks back and retry once
         sf_pool_trim(ctx);
         e = hipMalloc(&p, bytes);
     }
+    if (ctx->capture) (void)hipThreadExchangeStreamCaptureMode(&mode);
     if (e != hipSuccess) {
         sf_set_error("out of device memory allocating %zu bytes: %s", bytes, hipGetErrorString(e));
         return SF_ERR_NOMEM;

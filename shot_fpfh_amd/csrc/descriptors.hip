@@ -1548,6 +1548,7 @@ static int check_nbrs(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, const char *who)
 {
     if (!ctx || !c || !nb) { sf_set_error("%s: null argument", who); return SF_ERR_ARG; }
     if (!c->xs) { sf_set_error("%s: grid not built", who); return SF_ERR_STATE; }
+    SF_CHECK(sf_nbrs_on_grid(nb, c, who));
     SF_HIP(hipSetDevice(ctx->device));
     return SF_OK;
 }

@@ -1103,6 +1103,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
 {
     if (!ctx || !c || !nb || !sp || !edges) { sf_set_error("sf_spfh_compute: null argument"); return SF_ERR_ARG; }
     if (!nb->self) { sf_set_error("sf_spfh_compute: needs a sf_radius_search_self result"); return SF_ERR_ARG; }
+    SF_CHECK(sf_nbrs_on_grid(nb, c, "sf_spfh_compute"));
     if (sp->n != c->n || nb->self_begin + nb->m > sp->n) { sf_set_error("sf_spfh_compute: table/cloud size mismatch"); return SF_ERR_ARG; }
     if (sp->elem_bytes == 1 && nb->max_count > 255 && !sp->hi) {
         sf_set_error("sf_spfh_compute: neighbourhood of %lld points needs a wider table (pass max_count to sf_spfh_create)",
@@ -1614,6 +1615,7 @@ extern "C" int sf_fpfh(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, const
 {
     if (!ctx || !c || !nb || !sp || !out || m < 0) { sf_set_error("sf_fpfh: bad argument"); return SF_ERR_ARG; }
     if (!nb->self) { sf_set_error("sf_fpfh: needs a sf_radius_search_self result"); return SF_ERR_ARG; }
+    SF_CHECK(sf_nbrs_on_grid(nb, c, "sf_fpfh"));
     if (!kp_idx && m != nb->m) { sf_set_error("sf_fpfh: m must equal the query count when kp_idx is NULL"); return SF_ERR_ARG; }
     if (kp_idx && !(nb->self_begin == 0 && nb->m == c->n)) {
         sf_set_error("sf_fpfh: keypoints by index need neighbour lists of the whole cloud");

@@ -643,6 +643,7 @@ static int build_grid(sf_ctx *ctx, sf_cloud *c, double cell, int64_t block_begin
 {
     SF_HIP(hipSetDevice(ctx->device));
     cloud_release_grid(ctx, c);
+    ++c->grid_gen; // (list sets made on the previous build are refused from here on: sf_nbrs_on_grid)
     const int64_t n = c->n;
     // ---- bounding box -------------------------------------------------------------------------
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};

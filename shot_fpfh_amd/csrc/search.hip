@@ -1201,8 +1201,23 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
     sf_grid_desc g = sf_make_grid_desc(c);
     const dim3 grid(sf_xcd_grid(sf_div_up(m ? m : 1, 4 * SF_K2_WPB))), block(64 * SF_K2_WPB); // waves x 4 queries
     if (!m) {
-        // (an empty block of a sharded job still takes part in the all-reduce of the list statistics its peers are in)
-        if (ctx->collective_stats && ctx->comm) SF_CHECK(count_stats(ctx, nb, 0x7fffffff, nullptr));
+        // (an empty block of a sharded job still takes part in the all-reduce of the list statistics its peers are in -- and
+        // stays out of it exactly when they do: on the repeated search of its (empty) range, which its peers serve from their records)
+        if (ctx->collective_stats && ctx->comm) {
+            const sf_cloud::search_key ekey{nb->radius, c->cell, c->xsub, nb->self_begin, 0};
+            const bool seen = nb->self && !getenv("SF_K2_NO_HINT") && c->search_records.count(ekey);
+            if (!seen || getenv("SF_K2_CHECK_RECORD")) {
+                SF_CHECK(count_stats(ctx, nb, 0x7fffffff, nullptr));
+                if (nb->self) {
+                    sf_cloud::search_record r;
+                    r.max_count_all = (int32_t)nb->max_count_all;
+                    r.folded = true;
+                    c->search_records[ekey] = r;
+                }
+            } else {
+                nb->max_count_all = c->search_records[ekey].max_count_all;
+            }
+        }
         SF_CHECK(sf_palloc(ctx, &nb->idx, (size_t)8));
         return SF_OK;
     }
@@ -1229,7 +1244,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
                   nb->qz, m, r2, 0, nb->count, nb->offset, (int32_t *)nullptr, (const int32_t *)nullptr);
         // (small query sets: count -> scan -> fill.  A repeated self search of the range takes the total -- the size of the index
         // array -- and the rest of the statistics from its record, like the single sweep below: no read-back)
-        const std::tuple<double, int64_t, int64_t> xkey{nb->radius, nb->self_begin, -m}; // (-m: the exact scheme's records)
+        const sf_cloud::search_key xkey{nb->radius, c->cell, c->xsub, nb->self_begin, -m}; // (-m: the exact scheme's records)
         auto xit = nb->self && !getenv("SF_K2_NO_HINT") && !getenv("SF_K2_CHECK_RECORD") ? c->search_records.find(xkey) : c->search_records.end();
         if (xit != c->search_records.end() && (xit->second.folded || !(ctx->collective_stats && ctx->comm))) {
             const sf_cloud::search_record &r = xit->second;
@@ -1253,7 +1268,7 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
         return plan_dispatch(ctx, c, nb);
     }
     // a self search of a range that has been searched before with this radius: its record (sf_cloud::search_records)
-    const std::tuple<double, int64_t, int64_t> rkey{nb->radius, nb->self_begin, m};
+    const sf_cloud::search_key rkey{nb->radius, c->cell, c->xsub, nb->self_begin, m};
     const sf_cloud::search_record *rec = nullptr;
     if (nb->self && !getenv("SF_K2_NO_HINT")) {
         auto it = c->search_records.find(rkey);
@@ -1281,7 +1296,11 @@ static int run_search(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb)
                          (long long)nb->total, (long long)rec->total);
             return SF_ERR_STATE;
         }
-        if (nb->self && nb->n_overflow * 2 <= m) {
+        // (a record is stored after EVERY first search of a range -- also the one whose sample misjudged the cloud and is re-done
+        // exactly below: with the statistics folded over the ranks, count_stats is a collective, and a rank that kept no record
+        // would issue its all-reduce in the next step while its peers, holding theirs, skip it -- advisor, round 5.  Such a record
+        // either names slots that hold the longest list, or replays the exact re-do from its numbers.)
+        if (nb->self) {
             if (c->search_records.size() > 256) c->search_records.clear();
             sf_cloud::search_record r;
             r.total = nb->total; r.n_overflow = nb->n_overflow; r.ovf_total = ovf_total; r.cap = cap;
@@ -1364,6 +1383,7 @@ extern "C" sf_nbrs *sf_radius_search_self(sf_ctx *ctx, sf_cloud *c, double radiu
     nb->qx = c->xs + begin;
     nb->qy = c->ys + begin;
     nb->qz = c->zs + begin;
+    sf_nbrs_stamp(nb, c);
     if (run_search(ctx, c, nb) != SF_OK) {
         sf_nbrs_free(ctx, nb);
         return nullptr;
@@ -1433,6 +1453,7 @@ extern "C" sf_nbrs *sf_radius_search(sf_ctx *ctx, sf_cloud *c, const double *que
     nb->m = m;
     nb->radius = radius;
     nb->self = false;
+    sf_nbrs_stamp(nb, c);
     if (prepare_queries(ctx, c, nb, queries, flags) != SF_OK || run_search(ctx, c, nb) != SF_OK) {
         sf_nbrs_free(ctx, nb);
         return nullptr;
@@ -1777,6 +1798,123 @@ extern "C" sf_nbrs *sf_knn_search(sf_ctx *ctx, sf_cloud *c, const double *querie
         hipLaunchKernelGGL(k_knn_to_positions, dim3((unsigned)sf_div_up(nb->total, 256)), dim3(256), 0, ctx->stream, nb->total,
                            c->inv_perm, nb->idx);
     }
+    sf_nbrs_stamp(nb, c); // (positions of the FINAL grid of the rounds above)
+    return nb;
+}
+
+// ---- caller-supplied neighbourhoods ------------------------------------------------------------------------------------------
+// ShotMultiprocessor.compute_local_rf / compute_descriptor take the lists the caller hands them -- support[neighborhoods[i]],
+// shot_parallelization.py:46-84, 86-133 -- whatever produced them: KDTree.query_radius of another radius, KDTree.query (k-NN),
+// a hand-made selection.  sf_nbrs_import turns such lists (CSR: offsets[m + 1], idx[offsets[m]] in the caller's point numbering)
+// into a list set the list-driven kernels (K3, K4, K5) consume like a search result: indices -> cell-sorted positions of the
+// cloud's current grid (inv_perm), queries in the caller's order (no qrow), `radius` the value K4 / K5 put in their formulas
+// (shot.py:28, 95-117 -- NOT a filter: a neighbour beyond it keeps its, then negative, weight exactly as in the reference).
+// Order inside a list matters to no consumer beyond the rounding of a sum (K5's statements are elections by distance, K3 / K4
+// are sums over the list); an index listed twice counts twice, as support[neighborhoods[i]] repeats the point.
+__global__ void k_import_lists(const int64_t *__restrict__ src, int64_t total, int64_t n, const int32_t *__restrict__ inv_perm,
+                               int32_t *__restrict__ idx, int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t j = src[i];
+    if (j < 0 || j >= n) { atomicOr(bad, 1); idx[i] = 0; return; }
+    idx[i] = inv_perm[j];
+}
+
+__global__ void k_import_csr(const int64_t *__restrict__ offsets, int64_t m, int32_t *__restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > m) return;
+    count[i] = i < m ? (int32_t)(offsets[i + 1] - offsets[i]) : 0;
+}
+
+__global__ void k_split_queries(const double *__restrict__ q, int64_t m, double *__restrict__ qx, double *__restrict__ qy,
+                                double *__restrict__ qz)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    qx[i] = q[3 * i];
+    qy[i] = q[3 * i + 1];
+    qz[i] = q[3 * i + 2];
+}
+
+extern "C" sf_nbrs *sf_nbrs_import(sf_ctx *ctx, sf_cloud *c, const double *queries, int64_t m, const int64_t *offsets,
+                                   const int64_t *idx, double radius, int flags)
+{
+    if (!ctx || !c || m < 0 || m > 2147483000LL || !offsets || (!queries && m > 0)) {
+        sf_set_error("sf_nbrs_import: bad arguments (m=%lld)", (long long)m);
+        return nullptr;
+    }
+    if (!(radius > 0.0) || !std::isfinite(radius)) { sf_set_error("sf_nbrs_import: radius must be positive and finite (got %g)", radius); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
+    const bool dev_in = (flags & SF_IN_DEVICE) != 0;
+    // the offsets are looked at on the host (m + 1 words): monotone from 0, no list of 2^31 entries
+    std::vector<int64_t> hoff;
+    const int64_t *ho = offsets;
+    if (dev_in) {
+        hoff.resize((size_t)m + 1);
+        if (hipMemcpyAsync(hoff.data(), offsets, ((size_t)m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { sf_set_error("sf_nbrs_import: reading the offsets failed"); return nullptr; }
+        ho = hoff.data();
+    }
+    if (ho[0] != 0) { sf_set_error("sf_nbrs_import: offsets[0] must be 0 (got %lld)", (long long)ho[0]); return nullptr; }
+    int64_t longest = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t k = ho[i + 1] - ho[i];
+        if (k < 0 || k > 2147483000LL) { sf_set_error("sf_nbrs_import: offsets must ascend (list %lld has %lld entries)", (long long)i, (long long)k); return nullptr; }
+        longest = std::max(longest, k);
+    }
+    const int64_t total = ho[m];
+    if (total > 0 && !idx) { sf_set_error("sf_nbrs_import: null index array"); return nullptr; }
+    // any grid of the cloud will do (the lists are not searched for): the current one, else one of `radius`
+    if (!c->cell_start || !(c->pop_begin == 0 && c->pop_end == c->n)) {
+        if (sf_cloud_build_grid(ctx, c, radius) != SF_OK) return nullptr;
+    }
+    if (sf_cloud_ensure_inv_perm(ctx, c) != SF_OK) return nullptr;
+    sf_nbrs *nb = new sf_nbrs();
+    nb->m = m;
+    nb->radius = radius;
+    nb->self = false;
+    nb->total = total;
+    nb->max_count = longest;
+    nb->max_count_all = longest;
+    sf_nbrs_stamp(nb, c);
+    auto fail = [&]() { sf_nbrs_free(ctx, nb); return (sf_nbrs *)nullptr; };
+    const size_t mm = (size_t)(m ? m : 1);
+    if (sf_palloc(ctx, &nb->qx, mm) != SF_OK || sf_palloc(ctx, &nb->qy, mm) != SF_OK || sf_palloc(ctx, &nb->qz, mm) != SF_OK ||
+        sf_palloc(ctx, &nb->count, (size_t)m + 1) != SF_OK || sf_palloc(ctx, &nb->offset, (size_t)m + 1) != SF_OK ||
+        sf_palloc(ctx, &nb->idx, (size_t)total + 4) != SF_OK)
+        return fail();
+    sf_pool_guard tmp(ctx);
+    const double *dq = queries;
+    const int64_t *didx = idx;
+    int *dbad = nullptr;
+    if (tmp.alloc(&dbad, 1) != SF_OK) return fail();
+    if (!dev_in) {
+        double *q = nullptr;
+        int64_t *ix = nullptr;
+        if (tmp.alloc(&q, mm * 3) != SF_OK || tmp.alloc(&ix, (size_t)total + 1) != SF_OK) return fail();
+        if ((m && hipMemcpyAsync(q, queries, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) ||
+            (total && hipMemcpyAsync(ix, idx, (size_t)total * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) {
+            sf_set_error("sf_nbrs_import: upload failed");
+            return fail();
+        }
+        dq = q;
+        didx = ix;
+    }
+    if (hipMemcpyAsync(nb->offset, ho, ((size_t)m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(dbad, 0, sizeof(int), ctx->stream) != hipSuccess) { sf_set_error("sf_nbrs_import: upload failed"); return fail(); }
+    {
+        sf_launch_timer t_(ctx, "k2_import");
+        hipLaunchKernelGGL(k_import_csr, dim3((unsigned)sf_div_up(m + 1, 256)), dim3(256), 0, ctx->stream, (const int64_t *)nb->offset, m, nb->count);
+        if (m) hipLaunchKernelGGL(k_split_queries, dim3((unsigned)sf_div_up(m, 256)), dim3(256), 0, ctx->stream, dq, m, nb->qx, nb->qy, nb->qz);
+        if (total) hipLaunchKernelGGL(k_import_lists, dim3((unsigned)sf_div_up(total, 256)), dim3(256), 0, ctx->stream, didx, total, c->n,
+                                      (const int32_t *)c->inv_perm, nb->idx, dbad);
+    }
+    int bad = 0;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { sf_set_error("sf_nbrs_import: launch failed"); return fail(); }
+    if (bad) { sf_set_error("sf_nbrs_import: a neighbour index lies outside 0 .. %lld", (long long)c->n - 1); return fail(); }
     return nb;
 }
 
@@ -1812,6 +1950,7 @@ extern "C" sf_nbrs *sf_nbrs_slice(sf_ctx *ctx, sf_nbrs *nb, int64_t first, int64
     v->n_mid = nb->n_mid;
     v->view_first = nb->view_first + first;
     v->cap = nb->cap;
+    v->grid_gen = nb->grid_gen;
     v->total = -1; // unknown without a device read; views are for compute, not export
     return v;
 }
@@ -1828,6 +1967,7 @@ extern "C" int sf_nbrs_export(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, int64_t *of
     // row i is the point at cell-sorted position self_begin + i.
     if (!ctx || !c || !nb || !offsets) { sf_set_error("sf_nbrs_export: null argument"); return SF_ERR_ARG; }
     if (nb->view) { sf_set_error("sf_nbrs_export: not available on a slice view"); return SF_ERR_ARG; }
+    SF_CHECK(sf_nbrs_on_grid(nb, c, "sf_nbrs_export"));
     SF_HIP(hipSetDevice(ctx->device));
     const int64_t m = nb->m, total = nb->total;
     std::vector<int32_t> cnt((size_t)m + 1), qrow;

@@ -66,12 +66,20 @@ class ShotMultiprocessor:
         return Cloud(self._eng(), point_cloud, normals, subset=keep)  # (gathered on the device)
 
     # ---- pieces (names follow the reference's public methods) ----------------------------------------
+    def _lists(self, cloud: Cloud, keypoints, neighborhoods, radius):
+        """The lists the reference would use: the caller's (`support[neighborhoods[i]]`, shot_parallelization.py:71, 121-122)
+        whatever made them -- another radius, KDTree.query, a hand-picked subset.  `neighborhoods=None` (an extension: the
+        reference has no default) searches `radius` on the device instead, with no list crossing the host link."""
+        if neighborhoods is None:
+            return cloud.radius_search(keypoints, radius)
+        return cloud.import_neighbors(keypoints, neighborhoods, radius)
+
     def compute_local_rf(self, keypoints, neighborhoods, support, radius):
-        """Local reference frames of `keypoints` over `support` within `radius` (M, 3, 3).
-        `neighborhoods` is accepted for signature parity; the lists are rebuilt on the device."""
+        """Local reference frames of `keypoints` over `support[neighborhoods[i]]` with `radius` in the weights (M, 3, 3) --
+        shot_parallelization.py:46-84."""
         cloud = Cloud(self._eng(), support)
         try:
-            nb = cloud.radius_search(keypoints, radius)
+            nb = self._lists(cloud, keypoints, neighborhoods, radius)
             try:
                 return nb.shot_lrf()
             finally:
@@ -80,9 +88,10 @@ class ShotMultiprocessor:
             cloud.free()
 
     def compute_descriptor(self, keypoints, normals, neighborhoods, local_rfs, support, radius):
+        """(M, 352) descriptors over `support[neighborhoods[i]]`, `normals[neighborhoods[i]]` -- shot_parallelization.py:86-133."""
         cloud = Cloud(self._eng(), support, normals)
         try:
-            nb = cloud.radius_search(keypoints, radius)
+            nb = self._lists(cloud, keypoints, neighborhoods, radius)
             try:
                 return nb.shot(local_rfs, self.normalize, self.min_neighborhood_size)
             finally:

@@ -587,6 +587,43 @@ class Cloud:
         )
         return Neighbors(self, h)
 
+    def import_neighbors(self, queries, neighborhoods, radius: float) -> "Neighbors":
+        """The caller's own lists as a list set (sf_nbrs_import): `neighborhoods[i]` = integer indices into this cloud's points
+        that make up keypoint i's neighbourhood -- the object array KDTree.query_radius returns, the 2-D array of KDTree.query,
+        or any sequence of index sequences (shot_parallelization.py:46-84: `support[neighborhoods[i]]`).  `radius` is what the
+        frame / descriptor formulas are evaluated with; it selects nothing."""
+        q = _f64(queries, 3)
+        m = q.shape[0]
+        if len(neighborhoods) != m:
+            raise ValueError(f"one neighbourhood per keypoint expected ({len(neighborhoods)} lists for {m} keypoints)")
+        nb_arr = neighborhoods if isinstance(neighborhoods, np.ndarray) and neighborhoods.dtype != object else None
+        if nb_arr is not None and nb_arr.ndim == 2:  # (KDTree.query: every list of one length)
+            offsets = np.arange(m + 1, dtype=np.int64) * nb_arr.shape[1]
+            idx = np.ascontiguousarray(nb_arr, dtype=np.int64).reshape(-1)
+        else:
+            lists = [np.asarray(a).reshape(-1) for a in neighborhoods]
+            for a in lists:
+                if a.size and a.dtype.kind not in "iu":  # (support[float_array] raises IndexError in NumPy)
+                    raise IndexError("arrays used as indices must be of integer (or boolean) type")
+            offsets = np.zeros(m + 1, dtype=np.int64)
+            if m:
+                np.cumsum([a.size for a in lists], out=offsets[1:])
+            idx = np.concatenate(lists).astype(np.int64, copy=False) if offsets[-1] else np.zeros(0, dtype=np.int64)
+            idx = np.ascontiguousarray(idx)
+        if idx.size:
+            # NumPy's fancy indexing accepts -n .. n-1 and raises IndexError beyond: the same here
+            lo, hi = int(idx.min()), int(idx.max())
+            if lo < -self.n or hi >= self.n:
+                bad = lo if lo < -self.n else hi
+                raise IndexError(f"index {bad} is out of bounds for axis 0 with size {self.n}")
+            if lo < 0:
+                idx = np.where(idx < 0, idx + self.n, idx)
+        h = _ffi.check_handle(
+            self.engine.lib.sf_nbrs_import(self.engine.h, self.h, _ptr(q), m, _ptr(offsets), _ptr(idx), float(radius), SF_HOST),
+            "sf_nbrs_import",
+        )
+        return Neighbors(self, h)
+
     def normals_radius(self, queries, radius: float, pre_computed_normals=None) -> np.ndarray:
         """compute_normals(queries, cloud, radius=...) in one sweep: the neighbour lists are never materialised
         (sf_normals_radius); bit-identical to radius_search(queries, radius).normals(pre_computed_normals)."""

@@ -100,6 +100,23 @@ def _match_multiscale(eng, scan, ref, filter_callback, filter_nonreciprocal, ver
 
 
 def double_matching_with_rejects(scan_descriptors, ref_descriptors, threshold, verbose=True):
-    """Present in the reference's export list but broken there: it always raises IndexError
-    (matching.py:202/220).  Kept as an explicit non-feature."""
-    raise NotImplementedError("double_matching_with_rejects always raises in the reference implementation; not provided")
+    """Present in the reference's export list but broken there (matching.py:172-221): whatever it is handed, it
+    ends in an exception -- `distance_matrix[np.arange(S), indices]` (:202) does not broadcast unless as many ref rows are
+    non-empty as there are scan rows, and the last line (:220) indexes with FLOAT distances.  A drop-in raises what the
+    reference raises, from the shapes alone (no distance matrix is formed): the table of
+    tests/golden/double_matching_errors.json, generated by calling the reference, is held in tests/test_host_logic.py."""
+    scan_descriptors, ref_descriptors = np.asarray(scan_descriptors), np.asarray(ref_descriptors)
+    s = scan_descriptors.shape[0]
+    s1 = int(np.any(scan_descriptors, axis=1).sum())
+    r1 = int(np.any(ref_descriptors, axis=1).sum())
+    if 0 < r1 < 3:  # np.argpartition(distance_matrix, kth=2, axis=1), :201 (an empty axis passes)
+        raise ValueError(f"kth(=2) out of bounds ({r1})")
+    try:  # distance_matrix[np.arange(S), indices] with indices of shape (S', R'), :202
+        shape = np.broadcast_shapes((s,), (s1, r1))
+    except ValueError:
+        raise IndexError(f"shape mismatch: indexing arrays could not be broadcast together with shapes ({s},) ({s1},{r1}) ") from None
+    if int(np.prod(shape)) > 0 and s > s1:
+        raise IndexError(f"index {s1} is out of bounds for axis 0 with size {s1}")
+    if shape[0] != s:  # np.divide(..., out=np.ones(S)), :204-209
+        raise ValueError(f"non-broadcastable output operand with shape ({s},) doesn't match the broadcast shape ({shape[0]},)")
+    raise IndexError("arrays used as indices must be of integer (or boolean) type")  # :220

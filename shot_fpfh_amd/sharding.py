@@ -174,10 +174,7 @@ class DescriptorJob:
         if self.spfh is None or wide != self._spfh_wide:
             if self.spfh is not None:
                 self.spfh.free()
-            try:
-                self.spfh = self.engine.spfh(self.cloud, self.n_bins, max_count, self.radius)
-            except TypeError:  # (an engine stand-in without the radius argument)
-                self.spfh = self.engine.spfh(self.cloud, self.n_bins, max_count)
+            self.spfh = self.engine.spfh(self.cloud, self.n_bins, max_count, self.radius)
             self._spfh_bytes = getattr(self.spfh, "elem_bytes", 0) == 1
             if self._spfh_bytes and max_count <= 65535:
                 wide = 3 if (max_count > 255 or wide == 3) else 0

@@ -280,5 +280,5 @@ class FakeEngine:
         if dist is not None:
             dist.a[:m1] = d
 
-    def spfh(self, cloud, n_bins, max_count):
+    def spfh(self, cloud, n_bins, max_count, radius=None):
         return FakeSpfh(cloud, n_bins, max_count)

@@ -1,0 +1,206 @@
+"""GPU parity tests added in round 6 (all through the C ABI).
+
+  * caller-supplied neighbourhoods (sf_nbrs_import): ShotMultiprocessor.compute_local_rf / compute_descriptor on KDTree.query lists,
+    on lists of another radius and on lists of the radius itself, against rows the reference produced for exactly those lists;
+  * float32 clouds against rows the REFERENCE computed from the float32 arrays (not against the build's own float64 call);
+  * compute_metrics_post_icp against the reference's numbers;
+  * the per-range search record across grid rebuilds (advisor, round 5) and the grid stamp on list sets.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, synth_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import shot_fpfh_amd as s
+
+    return s.default_engine()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+def _object_lists(off, idx):
+    arr = np.empty(off.size - 1, dtype=object)
+    for i in range(off.size - 1):
+        arr[i] = idx[off[i]:off[i + 1]]
+    return arr
+
+
+# ---- caller-supplied neighbourhoods ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["knn", "wide", "same"])
+def test_shot_pieces_use_the_lists_they_are_handed(kind):
+    """shot_parallelization.py:46-133: frames and descriptors over support[neighborhoods[i]] -- k-NN lists (40 points whatever the
+    radius), lists of 1.5 x the radius (the points beyond it weigh negatively in the frame, as in the reference) and the radius's
+    own lists.  Expected rows: the reference's, for these very lists (tools/gen_golden_r6.py)."""
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    g = load_golden("shot_lists.npz")
+    off, idx, r = g[f"{kind}_offsets"], g[f"{kind}_idx"], float(g["radius"])
+    lists = _object_lists(off, idx)
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=10, verbose=False) as sm:
+        lrf = sm.compute_local_rf(g["keypoints"], lists, g["cloud"], r)
+        desc = sm.compute_descriptor(g["keypoints"], g["normals"], lists, g[f"{kind}_lrf"], g["cloud"], r)
+        assert lrf.shape == (off.size - 1, 3, 3) and desc.shape == (off.size - 1, 352)
+        assert np.abs(lrf - g[f"{kind}_lrf"]).max() < 1e-9
+        assert np.abs(desc - g[f"{kind}_desc"]).max() < 1e-9
+        if kind == "knn":  # KDTree.query's 2-D array, and lists in another order / with negative indices, name the same sets
+            two_d = idx.reshape(off.size - 1, -1)
+            assert np.array_equal(sm.compute_descriptor(g["keypoints"], g["normals"], two_d, g[f"{kind}_lrf"], g["cloud"], r), desc)
+            n = g["cloud"].shape[0]
+            flipped = _object_lists(off, idx)
+            for i in range(flipped.size):
+                flipped[i] = flipped[i][::-1] - (n if i % 2 else 0)
+            d2 = sm.compute_descriptor(g["keypoints"], g["normals"], flipped, g[f"{kind}_lrf"], g["cloud"], r)
+            assert np.abs(d2 - desc).max() < 1e-12
+        if kind == "wide":  # the lists matter: the radius's own lists give other rows for most keypoints
+            own = sm.compute_descriptor(g["keypoints"], g["normals"], None, g[f"{kind}_lrf"], g["cloud"], r)
+            assert (np.abs(own - desc).max(axis=1) > 1e-3).sum() > 60
+
+
+def test_imported_lists_refuse_what_numpy_indexing_refuses(eng):
+    from shot_fpfh_amd._ffi import ShotFpfhError
+
+    p, nr, rng = synth_cloud(500, 71)
+    cloud = eng.cloud(p, nr)
+    try:
+        kp = p[:4]
+        ok = [np.array([0, 1, 2]), np.array([], dtype=np.int64), np.array([499]), np.array([-500, 3])]
+        nb = cloud.import_neighbors(kp, ok, 0.2)
+        assert (nb.m, nb.total, nb.max_count) == (4, 6, 3)
+        lrf = nb.shot_lrf()
+        assert np.array_equal(lrf[1], np.eye(3))  # (an empty neighbourhood: the identity, shot.py:24-25)
+        # the lists are bound to the grid they were imported on: a search with a much larger radius rebuilds it
+        other = cloud.radius_search(kp, 0.9)
+        with pytest.raises(ShotFpfhError, match="another grid"):
+            nb.shot_lrf()
+        other.free()
+        nb.free()
+        for bad in ([np.array([0]), np.array([500]), np.array([1]), np.array([2])],
+                    [np.array([0]), np.array([-501]), np.array([1]), np.array([2])],
+                    [np.array([0.0]), np.array([1]), np.array([1]), np.array([2])]):
+            with pytest.raises(IndexError):
+                cloud.import_neighbors(kp, bad, 0.2)
+        with pytest.raises(ValueError):
+            cloud.import_neighbors(kp, ok[:3], 0.2)
+    finally:
+        cloud.free()
+
+
+# ---- float32 clouds -----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["unit", "offset"])
+@pytest.mark.parametrize("ntag", ["n64", "n32"])
+def test_float32_clouds_against_the_reference_run_on_float32_arrays(tag, ntag):
+    """get_data hands the PLY's float32 columns on (io_ply.py:269) and the reference then subtracts and takes norms in float32
+    (shot.py:211-214, fpfh.py:45-48).  The drop-ins cast to float64 at the boundary; held against the rows the reference itself
+    computed from the float32 arrays -- a unit-cube cloud and the same cloud at (40, -25, 12), float64 and float32 normals.
+    Tolerance (north_star): abs(a - b) <= 1e-5 (SHOT), <= 1e-5 max(1, abs(b)) (FPFH); the COUNT of rows outside it must be 0."""
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.descriptors import ShotMultiprocessor
+
+    g = load_golden("shot_f32.npz")
+    p = g[f"{tag}_cloud"]
+    assert p.dtype == np.float32
+    nrm = g["normals64"] if ntag == "n64" else g["normals64"].astype(np.float32)
+    kp = p[g["keypoints_indices"]][g["rows"]]
+    with ShotMultiprocessor(normalize=True, min_neighborhood_size=int(g["min_neighborhood_size"]), verbose=False) as sm:
+        d = sm.compute_descriptor_single_scale(p, nrm, kp, float(g["radius"]))
+    gap = np.abs(d - g[f"{tag}_{ntag}_desc"]).max(axis=1)
+    print(f"SHOT {tag}/{ntag}: {int((gap > 1e-5).sum())} of {gap.size} rows outside 1e-5, largest gap {gap.max():.3g}")
+    assert int((gap > 1e-5).sum()) == 0
+    f = load_golden("fpfh_f32.npz")
+    pf = f[f"{tag}_cloud"]
+    nf = f["normals64"] if ntag == "n64" else f["normals64"].astype(np.float32)
+    got = s.compute_fpfh_descriptor(f["keypoints_indices"], pf, nf, float(f["radius"]), int(f["n_bins"]), verbose=False)
+    want = f[f"{tag}_{ntag}_desc"]
+    bad = (np.abs(got - want) > 1e-5 * np.maximum(1.0, np.abs(want))).any(axis=1)
+    print(f"FPFH {tag}/{ntag}: {int(bad.sum())} of {bad.size} rows outside tolerance, largest gap {np.abs(got - want).max():.3g}")
+    assert int(bad.sum()) == 0
+
+
+# ---- post-ICP metrics ---------------------------------------------------------------------------------------------------------
+def test_metrics_post_icp_equal_the_references():
+    """pipeline.py:544-587: share of aligned scan points with a ref point within the threshold, and the same for the keypoints."""
+    from shot_fpfh_amd.core import RigidTransform
+    from shot_fpfh_amd.pipeline import RegistrationPipeline
+
+    g, icp = load_golden("metrics_post_icp.npz"), load_golden("icp_3500.npz")
+    pipe = RegistrationPipeline(scan=icp["scan"], scan_normals=np.zeros_like(icp["scan"]), ref=icp["ref"], ref_normals=icp["ref_normals"])
+    pipe.scan_keypoints, pipe.ref_keypoints = g["scan_keypoints"], g["ref_keypoints"]
+    for i in range(int(g["n_cases"])):
+        tf = RigidTransform(g[f"case{i}_rotation"], g[f"case{i}_translation"])
+        overlap, ratio = pipe.compute_metrics_post_icp(tf, float(g[f"case{i}_threshold"]))
+        assert (overlap, ratio) == tuple(g[f"case{i}_metrics"]), (i, overlap, ratio, g[f"case{i}_metrics"])
+
+
+# ---- the search record and the grid it belongs to -----------------------------------------------------------------------------
+def _self_lists(cloud, O, p, radius, begin, end):
+    nb = cloud.radius_search_self(radius, begin, end)
+    off, idx = nb.export()
+    nb.free()
+    perm = cloud.perm()
+    q = p[perm[begin:end]]
+    eo, ei = O.radius_search(p, q, radius)
+    return (off, idx), (eo, ei.astype(np.int32))
+
+
+def test_search_record_of_a_sub_range_does_not_outlive_its_grid(eng, O, monkeypatch):
+    """Advisor (round 5, high): records were keyed by (radius, first position, count); ensure_grid serves radius r from any grid
+    with cell in [r, 2r], and positions [b, e) name other points on another grid.  Sequence: grid of 0.05 -> self search of a
+    sub-range at 0.03 (twice: the second from the record) -> k-NN search (rebuilds) -> the same sub-range at 0.03 on the new
+    grid -> a 0.1 search -> again.  Every search's lists against the oracle's, in both the slot scheme and the exact scheme."""
+    monkeypatch.delenv("SF_K2_CHECK_RECORD", raising=False)
+    for n, b, e in ((60000, 7000, 41000), (3000, 500, 2500)):  # (slots: m >= 16 384; exact: below)
+        p, nr, rng = synth_cloud(n, 81)
+        r = 0.03 if n > 10000 else 0.08
+        cloud = eng.cloud(p, nr)
+        try:
+            cloud.build_grid(r * 5 / 3)
+            for step in range(7):
+                got, want = _self_lists(cloud, O, p, r, b, e)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (n, step)
+                if step == 1:
+                    cloud.knn_search(p[:200], 12).free()
+                elif step == 3:
+                    cloud.radius_search(p[:50], 0.1 if n > 10000 else 0.3).free()
+                elif step == 5:
+                    cloud.build_grid(r * 1.9)
+        finally:
+            cloud.free()
+
+
+def test_lists_of_a_rebuilt_grid_are_refused_not_misread(eng):
+    from shot_fpfh_amd._ffi import ShotFpfhError
+
+    p, nr, rng = synth_cloud(20000, 82)
+    cloud = eng.cloud(p, nr)
+    try:
+        nb = cloud.radius_search_self(0.04)
+        first = nb.shot_single_scale(True, 10)
+        cloud.radius_search(p[:10], 0.03).free()  # (the 0.04 grid serves 0.03 too: no rebuild, the lists stay valid)
+        assert np.array_equal(nb.shot_single_scale(True, 10), first)
+        cloud.radius_search(p[:10], 0.2).free()  # another grid
+        for call in (lambda: nb.shot_single_scale(True, 10), lambda: nb.shot_lrf(), lambda: nb.normals(), lambda: nb.export()):
+            with pytest.raises(ShotFpfhError, match="another grid"):
+                call()
+        nb.free()
+        nb = cloud.radius_search_self(0.04)
+        again = nb.shot_single_scale(True, 10)
+        nb.free()
+        assert np.array_equal(again, first)  # (rebuilt with the first grid's cells: the same order, the same rows)
+        # a rebuild with the SAME cells re-allocates the sorted arrays a self search's queries point into: refused as well
+        nb = cloud.radius_search_self(0.04)
+        cloud.build_grid(0.04)
+        with pytest.raises(ShotFpfhError, match="another grid"):
+            nb.shot_single_scale(True, 10)
+        nb.free()
+    finally:
+        cloud.free()

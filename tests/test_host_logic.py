@@ -187,6 +187,28 @@ def test_every_mirrored_function_keeps_the_reference_signature():
                 assert default is not None and kind == "KEYWORD_ONLY", f"{key}: extra parameter {n} must be an optional keyword"
 
 
+def test_double_matching_with_rejects_raises_what_the_reference_raises():
+    """matching.py:172-221 is broken in the reference: every call ends in an exception.  Which one -- IndexError from the
+    indexing at :202 / :220, ValueError from np.argpartition(kth=2) or np.divide(out=) -- for a table of shapes the reference
+    was called with (tools/gen_golden_r6.py -> tests/golden/double_matching_errors.json)."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from shot_fpfh_amd.matching import double_matching_with_rejects
+
+    with open(os.path.join(GOLDEN, "double_matching_errors.json")) as fh:
+        table = json.load(fh)["cases"]
+    assert len(table) >= 12 and {c["raises"] for c in table} == {"IndexError", "ValueError"}
+    rng = np.random.default_rng(0)
+    for c in table:
+        a, b = rng.random((c["scan_rows"], 12)) + 0.1, rng.random((c["ref_rows"], 12)) + 0.1
+        a[c["scan_nonempty"]:], b[c["ref_nonempty"]:] = 0.0, 0.0
+        with pytest.raises(Exception) as info:
+            double_matching_with_rejects(a, b, 0.8, verbose=False)
+        assert type(info.value).__name__ == c["raises"], (c, info.value)
+
+
 def test_stacked_kabsch_is_bit_identical_to_the_per_draw_solver():
     """ransac_on_matches solves all draws as one stack; every transform must equal solver_point_to_point's bit for
     bit (plain, mirrored = every draw a reflection, noisy, planar = rank-deficient covariances)."""

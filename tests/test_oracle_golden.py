@@ -283,3 +283,41 @@ def test_config_c4_shaped_pair_match_vector():
     assert np.abs(ds[g["sample_rows"]] - g["scan_desc_sample"]).max() < 1e-12
     si, ri = O.basic_matching(ds, dr)
     assert np.array_equal(si, g["match_scan"]) and np.array_equal(ri, g["match_ref"])
+
+
+# ---- round 6: caller-supplied lists, float32 inputs, post-ICP metrics ---------------------------------------------------------
+@pytest.mark.parametrize("kind", ["knn", "wide", "same"])
+def test_shot_on_caller_supplied_lists(kind):
+    """compute_local_rf / compute_descriptor on lists that did not come from a search of `radius` (shot_parallelization.py:46-133):
+    KDTree.query lists, lists of 1.5 x the radius (neighbours beyond the radius keep their negative weights), the radius itself."""
+    g = load_golden("shot_lists.npz")
+    off, idx, r = g[f"{kind}_offsets"], g[f"{kind}_idx"], float(g["radius"])
+    lrf = O.shot_lrf_lists(g["cloud"], g["keypoints"], off, idx, r)
+    assert np.abs(lrf - g[f"{kind}_lrf"]).max() < 1e-9
+    d = O.shot_lists(g["cloud"], g["normals"], g["keypoints"], off, idx, r, g[f"{kind}_lrf"], True, 10)
+    assert np.abs(d - g[f"{kind}_desc"]).max() < TOL * 10
+
+
+@pytest.mark.parametrize("tag", ["unit", "offset"])
+@pytest.mark.parametrize("ntag", ["n64", "n32"])
+def test_float32_clouds_stay_within_the_tolerance_of_the_float64_arithmetic(tag, ntag):
+    """The reference run on float32 arrays (get_data hands the PLY's float32 columns on, io_ply.py:269; `neighbors - point` and
+    `np.linalg.norm` then round to float32, shot.py:211-214, fpfh.py:45-48) against the float64 arithmetic on the same values --
+    which is what the build computes after its cast at the boundary: every row within 1e-5 (the count is asserted to be 0)."""
+    g = load_golden("shot_f32.npz")
+    p = g[f"{tag}_cloud"]
+    assert p.dtype == np.float32
+    nrm = g["normals64"] if ntag == "n64" else g["normals64"].astype(np.float32)
+    kp = p[g["keypoints_indices"]][g["rows"]]
+    d = O.shot_single_scale(p.astype(np.float64), nrm.astype(np.float64), kp.astype(np.float64), float(g["radius"]), True,
+                            int(g["min_neighborhood_size"]))
+    gap = np.abs(d - g[f"{tag}_{ntag}_desc"]).max(axis=1)
+    assert int((gap > 1e-5).sum()) == 0, (int((gap > 1e-5).sum()), gap.max())
+    assert int(g[f"{tag}_{ntag}_rows_beyond_1e5"]) == 0  # (reference on float32 arrays vs reference on float64 arrays, all 2 000 rows)
+    f = load_golden("fpfh_f32.npz")
+    pf = f[f"{tag}_cloud"]
+    nf = f["normals64"] if ntag == "n64" else f["normals64"].astype(np.float32)
+    got = O.compute_fpfh_descriptor(f["keypoints_indices"], pf.astype(np.float64), nf.astype(np.float64), float(f["radius"]), int(f["n_bins"]))
+    want = f[f"{tag}_{ntag}_desc"]
+    bad = (np.abs(got - want) > 1e-5 * np.maximum(1.0, np.abs(want))).any(axis=1)
+    assert int(bad.sum()) == 0, int(bad.sum())
