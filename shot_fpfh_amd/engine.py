@@ -408,6 +408,15 @@ class Engine:
         )
         return out
 
+    def ransac_score_device(self, a: DeviceArray, b: DeviceArray, m: int, rt: DeviceArray, n_draws: int, thr: float,
+                            out: DeviceArray) -> DeviceArray:
+        """K9 on resident operands, asynchronous: a, b (m, 3) matched points, rt (n_draws, 12), out (n_draws,) int64."""
+        if out.dtype != np.int64 or out.shape[0] < n_draws or rt.shape[0] < n_draws or a.shape[0] < m or b.shape[0] < m:
+            raise ValueError("ransac_score_device: operands smaller than the counts given")
+        _ffi.check(self.lib.sf_ransac_score(self.h, a.ptr, b.ptr, int(m), rt.ptr, int(n_draws), float(thr), out.ptr,
+                                            SF_IN_DEVICE | SF_OUT_DEVICE), "sf_ransac_score")
+        return out
+
     # ---- multi-GPU (RCCL) -------------------------------------------------------------------------
     def comm_unique_id(self) -> bytes:
         buf = C.create_string_buffer(128)

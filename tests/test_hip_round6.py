@@ -204,3 +204,48 @@ def test_lists_of_a_rebuilt_grid_are_refused_not_misread(eng):
         nb.free()
     finally:
         cloud.free()
+
+
+# ---- RANSAC: device gather, draws from the raw stream, fits in stacks while K9 scores ---------------------------------------------
+def test_ransac_pipeline_equals_the_per_draw_formulation(eng):
+    """ransac_on_matches now gathers keypoints[indices] on the device, takes all draws from the generator's raw stream and fits
+    chunks of draws while K9 scores the previous chunk.  Against the plain formulation -- rng.choice per draw, solver_point_to_point
+    per draw, one sf_ransac_score over host-gathered points -- ratio and transform bit for bit, with negative indices among the
+    matches (keypoints[-1] is the last keypoint)."""
+    import shot_fpfh_amd.matching.ransac as R
+    from shot_fpfh_amd.core import solver_point_to_point
+
+    rng = np.random.default_rng(91)
+    n_kp, n_m, n_draws, thr = 50_000, 120_000, 5_000, 0.01
+    scan_kp = rng.random((n_kp, 3))
+    rot = np.array([[0.8, -0.6, 0.0], [0.6, 0.8, 0.0], [0.0, 0.0, 1.0]])
+    ref_kp = (scan_kp @ rot.T + np.array([0.2, -0.1, 0.3]))[rng.permutation(n_kp)]
+    si = rng.integers(0, n_kp, n_m)
+    ri = rng.integers(0, n_kp, n_m)
+    good = rng.random(n_m) < 0.3  # a third of the matches are true correspondences
+    back = np.empty(n_kp, np.int64)
+    # (ref_kp = moved[perm]: the ref row that holds scan row s is inv_perm[s]; rebuilt from the points themselves)
+    order = np.lexsort(ref_kp.T[::-1])
+    moved = scan_kp @ rot.T + np.array([0.2, -0.1, 0.3])
+    back[np.lexsort(moved.T[::-1])] = order
+    ri[good] = back[si[good]]
+    si[:50] -= n_kp  # negative indices
+    R.rng = np.random.default_rng(seed=72)
+    ratio, tf = R.ransac_on_matches(si, ri, scan_kp, ref_kp, n_draws=n_draws, draw_size=4, distance_threshold=thr, disable_progress_bar=True)
+    gen = np.random.default_rng(seed=72)
+    a, b = scan_kp[si], ref_kp[ri]
+    records = np.empty((n_draws, 12))
+    for d in range(n_draws):
+        pick = gen.choice(n_m, 4, replace=False, shuffle=False)
+        records[d] = solver_point_to_point(a[pick], b[pick]).as_row12()
+    inl = eng.ransac_score(a, b, records, thr)
+    best = int(np.argmax(inl))
+    assert ratio == inl[best] / n_m and ratio > 0.25
+    want = R.RigidTransform(records[best, :9].reshape(3, 3).copy(), records[best, 9:].copy())
+    want.normalize_rotation()
+    assert np.array_equal(tf.rotation, want.rotation) and np.array_equal(tf.translation, want.translation)
+    assert R.rng.bit_generator.state == gen.bit_generator.state
+    with pytest.raises(IndexError):
+        R.ransac_on_matches(np.array([0, 1, 2, 3, n_kp]), np.arange(5), scan_kp, ref_kp, n_draws=40, disable_progress_bar=True)
+    with pytest.raises(AttributeError):
+        R.ransac_on_matches(si, ri, scan_kp, ref_kp, n_draws=0)

@@ -29,6 +29,30 @@ def test_ransac_draw_stream_is_the_reference_stream():
     assert np.array_equal(mine, g["draws"])
 
 
+def test_vectorised_draw_stream_equals_the_per_draw_generator_calls():
+    """matching.ransac.draw_stream produces, from the generator's raw output, what n_draws successive
+    rng.choice(n, size, replace=False, shuffle=False) return (ransac.py:50-55) and leaves the generator in the state those calls
+    leave it in: the reference's recorded draws, populations where Floyd's algorithm meets repeats, where the bounded-integer
+    sampler rejects, a pending half-word in the generator, and a second call continuing the stream."""
+    import shot_fpfh_amd.matching.ransac as R
+
+    g = load_golden("ransac_500.npz")
+    assert R._replica_matches_this_numpy()  # (else every call below is the loop itself)
+    assert np.array_equal(R.draw_stream(np.random.default_rng(seed=72), 500, 4, len(g["draws"])), g["draws"])
+    for seed, n, size, k, pre in ((72, 1_000_000, 4, 10_000, 0), (1, 9, 4, 4_000, 1), (2, 60_000_000, 4, 6_000, 0), (3, 100_000, 7, 1_500, 1),
+                                  (4, 5, 4, 300, 0), (5, 2_000_000_000, 4, 500, 0), (6, 30, 2, 40, 1)):
+        a, b = np.random.default_rng(seed), np.random.default_rng(seed)
+        for gen in (a, b):
+            for _ in range(pre):
+                gen.integers(0, 10, dtype=np.uint32)  # leaves a buffered 32-bit half-word behind
+        first = R.draw_stream(a, n, size, k)
+        assert np.array_equal(first, R._draws_by_loop(b, n, size, k)), (seed, n, size)
+        assert (np.sort(first, axis=1)[:, 1:] != np.sort(first, axis=1)[:, :-1]).all() and first.min() >= 0 and first.max() < n
+        assert a.bit_generator.state == b.bit_generator.state
+        assert np.array_equal(R.draw_stream(a, n, size, 77), R._draws_by_loop(b, n, size, 77))
+        assert np.array_equal(a.random(4), b.random(4))
+
+
 def test_filters():
     from shot_fpfh_amd.matching import left_median_filter, quantile_filter, threshold_filter
 
