@@ -644,16 +644,13 @@ int sf_match_i8(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int
     SF_HIP(hipMemsetAsync(counters, 0, (size_t)(2 * nsplit + 2) * sizeof(int), ctx->stream));
     SF_LAUNCH(ctx, "k8_i8_window", k_i8_window, dim3((unsigned)sf_div_up(m1p, 256)), dim3(256), (const double *)ea, (const double *)qa,
               (const double *)na2, m1, m1p, std::sqrt(nbmax), ebmax, nbmax, unit, win);
-    // pass 1 over row slabs: the first one is the PILOT (64 workgroups' worth of rows) when the problem is many times that
-    static const double max_flagged = [] { const char *e = getenv("SF_I8_MAX_FLAGGED"); const double v = e ? atof(e) : 0.35; return v > 0.0 ? v : 0.35; }();
-    const int64_t pilot_rows = (int64_t)IM * 256;
-    const bool pilot = m1 >= 8 * pilot_rows && sf_match_i8_mode() != 1;
-    std::vector<int> hcount((size_t)(2 * nsplit + 2));
-    for (int64_t r0 = 0; r0 < m1;) {
-        const bool is_pilot = pilot && r0 == 0;
-        const int64_t ms = is_pilot ? pilot_rows : m1 - r0, msp = sf_div_up(ms, IM) * IM, row_blocks = msp / IM;
+    // Steps 2-5 for the scan rows [r0, r0 + ms): pass 1, live splits, pairs, collect pass, decision.  Rows that end flagged
+    // (counted in *nflag) are left to the caller.
+    auto run_rows = [&](int64_t r0, int64_t ms) -> int {
+        const int64_t msp = sf_div_up(ms, IM) * IM, row_blocks = msp / IM;
         const int64_t wgs = sf_xcd_grid(nsplit * row_blocks);
         if (wgs > 0x7fffffffLL) { sf_set_error("sf_match_i8: %lld workgroups exceed a launch", (long long)wgs); return SF_ERR_UNSUPPORTED; }
+        SF_HIP(hipMemsetAsync(split_count, 0, (size_t)(2 * nsplit) * sizeof(int), ctx->stream)); // (counts and cursors)
         // (smin rows are addressed split * m1p + row: a slab writes its own rows of every split's stripe)
 #define SF_I8_MIN(KS_, RB_)                                                                                             \
         SF_LAUNCH(ctx, name, (k_i8_min<KS_, RB_>), dim3((unsigned)wgs), dim3(512), (const unsigned char *)(ai + r0 * dp),  \
@@ -664,58 +661,70 @@ int sf_match_i8(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int
         SF_LAUNCH(ctx, "k8_i8_live", k_i8_live, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), (const int *)(smin + r0), (const int *)(win + r0),
                   a_ok ? a_ok + r0 : a_ok, ms, m1p, (int)nsplit, kmin + r0, live + r0 * I_LIVE, split_count, didx + r0,
                   ddist ? ddist + r0 : ddist, flag + r0, nflag);
-        if (is_pilot) {
-            int nf = 0;
-            SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            SF_HIP(hipStreamSynchronize(ctx->stream));
-            if ((double)nf > max_flagged * (double)ms) return SF_OK; // (*used = 0: the caller's pass overwrites what was written)
+        // the pairs, split by split, each split's run padded to whole workgroups of 256
+        std::vector<int> hcount((size_t)nsplit), hbase((size_t)nsplit), hblk;
+        SF_HIP(hipMemcpyAsync(hcount.data(), split_count, (size_t)nsplit * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        int64_t n_pairs_pad = 0;
+        for (int64_t s = 0; s < nsplit; ++s) {
+            hbase[(size_t)s] = (int)n_pairs_pad;
+            const int64_t nb = sf_div_up(hcount[(size_t)s], 256);
+            for (int64_t k = 0; k < nb; ++k) hblk.push_back((int)s);
+            n_pairs_pad += nb * 256;
+            if (n_pairs_pad > 0x7fffff00LL) { sf_set_error("sf_match_i8: too many (row, split) pairs"); return SF_ERR_UNSUPPORTED; }
         }
-        r0 += ms;
-    }
-    // the pairs, split by split, each split's run padded to whole workgroups of 256
-    SF_HIP(hipMemcpyAsync(hcount.data(), counters, (size_t)(2 + nsplit) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int> hbase((size_t)nsplit), hblk;
-    int64_t n_pairs_pad = 0;
-    for (int64_t s = 0; s < nsplit; ++s) {
-        hbase[(size_t)s] = (int)n_pairs_pad;
-        const int64_t nb = sf_div_up(hcount[(size_t)(2 + s)], 256);
-        for (int64_t k = 0; k < nb; ++k) hblk.push_back((int)s);
-        n_pairs_pad += nb * 256;
-        if (n_pairs_pad > 0x7fffff00LL) return SF_OK;
-    }
-    const int64_t n_blocks = (int64_t)hblk.size();
-    int *split_base = nullptr, *blk_split = nullptr, *pair_row = nullptr, *pair_thr = nullptr, *cnt = nullptr, *candk = nullptr;
-    int32_t *candj = nullptr;
-    SF_IALLOC(split_base, nsplit); SF_IALLOC(blk_split, std::max<int64_t>(n_blocks, 1));
-    SF_IALLOC(pair_row, std::max<int64_t>(n_pairs_pad, 1)); SF_IALLOC(pair_thr, std::max<int64_t>(n_pairs_pad, 1));
-    SF_IALLOC(cnt, std::max<int64_t>(n_pairs_pad, 1));
-    SF_IALLOC(candj, std::max<int64_t>(n_pairs_pad, 1) * ICAP); SF_IALLOC(candk, std::max<int64_t>(n_pairs_pad, 1) * ICAP);
-    SF_HIP(hipMemcpyAsync(split_base, hbase.data(), (size_t)nsplit * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    if (n_blocks) {
-        SF_HIP(hipMemcpyAsync(blk_split, hblk.data(), (size_t)n_blocks * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        SF_HIP(hipMemsetAsync(pair_row, 0xff, (size_t)n_pairs_pad * sizeof(int), ctx->stream)); // -1: padding
-        SF_HIP(hipMemsetAsync(cnt, 0, (size_t)n_pairs_pad * sizeof(int), ctx->stream));
-        SF_LAUNCH(ctx, "k8_i8_live", k_i8_place, dim3((unsigned)sf_div_up(m1, 256)), dim3(256), (const int *)kmin, (const int *)win, live, m1,
-                  (int)nsplit, (const int *)split_base, split_cursor, pair_row, pair_thr);
-        const int64_t wgs = sf_xcd_grid(n_blocks);
-        if (ks == 4) {
-            SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<4>, dim3((unsigned)wgs), dim3(512), (const unsigned char *)ai, (const unsigned char *)bi,
-                      m2p, (const int *)nbi, tiles_per_split, n_blocks, (const int *)blk_split, (const int *)pair_row, (const int *)pair_thr,
-                      cnt, candj, candk);
-        } else {
-            SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<11>, dim3((unsigned)wgs), dim3(512), (const unsigned char *)ai, (const unsigned char *)bi,
-                      m2p, (const int *)nbi, tiles_per_split, n_blocks, (const int *)blk_split, (const int *)pair_row, (const int *)pair_thr,
-                      cnt, candj, candk);
+        const int64_t n_blocks = (int64_t)hblk.size();
+        sf_pool_guard ptmp(ctx);
+        int *split_base = nullptr, *blk_split = nullptr, *pair_row = nullptr, *pair_thr = nullptr, *cnt = nullptr, *candk = nullptr;
+        int32_t *candj = nullptr;
+        const size_t np1 = (size_t)std::max<int64_t>(n_pairs_pad, 1);
+        SF_CHECK(ptmp.alloc(&split_base, (size_t)nsplit)); SF_CHECK(ptmp.alloc(&blk_split, (size_t)std::max<int64_t>(n_blocks, 1)));
+        SF_CHECK(ptmp.alloc(&pair_row, np1)); SF_CHECK(ptmp.alloc(&pair_thr, np1)); SF_CHECK(ptmp.alloc(&cnt, np1));
+        SF_CHECK(ptmp.alloc(&candj, np1 * ICAP)); SF_CHECK(ptmp.alloc(&candk, np1 * ICAP));
+        SF_HIP(hipMemcpyAsync(split_base, hbase.data(), (size_t)nsplit * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        if (n_blocks) {
+            SF_HIP(hipMemcpyAsync(blk_split, hblk.data(), (size_t)n_blocks * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            SF_HIP(hipMemsetAsync(pair_row, 0xff, (size_t)n_pairs_pad * sizeof(int), ctx->stream)); // -1: padding
+            SF_HIP(hipMemsetAsync(cnt, 0, (size_t)n_pairs_pad * sizeof(int), ctx->stream));
+            SF_LAUNCH(ctx, "k8_i8_live", k_i8_place, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), (const int *)(kmin + r0), (const int *)(win + r0),
+                      live + r0 * I_LIVE, ms, (int)nsplit, (const int *)split_base, split_cursor, pair_row, pair_thr);
+            const int64_t cw = sf_xcd_grid(n_blocks);
+            if (ks == 4) {
+                SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<4>, dim3((unsigned)cw), dim3(512), (const unsigned char *)(ai + r0 * dp),
+                          (const unsigned char *)bi, m2p, (const int *)nbi, tiles_per_split, n_blocks, (const int *)blk_split,
+                          (const int *)pair_row, (const int *)pair_thr, cnt, candj, candk);
+            } else {
+                SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<11>, dim3((unsigned)cw), dim3(512), (const unsigned char *)(ai + r0 * dp),
+                          (const unsigned char *)bi, m2p, (const int *)nbi, tiles_per_split, n_blocks, (const int *)blk_split,
+                          (const int *)pair_row, (const int *)pair_thr, cnt, candj, candk);
+            }
         }
-    }
 #define SF_I8_FINAL(LPR)                                                                                               \
-    SF_LAUNCH(ctx, "k8_i8_final", k_i8_final<LPR>, dim3((unsigned)sf_div_up(m1 * LPR, 256)), dim3(256), da, m1, db, d, a_ok,  \
-              (const int *)live, (const int *)cnt, (const int32_t *)candj, (const int *)candk, (const int *)win,       \
-              (const double *)na2, unit, didx, ddist, flag, nflag)
-    if (m1 <= 65536) { SF_I8_FINAL(16); } else { SF_I8_FINAL(1); }
+        SF_LAUNCH(ctx, "k8_i8_final", k_i8_final<LPR>, dim3((unsigned)sf_div_up(ms * LPR, 256)), dim3(256), da + r0 * d, ms, db, d, \
+                  a_ok ? a_ok + r0 : a_ok, (const int *)(live + r0 * I_LIVE), (const int *)cnt, (const int32_t *)candj,   \
+                  (const int *)candk, (const int *)(win + r0), (const double *)(na2 + r0), unit, didx + r0,              \
+                  ddist ? ddist + r0 : ddist, flag + r0, nflag)
+        if (ms <= 65536) { SF_I8_FINAL(16); } else { SF_I8_FINAL(1); }
 #undef SF_I8_FINAL
-    SF_HIP(hipStreamSynchronize(ctx->stream)); // (hbase / hblk are host buffers of the copies above)
+        SF_HIP(hipStreamSynchronize(ctx->stream)); // (hbase / hblk are host buffers of the copies above)
+        return SF_OK;
+    };
+    // the first slab is the PILOT when the problem is many times its size: its flagged share decides whether the integer pass pays
+    static const double max_flagged = [] { const char *e = getenv("SF_I8_MAX_FLAGGED"); const double v = e ? atof(e) : 0.35; return v > 0.0 ? v : 0.35; }();
+    // (SF_I8_PILOT_ROWS: the pilot's size, for tests -- it then runs in the forced mode too)
+    const char *pilot_env = getenv("SF_I8_PILOT_ROWS");
+    const int64_t pilot_rows = pilot_env ? std::max<int64_t>(IM, sf_div_up(atoll(pilot_env), IM) * IM) : (int64_t)IM * 64;
+    const bool pilot = pilot_env ? m1 > pilot_rows : (m1 >= 4 * pilot_rows && sf_match_i8_mode() != 1);
+    int64_t done = 0;
+    if (pilot) {
+        SF_CHECK(run_rows(0, pilot_rows));
+        int nf = 0;
+        SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SF_HIP(hipStreamSynchronize(ctx->stream));
+        if ((double)nf > max_flagged * (double)pilot_rows) return SF_OK; // (*used = 0: the caller's pass overwrites what was written)
+        done = pilot_rows;
+    }
+    SF_CHECK(run_rows(done, m1 - done));
     int nf = 0;
     SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));

@@ -897,9 +897,10 @@ def test_fpfh_matrix_core_path_with_peaked_histograms(eng, O, n, r, kmin):
     assert close(f, f_o).all() and np.abs(f - f_o).max() < 1e-9 * max(1.0, np.abs(f_o).max())
 
 
-def test_match_large_permutation_property(eng, O):
-    """BASELINE config 4's matching step at a size the CPU cannot check pair by pair (400k x 400k x 352, the FP16
-    pre-filter by default), through properties: the reference set is a row permutation of the scan set plus noise far
+@pytest.mark.parametrize("prefilter", ["int8", "fp16"])
+def test_match_large_permutation_property(eng, O, monkeypatch, prefilter):
+    """BASELINE config 4's matching step at a size the CPU cannot check pair by pair (400k x 400k x 352: the integer
+    pre-filter by default since round 6, the FP16 pre-filter with SF_MATCH_I8=0), through properties: the reference set is a row permutation of the scan set plus noise far
     below the spacing of the descriptors, so the arg-min must invert the permutation exactly; the distances must be the
     sequential float64 ones of those pairs; and a sample of rows must equal the exact kernel / oracle bit for bit."""
     rng = np.random.default_rng(404)
@@ -913,12 +914,18 @@ def test_match_large_permutation_property(eng, O):
     inv[perm] = np.arange(m)
     da, db = eng.empty((m, d)).from_host(a), eng.empty((m, d)).from_host(b)
     idx, dist = eng.empty((m,), np.int64), eng.empty((m,), np.float64)
+    if prefilter == "fp16":
+        monkeypatch.setenv("SF_MATCH_I8", "0")
     eng.profile_reset()
     eng.profile(True)
     eng.match_argmin_device(da, db, idx, dist)
     eng.sync()
     eng.profile(False)
-    assert eng.profile_report().get("k8_match_half", (0, 0))[0] >= 1, "this size was expected to take the FP16 pre-filter"
+    rep = eng.profile_report()
+    if prefilter == "int8":
+        assert rep.get("k8_match_i8", (0, 0))[0] >= 1, "this size was expected to take the integer pre-filter"
+    else:
+        assert rep.get("k8_match_half", (0, 0))[0] >= 1 and "k8_match_i8" not in rep, "this size was expected to take the FP16 pre-filter"
     i_h, d_h = idx.to_host(), dist.to_host()
     assert np.array_equal(i_h, inv)
     pick = rng.choice(m, 2000, replace=False)

@@ -249,3 +249,85 @@ def test_ransac_pipeline_equals_the_per_draw_formulation(eng):
         R.ransac_on_matches(np.array([0, 1, 2, 3, n_kp]), np.arange(5), scan_kp, ref_kp, n_draws=40, disable_progress_bar=True)
     with pytest.raises(AttributeError):
         R.ransac_on_matches(si, ri, scan_kp, ref_kp, n_draws=0)
+
+
+# ---- K8: the integer pre-filter (match_i8.hip) ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("splits", [None, 3, 11])
+@pytest.mark.parametrize("case", ["shot_like", "fpfh_like", "wide_range", "descending"])
+def test_match_i8_prefilter_equals_exact(eng, O, monkeypatch, case, splits):
+    """The int8 matrix-core pre-filter only prunes: index AND distance equal scipy's / the exact kernel's bit for bit on the cases
+    the FP16 pre-filter is held to (exact ties and duplicates, an equidistant pair, zero rows, 125- and 33-column rows, norms over
+    twelve orders of magnitude, an order in which every later column is nearer) -- with the column range in one split, and cut
+    into 3 and 11 (a row's minimum and its ties then sit in different splits: several live pairs per row)."""
+    from test_hip_parity import _half_cases
+
+    a, b = next((a, b) for name, a, b in _half_cases() if name == case)
+    monkeypatch.setenv("SF_MATCH_I8", "1")
+    if splits:
+        monkeypatch.setenv("SF_MATCH_I8_SPLITS", str(splits))
+    eng.profile_reset()
+    eng.profile(True)
+    idx, dist, col = eng.match_argmin(a, b, want_col=True)
+    eng.profile(False)
+    rep = eng.profile_report()
+    io, do, co = O.match_argmin(a, b, want_col=True)
+    assert np.array_equal(idx, io) and np.array_equal(dist, do) and np.array_equal(col, co)
+    assert rep.get("k8_match_i8", (0, 0))[0] == 2, "the integer pre-filter was expected to run for both directions"
+    if case == "shot_like":  # rows with a clear nearest descriptor are served without the FP16 pass ... mostly
+        assert rep.get("k8_i8_collect", (0, 0))[0] == 2
+
+
+def test_match_i8_masked_rows_and_rows_without_a_clear_minimum(eng, monkeypatch):
+    """Resident, masked form through the integer pre-filter; a block of near-identical reference rows puts hundreds of columns
+    inside the integer window of the scan rows that match them (candidate lists overflow -> the FP16 pass decides those rows)."""
+    from shot_fpfh_amd.matching import basic_matching
+    from shot_fpfh_amd.sharding import MatchJob
+
+    rng = np.random.default_rng(833)
+    a = rng.random((3000, 352)) * (rng.random((3000, 352)) < 0.3)
+    b = a[rng.permutation(3000)][:2800] + 0.01 * rng.standard_normal((2800, 352))
+    b[1000:1400] = b[1000] + 1e-5 * rng.standard_normal((400, 352))
+    a[:60] = b[1000] + 1e-5 * rng.standard_normal((60, 352))
+    a[[3, 99, 500]] = 0.0
+    b[[7, 640]] = 0.0
+    monkeypatch.setenv("SF_MATCH_I8", "1")
+    job = MatchJob(eng, 352, 3000, 2800)
+    eng.profile_reset()
+    eng.profile(True)
+    job.run(eng.empty((3000, 352)).from_host(a), eng.empty((2800, 352)).from_host(b))
+    eng.profile(False)
+    s1, r1 = job.matches()
+    dist = job.dist.to_host()
+    s2, r2 = basic_matching(a, b)
+    assert np.array_equal(s1, s2) and np.array_equal(r1, r2)
+    assert np.isinf(dist[[3, 99, 500]]).all() and np.isfinite(np.delete(dist, [3, 99, 500])).all()
+    rep = eng.profile_report()
+    assert rep.get("k8_match_i8", (0, 0))[0] >= 1 and rep.get("k8_match_half", (0, 0))[0] >= 1
+    job.close()
+
+
+def test_match_i8_pilot_hands_unclear_problems_to_the_fp16_pass(eng, O, monkeypatch):
+    """Dense random rows have no nearest descriptor that stands clear of the rest: the pilot slab sees nearly every row flagged and
+    the whole problem takes the FP16 pass; with planted copies the pilot passes and the rows beyond it are served.  Results equal
+    the exact kernel's either way."""
+    rng = np.random.default_rng(834)
+    m = 6000
+    b = rng.random((m, 352))
+    b /= np.linalg.norm(b, axis=1)[:, None]
+    a_clear = b[rng.permutation(m)] + 1e-4 * rng.standard_normal((m, 352))
+    a_unclear = rng.random((m, 352))
+    a_unclear /= np.linalg.norm(a_unclear, axis=1)[:, None]
+    monkeypatch.setenv("SF_MATCH_I8", "1")
+    monkeypatch.setenv("SF_I8_PILOT_ROWS", "1024")
+    for a, pilot_passes in ((a_clear, True), (a_unclear, False)):
+        eng.profile_reset()
+        eng.profile(True)
+        idx, dist = eng.match_argmin(a, b)[:2]
+        eng.profile(False)
+        rep = eng.profile_report()
+        io, do = O.match_argmin(a, b)[:2]
+        assert np.array_equal(idx, io) and np.array_equal(dist, do)
+        assert rep.get("k8_match_i8", (0, 0))[0] == (2 if pilot_passes else 1), rep.get("k8_match_i8")
+        assert rep.get("k8_i8_collect", (0, 0))[0] == (2 if pilot_passes else 1)  # (the pilot runs all steps on its slab)
+        other = rep.get("k8_match_half", (0, 0))[0] + rep.get("k8_match_gemm", (0, 0))[0]  # (this size: the FP64 GEMM form)
+        assert (other >= 1) == (not pilot_passes)
