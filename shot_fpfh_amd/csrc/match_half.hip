@@ -593,7 +593,9 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
                   flag + r0, nflag);
         static const int lpr_env = [] { const char *e = getenv("SF_MATCH_FINAL_LPR"); return e ? atoi(e) : 0; }(); // (A/B)
         // (10^4 rows: 1.53 / 0.48 / 0.26 ms with 1 / 4 / 16 lanes per row; 262 144 rows: 3.9 / 4.5 / 5.5 ms -- the chip is full with one)
-        const int lpr = lpr_env ? lpr_env : (ms <= 65536 ? 16 : 1);
+        // (75 000 rows -- what the integer pass hands on of config 4's 10^6 -- with one lane per row: 1 172 waves, one per SIMD, every
+        // one of them a serial chain of 2 x 352 scattered loads: 4.7 ms; sixteen lanes per row there: round 6)
+        const int lpr = lpr_env ? lpr_env : (ms <= 160000 ? 16 : 1);
         if (lpr == 1) { SF_HALF_FINAL(1) } else if (lpr == 4) { SF_HALF_FINAL(4) } else { SF_HALF_FINAL(16) }
 #undef SF_HALF_FINAL
     }

@@ -42,6 +42,15 @@ mj = MatchJob(eng, 352, n, n)
 mj.run(js.shot_out, jr.shot_out)
 eng.sync()
 t3 = time.perf_counter()
+# (the same pass once more with the launch timers on: per-kernel times of K8; the wall time above is the untimed run's)
+eng.profile_reset()
+eng.profile(True)
+mj.run(js.shot_out, jr.shot_out)
+eng.sync()
+eng.profile(False)
+k8_report = {k: (v[0], round(v[1], 3)) for k, v in eng.profile_report().items() if k.startswith("k8")}
+eng.profile_reset()
+eng.profile(True)
 rows_s, rows_r = mj.matches()  # cell-sorted numbering of each cloud
 scan_idx, ref_idx = js.block_original_indices()[rows_s], jr.block_original_indices()[rows_r]
 inv = np.argsort(perm)
@@ -59,4 +68,6 @@ print(f"  matches kept {len(scan_idx)}, equal to the true correspondence: {100 *
 print(f"  RANSAC {n_draws} draws x {len(scan_idx)} matches    {t5 - t4:8.3f} s   (host draws + Kabsch, K9 scoring)")
 print(f"  inlier ratio {ratio:.4f}, max |R - R_true| = {np.abs(tf.rotation - rot).max():.2e}, "
       f"max |t - t_true| = {np.abs(tf.translation - t).max():.2e}")
-print("  kernels:", {k: (v[0], round(v[1], 2)) for k, v in eng.profile_report().items() if k.startswith(("k8", "k9"))})
+eng.profile(False)
+print("  K8 kernels (launches, ms) of a second, timed pass:", k8_report)
+print("  K9 kernels (launches, ms):", {k: (v[0], round(v[1], 3)) for k, v in eng.profile_report().items() if k.startswith("k9")})
