@@ -431,11 +431,21 @@ def finish_numpy_shaped_baseline(proc) -> dict:
     if proc.returncode != 0:
         raise RuntimeError("oracle/numpy_shaped.py failed")
     r = json.loads(out.strip().splitlines()[-1])
-    cal = None
+    # the calibration against the reference itself, and the reference's own times at config 2 / a 200 000-point slice of config 3
+    # (tools/cpu_reference_r6.py, build container: the reference cannot travel to the GPU box)
+    cal, ref_runs = None, None
     try:
-        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r06_cpu_reference.json")))
+        cal = dict(rec["calibration_of_numpy_shaped"])
+        cal["ratio_total"] = cal["ratio_total"]
+        ref_runs = {"config2_as_written": {k: rec["config2_as_written"][k] for k in ("fpfh_s", "shot_s", "descriptors_per_s")},
+                    "config3_200k_slice": {k: rec["config3_200k_slice"][k] for k in ("fpfh_s", "shot_s", "descriptors_per_s", "implied_seconds_for_config3_full")},
+                    "host_cores": rec["host"]["cores"], "versions": rec["versions"], "source": "profiles/r06_cpu_reference.json"}
     except Exception:
-        pass
+        try:
+            cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")))
+        except Exception:
+            pass
     return {
         "value": r["desc_per_s"],
         "unit": "descriptors/s",
@@ -450,7 +460,8 @@ def finish_numpy_shaped_baseline(proc) -> dict:
         "calibration_vs_reference": None if cal is None else {
             "ratio_time_restatement_over_reference": cal["ratio_total"], "reference_desc_per_s_build_container": cal["ref_desc_per_s"],
             "max_abs_diff_vs_reference": max(cal["fpfh_max_abs_diff"], cal["shot_max_abs_diff"]),
-            "where": "build container, 8 vCPU (tools/calibrate_cpu_baseline.py; the reference cannot travel to the GPU box)"},
+            "where": "build container, 8 vCPU (tools/cpu_reference_r6.py; the reference cannot travel to the GPU box)"},
+        "reference_itself_build_container": ref_runs,
     }
 
 

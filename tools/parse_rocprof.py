@@ -36,6 +36,9 @@ SHORT = [
 
 # round 4: second launches and selections (checked before the table above; template arguments as rocprofv3 prints them)
 SHORT_RE = [
+    (r"k_i8_min", "k8_match_i8"), (r"k_i8_collect", "k8_i8_collect"), (r"k_i8_final", "k8_i8_final"), (r"k_i8_live|k_i8_place", "k8_i8_live"),
+    (r"k_i8_convert|k_i8_rowstat", "k8_i8_convert"), (r"k_i8_max", "k8_i8_max"), (r"k_i8_window", "k8_i8_window"),
+    (r"k_i8_gather_rows|k_half_gather_rows", "k8_gather_rows"), (r"k_i8_scatter|k_half_scatter", "k8_scatter_results"),
     (r"radix_sort", "rocprim_radix_sort"), (r"k_radius<2, ", "k2_radius_slots"), (r"k_radius<1, true>", "k2_radius_refill"), (r"k_radius<1, false>", "k2_radius_fill"),
     (r"k_radius<0, true>", "k2_sample"), (r"k_radius<0, false>", "k2_radius_count"), (r"k_iota_stride", "k2_sample"),
     (r"k_patch_offsets", "k2_select"), (r"select|partition", "rocprim_select"), (r"k_shot_long|k_shot_team", "k5_shot_tail"), (r"k_fpfh_mcl", "k7_fpfh_tail"),
