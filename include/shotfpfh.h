@@ -314,6 +314,16 @@ int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, in
 int sf_match_col_candidates(sf_ctx *ctx, const double *local_dist_dev, const double *global_dist_dev,
                             const int64_t *local_idx_dev, int64_t row_offset, int64_t m, void *cand_dev);
 
+/* The descriptor all-gather of a sharded matching (every scan row must see every reference row) in CHUNKS, so that K8 runs on
+ * chunk c while chunk c + 1 is still crossing xGMI: chunk c gathers rows [col0, col0 + piece) of EVERY rank's block of
+ * rows_per_rank rows into one contiguous buffer (ncclAllGather: piece r of the buffer is rank r's), K8 gives the row arg-min
+ * over that buffer, and sf_match_fold maps its column j to the row (j / piece) * rows_per_rank + col0 + j % piece of the
+ * gathered set and keeps, per scan row, the smaller distance -- the smaller gathered row on a tie, so that the result is the
+ * arg-min over the whole set, first minimum included (matching.py:164-168).  first != 0: the running minimum is overwritten.
+ * All pointers device memory; stream-ordered. */
+int sf_match_fold(sf_ctx *ctx, const int64_t *idx_chunk_dev, const double *dist_chunk_dev, int64_t m, int64_t piece,
+                  int64_t rows_per_rank, int64_t col0, int first, int64_t *best_idx_dev, double *best_dist_dev);
+
 /* ---- RANSAC scoring: inlier count of ransac.py:60-67, K9 ----------------------------------
  * a, b: m x 3 matched points; Rt: n_draws x 12 (row-major R, then t); counts ||a R^T + t - b|| <= thr. */
 int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, int64_t m, const double *Rt, int64_t n_draws,

@@ -96,6 +96,7 @@ SIGNATURES = {
     "sf_rows_gather": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "sf_match_argmin_multiscale": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _f64, _vp, _vp, _int]),
     "sf_match_col_candidates": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "sf_match_fold": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
     "sf_ransac_score": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _int]),
     "sf_voxels_build": (_vp, [_vp, _vp, _i64, _f64, _int]),
     "sf_voxels_count": (_i64, [_vp]),

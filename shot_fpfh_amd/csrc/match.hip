@@ -369,6 +369,22 @@ extern "C" int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, int64_t n_row
 }
 
 namespace {
+// Fold of one column CHUNK's row arg-min into the running one (see sf_match_fold): the chunk's columns are `world` pieces of
+// `piece` rows, piece r of the chunk being rows r * rows_per_rank + col0 .. of the gathered set.
+__global__ void k_match_fold(const int64_t *__restrict__ idx_c, const double *__restrict__ dist_c, int64_t m, int64_t piece,
+                             int64_t rows_per_rank, int64_t col0, int first, int64_t *__restrict__ best_idx,
+                             double *__restrict__ best_dist)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int64_t j = idx_c[i], g = (j / piece) * rows_per_rank + col0 + j % piece;
+    const double d = dist_c[i];
+    if (first || d < best_dist[i] || (d == best_dist[i] && g < best_idx[i])) {
+        best_idx[i] = g;
+        best_dist[i] = d;
+    }
+}
+
 // second half of a sharded column arg-min (see sf_match_col_candidates)
 __global__ void k_col_candidates(const double *__restrict__ local_dist, const double *__restrict__ global_dist,
                                  const int64_t *__restrict__ local_idx, int64_t row_offset, int64_t m,
@@ -388,6 +404,20 @@ __global__ void k_col_candidates(const double *__restrict__ local_dist, const do
 // doubles order like their bit patterns, sf_comm_allreduce_min_u64 -- and the winner is the LOWEST scan row that
 // attains it: this call turns (local, global) distances into candidates `row_offset + local_idx` where the rank attains
 // the global minimum and ~0 where it does not, and a second all-reduce(min) picks the first minimum, as NumPy does.
+extern "C" int sf_match_fold(sf_ctx *ctx, const int64_t *idx_chunk_dev, const double *dist_chunk_dev, int64_t m, int64_t piece,
+                             int64_t rows_per_rank, int64_t col0, int first, int64_t *best_idx_dev, double *best_dist_dev)
+{
+    if (!ctx || !idx_chunk_dev || !dist_chunk_dev || !best_idx_dev || !best_dist_dev || m < 0 || piece < 1 || rows_per_rank < piece || col0 < 0) {
+        sf_set_error("sf_match_fold: bad argument");
+        return SF_ERR_ARG;
+    }
+    SF_HIP(hipSetDevice(ctx->device));
+    if (m)
+        SF_LAUNCH(ctx, "k8_match_fold", k_match_fold, dim3((unsigned)sf_div_up(m, 256)), dim3(256), idx_chunk_dev, dist_chunk_dev, m, piece,
+                  rows_per_rank, col0, first, best_idx_dev, best_dist_dev);
+    return SF_OK;
+}
+
 extern "C" int sf_match_col_candidates(sf_ctx *ctx, const double *local_dist_dev, const double *global_dist_dev,
                                        const int64_t *local_idx_dev, int64_t row_offset, int64_t m, void *cand_dev)
 {

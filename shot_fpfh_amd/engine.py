@@ -437,6 +437,21 @@ class Engine:
             "sf_comm_allgather",
         )
 
+    def allgather_into(self, send: DeviceArray, send_byte_offset: int, recv: DeviceArray, recv_byte_offset: int,
+                       bytes_per_rank: int) -> None:
+        """All-gather of `bytes_per_rank` bytes at send + offset into recv + offset (rank r's block at r * bytes_per_rank
+        behind it): one chunk of a chunked gather, issued on the context's CURRENT stream (sf_fork / sf_switch)."""
+        if send_byte_offset + bytes_per_rank > send.nbytes or recv_byte_offset + bytes_per_rank * self.nranks > recv.nbytes:
+            raise ValueError("all-gather chunk outside its buffers")
+        _ffi.check(self.lib.sf_comm_allgather(self.h, send.offset_ptr(send_byte_offset), recv.offset_ptr(recv_byte_offset),
+                                              bytes_per_rank), "sf_comm_allgather")
+
+    def match_fold_device(self, idx_chunk: DeviceArray, dist_chunk: DeviceArray, m: int, piece: int, rows_per_rank: int, col0: int,
+                          first: bool, best_idx: DeviceArray, best_dist: DeviceArray) -> None:
+        """sf_match_fold: one column chunk's row arg-min folded into the running one (first minimum over the gathered set)."""
+        _ffi.check(self.lib.sf_match_fold(self.h, idx_chunk.ptr, dist_chunk.ptr, int(m), int(piece), int(rows_per_rank), int(col0),
+                                          int(bool(first)), best_idx.ptr, best_dist.ptr), "sf_match_fold")
+
     def exchange(self, ops) -> None:
         """Grouped point-to-point exchange (ncclSend / ncclRecv in ONE group).  ops: iterable of
         (peer, send DeviceArray | None, send_byte_offset, send_bytes, recv DeviceArray | None, recv_byte_offset, recv_bytes)."""

@@ -397,6 +397,22 @@ class DescriptorJob:
         self.spfh = self.fpfh_out = self.lrf_out = self.shot_out = self.moments = None
 
 
+class _ByteView:
+    """A device array seen from a byte offset (source operand of DeviceArray.copy_from_device)."""
+
+    def __init__(self, base, byte_offset: int):
+        self.base, self.byte_offset = base, int(byte_offset)
+        self.nbytes = base.nbytes - self.byte_offset
+
+    @property
+    def ptr(self):
+        return self.base.offset_ptr(self.byte_offset).value
+
+    @property
+    def a(self):  # (the CPU stand-in's arrays: tests/fake_engine.py)
+        return self.base.a.reshape(-1).view(np.uint8)[self.byte_offset:]
+
+
 class MatchJob:
     """basic_matching (matching.py:149-169) of two descriptor sets that live SHARDED in HBM: rank g holds its block
     of the scan descriptors and its block of the reference descriptors (rows in the cell-sorted order of their
@@ -409,7 +425,9 @@ class MatchJob:
     (index, flag) vectors are what a caller gathers afterwards.
     """
 
-    def __init__(self, engine: Engine, length: int, n_scan: int, n_ref: int, world: int = 1, rank: int = 0):
+    def __init__(self, engine: Engine, length: int, n_scan: int, n_ref: int, world: int = 1, rank: int = 0, chunks: int = 1):
+        """chunks > 1: the all-gather of the reference rows is cut into that many pieces per rank and K8 runs on chunk c while
+        chunk c + 1 crosses xGMI on the context's side stream (`run`); same matches bit for bit."""
         self.engine, self.d = engine, int(length)
         self.scan_plan, self.ref_plan = ShardPlan(n_scan, world, rank), ShardPlan(n_ref, world, rank)
         rpr = max(self.ref_plan.rows_per_rank, 1)
@@ -420,6 +438,27 @@ class MatchJob:
         self.idx: DeviceArray = engine.empty((max(m, 1),), np.int64)
         self.dist: DeviceArray = engine.empty((max(m, 1),), np.float64)
         self.m = m
+        self.chunks = max(1, min(int(chunks), rpr))
+        self.exchange_timing: Optional[dict] = None
+        self._assembled = True
+        self._chunk_bufs: list = []
+        if self.chunks > 1:
+            piece = -(-rpr // self.chunks)
+            self.chunks = -(-rpr // piece)
+            self._piece = piece
+            for c in range(self.chunks):
+                pc = min(piece, rpr - c * piece)
+                self._chunk_bufs.append((engine.empty((pc * world, self.d)), engine.empty((pc * world,), np.uint8), pc))
+            self._idx_c: DeviceArray = engine.empty((max(m, 1),), np.int64)
+            self._dist_c: DeviceArray = engine.empty((max(m, 1),), np.float64)
+            pad = rpr * world - self.ref_plan.n  # rows behind the last rank's block: sent as they are, so they must be empty
+            if pad > 0:
+                zeros = engine.empty((pad, self.d)).from_host(np.zeros((pad, self.d)))
+                try:
+                    self.ref_all.copy_from_device(zeros, dst_byte_offset=self.ref_plan.n * self.d * 8)
+                    engine.sync()
+                finally:
+                    zeros.free()
 
     def run(self, scan_block: DeviceArray, ref_block: DeviceArray) -> None:
         """scan_block: (m, d) rows of this rank's scan block; ref_block: this rank's reference block."""
@@ -427,15 +466,69 @@ class MatchJob:
         row_bytes = self.d * 8
         b, e = plan.block()
         self.ref_all.copy_from_device(ref_block, dst_byte_offset=b * row_bytes, nbytes=(e - b) * row_bytes)
+        self._scan_block = scan_block
+        if self.chunks > 1:
+            return self._run_chunked(scan_block)
         # (a lone context without a communicator has nothing to exchange and the call returns at once; with a
         # communicator -- of ONE rank too -- this is ncclAllGather)
         eng.allgather(self.ref_all, plan.rows_per_rank * row_bytes)
         eng.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=plan.n)
-        self._scan_block = scan_block
         if self.m:
             eng.rows_nonzero_device(scan_block, self.scan_ok, n_rows=self.m)
             eng.match_masked_device(scan_block, self.scan_ok, self.ref_all, self.ref_ok, self.idx, self.dist,
                                     a_rows=self.m, b_rows=plan.n)
+
+    def _run_chunked(self, scan_block: DeviceArray) -> None:
+        """The exchange under K8 ("overlap C2 with the tail of K5 / K7 by chunking rows" -- here with K8 itself, the
+        only consumer of the gathered rows).  Chunk c = rows [c piece, (c + 1) piece) of EVERY rank's block, gathered into one
+        contiguous buffer by ncclAllGather on the context's SIDE stream; the main stream waits for chunk c only (sf_mark /
+        sf_wait_mark), runs K8 of this rank's scan block against it and folds the chunk's row arg-min into the running one
+        (sf_match_fold: smaller distance, smaller gathered row on a tie -- the arg-min over the whole set, first minimum
+        included).  Chunk c + 1 is in flight the whole time K8 works on chunk c."""
+        eng, plan, rank = self.engine, self.ref_plan, self.ref_plan.rank
+        rpr, piece, row_bytes = max(plan.rows_per_rank, 1), self._piece, self.d * 8
+        self._assembled = False
+        if self.m:
+            eng.rows_nonzero_device(scan_block, self.scan_ok, n_rows=self.m)
+
+        def gather(c: int) -> None:
+            buf, _, pc = self._chunk_bufs[c]
+            eng.allgather_into(self.ref_all, (rank * rpr + c * piece) * row_bytes, buf, 0, pc * row_bytes)
+
+        eng.fork()  # the side stream starts behind everything issued so far (the copy of this rank's block into place)
+        try:
+            gather(0)
+            eng.mark()
+            for c in range(self.chunks):
+                eng.switch(0)
+                eng.wait_mark()  # chunk c has landed (and only that is waited for)
+                if c + 1 < self.chunks:
+                    eng.switch(1)
+                    gather(c + 1)
+                    eng.mark()
+                    eng.switch(0)
+                buf, ok, pc = self._chunk_bufs[c]
+                eng.rows_nonzero_device(buf, ok, n_rows=pc * plan.world)
+                if self.m:
+                    eng.match_masked_device(scan_block, self.scan_ok, buf, ok, self._idx_c, self._dist_c, a_rows=self.m,
+                                            b_rows=pc * plan.world)
+                    eng.match_fold_device(self._idx_c, self._dist_c, self.m, pc, rpr, c * piece, c == 0, self.idx, self.dist)
+        finally:
+            eng.join()
+
+    def _assemble(self) -> None:
+        """After a chunked run: the gathered rows in their global order in `ref_all` (+ `ref_ok`), for the callers that want the
+        whole set (column_argmin).  Device copies, on demand."""
+        if self._assembled:
+            return
+        plan, row_bytes = self.ref_plan, self.d * 8
+        rpr, piece = max(plan.rows_per_rank, 1), self._piece
+        for c, (buf, _, pc) in enumerate(self._chunk_bufs):
+            for r in range(plan.world):
+                self.ref_all.copy_from_device(_ByteView(buf, r * pc * row_bytes), dst_byte_offset=(r * rpr + c * piece) * row_bytes,
+                                              nbytes=pc * row_bytes)
+        self.engine.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=plan.n)
+        self._assembled = True
 
     # ---- the rest of match_descriptors (matching.py:54-74) on sharded rows ------------------------------------------------
     def _all_ranks(self, mine: np.ndarray, fill) -> np.ndarray:
@@ -475,6 +568,7 @@ class MatchJob:
         numbers; 2^64 - 1 where no non-empty scan row exists): local column arg-min over this rank's block, all-reduce(min)
         of the column minima, then all-reduce(min) of the rows that attain them -- the first minimum, as NumPy takes it."""
         eng, n_ref = self.engine, self.ref_plan.n
+        self._assemble()
         rows = max(self.ref_all.shape[0], 1)
         cd, ci = eng.empty((rows,), np.float64), eng.empty((rows,), np.int64)
         gd, cand = eng.empty((rows,), np.uint64), eng.empty((rows,), np.uint64)
@@ -527,6 +621,13 @@ class MatchJob:
     def close(self) -> None:
         for a in (self.ref_all, self.ref_ok, self.scan_ok, self.idx, self.dist):
             a.free()
+        for buf, ok, _ in self._chunk_bufs:
+            buf.free()
+            ok.free()
+        if self._chunk_bufs:
+            self._idx_c.free()
+            self._dist_c.free()
+        self._chunk_bufs = []
 
 
 class SubsetMatchJob:
@@ -541,12 +642,12 @@ class SubsetMatchJob:
     scan subset over the gathered set.  `matches()` returns label pairs, so ranks need no common row numbering.
     """
 
-    def __init__(self, engine: Engine, length: int, rows_per_rank: int, world: int = 1, rank: int = 0):
+    def __init__(self, engine: Engine, length: int, rows_per_rank: int, world: int = 1, rank: int = 0, chunks: int = 1):
         if rows_per_rank < 1:
             raise ValueError("rows_per_rank must be positive")
         self.engine, self.d, self.rows, self.world, self.rank = engine, int(length), int(rows_per_rank), world, rank
         total = self.rows * world
-        self.job = MatchJob(engine, length, total, total, world, rank)
+        self.job = MatchJob(engine, length, total, total, world, rank, chunks=chunks)
         self.scan_sub: DeviceArray = engine.empty((self.rows, self.d))
         self.ref_sub: DeviceArray = engine.empty((self.rows, self.d))
         self.sel: DeviceArray = engine.empty((self.rows,), np.int64)

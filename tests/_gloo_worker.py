@@ -14,6 +14,8 @@ from conftest import synth_cloud  # noqa: E402
 from fake_engine import FakeEngine  # noqa: E402
 from shot_fpfh_amd.sharding import DescriptorJob  # noqa: E402
 
+CHUNKS = int(os.environ.get("SF_TEST_CHUNKS", "1"))  # pieces of the reference all-gather (MatchJob(chunks=...))
+
 
 def match_main(out_path, rank, world):
     """Sharded basic_matching: each rank holds a block of scan and of ref rows; ref rows are all-gathered."""
@@ -25,7 +27,7 @@ def match_main(out_path, rank, world):
     a[[0, 150, 300]] = 0.0
     b[[5, 276]] = 0.0
     eng = FakeEngine()
-    job = MatchJob(eng, 40, 301, 277, world, rank)
+    job = MatchJob(eng, 40, 301, 277, world, rank, chunks=CHUNKS)
     sb, se = ShardPlan(301, world, rank).block()
     rb, re = ShardPlan(277, world, rank).block()
     job.run(eng.empty((se - sb, 40)).from_host(a[sb:se]), eng.empty((max(re - rb, 1), 40)).from_host(b[rb:re] if re > rb else 0.0))
@@ -46,7 +48,7 @@ def reciprocal_main(out_path, rank, world):
     g = load_golden("match_300.npz")
     a, b = g["scan"], g["ref"]
     eng = FakeEngine()
-    job = MatchJob(eng, a.shape[1], a.shape[0], b.shape[0], world, rank)
+    job = MatchJob(eng, a.shape[1], a.shape[0], b.shape[0], world, rank, chunks=CHUNKS)
     sb, se = ShardPlan(a.shape[0], world, rank).block()
     rb, re = ShardPlan(b.shape[0], world, rank).block()
     job.run(eng.empty((se - sb, a.shape[1])).from_host(a[sb:se]), eng.empty((max(re - rb, 1), b.shape[1])).from_host(b[rb:re] if re > rb else 0.0))
@@ -85,7 +87,7 @@ def subset_main(out_path, rank, world):
     r_lab_block = perm[sb:se]
     r_sel = np.flatnonzero(in_subset[r_lab_block])
     rows = int(in_subset.sum())  # generous per-rank capacity: exercises the zero-row padding
-    job = SubsetMatchJob(eng, d, rows, world, rank)
+    job = SubsetMatchJob(eng, d, rows, world, rank, chunks=CHUNKS)
     job.select(eng.empty((se - sb, d)).from_host(scan[sb:se]), s_sel, s_sel + sb,
                eng.empty((se - sb, d)).from_host(ref[sb:se]), r_sel, r_lab_block[r_sel])
     job.run()

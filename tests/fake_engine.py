@@ -238,6 +238,23 @@ class FakeEngine:
         dist.all_gather(parts, mine)
         flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
 
+    def allgather_into(self, send, send_byte_offset, recv, recv_byte_offset, bytes_per_rank):
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size()
+        mine = torch.from_numpy(send.a.reshape(-1).view(np.uint8)[send_byte_offset:send_byte_offset + bytes_per_rank].copy())
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        recv.a.reshape(-1).view(np.uint8)[recv_byte_offset:recv_byte_offset + world * bytes_per_rank] = torch.cat(parts).numpy()
+
+    def match_fold_device(self, idx_chunk, dist_chunk, m, piece, rows_per_rank, col0, first, best_idx, best_dist):
+        j, d = idx_chunk.a[:m].astype(np.int64), dist_chunk.a[:m]
+        g = (j // piece) * rows_per_rank + col0 + j % piece
+        take = np.ones(m, bool) if first else (d < best_dist.a[:m]) | ((d == best_dist.a[:m]) & (g < best_idx.a[:m]))
+        best_idx.a[:m] = np.where(take, g, best_idx.a[:m])
+        best_dist.a[:m] = np.where(take, d, best_dist.a[:m])
+
     def sync(self):
         pass
 
@@ -275,6 +292,11 @@ class FakeEngine:
         m1 = a.shape[0] if a_rows is None else a_rows
         m2 = b.shape[0] if b_rows is None else b_rows
         ok_b = np.flatnonzero(b_ok.a[:m2])
+        if ok_b.size == 0:  # every column masked (a chunk of padding rows): +inf from everything, first column -- as the device does
+            idx.a[:m1] = 0
+            if dist is not None:
+                dist.a[:m1] = np.inf
+            return
         i, d = O.match_argmin(a.a[:m1], b.a[:m2][ok_b])
         idx.a[:m1] = ok_b[i]
         if dist is not None:

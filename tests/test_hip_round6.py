@@ -331,3 +331,52 @@ def test_match_i8_pilot_hands_unclear_problems_to_the_fp16_pass(eng, O, monkeypa
         assert rep.get("k8_i8_collect", (0, 0))[0] == (2 if pilot_passes else 1)  # (the pilot runs all steps on its slab)
         other = rep.get("k8_match_half", (0, 0))[0] + rep.get("k8_match_gemm", (0, 0))[0]  # (this size: the FP64 GEMM form)
         assert (other >= 1) == (not pilot_passes)
+
+
+# ---- the descriptor all-gather under K8 (chunks) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("chunks", [2, 5])
+def test_chunked_allgather_under_k8_gives_the_unchunked_matches(O, chunks):
+    """MatchJob(chunks=C): the reference rows cross the (one-rank) RCCL communicator in C ncclAllGather calls on the side stream
+    while K8 works on the chunk that has landed, and the chunks' row arg-mins are folded by sf_match_fold.  Index and distance
+    vectors equal the unchunked job's bit for bit -- exact ties across chunks (duplicated reference rows far apart in the set),
+    masked (zero) rows on both sides, a chunk that holds nothing but zero rows -- and basic_matching's pairs; the filters and the
+    reciprocity test (column arg-min over the re-assembled set) agree as well."""
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.sharding import MatchJob
+
+    e2 = s.Engine(0)
+    e2.comm_init(e2.comm_unique_id(), 1, 0)
+    try:
+        rng = np.random.default_rng(97)
+        m1, m2, d = 2300, 2100, 352
+        b = rng.random((m2, d)) * (rng.random((m2, d)) < 0.3)
+        a = b[rng.integers(0, m2, m1)] + 1e-3 * rng.standard_normal((m1, d))
+        b[1900] = b[30]      # exact duplicates in different chunks: the first (row 30) must win
+        b[1050] = b[30]
+        a[9] = b[30]
+        a[[4, 700]] = 0.0
+        b[[8, 2099]] = 0.0
+        b[m2 - m2 // chunks + 5:] = 0.0 if chunks == 5 else b[m2 - m2 // chunks + 5:]  # (chunks = 5: the last chunk is all zero rows)
+        da, db = e2.empty((m1, d)).from_host(a), e2.empty((m2, d)).from_host(b)
+        plain = MatchJob(e2, d, m1, m2)
+        plain.run(da, db)
+        e2.profile_reset()
+        e2.profile(True)
+        job = MatchJob(e2, d, m1, m2, chunks=chunks)
+        job.run(da, db)
+        e2.sync()
+        e2.profile(False)
+        rep = e2.profile_report()
+        assert rep["c_allgather"][0] == job.chunks == chunks and rep["k8_match_fold"][0] == chunks
+        assert np.array_equal(job.idx.to_host(), plain.idx.to_host()) and np.array_equal(job.dist.to_host(), plain.dist.to_host())
+        s1, r1 = job.matches()
+        s2, r2 = O.basic_matching(a, b)
+        assert np.array_equal(s1, s2) and np.array_equal(r1, r2)
+        assert r1[np.flatnonzero(s1 == 9)[0]] == 30
+        for kw in (dict(filter_nonreciprocal=True, n_min_matches=10), dict(filter_nonreciprocal=True, n_min_matches=10**6)):
+            x, y = job.matches(**kw), plain.matches(**kw)
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+        job.close()
+        plain.close()
+    finally:
+        e2.close()

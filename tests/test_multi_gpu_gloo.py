@@ -131,8 +131,10 @@ def test_exchange_plan_covers_every_halo_and_pairs_up(world):
                 assert reach[0] < b or reach[-1] >= e
 
 
-def test_two_rank_gloo_sharded_matching_equals_basic_matching(tmp_path):
-    """MatchJob over two gloo ranks: reference rows all-gathered, each rank matches its scan block; the union of
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_two_rank_gloo_sharded_matching_equals_basic_matching(tmp_path, chunks):
+    """MatchJob over two gloo ranks: reference rows all-gathered -- at once, or in three chunks with K8 on chunk c while chunk
+    c + 1 is gathered and the chunks' arg-mins folded (MatchJob(chunks=3)) -- each rank matches its scan block; the union of
     the per-rank results must equal basic_matching on the whole sets (oracle restatement)."""
     from oracle import oracle as O
 
@@ -141,7 +143,7 @@ def test_two_rank_gloo_sharded_matching_equals_basic_matching(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1", SF_TEST_CHUNKS=str(chunks))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, "match"], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -150,7 +152,8 @@ def test_two_rank_gloo_sharded_matching_equals_basic_matching(tmp_path):
     assert np.array_equal(got["s"], s) and np.array_equal(got["r"], r)
 
 
-def test_two_rank_gloo_subset_matching_by_label(tmp_path):
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_two_rank_gloo_subset_matching_by_label(tmp_path, chunks):
     """SubsetMatchJob (the tail of BASELINE config 5) over two gloo ranks: a keypoint subset picked out of every rank's
     blocks, reference subset + labels all-gathered, sharded K8; the label pairs must be those of basic_matching on the
     subset rows taken in label order."""
@@ -161,7 +164,7 @@ def test_two_rank_gloo_subset_matching_by_label(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1", SF_TEST_CHUNKS=str(chunks))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, "subset"], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -176,8 +179,8 @@ def test_two_rank_gloo_subset_matching_by_label(tmp_path):
     assert np.mean([k == v for k, v in have.items()]) > 0.9  # and the matches do recover the correspondence
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_sharded_match_descriptors_with_filters_and_reciprocity(tmp_path, world):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (3, 5)])
+def test_gloo_sharded_match_descriptors_with_filters_and_reciprocity(tmp_path, world, chunks):
     """MatchJob.matches(filter_callback, filter_nonreciprocal, n_min_matches) over gloo ranks on the reference's golden
     inputs (match_300.npz): the union of the per-rank results, mapped back through the non-empty-row numbering, equals
     the reference's match_descriptors outputs -- the reciprocity fallback (n_min_matches = 10^6) and a filter that needs
@@ -191,7 +194,7 @@ def test_gloo_sharded_match_descriptors_with_filters_and_reciprocity(tmp_path, w
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1", SF_TEST_CHUNKS=str(chunks))  # (chunks > 1: the column arg-min re-assembles the set)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, "reciprocal"], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
