@@ -109,6 +109,139 @@ def c4_partner(points, normals, seed: int):
     return points[perm] @ rot.T + np.asarray(C4_T), normals[perm] @ rot.T, perm, rot
 
 
+def dry_run_n(args) -> int:
+    """`--dry-run-n N`: everything a `--gpus N` run would plan AND compute, rank after rank, on this ONE GPU (no RCCL: what a
+    collective would deliver is put in place by device copies) -- so that a first real N-GPU launch cannot fail on something a
+    single GPU can find out: index widths, buffer sizes, list capacities, the exchange plan of every rank, the chunked matching
+    phase at its true shapes.  Nothing here is a scaling measurement; the times are one GPU's, per rank's share."""
+    import shot_fpfh_amd as s
+    from shot_fpfh_amd.sharding import DescriptorJob, MatchJob, ShardPlan, exchange_plan
+
+    world = int(args.dry_run_n)
+    n_total = args.points_per_gpu * world
+    radius = args.radius * world ** (-1.0 / 3.0)
+    total_rows = min(args.match_rows or 131072 * world, n_total)
+    chunks = args.match_chunks or 4
+    problems = []
+    if n_total >= 2**31 - 1024:
+        problems.append(f"{n_total} points exceed the 32-bit cell-sorted positions")
+    points, normals = make_cloud(n_total, 3)
+    ref_pts, ref_nrm, perm, rot = c4_partner(points, normals, 4)
+    eng = s.Engine(0)
+    out = {"dry_run_ranks": world, "points_total": n_total, "radius": radius, "spfh_exchange": args.spfh_exchange,
+           "host_bytes_per_rank_process": int(2 * (points.nbytes + normals.nbytes) + perm.nbytes),
+           "what": "every rank's descriptor pass (emulate_peers: the adjacent ranks' SPFH rows computed here) and every rank's share of the "
+                   "chunked matching phase, one after the other on ONE GPU; collectives replaced by device copies"}
+    ranks, scan_sub, ref_sub, scan_lab, ref_lab = [], [], [], [], []
+    first = None
+    cap = 0
+    picks = []
+    for r in range(world):
+        row = {"rank": r}
+        job = DescriptorJob(eng, points, normals, radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=r,
+                            spfh_exchange=args.spfh_exchange, emulate_peers=True)
+        ref_job = DescriptorJob(eng, ref_pts, ref_nrm, radius, n_bins=5, normalize=True, min_neighborhood_size=10, world=world, rank=r,
+                                spfh_exchange="halo", do_fpfh=False, do_shot=True)
+        try:
+            job.step()
+            eng.sync()
+            t0 = time.perf_counter()
+            job.step()
+            eng.sync()
+            row["descriptor_step_ms"] = 1000.0 * (time.perf_counter() - t0)
+            ref_job.step()
+            eng.sync()
+            if first is None:
+                first = job.cloud.layer_table()
+                out["z_layers"] = int(first.size - 1)
+            xp = exchange_plan(first, n_total, world, r)
+            b, e = job.plan.block()
+            row.update({"block": [int(b), int(e)], "halo": [int(xp.halo[0]), int(xp.halo[1])], "interior": [int(xp.interior[0]), int(xp.interior[1])],
+                        "pairs": int(job.last_pairs), "mean_list": job.last_pairs / max(e - b, 1),
+                        "exchange_ops": [{"peer": int(p_), "send_rows": int(se - sb), "recv_rows": int(re - rb)} for (p_, sb, se, rb, re) in xp.ops],
+                        "output_bytes": int((e - b) * (125 + 352 + 9) * 8)})
+            if len(xp.ops) > 2:
+                problems.append(f"rank {r} exchanges with {len(xp.ops)} peers (a block thinner than a z-layer)")
+            scan_orig = job.block_original_indices()
+            ref_label = perm[ref_job.block_original_indices()]
+            picks.append((np.flatnonzero(scan_orig < total_rows), scan_orig, np.flatnonzero(ref_label < total_rows), ref_label))
+            cap = max(cap, picks[-1][0].size, picks[-1][2].size)
+            # this rank's subset rows stay on the device (what select() would gather), compacted to their count for now
+            for sel_rows, rows_dev, store in ((picks[-1][0], job.shot_out, scan_sub), (picks[-1][2], ref_job.shot_out, ref_sub)):
+                sel = eng.empty((max(sel_rows.size, 1),), np.int64).from_host(sel_rows if sel_rows.size else np.zeros(1, np.int64))
+                dst = eng.empty((max(sel_rows.size, 1), 352))
+                eng.rows_gather_device(rows_dev, sel, dst)
+                eng.sync()
+                sel.free()
+                store.append(dst)
+        finally:
+            job.close()
+            ref_job.close()
+        ranks.append(row)
+    cap = int(-(-cap // 256) * 256)
+    out["match"] = {"subset_keypoints_total": int(total_rows), "rows_per_rank_padded": cap, "chunks": chunks,
+                    "allgather_bytes_per_rank": cap * 352 * 8, "gathered_set_bytes": cap * world * 352 * 8}
+    # the gathered reference set as ncclAllGather would leave it: rank-major blocks of `cap` rows, zero rows behind each rank's own
+    gathered = eng.empty((cap * world, 352)).from_host(np.zeros((cap * world, 352)))
+    labels_all = np.full(cap * world, -1, np.int64)
+    for r in range(world):
+        n_r = picks[r][2].size
+        if n_r:
+            gathered.copy_from_device(ref_sub[r], dst_byte_offset=r * cap * 352 * 8, nbytes=n_r * 352 * 8)
+        labels_all[r * cap:r * cap + n_r] = picks[r][3][picks[r][2]]
+    eng.sync()
+    good = total = 0
+    for r in range(world):
+        n_s = picks[r][0].size
+        blk = eng.empty((cap, 352)).from_host(np.zeros((cap, 352)))
+        if n_s:
+            blk.copy_from_device(scan_sub[r], nbytes=n_s * 352 * 8)
+        res = {}
+        for c in (1, chunks):
+            mj = MatchJob(eng, 352, cap, cap * world, 1, 0, chunks=c)
+            try:
+                t0 = time.perf_counter()
+                mj.run(blk, gathered)
+                eng.sync()
+                res[c] = (mj.idx.to_host().copy(), mj.dist.to_host().copy(), 1000.0 * (time.perf_counter() - t0))
+                if c == 1:
+                    rows_m, idx_m = mj.matches()
+            finally:
+                mj.close()
+        same = bool(np.array_equal(res[1][0], res[chunks][0]) and np.array_equal(res[1][1], res[chunks][1]))
+        if not same:
+            problems.append(f"rank {r}: the chunked matching differs from the one-shot one")
+        ranks[r]["k8_ms_one_shot"], ranks[r]["k8_ms_chunked"], ranks[r]["chunked_equals_one_shot"] = res[1][2], res[chunks][2], same
+        s_lab = picks[r][1][picks[r][0]][rows_m] if n_s else np.zeros(0, np.int64)
+        r_lab = labels_all[idx_m]
+        good += int((s_lab == r_lab).sum())
+        total += int(s_lab.size)
+        blk.free()
+    out["match"]["matches"] = total
+    out["match"]["matches_recovering_true_correspondence"] = good / max(total, 1)
+    if total and good / total < 0.85:
+        problems.append(f"only {good / total:.3f} of the matches recover the true correspondence")
+    for a in scan_sub + ref_sub + [gathered]:
+        a.free()
+    out["ranks"] = ranks
+    out["problems"] = problems
+    out["ok"] = not problems
+    eng.close()
+    path = os.path.join(os.environ.get("SF_BENCH_DETAIL_DIR", ROOT), f"bench_detail_dry_run_n{world}.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as exc:
+        sys.stderr.write(f"bench.py: could not write {path}: {exc}\n")
+    brief = {"dry_run_ranks": world, "ok": out["ok"], "problems": problems, "points_total": n_total, "z_layers": out.get("z_layers"),
+             "descriptor_step_ms_per_rank": [round(x["descriptor_step_ms"], 3) for x in ranks],
+             "exchange_peers_per_rank": [len(x["exchange_ops"]) for x in ranks],
+             "k8_ms_per_rank_chunked": [round(x["k8_ms_chunked"], 2) for x in ranks], "match": out["match"],
+             "note": "one GPU stood in for every rank in turn: a functional dry run, no scaling curve exists", "detail": os.path.relpath(path, ROOT)}
+    print(json.dumps(brief, separators=(",", ":")))
+    return 0 if out["ok"] else 4
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -388,6 +521,12 @@ def compact_record(out: dict, detail_path: str | None) -> dict:
     em = out.get("exchange_match")
     if em is not None:
         line["end_to_end_config5_ms"] = out.get("end_to_end_config5_ms")
+        ov = em.get("allgather_under_k8")
+        if isinstance(ov, dict) and "allgather_exposed_ms" in ov:  # the descriptor all-gather in chunks under K8: what stays exposed
+            line["exchange_ms"] = dict(line.get("exchange_ms") or {}, allgather_chunks=ov["chunks"], allgather_exposed=ov["allgather_exposed_ms"],
+                                       allgather_hidden=ov["allgather_hidden_ms"])
+        if out.get("n_gpus", 1) == 1:
+            line["scaling_note"] = "no scaling curve exists (one GPU); --dry-run-n 8 plans and runs every rank's share on this GPU"
     line["detail"] = detail_path
     line = _r(line)
     text = json.dumps(line, separators=(",", ":"))
@@ -663,6 +802,12 @@ def main() -> int:
     ap.add_argument("--match-rows", type=int, default=None,
                     help="keypoints of the matched subset, whole job (default 262144 at N = 1, 131072 x N otherwise)")
     ap.add_argument("--match-steps", type=int, default=2)
+    ap.add_argument("--match-chunks", type=int, default=None,
+                    help="pieces of the descriptor all-gather, gathered on the side stream while K8 works on the piece that has "
+                         "landed (default: 4 at N > 1, 1 at N = 1 -- where a second, chunked pass is measured beside the timed one)")
+    ap.add_argument("--dry-run-n", type=int, default=None, metavar="N",
+                    help="plan a --gpus N run on THIS one GPU and exit: the N x points-per-gpu cloud's layer table, every rank's block / "
+                         "halo / interior / exchange operations and buffer sizes, the matching phase's buffers -- nothing is timed")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-to-host drop-in timing (N = 1)")
     ap.add_argument("--no-normals", action="store_true", help="skip the compute_normals line (N = 1)")
@@ -693,6 +838,8 @@ def main() -> int:
     COUNTERS_APPLY = args.points_per_gpu == 1_000_000 and abs(args.radius - 0.03) < 1e-12
 
     emulated = args.emulate_rank is not None
+    if args.dry_run_n:
+        return dry_run_n(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not emulated:
         return spawn_ranks(args.gpus)
 
@@ -1116,7 +1263,8 @@ def main() -> int:
         s_sel, r_sel = np.flatnonzero(scan_orig < total_rows), np.flatnonzero(ref_label < total_rows)
         cap = max_over_ranks(float(max(s_sel.size, r_sel.size, 1)))
         cap = int(-(-int(cap) // 256) * 256)
-        sub = SubsetMatchJob(eng, 352, cap, world, rank)
+        match_chunks = args.match_chunks or (1 if single else 4)
+        sub = SubsetMatchJob(eng, 352, cap, world, rank, chunks=match_chunks)
         sub.select(job.shot_out, s_sel, scan_orig[s_sel], ref_job.shot_out, r_sel, ref_label[r_sel])
         sub.run()  # warm-up (RCCL channel setup, pool growth)
         barrier()
@@ -1130,6 +1278,37 @@ def main() -> int:
         eng.profile(False)
         mrep = eng.profile_report()
         s_lab, r_lab = sub.matches()
+
+        # ---- how much of the descriptor all-gather K8 hides: the chunked job's pass, its K8 alone (on the rows the previous pass
+        #      gathered) and its gathers alone, each between barriers.  At N = 1 a second job with 4 chunks is measured beside the
+        #      timed one-shot job (the gather is then a local copy through the one-rank communicator: the mechanics, not xGMI) ----
+        def exposure(j, n_chunks):
+            def timed(**kw):
+                j.run(**kw)
+                barrier()
+                t0 = time.perf_counter()
+                j.run(**kw)
+                barrier()
+                return max_over_ranks(time.perf_counter() - t0)
+            t_all, t_k8, t_ag = timed(), timed(gather=False), timed(match=False)
+            exposed = max(t_all - t_k8, 0.0)
+            return {"chunks": n_chunks, "pass_ms": 1000.0 * t_all, "k8_alone_ms": 1000.0 * t_k8, "gathers_alone_ms": 1000.0 * t_ag,
+                    "allgather_exposed_ms": 1000.0 * exposed, "allgather_hidden_ms": 1000.0 * max(t_ag - exposed, 0.0)}
+        overlap_rec = None
+        try:
+            if match_chunks > 1:
+                overlap_rec = exposure(sub, match_chunks)
+            elif single:
+                sub4 = SubsetMatchJob(eng, 352, cap, world, rank, chunks=4)
+                try:
+                    sub4.select(job.shot_out, s_sel, scan_orig[s_sel], ref_job.shot_out, r_sel, ref_label[r_sel])
+                    overlap_rec = exposure(sub4, 4)
+                    a4, b4 = sub4.matches()
+                    overlap_rec["same_matches_as_the_one_shot_gather"] = bool(np.array_equal(a4, s_lab) and np.array_equal(b4, r_lab))
+                finally:
+                    sub4.close()
+        except Exception as exc:  # noqa: BLE001 -- a side measurement
+            overlap_rec = {"error": f"{type(exc).__name__}: {exc}"}
         stats = np.array([float((s_lab == r_lab).sum()), float(s_lab.size)])
         if ctl is not None:
             stats = np.sum(np.stack(ctl.allgather(stats)), axis=0)
@@ -1166,6 +1345,8 @@ def main() -> int:
                 "rows_per_rank_padded": cap,
                 "allgather_bytes_per_rank": cap * 352 * 8,
                 "ms_per_pass": 1000.0 * t_match,
+                "allgather_chunks": match_chunks,
+                "allgather_under_k8": overlap_rec,
                 "kernels_ms_per_pass": {k: round(v, 4) for k, v in sorted(k8.items())},
                 "k8_pair_dists_per_s": cap * gathered / (k8_ms * 1e-3) if k8_ms > 0 else None,
                 "k8_roofline": _k8_roofline(k8, k8_ms, flop),

@@ -314,15 +314,27 @@ int sf_match_argmin_multiscale(sf_ctx *ctx, const double *a, const double *b, in
 int sf_match_col_candidates(sf_ctx *ctx, const double *local_dist_dev, const double *global_dist_dev,
                             const int64_t *local_idx_dev, int64_t row_offset, int64_t m, void *cand_dev);
 
-/* The descriptor all-gather of a sharded matching (every scan row must see every reference row) in CHUNKS, so that K8 runs on
- * chunk c while chunk c + 1 is still crossing xGMI: chunk c gathers rows [col0, col0 + piece) of EVERY rank's block of
- * rows_per_rank rows into one contiguous buffer (ncclAllGather: piece r of the buffer is rank r's), K8 gives the row arg-min
- * over that buffer, and sf_match_fold maps its column j to the row (j / piece) * rows_per_rank + col0 + j % piece of the
- * gathered set and keeps, per scan row, the smaller distance -- the smaller gathered row on a tie, so that the result is the
- * arg-min over the whole set, first minimum included (matching.py:164-168).  first != 0: the running minimum is overwritten.
- * All pointers device memory; stream-ordered. */
-int sf_match_fold(sf_ctx *ctx, const int64_t *idx_chunk_dev, const double *dist_chunk_dev, int64_t m, int64_t piece,
-                  int64_t rows_per_rank, int64_t col0, int first, int64_t *best_idx_dev, double *best_dist_dev);
+/* K8 while the reference rows are still ARRIVING (a sharded matching: every scan row must see every reference row, and the rows
+ * of the other ranks cross xGMI in chunks -- sf_comm_exchange on the context's side stream).  sf_match_stream_begin takes the
+ * resident scan rows a (m1 x d, mask a_ok) and the buffer b (m2 x d, mask b_ok) the reference rows will land in, in their final
+ * order; b_entry_max: the largest |entry| of ANY reference row (sf_rows_abs_max of the local block, max over the ranks -- any
+ * positive value is valid, the quantisation error is measured, a poor one only costs speed); max_ranges: how many
+ * sf_match_stream_feed calls will follow.  sf_match_stream_feed(begin, end): rows [begin, end) of b AND of b_ok are now in place
+ * (begin a multiple of 64, end a multiple of 64 or m2; every row exactly once, any order): their int8 image is made and the
+ * integer pass (match_i8.hip) takes its minima over them for every scan row, on the context's current stream, while the next
+ * chunk travels.  sf_match_stream_end: the decision steps over all chunks' minima -- idx / dist as sf_match_argmin_multiscale
+ * (n_scales = 1) leaves them, bit for bit; the handle is released.  When the integer pass does not suit the problem (d > 352,
+ * most rows without a clear nearest descriptor, SF_MATCH_I8=0) the feeds cost nothing and _end runs the one-shot paths.
+ * All pointers device memory. */
+typedef struct sf_match_stream sf_match_stream;
+sf_match_stream *sf_match_stream_begin(sf_ctx *ctx, const double *a_dev, const unsigned char *a_ok_dev, int64_t m1,
+                                       const double *b_dev, const unsigned char *b_ok_dev, int64_t m2, int64_t d,
+                                       double b_entry_max, int64_t max_ranges);
+int sf_match_stream_feed(sf_ctx *ctx, sf_match_stream *stream, int64_t row_begin, int64_t row_end);
+int sf_match_stream_end(sf_ctx *ctx, sf_match_stream *stream, int64_t *idx_dev, double *dist_dev /* nullable */);
+void sf_match_stream_abort(sf_ctx *ctx, sf_match_stream *stream);
+/* largest |entry| of m x d resident rows (+inf when an entry is not finite) -> *out_host */
+int sf_rows_abs_max(sf_ctx *ctx, const double *rows_dev, int64_t m, int64_t d, double *out_host);
 
 /* ---- RANSAC scoring: inlier count of ransac.py:60-67, K9 ----------------------------------
  * a, b: m x 3 matched points; Rt: n_draws x 12 (row-major R, then t); counts ||a R^T + t - b|| <= thr. */

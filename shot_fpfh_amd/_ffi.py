@@ -96,7 +96,11 @@ SIGNATURES = {
     "sf_rows_gather": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "sf_match_argmin_multiscale": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _f64, _vp, _vp, _int]),
     "sf_match_col_candidates": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "sf_match_fold": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
+    "sf_match_stream_begin": (_vp, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f64, _i64]),
+    "sf_match_stream_feed": (_int, [_vp, _vp, _i64, _i64]),
+    "sf_match_stream_end": (_int, [_vp, _vp, _vp, _vp]),
+    "sf_match_stream_abort": (None, [_vp, _vp]),
+    "sf_rows_abs_max": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "sf_ransac_score": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _int]),
     "sf_voxels_build": (_vp, [_vp, _vp, _i64, _f64, _int]),
     "sf_voxels_count": (_i64, [_vp]),

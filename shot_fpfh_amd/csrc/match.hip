@@ -369,22 +369,6 @@ extern "C" int sf_rows_gather(sf_ctx *ctx, const double *rows_dev, int64_t n_row
 }
 
 namespace {
-// Fold of one column CHUNK's row arg-min into the running one (see sf_match_fold): the chunk's columns are `world` pieces of
-// `piece` rows, piece r of the chunk being rows r * rows_per_rank + col0 .. of the gathered set.
-__global__ void k_match_fold(const int64_t *__restrict__ idx_c, const double *__restrict__ dist_c, int64_t m, int64_t piece,
-                             int64_t rows_per_rank, int64_t col0, int first, int64_t *__restrict__ best_idx,
-                             double *__restrict__ best_dist)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const int64_t j = idx_c[i], g = (j / piece) * rows_per_rank + col0 + j % piece;
-    const double d = dist_c[i];
-    if (first || d < best_dist[i] || (d == best_dist[i] && g < best_idx[i])) {
-        best_idx[i] = g;
-        best_dist[i] = d;
-    }
-}
-
 // second half of a sharded column arg-min (see sf_match_col_candidates)
 __global__ void k_col_candidates(const double *__restrict__ local_dist, const double *__restrict__ global_dist,
                                  const int64_t *__restrict__ local_idx, int64_t row_offset, int64_t m,
@@ -404,20 +388,6 @@ __global__ void k_col_candidates(const double *__restrict__ local_dist, const do
 // doubles order like their bit patterns, sf_comm_allreduce_min_u64 -- and the winner is the LOWEST scan row that
 // attains it: this call turns (local, global) distances into candidates `row_offset + local_idx` where the rank attains
 // the global minimum and ~0 where it does not, and a second all-reduce(min) picks the first minimum, as NumPy does.
-extern "C" int sf_match_fold(sf_ctx *ctx, const int64_t *idx_chunk_dev, const double *dist_chunk_dev, int64_t m, int64_t piece,
-                             int64_t rows_per_rank, int64_t col0, int first, int64_t *best_idx_dev, double *best_dist_dev)
-{
-    if (!ctx || !idx_chunk_dev || !dist_chunk_dev || !best_idx_dev || !best_dist_dev || m < 0 || piece < 1 || rows_per_rank < piece || col0 < 0) {
-        sf_set_error("sf_match_fold: bad argument");
-        return SF_ERR_ARG;
-    }
-    SF_HIP(hipSetDevice(ctx->device));
-    if (m)
-        SF_LAUNCH(ctx, "k8_match_fold", k_match_fold, dim3((unsigned)sf_div_up(m, 256)), dim3(256), idx_chunk_dev, dist_chunk_dev, m, piece,
-                  rows_per_rank, col0, first, best_idx_dev, best_dist_dev);
-    return SF_OK;
-}
-
 extern "C" int sf_match_col_candidates(sf_ctx *ctx, const double *local_dist_dev, const double *global_dist_dev,
                                        const int64_t *local_idx_dev, int64_t row_offset, int64_t m, void *cand_dev)
 {
@@ -560,4 +530,51 @@ extern "C" int sf_ransac_score(sf_ctx *ctx, const double *a, const double *b, in
         SF_HIP(hipMemcpyAsync(inliers, dinl, (size_t)n_draws * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     if (!out_dev || !in_dev) SF_HIP(hipStreamSynchronize(ctx->stream));
     return SF_OK;
+}
+
+
+// ---- helpers of the streamed K8 (match_i8.hip: sf_match_stream_*) --------------------------------------------------------------------
+namespace {
+__global__ void k_rows_abs_max(const double *__restrict__ v, int64_t n, double *__restrict__ partial)
+{
+    double mx = 0.0;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = fabs(v[i]);
+        bad |= !(x <= 1.7976931348623157e308);
+        mx = fmax(mx, x);
+    }
+    if (bad) mx = INFINITY;
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
+}
+} // namespace
+
+extern "C" int sf_rows_abs_max(sf_ctx *ctx, const double *rows_dev, int64_t m, int64_t d, double *out_host)
+{
+    if (!ctx || !out_host || m < 0 || d <= 0 || (m && !rows_dev)) { sf_set_error("sf_rows_abs_max: bad argument"); return SF_ERR_ARG; }
+    SF_HIP(hipSetDevice(ctx->device));
+    *out_host = 0.0;
+    if (!m) return SF_OK;
+    sf_pool_guard tmp(ctx);
+    double *part = nullptr;
+    SF_CHECK(tmp.alloc(&part, 1024));
+    SF_LAUNCH(ctx, "k8_rows_abs_max", k_rows_abs_max, dim3(1024), dim3(256), rows_dev, m * d, part);
+    std::vector<double> h(1024);
+    SF_HIP(hipMemcpyAsync(h.data(), part, 1024 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    double mx = 0.0;
+    for (double x : h) mx = std::max(mx, x);
+    *out_host = mx;
+    return SF_OK;
+}
+
+// (what sf_match_stream_end falls back to: the resident, masked one-shot arg-min)
+int sf_match_argmin_masked_generic(sf_ctx *ctx, const double *a, const double *b, int64_t m1, int64_t m2, int64_t d,
+                                   const unsigned char *a_ok, const unsigned char *b_ok, int64_t *idx, double *dist)
+{
+    return sf_match_argmin_multiscale(ctx, a, b, 1, m1, m2, d, a_ok, b_ok, INFINITY, idx, dist, SF_IN_DEVICE | SF_OUT_DEVICE);
 }

@@ -225,11 +225,13 @@ __device__ __forceinline__ int dpp_i32(int v)
 // block) pairs, so the column split an XCD is working on stays in its L2 while its workgroups stream it.
 template <int KS, int RB>
 __global__ __launch_bounds__(512, 1) void k_i8_min(const unsigned char *__restrict__ ai, const unsigned char *__restrict__ bi,
-                                                    int64_t m2_pad, const int *__restrict__ nbs, int64_t tiles_per_split,
-                                                    int64_t m1_pad, int64_t row_blocks, int64_t nsplit, int *__restrict__ smin)
+                                                    const int *__restrict__ nbs, const int2 *__restrict__ split_tiles,
+                                                    int64_t split_first, int64_t m1_pad, int64_t row_blocks, int64_t nsplit,
+                                                    int *__restrict__ smin)
 {
-    const int64_t wv = sf_xcd_block(), split = wv / row_blocks, rb = wv - split * row_blocks;
-    if (split >= nsplit) return;
+    // (a launch serves the splits split_first .. split_first + nsplit - 1 of the table: all of them, or a chunk's)
+    const int64_t wv = sf_xcd_block(), sl = wv / row_blocks, rb = wv - sl * row_blocks, split = split_first + sl;
+    if (sl >= nsplit) return;
     SF_I_GEOMETRY
     constexpr int HMB = 256 * RB; // rows per workgroup
     const int64_t row0 = rb * HMB + 32 * RB * wave;
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(512, 1) void k_i8_min(const unsigned char *__restri
     for (int b = 0; b < RB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) best[b][r] = (int)0x80000000;
-    const int64_t jt0 = split * tiles_per_split;
-    const int64_t ntiles = (m2_pad / IN < jt0 + tiles_per_split) ? m2_pad / IN : jt0 + tiles_per_split;
+    const int2 st = split_tiles[split]; // tiles [x, y) of 64 columns
+    const int64_t jt0 = st.x, ntiles = st.y;
     SF_I_DMA(jt0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void k_i8_place(const int *__restrict__ kmin, 
 // split's tiles with the final thresholds.  Keys within the threshold are appended to the pair's list.
 template <int KS>
 __global__ __launch_bounds__(512, 1) void k_i8_collect(const unsigned char *__restrict__ ai, const unsigned char *__restrict__ bi,
-                                                        int64_t m2_pad, const int *__restrict__ nbs, int64_t tiles_per_split,
+                                                        const int *__restrict__ nbs, const int2 *__restrict__ split_tiles,
                                                         int64_t n_blocks, const int *__restrict__ blk_split,
                                                         const int *__restrict__ pair_row, const int *__restrict__ pair_thr,
                                                         int *__restrict__ cnt, int32_t *__restrict__ cand_j,
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(512, 1) void k_i8_collect(const unsigned char *__re
         const int64_t p = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         T[r] = pair_row[p] < 0 ? -I_BIG : pair_thr[p];
     }
-    const int64_t jt0 = split * tiles_per_split;
-    const int64_t ntiles = (m2_pad / IN < jt0 + tiles_per_split) ? m2_pad / IN : jt0 + tiles_per_split;
+    const int2 st = split_tiles[split];
+    const int64_t jt0 = st.x, ntiles = st.y;
     SF_I_DMA(jt0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -581,6 +583,260 @@ int sf_match_i8_mode()
     return e[0] == '0' ? 0 : 1;
 }
 
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+// One implementation behind two entry points: sf_match_i8 (every reference row present: convert, pass 1, decide -- with a pilot
+// slab of scan rows in front) and the STREAMED form sf_match_stream_* (match.hip's caller: the reference rows arrive in chunks --
+// an all-gather in flight -- and every chunk gets its conversion and its share of pass 1 while the next one travels; the decision
+// steps run once, over the minima of all chunks).  A column split is a run of 64-column tiles inside ONE fed range; the table of
+// splits grows with the feeds.
+struct sf_match_stream {
+    sf_ctx *ctx = nullptr;
+    const double *da = nullptr, *db = nullptr;
+    const unsigned char *a_ok = nullptr, *b_ok = nullptr;
+    int64_t m1 = 0, m2 = 0, d = 0, m1p = 0, m2p = 0;
+    int ks = 11, dp = 352, RB = 2, IM = 512;
+    double sa = 0.0, sb = 0.0, unit = 0.0;
+    bool integer = false;   // the integer pass serves this problem (else: sf_match_stream_end runs the generic path)
+    bool windowed = false;
+    unsigned char *ai = nullptr, *bi = nullptr;
+    double *ea = nullptr, *qa = nullptr, *na2 = nullptr, *eb = nullptr, *qb = nullptr, *nb2 = nullptr, *part = nullptr, *amx = nullptr;
+    int *nbi = nullptr, *win = nullptr, *smin = nullptr, *kmin = nullptr, *live = nullptr, *flag = nullptr, *counters = nullptr;
+    int2 *split_tiles = nullptr;
+    int64_t split_cap = 0, tiles_target = 0;
+    std::vector<int2> splits;
+    std::vector<void *> owned;
+    double nbmax = 0.0, ebmax = 0.0;
+};
+
+namespace {
+
+template <typename T>
+int st_alloc(sf_match_stream *st, T **p, size_t count)
+{
+    SF_CHECK(sf_palloc(st->ctx, p, count ? count : 1));
+    st->owned.push_back(*p);
+    return SF_OK;
+}
+
+void st_free(sf_match_stream *st)
+{
+    if (!st) return;
+    for (void *p : st->owned) sf_pool_release(st->ctx, p);
+    delete st;
+}
+
+// scales, the scan side's image, the buffers of the reference side.  *suitable = false: leave the problem to the other paths.
+int st_begin(sf_match_stream *st, double b_entry_max, int64_t max_ranges, bool *suitable)
+{
+    sf_ctx *ctx = st->ctx;
+    *suitable = false;
+    const int64_t m1 = st->m1, m2 = st->m2, d = st->d;
+    if (d > 352 || m1 <= 0 || m2 <= 0 || m2 > 0x7fffffff || m1 > 0x3fffffff) return SF_OK;
+    const char *rb_env = getenv("SF_MATCH_I8_RB");
+    st->RB = rb_env && rb_env[0] == '1' ? 1 : 2; // 32-row blocks per wave of the first pass
+    st->IM = 256 * st->RB;
+    st->ks = d <= 128 ? 4 : 11;
+    st->dp = 32 * st->ks;
+    st->m1p = sf_div_up(m1, 512) * 512;
+    st->m2p = sf_div_up(m2, IN) * IN;
+    const int64_t m1p = st->m1p, m2p = st->m2p;
+    SF_CHECK(st_alloc(st, &st->part, 256));
+    SF_CHECK(st_alloc(st, &st->na2, m1p)); SF_CHECK(st_alloc(st, &st->ea, m1p)); SF_CHECK(st_alloc(st, &st->qa, m1p));
+    SF_CHECK(st_alloc(st, &st->amx, std::max(m1, m2)));
+    double namax = 0.0, aamax = 0.0;
+    SF_LAUNCH(ctx, "k8_i8_convert", k_i8_rowstat, dim3((unsigned)sf_div_up(m1, 4)), dim3(256), st->da, m1, d, st->na2, st->amx);
+    SF_CHECK(i8_host_max(ctx, st->na2, m1, st->part, &namax));
+    SF_CHECK(i8_host_max(ctx, st->amx, m1, st->part, &aamax));
+    if (!(aamax > 0.0) || !(b_entry_max > 0.0) || !std::isfinite(namax) || !std::isfinite(aamax) || !std::isfinite(b_entry_max)) return SF_OK;
+    st->sa = 127.0 / aamax;
+    st->sb = 127.0 / b_entry_max;
+    st->unit = 0.5 * st->sa * st->sb;
+    if (!std::isfinite(st->sa) || !std::isfinite(st->sb) || !std::isfinite(st->unit) || !(st->unit > 0.0)) return SF_OK;
+    SF_CHECK(st_alloc(st, &st->ai, m1p * st->dp)); SF_CHECK(st_alloc(st, &st->bi, m2p * st->dp));
+    SF_CHECK(st_alloc(st, &st->nb2, m2p)); SF_CHECK(st_alloc(st, &st->eb, m2p)); SF_CHECK(st_alloc(st, &st->qb, m2p)); SF_CHECK(st_alloc(st, &st->nbi, m2p));
+    if (m1p > m1) SF_HIP(hipMemsetAsync(st->na2 + m1, 0, (size_t)(m1p - m1) * sizeof(double), ctx->stream));
+    SF_LAUNCH(ctx, "k8_i8_convert", k_i8_convert, dim3((unsigned)sf_div_up(m1p, 4)), dim3(256), st->da, m1, m1p, d, st->dp, st->sa,
+              (const unsigned char *)nullptr, reinterpret_cast<unsigned *>(st->ai), st->ea, st->qa, (const double *)st->na2, (int *)nullptr, st->unit);
+    // column splits: 8 MB of reference rows each, so that an XCD's workgroups share the split they stream in their L2 (as
+    // sf_match_half); with few row blocks, enough splits to fill the chip
+    const int64_t col_tiles = m2p / IN;
+    static const int64_t chunk_kb = [] { const char *e = getenv("SF_MATCH_I8_CHUNK_KB"); const long long v = e ? atoll(e) : 8192; return (int64_t)(v > 0 ? v : 8192); }();
+    const int64_t tiles_in_l2 = std::max<int64_t>(8, chunk_kb * 1024 / ((int64_t)IN * st->dp));
+    int64_t nsplit = sf_div_up(col_tiles, tiles_in_l2);
+    if ((m1p / st->IM) * nsplit < 512) nsplit = std::max<int64_t>(nsplit, std::min<int64_t>(sf_div_up(512, m1p / st->IM), std::max<int64_t>(col_tiles / 32, 1)));
+    if (const char *e = getenv("SF_MATCH_I8_SPLITS")) nsplit = std::max<int64_t>(1, std::min<int64_t>(atoll(e), col_tiles));
+    st->tiles_target = sf_div_up(col_tiles, nsplit);
+    st->split_cap = sf_div_up(col_tiles, st->tiles_target) + std::max<int64_t>(max_ranges, 1);
+    if (st->split_cap > 65536) return SF_OK;
+    SF_CHECK(st_alloc(st, &st->win, m1p)); SF_CHECK(st_alloc(st, &st->smin, st->split_cap * m1p)); SF_CHECK(st_alloc(st, &st->kmin, m1p));
+    SF_CHECK(st_alloc(st, &st->live, m1p * I_LIVE)); SF_CHECK(st_alloc(st, &st->flag, m1));
+    SF_CHECK(st_alloc(st, &st->counters, 2 * st->split_cap + 2)); // [0]: flagged rows, [1]: unused, then split_count, split_cursor
+    SF_CHECK(st_alloc(st, &st->split_tiles, st->split_cap));
+    SF_HIP(hipMemsetAsync(st->counters, 0, (size_t)(2 * st->split_cap + 2) * sizeof(int), ctx->stream));
+    *suitable = true;
+    st->integer = true;
+    return SF_OK;
+}
+
+// reference rows [rb, re) (rb a multiple of 64; re a multiple of 64 or m2) are in place: their int8 image, their norm terms,
+// their splits.  *first / *count: the new splits.
+int st_convert_cols(sf_match_stream *st, int64_t rb, int64_t re, int64_t *first, int64_t *count)
+{
+    sf_ctx *ctx = st->ctx;
+    const int64_t rows = re - rb, rows_p = sf_div_up(rows, IN) * IN; // (the last range is padded to whole tiles: masked columns)
+    if (rb % IN || rows <= 0 || re > st->m2 || (re % IN && re != st->m2)) { sf_set_error("sf_match_stream_feed: rows [%lld, %lld) are not whole 64-row tiles", (long long)rb, (long long)re); return SF_ERR_ARG; }
+    SF_LAUNCH(ctx, "k8_i8_convert", k_i8_rowstat, dim3((unsigned)sf_div_up(rows, 4)), dim3(256), st->db + rb * st->d, rows, st->d, st->nb2 + rb, st->amx);
+    if (rows_p > rows) SF_HIP(hipMemsetAsync(st->nb2 + re, 0, (size_t)(rows_p - rows) * sizeof(double), ctx->stream));
+    SF_LAUNCH(ctx, "k8_i8_convert", k_i8_convert, dim3((unsigned)sf_div_up(rows_p, 4)), dim3(256), st->db + rb * st->d, rows, rows_p, st->d, st->dp, st->sb,
+              st->b_ok ? st->b_ok + rb : st->b_ok, reinterpret_cast<unsigned *>(st->bi + rb * st->dp), st->eb + rb, st->qb + rb,
+              (const double *)(st->nb2 + rb), st->nbi + rb, st->unit);
+    const int64_t t0 = rb / IN, t1 = t0 + rows_p / IN, n = sf_div_up(t1 - t0, st->tiles_target), per = sf_div_up(t1 - t0, n);
+    *first = (int64_t)st->splits.size();
+    for (int64_t t = t0; t < t1; t += per) st->splits.push_back(make_int2((int)t, (int)std::min(t + per, t1)));
+    *count = (int64_t)st->splits.size() - *first;
+    if ((int64_t)st->splits.size() > st->split_cap) { sf_set_error("sf_match_stream_feed: more ranges than announced"); return SF_ERR_ARG; }
+    SF_HIP(hipMemcpyAsync(st->split_tiles + *first, st->splits.data() + *first, (size_t)*count * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream)); // (the vector may grow, and move, with the next feed)
+    return SF_OK;
+}
+
+// pass 1 of the scan rows [r0, r0 + ms) over the splits [first, first + count)
+int st_pass1(sf_match_stream *st, const char *name, int64_t first, int64_t count, int64_t r0, int64_t ms)
+{
+    sf_ctx *ctx = st->ctx;
+    const int64_t msp = sf_div_up(ms, st->IM) * st->IM, row_blocks = msp / st->IM;
+    const int64_t wgs = sf_xcd_grid(count * row_blocks);
+    if (wgs > 0x7fffffffLL) { sf_set_error("sf_match_i8: %lld workgroups exceed a launch", (long long)wgs); return SF_ERR_UNSUPPORTED; }
+    if (!count || !ms) return SF_OK;
+    // (smin rows are addressed split * m1p + row: a slab of scan rows writes its own rows of every split's stripe)
+#define SF_I8_MIN(KS_, RB_)                                                                                             \
+    SF_LAUNCH(ctx, name, (k_i8_min<KS_, RB_>), dim3((unsigned)wgs), dim3(512), (const unsigned char *)(st->ai + r0 * st->dp), \
+              (const unsigned char *)st->bi, (const int *)st->nbi, (const int2 *)st->split_tiles, first, st->m1p, row_blocks, count, st->smin + r0)
+    if (st->ks == 4) { if (st->RB == 1) { SF_I8_MIN(4, 1); } else { SF_I8_MIN(4, 2); } }
+    else { if (st->RB == 1) { SF_I8_MIN(11, 1); } else { SF_I8_MIN(11, 2); } }
+#undef SF_I8_MIN
+    return SF_OK;
+}
+
+// every reference row has been fed: the maxima the windows need.  *suitable = false: norms the integer keys cannot hold.
+int st_window(sf_match_stream *st, bool *suitable)
+{
+    sf_ctx *ctx = st->ctx;
+    *suitable = false;
+    SF_CHECK(i8_host_max(ctx, st->nb2, st->m2, st->part, &st->nbmax));
+    SF_CHECK(i8_host_max(ctx, st->eb, st->m2, st->part, &st->ebmax));
+    if (!std::isfinite(st->nbmax) || !std::isfinite(st->ebmax) || !(st->nbmax * st->unit < 4e6)) return SF_OK;
+    SF_LAUNCH(ctx, "k8_i8_window", k_i8_window, dim3((unsigned)sf_div_up(st->m1p, 256)), dim3(256), (const double *)st->ea, (const double *)st->qa,
+              (const double *)st->na2, st->m1, st->m1p, std::sqrt(st->nbmax), st->ebmax, st->nbmax, st->unit, st->win);
+    st->windowed = true;
+    *suitable = true;
+    return SF_OK;
+}
+
+// steps 3-5 for the scan rows [r0, r0 + ms): live splits, pairs, collect pass, decision.  Rows that end flagged (counted in
+// counters[0]) are left to the caller.
+int st_decide(sf_match_stream *st, int64_t r0, int64_t ms, int64_t *didx, double *ddist)
+{
+    sf_ctx *ctx = st->ctx;
+    const int64_t nsplit = (int64_t)st->splits.size(), m1p = st->m1p;
+    int *nflag = st->counters, *split_count = st->counters + 2, *split_cursor = st->counters + 2 + st->split_cap;
+    SF_HIP(hipMemsetAsync(split_count, 0, (size_t)(2 * st->split_cap) * sizeof(int), ctx->stream)); // (counts and cursors)
+    SF_LAUNCH(ctx, "k8_i8_live", k_i8_live, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), (const int *)(st->smin + r0), (const int *)(st->win + r0),
+              st->a_ok ? st->a_ok + r0 : st->a_ok, ms, m1p, (int)nsplit, st->kmin + r0, st->live + r0 * I_LIVE, split_count, didx + r0,
+              ddist ? ddist + r0 : ddist, st->flag + r0, nflag);
+    // the pairs, split by split, each split's run padded to whole workgroups of 256
+    std::vector<int> hcount((size_t)nsplit), hbase((size_t)nsplit), hblk;
+    SF_HIP(hipMemcpyAsync(hcount.data(), split_count, (size_t)nsplit * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t n_pairs_pad = 0;
+    for (int64_t s = 0; s < nsplit; ++s) {
+        hbase[(size_t)s] = (int)n_pairs_pad;
+        const int64_t nb = sf_div_up(hcount[(size_t)s], 256);
+        for (int64_t k = 0; k < nb; ++k) hblk.push_back((int)s);
+        n_pairs_pad += nb * 256;
+        if (n_pairs_pad > 0x7fffff00LL) { sf_set_error("sf_match_i8: too many (row, split) pairs"); return SF_ERR_UNSUPPORTED; }
+    }
+    const int64_t n_blocks = (int64_t)hblk.size();
+    sf_pool_guard ptmp(ctx);
+    int *split_base = nullptr, *blk_split = nullptr, *pair_row = nullptr, *pair_thr = nullptr, *cnt = nullptr, *candk = nullptr;
+    int32_t *candj = nullptr;
+    const size_t np1 = (size_t)std::max<int64_t>(n_pairs_pad, 1);
+    SF_CHECK(ptmp.alloc(&split_base, (size_t)nsplit)); SF_CHECK(ptmp.alloc(&blk_split, (size_t)std::max<int64_t>(n_blocks, 1)));
+    SF_CHECK(ptmp.alloc(&pair_row, np1)); SF_CHECK(ptmp.alloc(&pair_thr, np1)); SF_CHECK(ptmp.alloc(&cnt, np1));
+    SF_CHECK(ptmp.alloc(&candj, np1 * ICAP)); SF_CHECK(ptmp.alloc(&candk, np1 * ICAP));
+    SF_HIP(hipMemcpyAsync(split_base, hbase.data(), (size_t)nsplit * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (n_blocks) {
+        SF_HIP(hipMemcpyAsync(blk_split, hblk.data(), (size_t)n_blocks * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        SF_HIP(hipMemsetAsync(pair_row, 0xff, (size_t)n_pairs_pad * sizeof(int), ctx->stream)); // -1: padding
+        SF_HIP(hipMemsetAsync(cnt, 0, (size_t)n_pairs_pad * sizeof(int), ctx->stream));
+        SF_LAUNCH(ctx, "k8_i8_live", k_i8_place, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), (const int *)(st->kmin + r0), (const int *)(st->win + r0),
+                  st->live + r0 * I_LIVE, ms, (int)nsplit, (const int *)split_base, split_cursor, pair_row, pair_thr);
+        const int64_t cw = sf_xcd_grid(n_blocks);
+        if (st->ks == 4) {
+            SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<4>, dim3((unsigned)cw), dim3(512), (const unsigned char *)(st->ai + r0 * st->dp),
+                      (const unsigned char *)st->bi, (const int *)st->nbi, (const int2 *)st->split_tiles, n_blocks, (const int *)blk_split,
+                      (const int *)pair_row, (const int *)pair_thr, cnt, candj, candk);
+        } else {
+            SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<11>, dim3((unsigned)cw), dim3(512), (const unsigned char *)(st->ai + r0 * st->dp),
+                      (const unsigned char *)st->bi, (const int *)st->nbi, (const int2 *)st->split_tiles, n_blocks, (const int *)blk_split,
+                      (const int *)pair_row, (const int *)pair_thr, cnt, candj, candk);
+        }
+    }
+#define SF_I8_FINAL(LPR)                                                                                               \
+    SF_LAUNCH(ctx, "k8_i8_final", k_i8_final<LPR>, dim3((unsigned)sf_div_up(ms * LPR, 256)), dim3(256), st->da + r0 * st->d, ms, st->db, st->d, \
+              st->a_ok ? st->a_ok + r0 : st->a_ok, (const int *)(st->live + r0 * I_LIVE), (const int *)cnt, (const int32_t *)candj, \
+              (const int *)candk, (const int *)(st->win + r0), (const double *)(st->na2 + r0), st->unit, didx + r0,          \
+              ddist ? ddist + r0 : ddist, st->flag + r0, nflag)
+    if (ms <= 65536) { SF_I8_FINAL(16); } else { SF_I8_FINAL(1); }
+#undef SF_I8_FINAL
+    SF_HIP(hipStreamSynchronize(ctx->stream)); // (hbase / hblk are host buffers of the copies above)
+    return SF_OK;
+}
+
+int st_flagged(sf_match_stream *st, int *nf)
+{
+    SF_HIP(hipMemcpyAsync(nf, st->counters, sizeof(int), hipMemcpyDeviceToHost, st->ctx->stream));
+    SF_HIP(hipStreamSynchronize(st->ctx->stream));
+    return SF_OK;
+}
+
+// the flagged rows -- no clear nearest descriptor, or overflowing lists -- through the FP16 pass on the gathered rows
+int st_fallback(sf_match_stream *st, int nf, int64_t *didx, double *ddist, int64_t *n_slow)
+{
+    sf_ctx *ctx = st->ctx;
+    const int64_t m1 = st->m1, d = st->d;
+    if (n_slow) *n_slow = 0;
+    if (nf <= 0) return SF_OK;
+    std::vector<int> hflag((size_t)m1);
+    SF_HIP(hipMemcpyAsync(hflag.data(), st->flag, (size_t)m1 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> rows;
+    rows.reserve((size_t)nf);
+    for (int64_t i = 0; i < m1; ++i)
+        if (hflag[(size_t)i]) rows.push_back(i);
+    const int64_t nr = (int64_t)rows.size();
+    sf_pool_guard tmp(ctx);
+    int64_t *drows = nullptr, *sidx = nullptr;
+    double *sub = nullptr, *sdist = nullptr;
+    SF_CHECK(tmp.alloc(&drows, (size_t)nr)); SF_CHECK(tmp.alloc(&sidx, (size_t)nr)); SF_CHECK(tmp.alloc(&sdist, (size_t)nr)); SF_CHECK(tmp.alloc(&sub, (size_t)(nr * d)));
+    SF_HIP(hipMemcpyAsync(drows, rows.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    SF_LAUNCH(ctx, "k8_gather_rows", k_i8_gather_rows, dim3((unsigned)sf_div_up(nr * d, 256)), dim3(256), st->da, d, (const int64_t *)drows, nr, sub);
+    SF_HIP(hipStreamSynchronize(ctx->stream)); // rows.data() is a host buffer
+    int64_t slow2 = 0;
+    int used2 = 0;
+    int rc = sf_match_half(ctx, sub, nr, st->db, st->m2, d, sidx, sdist, "k8_match_half", &slow2, nullptr, st->b_ok, &used2);
+    if (rc == SF_OK && !used2) // (norms the FP16 image cannot hold: float64 all the way)
+        rc = sf_match_gemm_f64(ctx, sub, nr, st->db, st->m2, d, sidx, sdist, "k8_match_gemm_overflow", &slow2, nullptr, st->b_ok);
+    if (rc == SF_OK) {
+        SF_LAUNCH(ctx, "k8_scatter_results", k_i8_scatter, dim3((unsigned)sf_div_up(nr, 256)), dim3(256), (const int64_t *)drows, nr,
+                  (const int64_t *)sidx, (const double *)sdist, didx, ddist);
+    }
+    if (n_slow) *n_slow = nr;
+    return rc;
+}
+
+} // namespace
+
 // rc SF_OK and *used = 1 when the result has been produced (flagged rows through the FP16 pass included); *used = 0
 // (nothing the caller relies on written) when the input is not suitable -- d > 352, zero / non-finite entries, or a pilot slab
 // that says the rows have no clear nearest descriptor -- and the caller must take the FP16 path.
@@ -589,175 +845,104 @@ int sf_match_i8(sf_ctx *ctx, const double *da, int64_t m1, const double *db, int
 {
     *used = 0;
     if (d > 352 || m1 <= 0 || m2 <= 0 || m2 > 0x7fffffff || m1 > 0x3fffffff) return SF_OK;
-    const char *rb_env = getenv("SF_MATCH_I8_RB");
-    const int RB = rb_env && rb_env[0] == '1' ? 1 : 2; // 32-row blocks per wave of the first pass
-    const int IM = 256 * RB;
-    const int ks = d <= 128 ? 4 : 11, dp = 32 * ks;
-    const int64_t m1p = sf_div_up(m1, 512) * 512, m2p = sf_div_up(m2, IN) * IN;
-    unsigned char *ai = nullptr, *bi = nullptr;
-    double *ea = nullptr, *qa = nullptr, *na2 = nullptr, *eb = nullptr, *qb = nullptr, *nb2 = nullptr, *part = nullptr, *amx = nullptr;
-    int *nbi = nullptr, *win = nullptr, *smin = nullptr, *kmin = nullptr, *live = nullptr, *flag = nullptr, *counters = nullptr;
-    sf_pool_guard tmp(ctx);
-#define SF_IALLOC(ptr, count) SF_CHECK(tmp.alloc(&ptr, (size_t)(count)))
-    SF_IALLOC(part, 256);
-    SF_IALLOC(nb2, m2p); SF_IALLOC(eb, m2p); SF_IALLOC(qb, m2p); SF_IALLOC(nbi, m2p);
-    SF_IALLOC(na2, m1p); SF_IALLOC(ea, m1p); SF_IALLOC(qa, m1p); SF_IALLOC(amx, std::max(m1, m2));
-    SF_IALLOC(ai, m1p * dp); SF_IALLOC(bi, m2p * dp);
-    double namax = 0.0, nbmax = 0.0, aamax = 0.0, abmax = 0.0;
+    sf_match_stream *st = new sf_match_stream();
+    st->ctx = ctx; st->da = da; st->db = db; st->a_ok = a_ok; st->b_ok = b_ok; st->m1 = m1; st->m2 = m2; st->d = d;
+    struct guard { sf_match_stream *s; ~guard() { st_free(s); } } g{st};
+    // the largest |entry| of the reference side: the scale of its image
+    double abmax = 0.0;
     {
-        SF_LAUNCH(ctx, "k8_i8_convert", k_i8_rowstat, dim3((unsigned)sf_div_up(m1, 4)), dim3(256), da, m1, d, na2, amx);
-        int rc = i8_host_max(ctx, na2, m1, part, &namax);
-        if (rc == SF_OK) rc = i8_host_max(ctx, amx, m1, part, &aamax);
-        if (rc != SF_OK) return rc;
-        SF_LAUNCH(ctx, "k8_i8_convert", k_i8_rowstat, dim3((unsigned)sf_div_up(m2, 4)), dim3(256), db, m2, d, nb2, amx);
-        rc = i8_host_max(ctx, nb2, m2, part, &nbmax);
-        if (rc == SF_OK) rc = i8_host_max(ctx, amx, m2, part, &abmax);
-        if (rc != SF_OK) return rc;
+        sf_pool_guard tmp(ctx);
+        double *n2 = nullptr, *mx = nullptr, *part = nullptr;
+        SF_CHECK(tmp.alloc(&n2, (size_t)m2)); SF_CHECK(tmp.alloc(&mx, (size_t)m2)); SF_CHECK(tmp.alloc(&part, 256));
+        SF_LAUNCH(ctx, "k8_i8_convert", k_i8_rowstat, dim3((unsigned)sf_div_up(m2, 4)), dim3(256), db, m2, d, n2, mx);
+        SF_CHECK(i8_host_max(ctx, mx, m2, part, &abmax));
     }
-    if (!(aamax > 0.0) || !(abmax > 0.0) || !std::isfinite(namax) || !std::isfinite(nbmax) || !std::isfinite(aamax) || !std::isfinite(abmax))
-        return SF_OK;
-    const double sa = 127.0 / aamax, sb = 127.0 / abmax, unit = 0.5 * sa * sb;
-    if (!std::isfinite(sa) || !std::isfinite(sb) || !std::isfinite(unit) || !(unit > 0.0) || !(nbmax * unit < 4e6)) return SF_OK;
-    if (m1p > m1) SF_HIP(hipMemsetAsync(na2 + m1, 0, (size_t)(m1p - m1) * sizeof(double), ctx->stream));
-    if (m2p > m2) SF_HIP(hipMemsetAsync(nb2 + m2, 0, (size_t)(m2p - m2) * sizeof(double), ctx->stream));
-    SF_LAUNCH(ctx, "k8_i8_convert", k_i8_convert, dim3((unsigned)sf_div_up(m1p, 4)), dim3(256), da, m1, m1p, d, dp, sa,
-              (const unsigned char *)nullptr, reinterpret_cast<unsigned *>(ai), ea, qa, (const double *)na2, (int *)nullptr, unit);
-    SF_LAUNCH(ctx, "k8_i8_convert", k_i8_convert, dim3((unsigned)sf_div_up(m2p, 4)), dim3(256), db, m2, m2p, d, dp, sb, b_ok,
-              reinterpret_cast<unsigned *>(bi), eb, qb, (const double *)nb2, nbi, unit);
-    double ebmax = 0.0;
-    SF_CHECK(i8_host_max(ctx, eb, m2, part, &ebmax));
-    if (!std::isfinite(ebmax)) return SF_OK;
-    // column splits: 8 MB of reference rows each, so that an XCD's workgroups share the split they stream in their L2 (as
-    // sf_match_half); with few row blocks, enough splits to fill the chip
-    const int64_t col_tiles = m2p / IN;
-    static const int64_t chunk_kb = [] { const char *e = getenv("SF_MATCH_I8_CHUNK_KB"); const long long v = e ? atoll(e) : 8192; return (int64_t)(v > 0 ? v : 8192); }();
-    const int64_t tiles_in_l2 = std::max<int64_t>(8, chunk_kb * 1024 / ((int64_t)IN * dp));
-    int64_t nsplit = sf_div_up(col_tiles, tiles_in_l2);
-    if ((m1p / IM) * nsplit < 512) nsplit = std::max<int64_t>(nsplit, std::min<int64_t>(sf_div_up(512, m1p / IM), std::max<int64_t>(col_tiles / 32, 1)));
-    if (const char *e = getenv("SF_MATCH_I8_SPLITS")) nsplit = std::max<int64_t>(1, std::min<int64_t>(atoll(e), col_tiles));
-    const int64_t tiles_per_split = sf_div_up(col_tiles, nsplit);
-    nsplit = sf_div_up(col_tiles, tiles_per_split);
-    if (nsplit > 65536) return SF_OK;
-    SF_IALLOC(win, m1p); SF_IALLOC(smin, nsplit * m1p); SF_IALLOC(kmin, m1p); SF_IALLOC(live, m1p * I_LIVE);
-    SF_IALLOC(flag, m1); SF_IALLOC(counters, 2 * nsplit + 2); // [0]: flagged rows, [1]: unused, then split_count, split_cursor
-    int *nflag = counters, *split_count = counters + 2, *split_cursor = counters + 2 + nsplit;
-    SF_HIP(hipMemsetAsync(counters, 0, (size_t)(2 * nsplit + 2) * sizeof(int), ctx->stream));
-    SF_LAUNCH(ctx, "k8_i8_window", k_i8_window, dim3((unsigned)sf_div_up(m1p, 256)), dim3(256), (const double *)ea, (const double *)qa,
-              (const double *)na2, m1, m1p, std::sqrt(nbmax), ebmax, nbmax, unit, win);
-    // Steps 2-5 for the scan rows [r0, r0 + ms): pass 1, live splits, pairs, collect pass, decision.  Rows that end flagged
-    // (counted in *nflag) are left to the caller.
-    auto run_rows = [&](int64_t r0, int64_t ms) -> int {
-        const int64_t msp = sf_div_up(ms, IM) * IM, row_blocks = msp / IM;
-        const int64_t wgs = sf_xcd_grid(nsplit * row_blocks);
-        if (wgs > 0x7fffffffLL) { sf_set_error("sf_match_i8: %lld workgroups exceed a launch", (long long)wgs); return SF_ERR_UNSUPPORTED; }
-        SF_HIP(hipMemsetAsync(split_count, 0, (size_t)(2 * nsplit) * sizeof(int), ctx->stream)); // (counts and cursors)
-        // (smin rows are addressed split * m1p + row: a slab writes its own rows of every split's stripe)
-#define SF_I8_MIN(KS_, RB_)                                                                                             \
-        SF_LAUNCH(ctx, name, (k_i8_min<KS_, RB_>), dim3((unsigned)wgs), dim3(512), (const unsigned char *)(ai + r0 * dp),  \
-                  (const unsigned char *)bi, m2p, (const int *)nbi, tiles_per_split, m1p, row_blocks, nsplit, smin + r0)
-        if (ks == 4) { if (RB == 1) { SF_I8_MIN(4, 1); } else { SF_I8_MIN(4, 2); } }
-        else { if (RB == 1) { SF_I8_MIN(11, 1); } else { SF_I8_MIN(11, 2); } }
-#undef SF_I8_MIN
-        SF_LAUNCH(ctx, "k8_i8_live", k_i8_live, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), (const int *)(smin + r0), (const int *)(win + r0),
-                  a_ok ? a_ok + r0 : a_ok, ms, m1p, (int)nsplit, kmin + r0, live + r0 * I_LIVE, split_count, didx + r0,
-                  ddist ? ddist + r0 : ddist, flag + r0, nflag);
-        // the pairs, split by split, each split's run padded to whole workgroups of 256
-        std::vector<int> hcount((size_t)nsplit), hbase((size_t)nsplit), hblk;
-        SF_HIP(hipMemcpyAsync(hcount.data(), split_count, (size_t)nsplit * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        int64_t n_pairs_pad = 0;
-        for (int64_t s = 0; s < nsplit; ++s) {
-            hbase[(size_t)s] = (int)n_pairs_pad;
-            const int64_t nb = sf_div_up(hcount[(size_t)s], 256);
-            for (int64_t k = 0; k < nb; ++k) hblk.push_back((int)s);
-            n_pairs_pad += nb * 256;
-            if (n_pairs_pad > 0x7fffff00LL) { sf_set_error("sf_match_i8: too many (row, split) pairs"); return SF_ERR_UNSUPPORTED; }
-        }
-        const int64_t n_blocks = (int64_t)hblk.size();
-        sf_pool_guard ptmp(ctx);
-        int *split_base = nullptr, *blk_split = nullptr, *pair_row = nullptr, *pair_thr = nullptr, *cnt = nullptr, *candk = nullptr;
-        int32_t *candj = nullptr;
-        const size_t np1 = (size_t)std::max<int64_t>(n_pairs_pad, 1);
-        SF_CHECK(ptmp.alloc(&split_base, (size_t)nsplit)); SF_CHECK(ptmp.alloc(&blk_split, (size_t)std::max<int64_t>(n_blocks, 1)));
-        SF_CHECK(ptmp.alloc(&pair_row, np1)); SF_CHECK(ptmp.alloc(&pair_thr, np1)); SF_CHECK(ptmp.alloc(&cnt, np1));
-        SF_CHECK(ptmp.alloc(&candj, np1 * ICAP)); SF_CHECK(ptmp.alloc(&candk, np1 * ICAP));
-        SF_HIP(hipMemcpyAsync(split_base, hbase.data(), (size_t)nsplit * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        if (n_blocks) {
-            SF_HIP(hipMemcpyAsync(blk_split, hblk.data(), (size_t)n_blocks * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            SF_HIP(hipMemsetAsync(pair_row, 0xff, (size_t)n_pairs_pad * sizeof(int), ctx->stream)); // -1: padding
-            SF_HIP(hipMemsetAsync(cnt, 0, (size_t)n_pairs_pad * sizeof(int), ctx->stream));
-            SF_LAUNCH(ctx, "k8_i8_live", k_i8_place, dim3((unsigned)sf_div_up(ms, 256)), dim3(256), (const int *)(kmin + r0), (const int *)(win + r0),
-                      live + r0 * I_LIVE, ms, (int)nsplit, (const int *)split_base, split_cursor, pair_row, pair_thr);
-            const int64_t cw = sf_xcd_grid(n_blocks);
-            if (ks == 4) {
-                SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<4>, dim3((unsigned)cw), dim3(512), (const unsigned char *)(ai + r0 * dp),
-                          (const unsigned char *)bi, m2p, (const int *)nbi, tiles_per_split, n_blocks, (const int *)blk_split,
-                          (const int *)pair_row, (const int *)pair_thr, cnt, candj, candk);
-            } else {
-                SF_LAUNCH(ctx, "k8_i8_collect", k_i8_collect<11>, dim3((unsigned)cw), dim3(512), (const unsigned char *)(ai + r0 * dp),
-                          (const unsigned char *)bi, m2p, (const int *)nbi, tiles_per_split, n_blocks, (const int *)blk_split,
-                          (const int *)pair_row, (const int *)pair_thr, cnt, candj, candk);
-            }
-        }
-#define SF_I8_FINAL(LPR)                                                                                               \
-        SF_LAUNCH(ctx, "k8_i8_final", k_i8_final<LPR>, dim3((unsigned)sf_div_up(ms * LPR, 256)), dim3(256), da + r0 * d, ms, db, d, \
-                  a_ok ? a_ok + r0 : a_ok, (const int *)(live + r0 * I_LIVE), (const int *)cnt, (const int32_t *)candj,   \
-                  (const int *)candk, (const int *)(win + r0), (const double *)(na2 + r0), unit, didx + r0,              \
-                  ddist ? ddist + r0 : ddist, flag + r0, nflag)
-        if (ms <= 65536) { SF_I8_FINAL(16); } else { SF_I8_FINAL(1); }
-#undef SF_I8_FINAL
-        SF_HIP(hipStreamSynchronize(ctx->stream)); // (hbase / hblk are host buffers of the copies above)
-        return SF_OK;
-    };
-    // the first slab is the PILOT when the problem is many times its size: its flagged share decides whether the integer pass pays
+    bool ok = false;
+    SF_CHECK(st_begin(st, abmax, 1, &ok));
+    if (!ok) return SF_OK;
+    int64_t first = 0, count = 0;
+    SF_CHECK(st_convert_cols(st, 0, m2, &first, &count));
+    SF_CHECK(st_window(st, &ok));
+    if (!ok) return SF_OK;
+    // the first slab of scan rows is the PILOT when the problem is many times its size: its flagged share decides whether the
+    // integer pass pays
     static const double max_flagged = [] { const char *e = getenv("SF_I8_MAX_FLAGGED"); const double v = e ? atof(e) : 0.35; return v > 0.0 ? v : 0.35; }();
     // (SF_I8_PILOT_ROWS: the pilot's size, for tests -- it then runs in the forced mode too)
     const char *pilot_env = getenv("SF_I8_PILOT_ROWS");
-    const int64_t pilot_rows = pilot_env ? std::max<int64_t>(IM, sf_div_up(atoll(pilot_env), IM) * IM) : (int64_t)IM * 64;
+    const int64_t pilot_rows = pilot_env ? std::max<int64_t>(st->IM, sf_div_up(atoll(pilot_env), st->IM) * st->IM) : (int64_t)st->IM * 64;
     const bool pilot = pilot_env ? m1 > pilot_rows : (m1 >= 4 * pilot_rows && sf_match_i8_mode() != 1);
     int64_t done = 0;
+    int nf = 0;
     if (pilot) {
-        SF_CHECK(run_rows(0, pilot_rows));
-        int nf = 0;
-        SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
+        SF_CHECK(st_pass1(st, name, first, count, 0, pilot_rows));
+        SF_CHECK(st_decide(st, 0, pilot_rows, didx, ddist));
+        SF_CHECK(st_flagged(st, &nf));
         if ((double)nf > max_flagged * (double)pilot_rows) return SF_OK; // (*used = 0: the caller's pass overwrites what was written)
         done = pilot_rows;
     }
-    SF_CHECK(run_rows(done, m1 - done));
-    int nf = 0;
-    SF_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipStreamSynchronize(ctx->stream));
-    int rc = SF_OK;
-    if (n_slow) *n_slow = 0;
-    if (nf > 0) { // rows without a clear nearest descriptor (or with overflowing lists): the FP16 pass on the gathered rows
-        std::vector<int> hflag((size_t)m1);
-        SF_HIP(hipMemcpyAsync(hflag.data(), flag, (size_t)m1 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SF_HIP(hipStreamSynchronize(ctx->stream));
-        std::vector<int64_t> rows;
-        rows.reserve((size_t)nf);
-        for (int64_t i = 0; i < m1; ++i)
-            if (hflag[(size_t)i]) rows.push_back(i);
-        const int64_t nr = (int64_t)rows.size();
-        int64_t *drows = nullptr, *sidx = nullptr;
-        double *sub = nullptr, *sdist = nullptr;
-        SF_IALLOC(drows, nr); SF_IALLOC(sidx, nr); SF_IALLOC(sdist, nr); SF_IALLOC(sub, nr * d);
-        SF_HIP(hipMemcpyAsync(drows, rows.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-        SF_LAUNCH(ctx, "k8_gather_rows", k_i8_gather_rows, dim3((unsigned)sf_div_up(nr * d, 256)), dim3(256), da, d,
-                  (const int64_t *)drows, nr, sub);
-        SF_HIP(hipStreamSynchronize(ctx->stream)); // rows.data() is a host buffer
-        int64_t slow2 = 0;
-        int used2 = 0;
-        rc = sf_match_half(ctx, sub, nr, db, m2, d, sidx, sdist, "k8_match_half", &slow2, nullptr, b_ok, &used2);
-        if (rc == SF_OK && !used2) // (norms the FP16 image cannot hold: float64 all the way)
-            rc = sf_match_gemm_f64(ctx, sub, nr, db, m2, d, sidx, sdist, "k8_match_gemm_overflow", &slow2, nullptr, b_ok);
-        if (rc == SF_OK) {
-            SF_LAUNCH(ctx, "k8_scatter_results", k_i8_scatter, dim3((unsigned)sf_div_up(nr, 256)), dim3(256), (const int64_t *)drows,
-                      nr, (const int64_t *)sidx, (const double *)sdist, didx, ddist);
-        }
-        if (n_slow) *n_slow = nr;
-    }
-#undef SF_IALLOC
+    SF_CHECK(st_pass1(st, name, first, count, done, m1 - done));
+    SF_CHECK(st_decide(st, done, m1 - done, didx, ddist));
+    SF_CHECK(st_flagged(st, &nf));
+    const int rc = st_fallback(st, nf, didx, ddist, n_slow);
     *used = 1;
     return rc;
+}
+
+// ---- the streamed form (include/shotfpfh.h: sf_match_stream_*) ---------------------------------------------------------------------
+int sf_match_argmin_masked_generic(sf_ctx *ctx, const double *a, const double *b, int64_t m1, int64_t m2, int64_t d,
+                                   const unsigned char *a_ok, const unsigned char *b_ok, int64_t *idx, double *dist); // match.hip
+
+extern "C" sf_match_stream *sf_match_stream_begin(sf_ctx *ctx, const double *a_dev, const unsigned char *a_ok_dev, int64_t m1,
+                                                  const double *b_dev, const unsigned char *b_ok_dev, int64_t m2, int64_t d,
+                                                  double b_entry_max, int64_t max_ranges)
+{
+    if (!ctx || !a_dev || !b_dev || !a_ok_dev || !b_ok_dev || m1 < 0 || m2 <= 0 || d <= 0) { sf_set_error("sf_match_stream_begin: bad argument"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sf_set_error("hipSetDevice failed"); return nullptr; }
+    sf_match_stream *st = new sf_match_stream();
+    st->ctx = ctx; st->da = a_dev; st->db = b_dev; st->a_ok = a_ok_dev; st->b_ok = b_ok_dev; st->m1 = m1; st->m2 = m2; st->d = d;
+    bool ok = false;
+    const bool wanted = sf_match_i8_mode() != 0 && m1 > 0;
+    if (wanted && st_begin(st, b_entry_max, max_ranges, &ok) != SF_OK) { st_free(st); return nullptr; }
+    // (not suitable -- or switched off: the handle stays, feeds do nothing, sf_match_stream_end runs the one-shot paths)
+    return st;
+}
+
+extern "C" int sf_match_stream_feed(sf_ctx *ctx, sf_match_stream *st, int64_t row_begin, int64_t row_end)
+{
+    if (!ctx || !st || st->ctx != ctx) { sf_set_error("sf_match_stream_feed: bad argument"); return SF_ERR_ARG; }
+    if (!st->integer) return SF_OK;
+    SF_HIP(hipSetDevice(ctx->device));
+    int64_t first = 0, count = 0;
+    SF_CHECK(st_convert_cols(st, row_begin, row_end, &first, &count));
+    return st_pass1(st, "k8_match_i8", first, count, 0, st->m1);
+}
+
+extern "C" int sf_match_stream_end(sf_ctx *ctx, sf_match_stream *st, int64_t *idx_dev, double *dist_dev)
+{
+    if (!ctx || !st || st->ctx != ctx || !idx_dev) { sf_set_error("sf_match_stream_end: bad argument"); return SF_ERR_ARG; }
+    struct guard { sf_match_stream *s; ~guard() { st_free(s); } } g{st};
+    SF_HIP(hipSetDevice(ctx->device));
+    if (st->integer) {
+        // every reference row must have been fed exactly once: the splits' tiles add up to the padded row count
+        int64_t tiles = 0;
+        for (const int2 &sp : st->splits) tiles += sp.y - sp.x;
+        if (tiles != st->m2p / IN) { sf_set_error("sf_match_stream_end: %lld of %lld column tiles were fed", (long long)tiles, (long long)(st->m2p / IN)); return SF_ERR_STATE; }
+        bool ok = false;
+        SF_CHECK(st_window(st, &ok));
+        if (ok) {
+            static const double max_flagged = [] { const char *e = getenv("SF_I8_MAX_FLAGGED"); const double v = e ? atof(e) : 0.35; return v > 0.0 ? v : 0.35; }();
+            int nf = 0;
+            SF_CHECK(st_decide(st, 0, st->m1, idx_dev, dist_dev));
+            SF_CHECK(st_flagged(st, &nf));
+            if ((double)nf <= max_flagged * (double)st->m1 || sf_match_i8_mode() == 1) return st_fallback(st, nf, idx_dev, dist_dev, nullptr);
+            // (most rows without a clear nearest descriptor: the one-shot paths for everything)
+        }
+    }
+    return sf_match_argmin_masked_generic(ctx, st->da, st->db, st->m1, st->m2, st->d, st->a_ok, st->b_ok, idx_dev, dist_dev);
+}
+
+extern "C" void sf_match_stream_abort(sf_ctx *ctx, sf_match_stream *st)
+{
+    (void)ctx;
+    st_free(st);
 }

@@ -205,6 +205,31 @@ class StepGraph:
             pass
 
 
+class MatchStream:
+    """Handle of a streamed K8 (Engine.match_stream)."""
+
+    def __init__(self, engine: "Engine", handle):
+        self.engine, self.h = engine, handle
+
+    def feed(self, row_begin: int, row_end: int) -> None:
+        _ffi.check(self.engine.lib.sf_match_stream_feed(self.engine.h, self.h, int(row_begin), int(row_end)), "sf_match_stream_feed")
+
+    def end(self, idx: DeviceArray, dist: Optional[DeviceArray] = None) -> None:
+        h, self.h = self.h, None  # (released by the call, whatever it returns)
+        _ffi.check(self.engine.lib.sf_match_stream_end(self.engine.h, h, idx.ptr, None if dist is None else dist.ptr), "sf_match_stream_end")
+
+    def abort(self) -> None:
+        if self.h is not None and self.engine.h:
+            self.engine.lib.sf_match_stream_abort(self.engine.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
+
+
 class Engine:
     """One GPU: a libshotfpfh context with its own HIP stream.  Fails loudly when the native library
     or the GPU is missing -- there is no CPU path."""
@@ -360,11 +385,13 @@ class Engine:
             )
         return idx, dist
 
-    def rows_nonzero_device(self, rows: DeviceArray, out: Optional[DeviceArray] = None, n_rows: Optional[int] = None) -> DeviceArray:
-        """uint8 mask on the device: 1 where a descriptor row has a non-zero entry."""
-        m = rows.shape[0] if n_rows is None else n_rows
+    def rows_nonzero_device(self, rows: DeviceArray, out: Optional[DeviceArray] = None, n_rows: Optional[int] = None,
+                            first_row: int = 0) -> DeviceArray:
+        """uint8 mask on the device: 1 where a descriptor row has a non-zero entry (rows first_row .. first_row + n_rows - 1)."""
+        m = rows.shape[0] - first_row if n_rows is None else n_rows
         out = out if out is not None else self.empty((rows.shape[0],), np.uint8)
-        _ffi.check(self.lib.sf_rows_nonzero(self.h, rows.ptr, m, rows.shape[1], out.ptr), "sf_rows_nonzero")
+        _ffi.check(self.lib.sf_rows_nonzero(self.h, rows.offset_ptr(first_row * rows.shape[1] * 8), m, rows.shape[1],
+                                            out.offset_ptr(first_row)), "sf_rows_nonzero")
         return out
 
     def rows_gather_device(self, rows: DeviceArray, sel: DeviceArray, out: DeviceArray) -> DeviceArray:
@@ -437,20 +464,19 @@ class Engine:
             "sf_comm_allgather",
         )
 
-    def allgather_into(self, send: DeviceArray, send_byte_offset: int, recv: DeviceArray, recv_byte_offset: int,
-                       bytes_per_rank: int) -> None:
-        """All-gather of `bytes_per_rank` bytes at send + offset into recv + offset (rank r's block at r * bytes_per_rank
-        behind it): one chunk of a chunked gather, issued on the context's CURRENT stream (sf_fork / sf_switch)."""
-        if send_byte_offset + bytes_per_rank > send.nbytes or recv_byte_offset + bytes_per_rank * self.nranks > recv.nbytes:
-            raise ValueError("all-gather chunk outside its buffers")
-        _ffi.check(self.lib.sf_comm_allgather(self.h, send.offset_ptr(send_byte_offset), recv.offset_ptr(recv_byte_offset),
-                                              bytes_per_rank), "sf_comm_allgather")
+    def rows_abs_max(self, rows: DeviceArray, n_rows: Optional[int] = None) -> float:
+        """Largest |entry| of the first n_rows resident rows (the scale of an int8 image: sf_rows_abs_max)."""
+        m = rows.shape[0] if n_rows is None else n_rows
+        out = C.c_double(0.0)
+        _ffi.check(self.lib.sf_rows_abs_max(self.h, rows.ptr, int(m), int(rows.shape[1]), C.byref(out)), "sf_rows_abs_max")
+        return float(out.value)
 
-    def match_fold_device(self, idx_chunk: DeviceArray, dist_chunk: DeviceArray, m: int, piece: int, rows_per_rank: int, col0: int,
-                          first: bool, best_idx: DeviceArray, best_dist: DeviceArray) -> None:
-        """sf_match_fold: one column chunk's row arg-min folded into the running one (first minimum over the gathered set)."""
-        _ffi.check(self.lib.sf_match_fold(self.h, idx_chunk.ptr, dist_chunk.ptr, int(m), int(piece), int(rows_per_rank), int(col0),
-                                          int(bool(first)), best_idx.ptr, best_dist.ptr), "sf_match_fold")
+    def match_stream(self, a: DeviceArray, a_ok: DeviceArray, m1: int, b: DeviceArray, b_ok: DeviceArray, m2: int, b_entry_max: float,
+                     max_ranges: int) -> "MatchStream":
+        """K8 while the reference rows are still arriving (sf_match_stream_*): feed(begin, end) as ranges of `b` land, end(idx, dist)."""
+        h = _ffi.check_handle(self.lib.sf_match_stream_begin(self.h, a.ptr, a_ok.ptr, int(m1), b.ptr, b_ok.ptr, int(m2), int(a.shape[1]),
+                                                             float(b_entry_max), int(max_ranges)), "sf_match_stream_begin")
+        return MatchStream(self, h)
 
     def exchange(self, ops) -> None:
         """Grouped point-to-point exchange (ncclSend / ncclRecv in ONE group).  ops: iterable of

@@ -397,22 +397,6 @@ class DescriptorJob:
         self.spfh = self.fpfh_out = self.lrf_out = self.shot_out = self.moments = None
 
 
-class _ByteView:
-    """A device array seen from a byte offset (source operand of DeviceArray.copy_from_device)."""
-
-    def __init__(self, base, byte_offset: int):
-        self.base, self.byte_offset = base, int(byte_offset)
-        self.nbytes = base.nbytes - self.byte_offset
-
-    @property
-    def ptr(self):
-        return self.base.offset_ptr(self.byte_offset).value
-
-    @property
-    def a(self):  # (the CPU stand-in's arrays: tests/fake_engine.py)
-        return self.base.a.reshape(-1).view(np.uint8)[self.byte_offset:]
-
-
 class MatchJob:
     """basic_matching (matching.py:149-169) of two descriptor sets that live SHARDED in HBM: rank g holds its block
     of the scan descriptors and its block of the reference descriptors (rows in the cell-sorted order of their
@@ -426,8 +410,10 @@ class MatchJob:
     """
 
     def __init__(self, engine: Engine, length: int, n_scan: int, n_ref: int, world: int = 1, rank: int = 0, chunks: int = 1):
-        """chunks > 1: the all-gather of the reference rows is cut into that many pieces per rank and K8 runs on chunk c while
-        chunk c + 1 crosses xGMI on the context's side stream (`run`); same matches bit for bit."""
+        """chunks > 1: the reference rows of the other ranks arrive in that many pieces per rank (grouped ncclSend / ncclRecv on
+        the context's side stream, every piece landing in place) and K8's integer pass works on the pieces that have landed
+        while the next ones travel (`run`, sf_match_stream_*); same matches bit for bit.  Needs blocks of a multiple of 64 rows
+        per rank (SubsetMatchJob's are); otherwise the rows are gathered at once."""
         self.engine, self.d = engine, int(length)
         self.scan_plan, self.ref_plan = ShardPlan(n_scan, world, rank), ShardPlan(n_ref, world, rank)
         rpr = max(self.ref_plan.rows_per_rank, 1)
@@ -438,97 +424,115 @@ class MatchJob:
         self.idx: DeviceArray = engine.empty((max(m, 1),), np.int64)
         self.dist: DeviceArray = engine.empty((max(m, 1),), np.float64)
         self.m = m
-        self.chunks = max(1, min(int(chunks), rpr))
-        self.exchange_timing: Optional[dict] = None
-        self._assembled = True
-        self._chunk_bufs: list = []
-        if self.chunks > 1:
-            piece = -(-rpr // self.chunks)
-            self.chunks = -(-rpr // piece)
-            self._piece = piece
-            for c in range(self.chunks):
-                pc = min(piece, rpr - c * piece)
-                self._chunk_bufs.append((engine.empty((pc * world, self.d)), engine.empty((pc * world,), np.uint8), pc))
-            self._idx_c: DeviceArray = engine.empty((max(m, 1),), np.int64)
-            self._dist_c: DeviceArray = engine.empty((max(m, 1),), np.float64)
-            pad = rpr * world - self.ref_plan.n  # rows behind the last rank's block: sent as they are, so they must be empty
-            if pad > 0:
-                zeros = engine.empty((pad, self.d)).from_host(np.zeros((pad, self.d)))
-                try:
-                    self.ref_all.copy_from_device(zeros, dst_byte_offset=self.ref_plan.n * self.d * 8)
-                    engine.sync()
-                finally:
-                    zeros.free()
+        self.chunks = 1
+        if chunks > 1 and rpr % 64 == 0 and m > 0:
+            self._piece = -(-(-(-rpr // int(chunks))) // 64) * 64  # rows of a piece: ceil(rpr / chunks), up to whole 64-row tiles
+            self.chunks = -(-rpr // self._piece)
 
-    def run(self, scan_block: DeviceArray, ref_block: DeviceArray) -> None:
-        """scan_block: (m, d) rows of this rank's scan block; ref_block: this rank's reference block."""
+    def _pieces(self, c: int):
+        """(rank, first row, end row) of chunk c's piece of every rank's block, in the gathered set's numbering, clipped to n."""
+        plan, rpr = self.ref_plan, max(self.ref_plan.rows_per_rank, 1)
+        out = []
+        for r in range(plan.world):
+            rb = r * rpr + c * self._piece
+            re = min(r * rpr + min((c + 1) * self._piece, rpr), plan.n)
+            if re > rb:
+                out.append((r, rb, re))
+        return out
+
+    def run(self, scan_block: DeviceArray, ref_block: DeviceArray, gather: bool = True, match: bool = True) -> None:
+        """scan_block: (m, d) rows of this rank's scan block; ref_block: this rank's reference block.
+        gather=False / match=False (chunked form, measurements): K8 on the rows the previous run gathered / the exchange alone."""
         eng, plan = self.engine, self.ref_plan
         row_bytes = self.d * 8
         b, e = plan.block()
         self.ref_all.copy_from_device(ref_block, dst_byte_offset=b * row_bytes, nbytes=(e - b) * row_bytes)
-        self._scan_block = scan_block
+        self._scan_block, self._ref_block = scan_block, ref_block
         if self.chunks > 1:
-            return self._run_chunked(scan_block)
+            return self._run_streamed(scan_block, gather, match)
         # (a lone context without a communicator has nothing to exchange and the call returns at once; with a
         # communicator -- of ONE rank too -- this is ncclAllGather)
-        eng.allgather(self.ref_all, plan.rows_per_rank * row_bytes)
+        if gather:
+            eng.allgather(self.ref_all, plan.rows_per_rank * row_bytes)
+        if not match:
+            return
         eng.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=plan.n)
         if self.m:
             eng.rows_nonzero_device(scan_block, self.scan_ok, n_rows=self.m)
             eng.match_masked_device(scan_block, self.scan_ok, self.ref_all, self.ref_ok, self.idx, self.dist,
                                     a_rows=self.m, b_rows=plan.n)
 
-    def _run_chunked(self, scan_block: DeviceArray) -> None:
-        """The exchange under K8 ("overlap C2 with the tail of K5 / K7 by chunking rows" -- here with K8 itself, the
-        only consumer of the gathered rows).  Chunk c = rows [c piece, (c + 1) piece) of EVERY rank's block, gathered into one
-        contiguous buffer by ncclAllGather on the context's SIDE stream; the main stream waits for chunk c only (sf_mark /
-        sf_wait_mark), runs K8 of this rank's scan block against it and folds the chunk's row arg-min into the running one
-        (sf_match_fold: smaller distance, smaller gathered row on a tie -- the arg-min over the whole set, first minimum
-        included).  Chunk c + 1 is in flight the whole time K8 works on chunk c."""
-        eng, plan, rank = self.engine, self.ref_plan, self.ref_plan.rank
-        rpr, piece, row_bytes = max(plan.rows_per_rank, 1), self._piece, self.d * 8
-        self._assembled = False
-        if self.m:
+    def _bmax_over_ranks(self, local: float) -> float:
+        """max over the ranks of a non-negative double, through the all-reduce(min) of 64-bit words the engine has: non-negative
+        doubles order like their bit patterns, so the maximum is the complement of the minimum of the complements."""
+        if self.ref_plan.world == 1:
+            return local
+        buf = self.engine.empty((1,), np.uint64)
+        try:
+            buf.from_host(~np.array([local], dtype=np.float64).view(np.uint64))
+            self.engine.allreduce_min_u64(buf, 1)
+            return float((~buf.to_host()).view(np.float64)[0])
+        finally:
+            buf.free()
+
+    def _run_streamed(self, scan_block: DeviceArray, do_gather: bool = True, do_match: bool = True) -> None:
+        """The exchange under K8 ("overlap C2 ... by chunking rows" -- here with K8 itself, the only consumer of the
+        gathered rows).  Chunk c = rows [c piece, (c + 1) piece) of EVERY rank's block; the pieces of the other ranks land IN
+        PLACE (one grouped ncclSend / ncclRecv per chunk, on the side stream), the main stream waits for chunk c only (sf_mark /
+        sf_wait_mark), marks its empty rows, makes its int8 image and runs the integer pass over it (sf_match_stream_feed) while
+        chunk c + 1 is in flight.  Cutting the COLUMNS must not cut the decision: a row's nearest descriptor sits in one chunk
+        only, and seen from the other chunks the row has no clear minimum -- so only the integer minima are taken per chunk
+        and the decision steps (live splits, candidates, float64) run once, over all chunks' minima (sf_match_stream_end)."""
+        eng, plan, me = self.engine, self.ref_plan, self.ref_plan.rank
+        row_bytes = self.d * 8
+        b, e = plan.block()
+
+        def exchange(c: int) -> None:
+            """chunk c: one grouped exchange -- my piece to every peer, every peer's piece into its place in ref_all"""
+            if not do_gather or plan.world == 1:
+                return
+            piece = {r: (rb, re) for (r, rb, re) in self._pieces(c)}
+            sb, se = piece.get(me, (0, 0))
+            ops = []
+            for p in range(plan.world):
+                if p == me:
+                    continue
+                rb, re = piece.get(p, (0, 0))
+                if se > sb or re > rb:
+                    ops.append((p, self.ref_all if se > sb else None, sb * row_bytes, (se - sb) * row_bytes,
+                                self.ref_all if re > rb else None, rb * row_bytes, (re - rb) * row_bytes))
+            eng.exchange(ops)
+
+        stream = None
+        if do_match:
             eng.rows_nonzero_device(scan_block, self.scan_ok, n_rows=self.m)
-
-        def gather(c: int) -> None:
-            buf, _, pc = self._chunk_bufs[c]
-            eng.allgather_into(self.ref_all, (rank * rpr + c * piece) * row_bytes, buf, 0, pc * row_bytes)
-
+            bmax = self._bmax_over_ranks(eng.rows_abs_max(self._ref_block, e - b) if e > b else 0.0)
+            stream = eng.match_stream(scan_block, self.scan_ok, self.m, self.ref_all, self.ref_ok, plan.n, bmax,
+                                      self.chunks * plan.world)
         eng.fork()  # the side stream starts behind everything issued so far (the copy of this rank's block into place)
         try:
-            gather(0)
+            exchange(0)
             eng.mark()
             for c in range(self.chunks):
                 eng.switch(0)
                 eng.wait_mark()  # chunk c has landed (and only that is waited for)
                 if c + 1 < self.chunks:
                     eng.switch(1)
-                    gather(c + 1)
+                    exchange(c + 1)
                     eng.mark()
                     eng.switch(0)
-                buf, ok, pc = self._chunk_bufs[c]
-                eng.rows_nonzero_device(buf, ok, n_rows=pc * plan.world)
-                if self.m:
-                    eng.match_masked_device(scan_block, self.scan_ok, buf, ok, self._idx_c, self._dist_c, a_rows=self.m,
-                                            b_rows=pc * plan.world)
-                    eng.match_fold_device(self._idx_c, self._dist_c, self.m, pc, rpr, c * piece, c == 0, self.idx, self.dist)
+                if stream is not None:
+                    for (_, rb, re) in self._pieces(c):
+                        eng.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=re - rb, first_row=rb)
+                        stream.feed(rb, re)
+        except Exception:
+            if stream is not None:
+                stream.abort()
+            raise
         finally:
             eng.join()
-
-    def _assemble(self) -> None:
-        """After a chunked run: the gathered rows in their global order in `ref_all` (+ `ref_ok`), for the callers that want the
-        whole set (column_argmin).  Device copies, on demand."""
-        if self._assembled:
-            return
-        plan, row_bytes = self.ref_plan, self.d * 8
-        rpr, piece = max(plan.rows_per_rank, 1), self._piece
-        for c, (buf, _, pc) in enumerate(self._chunk_bufs):
-            for r in range(plan.world):
-                self.ref_all.copy_from_device(_ByteView(buf, r * pc * row_bytes), dst_byte_offset=(r * rpr + c * piece) * row_bytes,
-                                              nbytes=pc * row_bytes)
-        self.engine.rows_nonzero_device(self.ref_all, self.ref_ok, n_rows=plan.n)
-        self._assembled = True
+        if stream is not None:
+            stream.end(self.idx, self.dist)
 
     # ---- the rest of match_descriptors (matching.py:54-74) on sharded rows ------------------------------------------------
     def _all_ranks(self, mine: np.ndarray, fill) -> np.ndarray:
@@ -568,7 +572,6 @@ class MatchJob:
         numbers; 2^64 - 1 where no non-empty scan row exists): local column arg-min over this rank's block, all-reduce(min)
         of the column minima, then all-reduce(min) of the rows that attain them -- the first minimum, as NumPy takes it."""
         eng, n_ref = self.engine, self.ref_plan.n
-        self._assemble()
         rows = max(self.ref_all.shape[0], 1)
         cd, ci = eng.empty((rows,), np.float64), eng.empty((rows,), np.int64)
         gd, cand = eng.empty((rows,), np.uint64), eng.empty((rows,), np.uint64)
@@ -621,13 +624,6 @@ class MatchJob:
     def close(self) -> None:
         for a in (self.ref_all, self.ref_ok, self.scan_ok, self.idx, self.dist):
             a.free()
-        for buf, ok, _ in self._chunk_bufs:
-            buf.free()
-            ok.free()
-        if self._chunk_bufs:
-            self._idx_c.free()
-            self._dist_c.free()
-        self._chunk_bufs = []
 
 
 class SubsetMatchJob:
@@ -678,8 +674,8 @@ class SubsetMatchJob:
         finally:
             mine.free()
 
-    def run(self) -> None:
-        self.job.run(self.scan_sub, self.ref_sub)                 # all-gather of descriptor rows (C2) + K8
+    def run(self, gather: bool = True, match: bool = True) -> None:
+        self.job.run(self.scan_sub, self.ref_sub, gather, match)  # all-gather of descriptor rows (C2) + K8
         self.engine.allgather(self.ref_labels, self.rows * 8)     # all-gather of the small label vector (C3)
 
     def matches(self) -> tuple[np.ndarray, np.ndarray]:

@@ -22,14 +22,18 @@ def match_main(out_path, rank, world):
     from shot_fpfh_amd.sharding import MatchJob, ShardPlan
 
     rng = np.random.default_rng(91)
+    n_ref = 277 if CHUNKS == 1 else 64 * world * 3 - 1  # (the streamed exchange needs whole 64-row tiles per rank: 192 rows each, the last rank one short)
     a = rng.random((301, 40)) * (rng.random((301, 40)) < 0.4)
-    b = a[rng.permutation(301)][:277] + 0.01 * rng.standard_normal((277, 40))
+    b = a[rng.permutation(301)][:n_ref] + 0.01 * rng.standard_normal((n_ref, 40)) if n_ref <= 301 else None
+    if b is None:
+        b = np.vstack([a[rng.permutation(301)], a[rng.permutation(301)]])[:n_ref] + 0.01 * rng.standard_normal((n_ref, 40))
     a[[0, 150, 300]] = 0.0
-    b[[5, 276]] = 0.0
+    b[[5, n_ref - 1]] = 0.0
     eng = FakeEngine()
-    job = MatchJob(eng, 40, 301, 277, world, rank, chunks=CHUNKS)
+    job = MatchJob(eng, 40, 301, n_ref, world, rank, chunks=CHUNKS)
+    assert (job.chunks > 1) == (CHUNKS > 1), (job.chunks, CHUNKS)
     sb, se = ShardPlan(301, world, rank).block()
-    rb, re = ShardPlan(277, world, rank).block()
+    rb, re = ShardPlan(n_ref, world, rank).block()
     job.run(eng.empty((se - sb, 40)).from_host(a[sb:se]), eng.empty((max(re - rb, 1), 40)).from_host(b[rb:re] if re > rb else 0.0))
     gathered = [None] * world
     dist.all_gather_object(gathered, job.matches())
@@ -87,7 +91,10 @@ def subset_main(out_path, rank, world):
     r_lab_block = perm[sb:se]
     r_sel = np.flatnonzero(in_subset[r_lab_block])
     rows = int(in_subset.sum())  # generous per-rank capacity: exercises the zero-row padding
+    if CHUNKS > 1:
+        rows = -(-rows // 64) * 64  # (whole 64-row tiles per rank: the streamed exchange)
     job = SubsetMatchJob(eng, d, rows, world, rank, chunks=CHUNKS)
+    assert (job.job.chunks > 1) == (CHUNKS > 1)
     job.select(eng.empty((se - sb, d)).from_host(scan[sb:se]), s_sel, s_sel + sb,
                eng.empty((se - sb, d)).from_host(ref[sb:se]), r_sel, r_lab_block[r_sel])
     job.run()

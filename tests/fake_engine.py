@@ -200,6 +200,39 @@ class FakeCloud:
         pass
 
 
+class FakeMatchStream:
+    """Stand-in of the streamed K8: a feed is only allowed to look at the rows it names -- it records their masks AS THEY ARE
+    when they are fed (rows fed before they have landed would be caught by the poison the workers put there) -- and the end runs
+    the oracle's masked arg-min over exactly what was fed."""
+
+    def __init__(self, eng, a, a_ok, m1, b, b_ok, m2, b_entry_max, max_ranges):
+        assert b_entry_max > 0.0 or m1 == 0
+        self.eng, self.a, self.a_ok, self.m1, self.b, self.b_ok, self.m2, self.max_ranges = eng, a, a_ok, m1, b, b_ok, m2, max_ranges
+        self.fed = np.zeros(m2, dtype=np.int32)
+        self.rows = np.full((m2, b.shape[1]), np.nan)
+        self.ok = np.zeros(m2, dtype=np.uint8)
+        self.n_feeds = 0
+
+    def feed(self, rb, re):
+        assert rb % 64 == 0 and (re % 64 == 0 or re == self.m2) and 0 <= rb < re <= self.m2, (rb, re, self.m2)
+        self.n_feeds += 1
+        assert self.n_feeds <= self.max_ranges
+        self.fed[rb:re] += 1
+        self.rows[rb:re] = self.b.a[rb:re]
+        self.ok[rb:re] = self.b_ok.a[rb:re]
+
+    def end(self, idx, dist=None):
+        assert (self.fed == 1).all(), "every reference row must be fed exactly once"
+        got = FakeArray((self.m2, self.rows.shape[1]))
+        got.a[:] = self.rows
+        okb = FakeArray((self.m2,), np.uint8)
+        okb.a[:] = self.ok
+        self.eng.match_masked_device(self.a, self.a_ok, got, okb, idx, dist, a_rows=self.m1, b_rows=self.m2)
+
+    def abort(self):
+        pass
+
+
 class FakeEngine:
     stats_on = False
 
@@ -238,22 +271,31 @@ class FakeEngine:
         dist.all_gather(parts, mine)
         flat[: world * bytes_per_rank] = torch.cat(parts).numpy()
 
-    def allgather_into(self, send, send_byte_offset, recv, recv_byte_offset, bytes_per_rank):
+    def exchange(self, ops):
+        """grouped point-to-point exchange over gloo: every receive posted, every send posted, all waited for"""
         import torch
         import torch.distributed as dist
 
-        world = dist.get_world_size()
-        mine = torch.from_numpy(send.a.reshape(-1).view(np.uint8)[send_byte_offset:send_byte_offset + bytes_per_rank].copy())
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        recv.a.reshape(-1).view(np.uint8)[recv_byte_offset:recv_byte_offset + world * bytes_per_rank] = torch.cat(parts).numpy()
+        reqs, landing = [], []
+        for (peer, sbuf, soff, sbytes, rbuf, roff, rbytes) in ops:
+            if rbytes:
+                t = torch.zeros(rbytes, dtype=torch.uint8)
+                reqs.append(dist.irecv(t, src=peer))
+                landing.append((rbuf, roff, rbytes, t))
+        for (peer, sbuf, soff, sbytes, rbuf, roff, rbytes) in ops:
+            if sbytes:
+                reqs.append(dist.isend(torch.from_numpy(sbuf.a.reshape(-1).view(np.uint8)[soff:soff + sbytes].copy()), dst=peer))
+        for r in reqs:
+            r.wait()
+        for rbuf, roff, rbytes, t in landing:
+            rbuf.a.reshape(-1).view(np.uint8)[roff:roff + rbytes] = t.numpy()
 
-    def match_fold_device(self, idx_chunk, dist_chunk, m, piece, rows_per_rank, col0, first, best_idx, best_dist):
-        j, d = idx_chunk.a[:m].astype(np.int64), dist_chunk.a[:m]
-        g = (j // piece) * rows_per_rank + col0 + j % piece
-        take = np.ones(m, bool) if first else (d < best_dist.a[:m]) | ((d == best_dist.a[:m]) & (g < best_idx.a[:m]))
-        best_idx.a[:m] = np.where(take, g, best_idx.a[:m])
-        best_dist.a[:m] = np.where(take, d, best_dist.a[:m])
+    def rows_abs_max(self, rows, n_rows=None):
+        m = rows.shape[0] if n_rows is None else n_rows
+        return float(np.abs(rows.a[:m]).max()) if m else 0.0
+
+    def match_stream(self, a, a_ok, m1, b, b_ok, m2, b_entry_max, max_ranges):
+        return FakeMatchStream(self, a, a_ok, m1, b, b_ok, m2, b_entry_max, max_ranges)
 
     def sync(self):
         pass
@@ -283,9 +325,9 @@ class FakeEngine:
         out.a[: pick.shape[0]] = np.where((pick >= 0)[:, None], np.nan_to_num(rows.a, nan=0.0)[np.maximum(pick, 0)], 0.0)
         return out
 
-    def rows_nonzero_device(self, rows, out=None, n_rows=None):
-        m = rows.shape[0] if n_rows is None else n_rows
-        out.a[:m] = np.any(np.nan_to_num(rows.a[:m], nan=1.0), axis=1)
+    def rows_nonzero_device(self, rows, out=None, n_rows=None, first_row=0):
+        m = rows.shape[0] - first_row if n_rows is None else n_rows
+        out.a[first_row:first_row + m] = np.any(np.nan_to_num(rows.a[first_row:first_row + m], nan=1.0), axis=1)
         return out
 
     def match_masked_device(self, a, a_ok, b, b_ok, idx, dist=None, a_rows=None, b_rows=None):

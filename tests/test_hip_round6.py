@@ -333,41 +333,44 @@ def test_match_i8_pilot_hands_unclear_problems_to_the_fp16_pass(eng, O, monkeypa
         assert (other >= 1) == (not pilot_passes)
 
 
-# ---- the descriptor all-gather under K8 (chunks) ------------------------------------------------------------------------------
+# ---- the descriptor exchange under K8 (streamed K8) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("chunks", [2, 5])
-def test_chunked_allgather_under_k8_gives_the_unchunked_matches(O, chunks):
-    """MatchJob(chunks=C): the reference rows cross the (one-rank) RCCL communicator in C ncclAllGather calls on the side stream
-    while K8 works on the chunk that has landed, and the chunks' row arg-mins are folded by sf_match_fold.  Index and distance
-    vectors equal the unchunked job's bit for bit -- exact ties across chunks (duplicated reference rows far apart in the set),
-    masked (zero) rows on both sides, a chunk that holds nothing but zero rows -- and basic_matching's pairs; the filters and the
-    reciprocity test (column arg-min over the re-assembled set) agree as well."""
+def test_streamed_k8_gives_the_one_shot_matches(O, monkeypatch, chunks):
+    """MatchJob(chunks=C): the reference rows become available in C pieces (between ranks: grouped ncclSend / ncclRecv on the side
+    stream) and every piece gets its int8 image and its share of the integer pass as it lands (sf_match_stream_feed); the decision
+    steps run once over all pieces' minima (sf_match_stream_end).  Index and distance vectors equal the one-shot job's bit for
+    bit -- exact ties across pieces (duplicated reference rows far apart in the set), masked (zero) rows on both sides, a piece
+    that holds nothing but zero rows -- and basic_matching's pairs; the reciprocity test (column arg-min) agrees as well."""
     import shot_fpfh_amd as s
     from shot_fpfh_amd.sharding import MatchJob
 
+    monkeypatch.setenv("SF_MATCH_I8", "1")  # (this size would take the FP64 GEMM form by itself)
     e2 = s.Engine(0)
     e2.comm_init(e2.comm_unique_id(), 1, 0)
     try:
         rng = np.random.default_rng(97)
-        m1, m2, d = 2300, 2100, 352
+        m1, m2, d = 2300, 2112, 352  # (2112 = 33 tiles of 64 rows)
         b = rng.random((m2, d)) * (rng.random((m2, d)) < 0.3)
         a = b[rng.integers(0, m2, m1)] + 1e-3 * rng.standard_normal((m1, d))
-        b[1900] = b[30]      # exact duplicates in different chunks: the first (row 30) must win
+        b[1900] = b[30]      # exact duplicates in different pieces: the first (row 30) must win
         b[1050] = b[30]
         a[9] = b[30]
         a[[4, 700]] = 0.0
         b[[8, 2099]] = 0.0
-        b[m2 - m2 // chunks + 5:] = 0.0 if chunks == 5 else b[m2 - m2 // chunks + 5:]  # (chunks = 5: the last chunk is all zero rows)
+        if chunks == 5:
+            b[m2 - 400:] = 0.0  # the last piece is all zero rows
         da, db = e2.empty((m1, d)).from_host(a), e2.empty((m2, d)).from_host(b)
         plain = MatchJob(e2, d, m1, m2)
         plain.run(da, db)
         e2.profile_reset()
         e2.profile(True)
         job = MatchJob(e2, d, m1, m2, chunks=chunks)
+        assert job.chunks == chunks
         job.run(da, db)
         e2.sync()
         e2.profile(False)
         rep = e2.profile_report()
-        assert rep["c_allgather"][0] == job.chunks == chunks and rep["k8_match_fold"][0] == chunks
+        assert rep["k8_match_i8"][0] == chunks and rep["k8_i8_collect"][0] == 1  # a first pass per piece, ONE decision
         assert np.array_equal(job.idx.to_host(), plain.idx.to_host()) and np.array_equal(job.dist.to_host(), plain.dist.to_host())
         s1, r1 = job.matches()
         s2, r2 = O.basic_matching(a, b)
@@ -376,6 +379,10 @@ def test_chunked_allgather_under_k8_gives_the_unchunked_matches(O, chunks):
         for kw in (dict(filter_nonreciprocal=True, n_min_matches=10), dict(filter_nonreciprocal=True, n_min_matches=10**6)):
             x, y = job.matches(**kw), plain.matches(**kw)
             assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+        # the integer pass switched off: the feeds cost nothing and the end runs the one-shot paths -- same vectors
+        monkeypatch.setenv("SF_MATCH_I8", "0")
+        job.run(da, db)
+        assert np.array_equal(job.idx.to_host(), plain.idx.to_host()) and np.array_equal(job.dist.to_host(), plain.dist.to_host())
         job.close()
         plain.close()
     finally:
