@@ -1266,7 +1266,8 @@ def main() -> int:
         match_chunks = args.match_chunks or (1 if single else 4)
         sub = SubsetMatchJob(eng, 352, cap, world, rank, chunks=match_chunks)
         sub.select(job.shot_out, s_sel, scan_orig[s_sel], ref_job.shot_out, r_sel, ref_label[r_sel])
-        sub.run()  # warm-up (RCCL channel setup, pool growth)
+        for _ in range(3):  # warm-up: RCCL channel setup, and the pool's blocks settling (its best-fit reuse hands a pass's large
+            sub.run()       # blocks to other requests of the next pass until it holds one of every size: a 50 ms pass among 26 ms ones)
         barrier()
         eng.profile_reset()
         eng.profile(True)
