@@ -902,7 +902,19 @@ def main() -> int:
             flat[:n] = np.min(np.stack(ctl.allgather(flat[:n].copy())), axis=0)
             buf.from_host(flat.reshape(buf.shape))
 
+        def host_staged_exchange(ops):
+            """Engine.exchange (grouped ncclSend / ncclRecv of byte ranges of device arrays) over the control plane"""
+            ops = list(ops)
+            mail = ctl.allgather({peer: sbuf.to_host().reshape(-1).view(np.uint8)[soff:soff + sbytes].tobytes()
+                                  for peer, sbuf, soff, sbytes, _, _, _ in ops if sbytes})
+            for peer, _, _, _, rbuf, roff, rbytes in ops:
+                if rbytes:
+                    flat = rbuf.to_host().reshape(-1).view(np.uint8)
+                    flat[roff:roff + rbytes] = np.frombuffer(mail[peer][rank], dtype=np.uint8)
+                    rbuf.from_host(flat.view(rbuf.dtype).reshape(rbuf.shape))
+
         eng.allgather = host_staged_allgather
+        eng.exchange = host_staged_exchange
         eng.allreduce_min_u64 = host_staged_min
         # the ranks size their SPFH tables by the longest list of ANY rank (same storage and wire format everywhere): without
         # RCCL that maximum goes over the control plane -- DescriptorJob asks for it through this hook (sharding.py)

@@ -549,17 +549,17 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
     }
     if (!std::isfinite(ebmax) || !std::isfinite(qbmax)) return SF_OK;
     // column splits: (1) each split is short enough for an XCD's workgroups to share its tiles through their L2 (8 MB: hit rate
-    // 0.83, profiles/r03_match_summary.md; SF_MATCH_HALF_CHUNK_KB overrides) -- see the note above k_match_half; (2) with few row blocks,
+    // 0.83 against 0.90 / 0.89 at 2 / 4 MB with fewer lists to walk, profiles/r03_match_summary.md) -- see the note above k_match_half; (2) with few row blocks,
     // enough workgroups for two per CU's worth of the chip, each with at least 32 tiles to scan
     const int64_t col_tiles = m2p / HN;
-    static const int64_t chunk_kb = [] { const char *e = getenv("SF_MATCH_HALF_CHUNK_KB"); const long long v = e ? atoll(e) : 8192; return (int64_t)(v > 0 ? v : 8192); }();
+    const int64_t chunk_kb = 8192;
     const int64_t tiles_in_l2 = std::max<int64_t>(8, chunk_kb * 1024 / ((int64_t)HN * dp * 2));
     int64_t nsplit = sf_div_up(col_tiles, tiles_in_l2);
     if ((m1p / HM) * nsplit < 512) nsplit = std::max<int64_t>(nsplit, std::min<int64_t>(sf_div_up(512, m1p / HM), std::max<int64_t>(col_tiles / 32, 1)));
     if (const char *e = getenv("SF_MATCH_HALF_SPLITS")) nsplit = std::max<int64_t>(1, std::min<int64_t>(atoll(e), col_tiles));
     const int64_t tiles_per_split = sf_div_up(col_tiles, nsplit);
     nsplit = sf_div_up(col_tiles, tiles_per_split);
-    static const bool seed = [] { const char *e = getenv("SF_MATCH_HALF_SEED"); return !(e && e[0] == '0'); }();
+    const bool seed = true; // (a row's threshold shared between its splits: without it the pass runs 2.3 x longer, same result)
     // scan rows go through in slabs: every (row, split) pair owns HCAP candidate slots, and 1M rows x 344 splits of them
     // would be 90 GB -- a slab keeps the lists within ~8 GB (at least 64 row blocks, so a slab still fills the chip)
     const int64_t slab_rows = std::min<int64_t>(m1p, HM * std::max<int64_t>(64, ((int64_t)8 << 30) / (nsplit * HCAP * 8 * HM)));
@@ -591,12 +591,11 @@ int sf_match_half(sf_ctx *ctx, const double *da, int64_t m1, const double *db, i
                   a_ok ? a_ok + r0 : a_ok, (const int *)cnt, (const int32_t *)candj, (const float *)candk, (const float *)thr, \
                   (const float *)win, (const double *)(na2 + r0), unit, (int)nsplit, msp, didx + r0, ddist ? ddist + r0 : ddist, \
                   flag + r0, nflag);
-        static const int lpr_env = [] { const char *e = getenv("SF_MATCH_FINAL_LPR"); return e ? atoi(e) : 0; }(); // (A/B)
         // (10^4 rows: 1.53 / 0.48 / 0.26 ms with 1 / 4 / 16 lanes per row; 262 144 rows: 3.9 / 4.5 / 5.5 ms -- the chip is full with one)
         // (75 000 rows -- what the integer pass hands on of config 4's 10^6 -- with one lane per row: 1 172 waves, one per SIMD, every
         // one of them a serial chain of 2 x 352 scattered loads: 4.7 ms; sixteen lanes per row there: round 6)
-        const int lpr = lpr_env ? lpr_env : (ms <= 160000 ? 16 : 1);
-        if (lpr == 1) { SF_HALF_FINAL(1) } else if (lpr == 4) { SF_HALF_FINAL(4) } else { SF_HALF_FINAL(16) }
+        const int lpr = ms <= 160000 ? 16 : 1;
+        if (lpr == 1) { SF_HALF_FINAL(1) } else { SF_HALF_FINAL(16) }
 #undef SF_HALF_FINAL
     }
     int nf = 0;

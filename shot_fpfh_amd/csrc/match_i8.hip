@@ -632,8 +632,7 @@ int st_begin(sf_match_stream *st, double b_entry_max, int64_t max_ranges, bool *
     *suitable = false;
     const int64_t m1 = st->m1, m2 = st->m2, d = st->d;
     if (d > 352 || m1 <= 0 || m2 <= 0 || m2 > 0x7fffffff || m1 > 0x3fffffff) return SF_OK;
-    const char *rb_env = getenv("SF_MATCH_I8_RB");
-    st->RB = rb_env && rb_env[0] == '1' ? 1 : 2; // 32-row blocks per wave of the first pass
+    st->RB = 2; // 32-row blocks per wave of the first pass (one per wave: + 11 % on the pass, measured; the instantiation is gone)
     st->IM = 256 * st->RB;
     st->ks = d <= 128 ? 4 : 11;
     st->dp = 32 * st->ks;
@@ -660,7 +659,7 @@ int st_begin(sf_match_stream *st, double b_entry_max, int64_t max_ranges, bool *
     // column splits: 8 MB of reference rows each, so that an XCD's workgroups share the split they stream in their L2 (as
     // sf_match_half); with few row blocks, enough splits to fill the chip
     const int64_t col_tiles = m2p / IN;
-    static const int64_t chunk_kb = [] { const char *e = getenv("SF_MATCH_I8_CHUNK_KB"); const long long v = e ? atoll(e) : 8192; return (int64_t)(v > 0 ? v : 8192); }();
+    const int64_t chunk_kb = 8192;
     const int64_t tiles_in_l2 = std::max<int64_t>(8, chunk_kb * 1024 / ((int64_t)IN * st->dp));
     int64_t nsplit = sf_div_up(col_tiles, tiles_in_l2);
     if ((m1p / st->IM) * nsplit < 512) nsplit = std::max<int64_t>(nsplit, std::min<int64_t>(sf_div_up(512, m1p / st->IM), std::max<int64_t>(col_tiles / 32, 1)));
@@ -712,8 +711,7 @@ int st_pass1(sf_match_stream *st, const char *name, int64_t first, int64_t count
 #define SF_I8_MIN(KS_, RB_)                                                                                             \
     SF_LAUNCH(ctx, name, (k_i8_min<KS_, RB_>), dim3((unsigned)wgs), dim3(512), (const unsigned char *)(st->ai + r0 * st->dp), \
               (const unsigned char *)st->bi, (const int *)st->nbi, (const int2 *)st->split_tiles, first, st->m1p, row_blocks, count, st->smin + r0)
-    if (st->ks == 4) { if (st->RB == 1) { SF_I8_MIN(4, 1); } else { SF_I8_MIN(4, 2); } }
-    else { if (st->RB == 1) { SF_I8_MIN(11, 1); } else { SF_I8_MIN(11, 2); } }
+    if (st->ks == 4) { SF_I8_MIN(4, 2); } else { SF_I8_MIN(11, 2); }
 #undef SF_I8_MIN
     return SF_OK;
 }

@@ -1,7 +1,6 @@
 """GPU parity tests added in round 5 (all through the C ABI).
 
-  * K7 on the matrix cores for lists of MORE than 255 points (k_fpfh_mcl): against the oracle, against the vector-ALU form it
-    replaces (SF_FPFH_TAIL_VECTOR=1), sparse-block form == full form bit for bit, consistent normals (high bytes really used);
+  * K7 on the matrix cores for lists of MORE than 255 points (k_fpfh_mcl): against the oracle, sparse-block form == full form bit for bit, consistent normals (high bytes really used);
   * K2's lists leave through an LDS ring (whole 256-byte runs): neighbour sets bit-exact at slot sizes around the ring's size.
 """
 import os
@@ -42,7 +41,8 @@ def dense_cloud(n, seed, consistent_normals=False):
 @pytest.mark.parametrize("n_bins", [5, 4, 3])
 def test_k7_matrix_core_form_for_long_lists(eng, O, monkeypatch, n_bins, consistent):
     """Lists of 300 .. 1500 points (one, two and three super-chunks of the long form; a list of exactly 256, 512 and 513 is
-    looked for among the keypoints): rows against the oracle and against the vector-ALU form with exact sums."""
+    looked for among the keypoints): rows against the oracle.  (The vector-ALU form with exact sums this form replaced was its
+    cross-check for a round -- 1e-12 apart -- and was removed in round 6.)"""
     import shot_fpfh_amd as s
 
     p, nr = dense_cloud(30000, 17 + n_bins, consistent)
@@ -59,12 +59,7 @@ def test_k7_matrix_core_form_for_long_lists(eng, O, monkeypatch, n_bins, consist
         lo = np.searchsorted(cnt[order], edge - 2)
         picks.append(order[lo:lo + 12])
     kp = np.unique(np.concatenate(picks + [np.random.default_rng(3).choice(p.shape[0], 200, replace=False)]))
-    monkeypatch.delenv("SF_FPFH_TAIL_VECTOR", raising=False)
     got = s.compute_fpfh_descriptor(kp, p, nr, r, n_bins, verbose=False)
-    monkeypatch.setenv("SF_FPFH_TAIL_VECTOR", "1")
-    vec = s.compute_fpfh_descriptor(kp, p, nr, r, n_bins, verbose=False)
-    monkeypatch.delenv("SF_FPFH_TAIL_VECTOR", raising=False)
-    assert np.abs(got - vec).max() <= 1e-12 * max(1.0, np.abs(vec).max()), np.abs(got - vec).max()
     sub = kp[:: max(1, kp.size // 120)]
     rows = np.searchsorted(kp, sub)
     want = O.compute_fpfh_descriptor(sub, p, nr, r, n_bins)
@@ -103,10 +98,9 @@ def test_k2_lists_through_the_lds_ring(eng, O, monkeypatch, cap):
 @pytest.mark.parametrize("k", [1, 8, 30, 64])
 @pytest.mark.parametrize("kind", ["uniform", "blob", "duplicates", "surface"])
 def test_knn_on_the_radius_search_mapping(eng, O, monkeypatch, kind, k):
-    """k <= 64: four queries per wave, the points within R ranked in ONE pass (k_knn4), against brute force and against the
-    one-wave-per-query kernel it replaces (SF_KNN_OLD=1): the same lists in the same (distance, position) order, so normals
-    computed from them are equal bit for bit.  Dense blob: queries with more than 256 points within R go to the old kernel at the
-    same R; duplicated points: exact distance ties, broken by position; queries far outside the cloud: radius doublings."""
+    """k <= 64: four queries per wave, the points within R ranked in ONE pass (k_knn4), against brute force; normals computed from
+    the lists against the oracle's.  Dense blob: queries with more than 256 points within R go to the one-wave-per-query kernel
+    at the same R; duplicated points: exact distance ties, broken by position; queries far outside the cloud: radius doublings."""
     from conftest import config1_cloud
     from shot_fpfh_amd.descriptors import compute_normals
 
@@ -121,28 +115,22 @@ def test_knn_on_the_radius_search_mapping(eng, O, monkeypatch, kind, k):
     q = np.vstack([p[rng.choice(n, m - 200, replace=False)], rng.random((200, 3)) * 3.0 - 1.0])
     cloud = eng.cloud(p)
     try:
-        monkeypatch.delenv("SF_KNN_OLD", raising=False)
         nb = cloud.knn_search(q, k)
         off, idx = nb.export()
-        monkeypatch.setenv("SF_KNN_OLD", "1")
-        off_old, idx_old = cloud.knn_search(q, k).export()
-        monkeypatch.delenv("SF_KNN_OLD", raising=False)
     finally:
         cloud.free()
-    assert np.array_equal(off, off_old) and np.array_equal(idx, idx_old)
+    assert np.array_equal(off, np.arange(m + 1) * k)
     sub = np.arange(0, m, 8)
     off_o, idx_o = O.knn_lists(p, q[sub], k)
     got, want = idx.reshape(m, k)[sub], np.sort(idx_o.reshape(sub.size, k), axis=1)
     for i in np.flatnonzero(~(got == want).all(axis=1)):  # rows may differ only where the k-th and (k+1)-th are equidistant
         d = np.sort(((p - q[sub[i]]) ** 2).sum(axis=1))
         assert d[k - 1] == d[k], f"query {sub[i]}: different neighbour set without a distance tie"
-    if k >= 8 and kind != "duplicates":  # (normals of k-NN lists: the lists' ORDER enters the sums)
-        monkeypatch.delenv("SF_KNN_OLD", raising=False)
-        a = compute_normals(q[: m - 200], p, k=k)
-        monkeypatch.setenv("SF_KNN_OLD", "1")
-        b = compute_normals(q[: m - 200], p, k=k)
-        monkeypatch.delenv("SF_KNN_OLD", raising=False)
-        assert np.array_equal(a, b)
+    if k >= 8 and kind in ("uniform", "surface"):  # normals from these lists against the oracle's (k-NN branch of compute_normals)
+        pre = np.tile(np.array([[0.3, -0.5, 0.8]]), (400, 1))
+        a = compute_normals(q[:400], p, k=k, pre_computed_normals=pre)
+        b = O.compute_normals(q[:400], p, k=k, pre_computed_normals=pre)
+        assert np.abs(a - b).max() < 1e-9
 
 
 # ---- 3-D matching ("minimum over scales") through the matrix-core matcher ---------------------------------------------------------
@@ -340,8 +328,8 @@ def test_k5_team_of_waves_for_long_lists(eng, O, monkeypatch, mean_k):
     """K5 for lists above 255 points: a team of waves per keypoint holds the list in registers (k_shot_team: three chunks per
     wave, as many waves as the list needs out of a workgroup of 4 / 8 / 16 -- lists up to 768 / 1 536 / 3 072 points), the
     streaming form takes what is longer.  Rows against the oracle at every boundary of the wave count, bit-identical from run
-    to run (one writer per slot, fixed order of the five tables), and against the streaming form (SF_SHOT_NO_TEAM=1), which
-    adds the same values in list order."""
+    to run (one writer per slot, fixed order of the five tables).  (The streaming form for EVERY long list was this form's
+    cross-check for a round -- 1e-13 apart -- behind a switch that is gone; beyond 3 072 points it still serves.)"""
     from shot_fpfh_amd.descriptors import ShotMultiprocessor
 
     n = 14000
@@ -361,7 +349,6 @@ def test_k5_team_of_waves_for_long_lists(eng, O, monkeypatch, mean_k):
         lo = np.searchsorted(cnt[order], edge)
         picks.append(order[max(lo - 2, 0):lo + 3])
     kp = np.unique(np.concatenate(picks))
-    monkeypatch.delenv("SF_SHOT_NO_TEAM", raising=False)
     rows = {}
     for normalize, min_nb in ((True, 100), (False, 300)):
         with ShotMultiprocessor(min_neighborhood_size=min_nb, normalize=normalize, verbose=False) as sm:
@@ -383,13 +370,6 @@ def test_k5_team_of_waves_for_long_lists(eng, O, monkeypatch, mean_k):
     nb.free()
     cloud.free()
     assert np.abs(unfused - rows[True][kp]).max() < 1e-13, np.abs(unfused - rows[True][kp]).max()
-    monkeypatch.setenv("SF_SHOT_NO_TEAM", "1")
-    with ShotMultiprocessor(min_neighborhood_size=100, normalize=True, verbose=False) as sm:
-        stream, rep = _shot_launches(eng, lambda: sm.compute_descriptor_single_scale(p, nr, p, r))
-    monkeypatch.delenv("SF_SHOT_NO_TEAM", raising=False)
-    assert "k5_shot_tail_stream" not in rep and rep.get("k5_shot_tail") == 1, rep
-    assert np.abs(stream - rows[True]).max() < 1e-13, np.abs(stream - rows[True]).max()
-
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
 def test_point_order_leaves_every_row_unchanged_at_full_size(eng, kind):

@@ -21,9 +21,8 @@ eng = s.default_engine()
 def run(da, db, m1, label):
     idx, dist = eng.empty((m1,), np.int64), eng.empty((m1,), np.float64)
     out = {}
-    for mode in ("0", "1", "1r1"):
+    for mode in ("0", "1"):
         os.environ["SF_MATCH_I8"] = mode[0]
-        os.environ["SF_MATCH_I8_RB"] = "1" if mode.endswith("r1") else "2"
         eng.match_argmin_device(da, db, idx, dist)
         eng.sync()
         eng.profile_reset()
@@ -36,7 +35,7 @@ def run(da, db, m1, label):
         rep = {k: (v[0], round(v[1], 3)) for k, v in eng.profile_report().items() if k.startswith("k8")}
         out[mode] = (idx.to_host().copy(), dist.to_host().copy())
         print(f"{label} SF_MATCH_I8={mode}: {t * 1e3:.2f} ms  {rep}", flush=True)
-    for mode in ("1", "1r1"):
+    for mode in ("1",):
         same_i, same_d = np.array_equal(out["0"][0], out[mode][0]), np.array_equal(out["0"][1], out[mode][1])
         print(f"{label} {mode}: identical idx {same_i}, identical dist {same_d}", flush=True)
         if not same_i:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Near-minimax polynomial coefficients for the two inverse-trig helpers of the SHOT kernel
-(shot_fpfh_amd/csrc/descriptors.hip: sf_atan_small, sf_acos).
+(shot_fpfh_amd/csrc/shot.hip: sf_atan_small, sf_acos).
 
     atan(t) = t * P(t^2)           t in [0, tan(pi/8) (1 + 1e-3)]
     asin(r) = r + r * s * R(s)     s = r^2 in [0, 0.25]

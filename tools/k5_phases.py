@@ -2,7 +2,7 @@
 """Instruction counts per phase of the register-cached SHOT kernel K5 (k_shot_cached<3, true>, the instantiation BASELINE
 config 3 runs), from the compiler's own listing -> profiles/r04_k5.md.
 
-Two listings of csrc/descriptors.hip are made with the shipped flags: the plain one (totals of the kernel as it ships) and an
+Two listings of csrc/shot.hip are made with the shipped flags: the plain one (totals of the kernel as it ships) and an
 ANALYSIS build with -DSF_K5_MARK_BUILD, in which every phase boundary of shot_cached_body / shot_geometry / shot_weights is a
 scheduling barrier plus an assembler comment `; K5MARK <id> <nch>`.  The marked listing is cut at the comments; the
 instructions between two marks belong to the phase of the first.  k_shot_cached<3, .> contains two inlined bodies (a keypoint
@@ -59,7 +59,7 @@ def classify(op: str) -> str:
 
 
 def listing(extra):
-    out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "descriptors.hip", "-o", "-"], cwd=SRC, capture_output=True, text=True)
+    out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "shot.hip", "-o", "-"], cwd=SRC, capture_output=True, text=True)
     if out.returncode:
         sys.exit(out.stderr[-3000:])
     return out.stdout.splitlines()
@@ -109,7 +109,7 @@ def main() -> int:
     cls = ["valu", "salu", "lds", "vmem", "smem", "waitcnt"]
     rows = []
     rows.append("# K5 `k_shot_cached<3, true>`: instructions per phase (round 4)\n")
-    rows.append("Produced by `tools/k5_phases.py` from the compiler's listing of `csrc/descriptors.hip` (gfx950, the shipped flags).\n")
+    rows.append("Produced by `tools/k5_phases.py` from the compiler's listing of `csrc/shot.hip` (gfx950, the shipped flags).\n")
     rows.append(f"Whole kernel as shipped (both inlined bodies, static): " + ", ".join(f"{k} {tot_plain[k]}" for k in cls) + ".")
     rows.append(f"Analysis build (scheduling barriers at the marks): " + ", ".join(f"{k} {tot_marked[k]}" for k in cls) +
                 " -- the barriers cost the scheduler a few instructions (spills / copies), the phase SHARES below are what the table is for.\n")
