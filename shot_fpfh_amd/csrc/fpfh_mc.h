@@ -40,6 +40,30 @@ __device__ __forceinline__ void fpfh_mc_zero_outside(double *__restrict__ o, con
             if (b < W.win_lo || b >= W.win_lo + W.win_len) sf_store_stream(o + b, 0.0);
 }
 
+// The keypoint's row leaves the wave as ONE run of 16-byte pieces.  A lane owns bins i0 and i1 = i0 + 16 (the layout the matrix
+// core leaves the sums in): stored from there, a row is eight 128-byte runs issued by two instructions, and -- a row of 125
+// doubles starting 1000 q bytes into the array -- every run straddles 32-byte sectors it shares with the run of the OTHER
+// instruction: 1.37 GB of write requests for 1.0 GB of rows at C3 (WRITE_SIZE, profiles/r05_summary.md).  So the two values go
+// through the wave's LDS region (free by now) and lane l stores the aligned piece l of the row, 16 bytes -- 8 at the row's two
+// ends when the row starts on an odd multiple of 8: one instruction, 1000 contiguous bytes, two partial sectors per row.
+// (A windowed table -- n_bins above 5 -- keeps the plain stores: its row has holes.)
+__device__ __forceinline__ void fpfh_mc_store_row(double *__restrict__ o, int n, int i0, double v0, int i1, double v1,
+                                                  double *stage /* this wave's, >= 128 doubles */, int lane)
+{
+    if (i0 < n) stage[i0] = v0;
+    if (i1 < n) stage[i1] = v1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int shift = (int)((reinterpret_cast<uintptr_t>(o) >> 3) & 1u); // (wave-uniform) the row starts in the middle of a piece
+    const int e = 2 * lane - shift;
+    const bool a_ok = e >= 0 && e < n, b_ok = e + 1 < n;
+    const double a = a_ok ? stage[e] : 0.0, b = b_ok ? stage[e + 1] : 0.0;
+    if (a_ok && b_ok) sf_store_stream2(o + e, a, b);
+    else if (a_ok) sf_store_stream(o + e, a);
+    else if (b_ok) sf_store_stream(o + e + 1, b);
+}
+
 // Staged rows: 128 B each, no padding -- the image is written by LDS-DMA (buffer_load_dwordx4 ... lds: a wave
 // instruction writes its 64 lanes' 16-byte chunks back to back), so the bank spread comes from the SOURCE side:
 // slot s of row r holds chunk s ^ f(r), f(r) = (r >> 1) & 7.  A transposing read of one 32-lane half (8 rows x 16
@@ -327,8 +351,13 @@ __device__ __forceinline__ void fpfh_mc_body(const double *__restrict__ rec, con
         s1 = __builtin_fma(__builtin_fma(-s1, kd, c1), inv_k, s1);
         double h0 = 0.0, h1 = 0.0;
         if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, b0, b1, h0, h1);
-        if (b0 < W.win_len) sf_store_stream(o + b0, s0 + (HI ? vsel0 + h0 : vsel0) * inv_k);
-        if (b1 < W.win_len) sf_store_stream(o + b1, s1 + (HI ? vsel1 + h1 : vsel1) * inv_k);
+        const double r0 = s0 + (HI ? vsel0 + h0 : vsel0) * inv_k, r1 = s1 + (HI ? vsel1 + h1 : vsel1) * inv_k;
+        if (W.win_len == W.nb3 && W.win_len <= 126) { // (wave-uniform)
+            fpfh_mc_store_row(o, W.win_len, b0, r0, b1, r1, reinterpret_cast<double *>(rowbuf), lane);
+        } else {
+            if (b0 < W.win_len) sf_store_stream(o + b0, r0);
+            if (b1 < W.win_len) sf_store_stream(o + b1, r1);
+        }
     }
 }
 
@@ -466,8 +495,13 @@ __device__ __forceinline__ void fpfh_mc_body_sparse(const double *__restrict__ r
         const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
         double h0 = 0.0, h1 = 0.0;
         if (HI) fpfh_mc_hi<NKS>(hi, jv, wv, lm, o0, o1, h0, h1);
-        if (o0 < W.win_len) sf_store_stream(o + o0, s0 + (HI ? v0 + h0 : v0) * inv_k);
-        if (o1 < W.win_len) sf_store_stream(o + o1, s1 + (HI ? v1 + h1 : v1) * inv_k);
+        const double r0 = s0 + (HI ? v0 + h0 : v0) * inv_k, r1 = s1 + (HI ? v1 + h1 : v1) * inv_k;
+        if (W.win_len == W.nb3 && W.win_len <= 126) { // (wave-uniform)
+            fpfh_mc_store_row(o, W.win_len, o0, r0, o1, r1, reinterpret_cast<double *>(rowbuf), lane);
+        } else {
+            if (o0 < W.win_len) sf_store_stream(o + o0, r0);
+            if (o1 < W.win_len) sf_store_stream(o + o1, r1);
+        }
     }
 }
 
@@ -641,8 +675,13 @@ __device__ __forceinline__ void fpfh_mcl_body_sparse(const double *__restrict__ 
         o += W.win_lo;
         const double v0 = bb0 == b0 ? tot0 : (bb0 == b1 ? tot1 : 0.0);
         const double v1 = bb0 + 1 == b0 ? tot0 : (bb0 + 1 == b1 ? tot1 : 0.0);
-        if (o0 < W.win_len) sf_store_stream(o + o0, (double)own0 / kd + (v0 + h0) * inv_k); // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
-        if (o1 < W.win_len) sf_store_stream(o + o1, (double)own1 / kd + (v1 + h1) * inv_k);
+        const double r0 = (double)own0 / kd + (v0 + h0) * inv_k, r1 = (double)own1 / kd + (v1 + h1) * inv_k; // spfh[kp] + sum / len(neighbourhood)  (fpfh.py:109-115)
+        if (W.win_len == W.nb3 && W.win_len <= 126) { // (wave-uniform)
+            fpfh_mc_store_row(o, W.win_len, o0, r0, o1, r1, reinterpret_cast<double *>(rowbuf), lane);
+        } else {
+            if (o0 < W.win_len) sf_store_stream(o + o0, r0);
+            if (o1 < W.win_len) sf_store_stream(o + o1, r1);
+        }
     }
 #undef SF_MCL_DMA
 }
@@ -764,8 +803,13 @@ __device__ __forceinline__ void fpfh_mcl_body(const double *__restrict__ rec, co
         double *o = out + q * (int64_t)W.nb3;
         fpfh_mc_zero_outside(o, W, lane);
         o += W.win_lo;
-        if (o0 < W.win_len) sf_store_stream(o + o0, (double)own0 / kd + (vsel0 + h0) * inv_k);
-        if (o1 < W.win_len) sf_store_stream(o + o1, (double)own1 / kd + (vsel1 + h1) * inv_k);
+        const double r0 = (double)own0 / kd + (vsel0 + h0) * inv_k, r1 = (double)own1 / kd + (vsel1 + h1) * inv_k;
+        if (W.win_len == W.nb3 && W.win_len <= 126) { // (wave-uniform)
+            fpfh_mc_store_row(o, W.win_len, o0, r0, o1, r1, reinterpret_cast<double *>(rowbuf), lane);
+        } else {
+            if (o0 < W.win_len) sf_store_stream(o + o0, r0);
+            if (o1 < W.win_len) sf_store_stream(o + o1, r1);
+        }
     }
 #undef SF_MCLF_DMA
 }
