@@ -311,31 +311,51 @@ class Control:
                     r = int(self._recv(c))
                     if not 1 <= r < world or r in got:
                         raise ValueError(f"rank {r} out of range or already connected")
+                    self._send(c, ("ok", r))  # (authenticated: the client knows its key is this job's)
                     got[r] = c
                 except (ConnectionError, ValueError, TypeError, OSError):
-                    c.close()  # (not one of this job's ranks)
+                    c.close()  # (not one of this job's ranks -- or one that read a stale token file: it retries)
             srv.close()
             self.peers = [got[r] for r in range(1, world)]
         else:
+            # A hello is only complete when rank 0 has ANSWERED it under the job's key: a rank that picked up the token file a
+            # crashed earlier run left behind (rank 0 replaces it, but may not have yet) is dropped by rank 0, reads the file again
+            # and retries until the deadline (advisor, round 5).
             deadline = time.time() + timeout
             self.sock = None
             while self.sock is None and time.time() < deadline:
+                c = None
                 for port in cands:
                     try:
                         c = socket.create_connection(("127.0.0.1", port), timeout=2.0)
                         c.settimeout(2.0)
                         if self._readline(c) == hello:
-                            c.settimeout(timeout)
-                            self.sock = c
                             break
                         c.close()
+                        c = None
                     except OSError:
-                        pass
-                else:
+                        c = None
+                if c is None:
+                    time.sleep(0.2)
+                    continue
+                try:
+                    c.settimeout(min(timeout, 20.0))
+                    self._send(c, rank)
+                    ack = self._recv(c)
+                    if ack == ("ok", rank) or ack == ["ok", rank]:
+                        c.settimeout(timeout)
+                        self.sock = c
+                        break
+                    raise ValueError("unexpected answer to the hello")
+                except (ConnectionError, ValueError, TypeError, OSError, EOFError):
+                    c.close()
+                    if not os.environ.get("SF_BENCH_TOKEN"):
+                        Control._token = None
+                        Control.establish_secret(rank, max(deadline - time.time(), 1.0))  # (the file may have been replaced)
                     time.sleep(0.2)
             if self.sock is None:
-                raise SystemExit("bench control plane: rank 0 did not answer")
-            self._send(self.sock, rank)
+                raise SystemExit("bench control plane: rank 0 did not answer (or refused this rank's key: set SF_BENCH_TOKEN to the "
+                                 "same 16+ random characters on every rank)")
 
     @staticmethod
     def _readline(c) -> bytes:
@@ -371,7 +391,13 @@ class Control:
                     os.unlink(path)  # (a stale file of an earlier run of this user on this port)
                 except FileNotFoundError:
                     pass
-                fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+                except OSError as exc:  # (somebody else's file squats the path)
+                    raise SystemExit(f"bench control plane: cannot replace {path} ({exc}); set SF_BENCH_TOKEN to 16+ random characters, "
+                                     "the same on every rank") from None
+                try:
+                    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+                except OSError as exc:
+                    raise SystemExit(f"bench control plane: cannot create {path} ({exc}); set SF_BENCH_TOKEN") from None
                 tok = os.urandom(16).hex()
                 os.write(fd, tok.encode())
                 os.close(fd)

@@ -356,6 +356,47 @@ def test_bench_control_plane_rendezvous_allgather_max_bcast(tmp_path, under_laun
         blocker.close()
 
 
+def test_bench_control_plane_survives_a_stale_token_file(tmp_path):
+    """Advisor (round 5): a run that crashed leaves its token file behind (right owner, mode 0600, 32 bytes); ranks started
+    before rank 0 has replaced it read the OLD token.  Rank 0 drops their hello, they read the file again and retry: the job
+    meets.  Here ranks 1 and 2 start two seconds before rank 0, with the stale file in place and no SF_BENCH_TOKEN."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    import time
+
+    from conftest import ROOT
+
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    path = os.path.join(tempfile.gettempdir(), f"sfbench-{os.getuid()}-{port}.token")
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+    os.write(fd, b"0" * 32)  # (what a crashed run left)
+    os.close(fd)
+    script = tmp_path / "w.py"
+    script.write_text(_CTL_WORKER)
+    procs = {}
+    try:
+        for rank in (1, 2, 0):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SF_BENCH_SELF_SPAWNED="1")
+            env.pop("SF_BENCH_TOKEN", None)
+            procs[rank] = subprocess.Popen([sys.executable, str(script), ROOT], env=env)
+            if rank == 2:
+                time.sleep(2.0)
+        for p in procs.values():
+            assert p.wait(timeout=120) == 0
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+        if os.path.exists(path):
+            os.unlink(path)
+
+
 def test_bench_control_plane_drops_a_client_without_the_job_secret(tmp_path):
     """No SF_BENCH_TOKEN and no launcher secret: rank 0 writes 16 random bytes to a file only this user can read and the other
     ranks read it back; a local process that connects to rank 0's port and sends a well-formed message under a guessed key (the
