@@ -88,7 +88,7 @@ ALG_BYTES = {
     "k1_cell_settle": 8 + 48 + 48 + 4 + 4,  # (index, cell) slot in, xyz + normal in, 48-byte record (+ SoA copy of xyz) out, both permutations
 }
 PER_PAIR = ("k2_radius_fill", "k2_radius_slots")
-PROFILE_TAG = "r05"  # profiles/<tag>_{traffic,k5_sq,sustained_clock}.json: counter files of THIS round's build (stamped)
+PROFILE_TAG = "r06"  # profiles/<tag>_{traffic,k5_sq,sustained_clock}.json: counter files of THIS round's build (stamped)
 C4_EULER, C4_T = (0.3, -0.2, 0.5), (0.1, -0.3, 0.2)  # SURVEY 8d, config C4's rigid motion
 
 
