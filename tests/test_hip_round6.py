@@ -6,6 +6,8 @@
   * compute_metrics_post_icp against the reference's numbers;
   * the per-range search record across grid rebuilds (advisor, round 5) and the grid stamp on list sets.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -387,3 +389,92 @@ def test_streamed_k8_gives_the_one_shot_matches(O, monkeypatch, chunks):
         plain.close()
     finally:
         e2.close()
+
+
+# ---- K8: every path on random problems -----------------------------------------------------------------------------------------
+def _random_match_problem(seed):
+    """A problem drawn at random: sizes, row length, the kind of rows, how the scan rows relate to the reference rows, ties,
+    zero rows, a block of near-identical reference rows, the scale of the numbers."""
+    rng = np.random.default_rng(10_000 + seed)
+    d = int(rng.choice([352, 352, 352, 125, 125, 33, 7, 64, 1, 351, 97]))
+    if rng.random() < 0.15:  # small and degenerate shapes (the exact tile kernel serves these whatever is forced)
+        m1, m2 = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+    else:  # at least 6e8 pair-dimensions where the row length allows: the matrix-core forms engage
+        m1 = int(rng.integers(400, 4500))
+        m2 = int(min(max(rng.integers(400, 6000), -(-600_000_000 // (m1 * d))), 60_000))
+    kind = rng.choice(["sparse", "dense", "percent", "signed", "lattice"])
+    if kind == "sparse":
+        b = rng.random((m2, d)) * (rng.random((m2, d)) < rng.choice([0.05, 0.3, 0.8]))
+    elif kind == "dense":
+        b = rng.random((m2, d))
+    elif kind == "percent":
+        b = rng.random((m2, d)) ** 4 * 100.0
+    elif kind == "signed":
+        b = rng.standard_normal((m2, d))
+    else:  # few distinct values per entry: exact ties between distances everywhere
+        b = rng.integers(0, 3, (m2, d)).astype(np.float64) * 0.25
+    if rng.random() < 0.5 and kind != "lattice":
+        b /= np.maximum(np.linalg.norm(b, axis=1)[:, None], 1e-300)
+    rel = rng.choice(["copies", "near", "unrelated", "mixed"])
+    if rel == "unrelated":
+        a = b[rng.integers(0, m2, m1)][:, rng.permutation(d)]
+    else:
+        noise = {"copies": 0.0, "near": 1e-3, "mixed": 0.05}[rel] * (b.std() + 1e-300)
+        a = b[rng.integers(0, m2, m1)] + noise * rng.standard_normal((m1, d)) * (rng.random((m1, 1)) < 0.8)
+    if m2 > 40 and rng.random() < 0.4:  # near-identical reference rows: long candidate lists
+        w = int(rng.integers(2, min(m2 // 2, 700)))
+        s = int(rng.integers(0, m2 - w))
+        b[s:s + w] = b[s] + rng.choice([0.0, 1e-9, 1e-5]) * rng.standard_normal((w, d))
+    if rng.random() < 0.5:  # duplicated reference rows far apart: the lower column must win
+        for _ in range(int(rng.integers(1, 6))):
+            i, j = rng.integers(0, m2, 2)
+            b[j] = b[i]
+    if rng.random() < 0.5:  # empty descriptors on both sides
+        a[rng.integers(0, m1, max(1, m1 // 50))] = 0.0
+        b[rng.integers(0, m2, max(1, m2 // 50))] = 0.0
+    scale = float(rng.choice([1.0, 1.0, 1e-6, 1e5, 3.0]))
+    return a * scale, b * scale
+
+
+_STRESS_SEEDS = int(os.environ.get("SF_STRESS_SEEDS", "24"))
+
+
+@pytest.mark.parametrize("seed", range(_STRESS_SEEDS))
+def test_every_matching_path_agrees_on_random_problems(eng, O, monkeypatch, seed):
+    """Integer pre-filter (forced, with a random number of column splits), FP16 pre-filter (forced), the dispatcher's own choice
+    and the resident masked form: index and distance vectors equal to each other bit for bit and, for the first seeds, to
+    SciPy's order of arithmetic in the oracle.  (SF_STRESS_SEEDS=n runs n problems.)"""
+    from shot_fpfh_amd.sharding import MatchJob
+
+    a, b = _random_match_problem(seed)
+    rng = np.random.default_rng(seed)
+    results = {}
+    for name, env in (("i8", {"SF_MATCH_I8": "1", "SF_MATCH_I8_SPLITS": str(int(rng.integers(1, 12)))}),
+                      ("half", {"SF_MATCH_I8": "0", "SF_MATCH_HALF": "1", "SF_MATCH_HALF_SPLITS": str(int(rng.integers(1, 7)))}),
+                      ("auto", {})):
+        with monkeypatch.context() as mp:
+            for k in ("SF_MATCH_I8", "SF_MATCH_I8_SPLITS", "SF_MATCH_HALF", "SF_MATCH_HALF_SPLITS"):
+                mp.delenv(k, raising=False)
+            for k, v in env.items():
+                mp.setenv(k, v)
+            results[name] = eng.match_argmin(a, b, want_col=True)
+    for name in ("half", "auto"):
+        for x, y in zip(results["i8"], results[name]):
+            assert np.array_equal(x, y), (seed, name)
+    if a.shape[0] * b.shape[0] * a.shape[1] < (3e9 if seed < 6 else 4e8):
+        for x, y in zip(results["i8"], O.match_argmin(a, b, want_col=True)):
+            assert np.array_equal(x, y), (seed, "oracle")
+    # the resident, masked form (zero rows never match and are never matched), streamed in a random number of pieces
+    with monkeypatch.context() as mp:
+        mp.setenv("SF_MATCH_I8", "1")
+        m1, m2, d = a.shape[0], b.shape[0], a.shape[1]
+        plain = MatchJob(eng, d, m1, m2)
+        da, db = eng.empty((m1, d)).from_host(a), eng.empty((m2, d)).from_host(b)
+        plain.run(da, db)
+        mp.setenv("SF_MATCH_I8", "0")
+        mp.setenv("SF_MATCH_HALF", "0")
+        other = MatchJob(eng, d, m1, m2)
+        other.run(da, db)
+        assert np.array_equal(plain.idx.to_host(), other.idx.to_host()) and np.array_equal(plain.dist.to_host(), other.dist.to_host()), seed
+        plain.close()
+        other.close()
