@@ -345,7 +345,7 @@ __device__ inline void shot_geometry(double cx, double cy, double cz, double d2,
     lzr = __builtin_fma(__builtin_fma(-lzr, rho, lz), inv_rho, lzr);
     o.rho = rho; o.dc = dc; o.tcross = cross; o.tdot = dot; o.lzr = lzr;
     o.bins0 = base | (bcos << 9) | (bth << 18);
-    o.bins1 = 0x80000000u;
+    o.bins1 = 0x80000000u | (base & 3u); // (bits 0-1: shell and half-space, for the form that re-maps its slot numbers)
 }
 
 // Radius-derived constants of the interpolation, computed once on the host (as kernel arguments they live in SGPRs;
@@ -367,8 +367,7 @@ struct shot_consts {
 // reference's 1e-10 band), so last-bit differences of the short polynomial forms cannot flip a term.
 __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, double &vA, double &v_cd, double &v_ef, double &adth)
 {
-    const unsigned base = g.bins0 & 511u;
-    const bool z_pos = base & 2u; // lz > 0, decided in shot_geometry
+    const bool z_pos = g.bins1 & 2u; // lz > 0, decided in shot_geometry
     const double rho = g.rho;
     const double adc = fabs(g.dc);
     // |dth|: angle off the octant's centre ray as a fraction of the octant, clipped to 1/2.  lx = ly = 0 has dot = 0:
@@ -417,6 +416,20 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
 #ifndef SF_SHOT_WPB
 #define SF_SHOT_WPB 2 // waves (= keypoints) per workgroup: 1.61 / 1.54 / 1.55 / 1.80 ms at C3 for 1 / 2 / 4 / 8
 #endif
+
+// Slot numbers of the cached form's LDS tables (round 6).  Bin b = ((cosine * 8 + azimuth) * 2 + half-space) * 2 + shell lives
+// in slot b ^ (3 (b >> 5)): with the plain numbering the bank pair of an 8-byte slot is b mod 32 = (azimuth, half-space, shell)
+// WHATEVER the cosine bin -- and seven neighbours in eight sit in the outer shell -- so the 64-bit election atomics of a wave
+// crowded into sixteen of the 32 bank pairs (SQ_LDS_BANK_CONFLICT 312 cycles per wave, 0.52 of the LDS pipe's active cycles).
+// XOR-ing the low five bits with three times the cosine bin (0, 3, .., 30: both parities) spreads them over all 32: 150 cycles
+// per wave, waiting behind an LDS instruction 239 -> 65 cycles, K5 -0.7 % (tools/pmc_k5.sh; same box, three rounds).  The XOR
+// stays inside the cosine bin's 32 slots and commutes with the ^ 1 / ^ 2 that reach the other shell / half-space; the row
+// read-out undoes it.  All three 9-bit fields of bins0 at once (the fields are nine bits apart, 3 x 10 < 32: no carry).
+__device__ inline unsigned shot_swz3(unsigned b)
+{
+    const unsigned t = (b >> 5) & 0x3C1E0Fu;
+    return b ^ (t * 3u);
+}
 
 template <int NCH, bool FUSED>
 __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
@@ -544,6 +557,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         // 72 / 80 registers it spills / runs 1.62 ms)
         if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
             shot_geometry(cx[c], cy[c], cz[c], d2[c], nx[c], ny[c], nz[c], E, K.half_r, g[c]);
+            g[c].bins0 = shot_swz3(g[c].bins0);
             SF_K5_MARK(6, NCH);
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             atomicMax(&sA[g[c].bins0 & 511u], key);
@@ -557,7 +571,7 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
         if (__builtin_amdgcn_inverse_ballot_w64(posm[c])) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(g[c].rho);
             const unsigned iA = g[c].bins0 & 511u;
-            const bool up = iA & 2u, odd = iA & 1u; // (bit 1: z > 0, bit 0: outer shell)
+            const bool up = g[c].bins1 & 2u, odd = g[c].bins1 & 1u; // (z > 0; outer shell -- iA is a SLOT number: shot_swz3)
             const unsigned long long own = sA[iA], other_shell = sA[iA ^ 1u], other_half = sA[iA ^ 2u];
             unsigned f = 0u;
             if (own == key) {
@@ -639,7 +653,10 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int b = 2 * lane + 128 * u;
-        vals[u] = b < 352 ? *reinterpret_cast<const double2 *>(acc + b) : make_double2(0.0, 0.0);
+        // bins b, b + 1 are the slots (b ^ g), (b ^ g) ^ 1: the same aligned pair, its halves exchanged when g is odd
+        const int gsw = 3 * (b >> 5), sb = (b ^ gsw) & ~1;
+        vals[u] = b < 352 ? *reinterpret_cast<const double2 *>(acc + sb) : make_double2(0.0, 0.0);
+        if (gsw & 1) { const double t_ = vals[u].x; vals[u].x = vals[u].y; vals[u].y = t_; }
         ss += vals[u].x * vals[u].x;
         ss += vals[u].y * vals[u].y;
     }
