@@ -34,6 +34,8 @@ namespace {
 struct fpfh_edges {
     double a[SF_WIN_FPFH_BINS + 1], p[SF_WIN_FPFH_BINS + 1], t[SF_WIN_FPFH_BINS + 1];
     double tan_t[SF_WIN_FPFH_BINS + 1]; // tan of the interior theta edges (index 1..nb-1)
+    double p_inv_width;                 // n_bins / (p[n_bins] - p[0]): formed on the host (in the kernel the IEEE division of two
+                                        // wave-uniform numbers was a 15-instruction vector sequence per point)
 };
 
 // np.histogramdd bin of x: searchsorted(edges, x, 'right') - 1, x == last edge -> last bin, out of
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(64 * SF_SPFH_WPB) __attribute__((amdgpu_waves_per_e
     const double px = rec[6 * i + 0], py = rec[6 * i + 1], pz = rec[6 * i + 2];
     const double ux = rec[6 * i + 3], uy = rec[6 * i + 4], uz = rec[6 * i + 5];
     __builtin_amdgcn_wave_barrier();
-    const double p_inv_width = (double)nb / (ed.p[nb] - ed.p[0]); // np.linspace edges: equal widths up to rounding
+    const double p_inv_width = ed.p_inv_width; // np.linspace edges: equal widths up to rounding
     // theta_bin_fast's margin: |a_fast - a_reference| <= ~24 eps |n_j| |u|^2 |c| (a dozen roundings on either side, each
     // relative to a product of those norms); 64 eps max|n| |u|^2 per unit of |c| is the bound used
     const double uu = (ux * ux + uy * uy) + uz * uz;
@@ -587,6 +589,7 @@ static int spfh_compute(sf_ctx *ctx, sf_cloud *c, sf_nbrs *nb, sf_spfh *sp, cons
         ed.t[i] = edges[2 * (nbn + 1) + (i <= nbn ? i : nbn)];
         ed.tan_t[i] = std::tan(ed.t[i]);
     }
+    ed.p_inv_width = (double)nbn / (ed.p[nbn] - ed.p[0]);
     const int64_t m = nb->m;
     if (!m) return SF_OK;
     // alpha's bin is known beforehand when every |alpha| <= radius * max|n|^2 stays clear of the histogram's edges (see
