@@ -418,17 +418,23 @@ __device__ inline void shot_weights(const shot_kept &g, const shot_consts &k, do
 #endif
 
 // Slot numbers of the cached form's LDS tables (round 6).  Bin b = ((cosine * 8 + azimuth) * 2 + half-space) * 2 + shell lives
-// in slot b ^ (3 (b >> 5)): with the plain numbering the bank pair of an 8-byte slot is b mod 32 = (azimuth, half-space, shell)
-// WHATEVER the cosine bin -- and seven neighbours in eight sit in the outer shell -- so the 64-bit election atomics of a wave
-// crowded into sixteen of the 32 bank pairs (SQ_LDS_BANK_CONFLICT 312 cycles per wave, 0.52 of the LDS pipe's active cycles).
-// XOR-ing the low five bits with three times the cosine bin (0, 3, .., 30: both parities) spreads them over all 32: 150 cycles
-// per wave, waiting behind an LDS instruction 239 -> 65 cycles, K5 -0.7 % (tools/pmc_k5.sh; same box, three rounds).  The XOR
-// stays inside the cosine bin's 32 slots and commutes with the ^ 1 / ^ 2 that reach the other shell / half-space; the row
-// read-out undoes it.  All three 9-bit fields of bins0 at once (the fields are nine bits apart, 3 x 10 < 32: no carry).
+// in slot b ^ (2 (b >> 5)).  With slot = b the bank pair of an 8-byte slot is b mod 32 = (azimuth, half-space, shell) WHATEVER
+// the cosine bin -- and the 32 lanes an LDS pass serves hold neighbours that follow each other in the cell-sorted order, i.e.
+// that lie in the same direction from the keypoint: same octant, same half-space, same shell, told apart by the cosine bin of
+// their normals alone.  Their 64-bit election atomics met in a handful of bank pairs (SQ_LDS_BANK_CONFLICT 312 cycles per wave,
+// half of the LDS pipe's active cycles; 239 cycles per wave waiting behind an LDS instruction).  XOR-ing bits 1-4 with the
+// cosine bin puts the eleven cosine bins of one direction into eleven bank pairs: 206 conflict cycles, 105 waiting, K5 -2 %
+// (tools/pmc_k5.sh and tools/ab_libs.sh, same box, three rounds).  Measured beside it: XOR with 3 x the cosine bin, which also
+// spreads the shell bit (148 conflict cycles, but the row read-out then has to exchange the halves of its pairs: +10 vector
+// instructions per keypoint, and the kernel is bound by those -- 1 % slower than this form); the shell bit moved to the top of
+// the slot number (slot = cell + 176 shell: no change, 288 cycles -- the shell does not tell the lanes of a pass apart).
+// The XOR stays inside the cosine bin's 32 slots, keeps a pair of adjacent bins adjacent and in order, and commutes with the
+// ^ 1 / ^ 2 that reach the other shell / half-space; bit 1 of a slot number is no longer the half-space (bins1 carries it).
+// All three 9-bit fields of bins0 at once.  (The team form keeps the plain numbering: with the two more registers the re-mapped
+// read-out of its four tables takes, its fused instantiations drop from eight waves per SIMD to seven.)
 __device__ inline unsigned shot_swz3(unsigned b)
 {
-    const unsigned t = (b >> 5) & 0x3C1E0Fu;
-    return b ^ (t * 3u);
+    return b ^ ((b >> 4) & 0x783C1Eu); // every 9-bit field f becomes f ^ (2 (f >> 5))
 }
 
 template <int NCH, bool FUSED>
@@ -653,10 +659,9 @@ __device__ __forceinline__ void shot_cached_body(const double *__restrict__ rec,
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int b = 2 * lane + 128 * u;
-        // bins b, b + 1 are the slots (b ^ g), (b ^ g) ^ 1: the same aligned pair, its halves exchanged when g is odd
-        const int gsw = 3 * (b >> 5), sb = (b ^ gsw) & ~1;
+        // bins b, b + 1 are the slots b ^ g, (b ^ g) + 1 with g = 2 (b >> 5) = 2 (lane >> 4) + 8 u: an aligned pair, in order
+        const int sb = ((2 * lane) ^ (2 * (lane >> 4)) ^ (8 * u)) + 128 * u;
         vals[u] = b < 352 ? *reinterpret_cast<const double2 *>(acc + sb) : make_double2(0.0, 0.0);
-        if (gsw & 1) { const double t_ = vals[u].x; vals[u].x = vals[u].y; vals[u].y = t_; }
         ss += vals[u].x * vals[u].x;
         ss += vals[u].y * vals[u].y;
     }
