@@ -834,6 +834,7 @@ def main() -> int:
     ap.add_argument("--dry-run-n", type=int, default=None, metavar="N",
                     help="plan a --gpus N run on THIS one GPU and exit: the N x points-per-gpu cloud's layer table, every rank's block / "
                          "halo / interior / exchange operations and buffer sizes, the matching phase's buffers -- nothing is timed")
+    ap.add_argument("--dry-run-n8", dest="dry_run_n", action="store_const", const=8, help="the same for N = 8 (--dry-run-n 8)")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-to-host drop-in timing (N = 1)")
     ap.add_argument("--no-normals", action="store_true", help="skip the compute_normals line (N = 1)")
