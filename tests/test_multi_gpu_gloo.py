@@ -21,7 +21,7 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("mode,world", [("neighbor", 2), ("neighbor", 3), ("halo", 2), ("allgather", 2)])
+@pytest.mark.parametrize("mode,world", [("neighbor", 2), ("neighbor", 3), ("neighbor", 5), ("halo", 2), ("allgather", 2)])
 def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode, world):
     from fake_engine import FakeEngine
     from oracle import oracle as O
@@ -30,7 +30,8 @@ def test_two_rank_gloo_equals_single_rank_and_oracle(tmp_path, mode, world):
     out = str(tmp_path / "stitched.npz")
     port = free_port()
     procs = []
-    for rank in range(world):  # (three ranks: the middle one borrows from and lends to both sides)
+    for rank in range(world):  # (three ranks: the middle one borrows from and lends to both sides; five: blocks thinner than a z-layer,
+                               #  a halo that reaches past the adjacent rank)
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out, mode], env=env))
@@ -179,7 +180,7 @@ def test_two_rank_gloo_subset_matching_by_label(tmp_path, chunks):
     assert np.mean([k == v for k, v in have.items()]) > 0.9  # and the matches do recover the correspondence
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (3, 5)])
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (3, 5), (4, 2)])
 def test_gloo_sharded_match_descriptors_with_filters_and_reciprocity(tmp_path, world, chunks):
     """MatchJob.matches(filter_callback, filter_nonreciprocal, n_min_matches) over gloo ranks on the reference's golden
     inputs (match_300.npz): the union of the per-rank results, mapped back through the non-empty-row numbering, equals
